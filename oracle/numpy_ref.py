@@ -1,0 +1,175 @@
+"""ORACLE (test infrastructure only) - NumPy restatement of the reference's host-side
+front end and evaluator, written to follow the reference statement by statement.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this.  The pieces restated here are NumPy code in the reference and run with the
+same NumPy calls (``np.hanning``, ``np.fft.rfft``, ``np.abs``, ``np.convolve``), so they
+are as close to "the reference run here" as the missing TFLite runtime allows; the
+framing grid is additionally pinned by fixtures produced by importing the reference's
+``RingBuffer`` (``tests/golden/make_golden.py``).  The mel/encode/detect graphs are
+evaluated by ``oracle/tflite_interp.py`` ("parity unpinned", see its header).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+
+class RefRing:
+    """Index arithmetic of reference ``spokestack/ring_buffer.py:9-130`` (one spare slot)."""
+
+    def __init__(self, capacity: int, item_shape=(), dtype=np.float32) -> None:
+        self._n = capacity + 1  # ring_buffer.py:15
+        self._buf = np.empty((self._n,) + tuple(item_shape), dtype=dtype)
+        self._r = 0
+        self._w = 0
+
+    @property
+    def is_empty(self) -> bool:
+        return self._r == self._w  # :28
+
+    @property
+    def is_full(self) -> bool:
+        return self._r == (self._w + 1) % self._n  # :37
+
+    def rewind(self):
+        self._r = (self._w + 1) % self._n  # :54
+        return self
+
+    def seek(self, k: int):
+        self._r = (self._r + k) % self._n  # :88
+        return self
+
+    def reset(self):
+        self._w = self._r  # :63
+        return self
+
+    def fill(self, v):
+        self._buf.fill(v)  # :75-76
+        self._r = (self._w + 1) % self._n
+        return self
+
+    def write(self, item) -> None:
+        if self.is_full:
+            raise IndexError("Buffer is full")  # :100-101
+        self._buf[self._w] = item
+        self._w = (self._w + 1) % self._n
+
+    def read(self):
+        if self.is_empty:
+            raise IndexError("Buffer is empty")  # :112-113
+        item = self._buf[self._r : self._r + 1]
+        self._r = (self._r + 1) % self._n
+        return item
+
+    def read_all(self):
+        self.rewind()  # :126
+        cur = []
+        while not self.is_empty:
+            cur.append(self.read())
+        return np.concatenate(cur).astype(self._buf.dtype)
+
+
+class RefFilter:
+    """Reference ``utils/tf_lite/filter.py:9-79`` with ``filter_model`` supplied as a callable
+    ``[1,257] f32 -> [1,40] f32`` (the TFLite graph evaluated by the op-by-op oracle)."""
+
+    def __init__(self, filter_model: Callable[[np.ndarray], np.ndarray], pre_emphasis: float = 0.0,
+                 sample_rate: int = 16000, fft_hop_length: int = 10, window_size: int = 512) -> None:
+        self.pre_emphasis = pre_emphasis
+        self.hop_length = int(fft_hop_length * sample_rate / 1000)  # filter.py:19
+        self.filter_model = filter_model
+        self._window_size = window_size  # filter.py:31
+        self._fft_window = np.hanning(self._window_size)  # filter.py:32
+        self.sample_window = RefRing(self._window_size)  # filter.py:35
+        self._prev_sample = 0.0
+
+    def filter_frame(self, frame: np.ndarray) -> List[np.ndarray]:
+        prev_sample = frame[-1]  # filter.py:42
+        frame -= self.pre_emphasis * np.append(self._prev_sample, frame[:-1])  # :43 (in place)
+        self._prev_sample = prev_sample
+        feats = []
+        for sample in frame:  # :50
+            self.sample_window.write(sample)
+            if self.sample_window.is_full:
+                feats.append(self._analyze().squeeze())
+                self.sample_window.rewind().seek(self.hop_length)  # :55
+        return feats
+
+    def stft_mag(self) -> np.ndarray:
+        fr = self.sample_window.read_all()  # :62
+        fr = np.fft.rfft(fr * self._fft_window, n=self._window_size)  # :63 (float64)
+        return np.abs(fr).astype(np.float32)  # :64
+
+    def _analyze(self) -> np.ndarray:
+        return self.filter_model(np.expand_dims(self.stft_mag(), 0))  # :72-73
+
+
+def normalise_pcm(frame_i16: np.ndarray) -> np.ndarray:
+    """Reference ``spokestack/wakeword/tflite.py:150-151``."""
+    f = frame_i16.astype(np.float32) / (2 ** 15 - 1)
+    return np.clip(f, -1.0, 1.0)
+
+
+def sliding_posteriors(filt: RefFilter, samples: np.ndarray, encoder_len: int,
+                       window_fn: Callable[[np.ndarray], float], frame_length: int = 320,
+                       inference_hop: int = 2, pad: int = 8000) -> List[float]:
+    """Per-file loop of reference ``utils/evaluate_models.py:45-88``.
+
+    ``samples`` are the floats librosa would return; ``window_fn`` maps a ``[T,40]`` window to
+    the scalar posterior.  Note the reference runs at most ONE inference per 20 ms chunk
+    (``if``, not ``while``, at :70) and discards the windows still pending at end of file."""
+    out: List[float] = []
+    window_buffer: List[np.ndarray] = []
+    samples = np.pad(samples, (pad, pad), mode="constant")  # :52-53
+    for start in np.arange(0, len(samples), frame_length):  # :57
+        frame = samples[start : start + frame_length]
+        if len(frame) < frame_length:
+            frame = np.pad(frame, (0, frame_length - len(frame)), mode="constant")  # :59-61
+        feats = filt.filter_frame(frame)  # :64
+        if len(feats) > 0:
+            window_buffer.extend(feats)
+        if len(window_buffer) >= encoder_len:  # :70
+            frames = window_buffer[:encoder_len]
+            window_buffer = window_buffer[inference_hop:]
+            out.append(window_fn(np.array(frames)))
+    return out
+
+
+def far_frr(keyword_post: np.ndarray, no_keyword_post: np.ndarray, num_wakewords: int, hours: float,
+            thresholds: Optional[np.ndarray] = None, windowsize: int = 30):
+    """Reference ``utils/evaluate_models.py:183-218`` (numbers only, no plots)."""
+    if thresholds is None:
+        thresholds = np.arange(0.5, 0.99999, 0.005)  # :185
+    neg = np.convolve(no_keyword_post, np.ones((windowsize,)) / windowsize, mode="same")  # :188-189
+    frr, far, cnt = [], [], []
+    for threshold in thresholds:
+        accepts = (keyword_post > threshold).sum()  # :201
+        frr.append((num_wakewords - accepts) / num_wakewords)  # :202-204
+        prev = False
+        fa = 0
+        for p in neg:  # :211-216
+            if p > threshold and not prev:
+                fa += 1
+            prev = bool(p > threshold)
+        cnt.append(fa)
+        far.append(fa / hours)  # :217
+    return np.array(frr), np.array(far), np.array(cnt), neg
+
+
+def frr_at_fa(frr: np.ndarray, far: np.ndarray, fa_limit: float = 0.5) -> float:
+    """BASELINE.json metric 'FRR @ 0.5 FA/h': min FRR over thresholds with FA/h <= limit
+    (SURVEY 8d)."""
+    ok = far <= fa_limit
+    return float(np.min(frr[ok])) if ok.any() else float("nan")
+
+
+def load_h5_like(features: Sequence[np.ndarray], timesteps: int, num_features: int) -> np.ndarray:
+    """Reference ``utils/evaluate_tf_lite_opts.py:35-47``: truncate to ``timesteps`` rows and
+    zero-pad at the end."""
+    X = np.zeros((len(features), timesteps, num_features), dtype=np.float32)
+    for i, f in enumerate(features):
+        f = np.asarray(f)[:timesteps]
+        X[i, : f.shape[0], : f.shape[1]] = f
+    return X

@@ -1,0 +1,549 @@
+/*
+ * ORACLE (test infrastructure only) - plain-C CPU restatement of the reference hot path.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product (wakeword-detection_amd/) never links or calls it.
+ *
+ * PARITY STATUS: the front end (framing, Hann, rFFT, magnitude) restates NumPy code of the
+ * reference that is executable here and is pinned by fixtures generated from the
+ * reference's own RingBuffer (tests/golden/make_golden.py).  The MODEL arithmetic is
+ * "parity unpinned": the reference runs it inside TensorFlow-Lite 2.4.0
+ * (requirements.txt:3), an un-vendored dependency absent from this image, and ships no
+ * golden vectors.  This file restates the networks from the Keras definitions and is
+ * cross-checked against the op-by-op evaluator oracle/tflite_interp.py.
+ *
+ * Reference lines followed (paths relative to /root/reference):
+ *   framing            utils/tf_lite/filter.py:50-55, spokestack/ring_buffer.py:37,54,88
+ *   normalise / clip   spokestack/wakeword/tflite.py:150-151
+ *   pre-emphasis       spokestack/wakeword/tflite.py:156-158, utils/tf_lite/filter.py:42-44
+ *   STFT magnitude     spokestack/wakeword/tflite.py:174-176 (float64 product + rfft, cast f32)
+ *   mel + log          tf_lite_models/x/filter.tflite ops 0-4 (FC, MAXIMUM, LOG, SUB, MUL)
+ *   CRNN               wwdetect/CRNN/model.py:21-56 (Conv2D SAME/ReLU, Permute+Reshape,
+ *                      2x Bidirectional GRU reset_after, Dense-ReLU, Dense, sigmoid|softmax)
+ *   Wavenet            wwdetect/wavenet/wavenet_model.py:11-128
+ *   smoothing / sweep  utils/evaluate_models.py:185-218
+ *
+ * Weights arrive in the packed blob written by wwhip/weights.py:pack_blob (sections by name).
+ */
+#define _USE_MATH_DEFINES
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define WWO_OK 0
+#define WWO_EBLOB (-1)
+#define WWO_EARG (-2)
+
+typedef struct {
+  const uint8_t *base;
+  uint32_t n;
+  uint32_t kind;
+} blob_t;
+
+static int blob_open(const void *p, size_t len, blob_t *b) {
+  const uint32_t *h = (const uint32_t *)p;
+  if (len < 16 || h[0] != 0x42485757u || h[1] != 1u) return WWO_EBLOB;
+  b->base = (const uint8_t *)p;
+  b->kind = h[2];
+  b->n = h[3];
+  return WWO_OK;
+}
+
+static const void *blob_find(const blob_t *b, const char *name, uint32_t *count) {
+  for (uint32_t i = 0; i < b->n; ++i) {
+    const uint8_t *e = b->base + 16 + 32 * i;
+    if (strncmp((const char *)e, name, 24) == 0) {
+      uint32_t off, cnt;
+      memcpy(&off, e + 24, 4);
+      memcpy(&cnt, e + 28, 4);
+      if (count) *count = cnt;
+      return b->base + off;
+    }
+  }
+  return NULL;
+}
+
+static const float *bf(const blob_t *b, const char *n) { return (const float *)blob_find(b, n, NULL); }
+static const int32_t *bi(const blob_t *b, const char *n) { return (const int32_t *)blob_find(b, n, NULL); }
+
+int wwo_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Front end                                                                            */
+/* ------------------------------------------------------------------------------------ */
+#define WIN 512
+#define HOP_DEFAULT 160
+#define NBIN 257
+
+/* number of full frames produced by the reference's framing loop for n samples */
+int64_t wwo_num_frames(int64_t n_samples, int hop) {
+  if (n_samples < WIN) return 0;
+  return (n_samples - WIN) / hop + 1;
+}
+
+typedef struct {
+  double hann[WIN];
+  double tw_re[WIN / 2], tw_im[WIN / 2]; /* e^{-2 pi i k / 512} */
+  int rev[WIN / 2];                      /* bit reversal for 256-point complex FFT */
+} fft_tab_t;
+
+static fft_tab_t g_tab;
+static int g_tab_ready = 0;
+
+static void tab_init(void) {
+  if (g_tab_ready) return;
+  /* np.hanning(M): 0.5 - 0.5 cos(2 pi n / (M-1)), symmetric */
+  for (int n = 0; n < WIN; ++n) g_tab.hann[n] = 0.5 - 0.5 * cos(2.0 * M_PI * (double)n / (double)(WIN - 1));
+  for (int k = 0; k < WIN / 2; ++k) {
+    g_tab.tw_re[k] = cos(-2.0 * M_PI * (double)k / (double)WIN);
+    g_tab.tw_im[k] = sin(-2.0 * M_PI * (double)k / (double)WIN);
+  }
+  for (int i = 0; i < WIN / 2; ++i) {
+    int r = 0;
+    for (int b = 0; b < 8; ++b)
+      if (i & (1 << b)) r |= 1 << (7 - b);
+    g_tab.rev[i] = r;
+  }
+  g_tab_ready = 1;
+}
+
+/* |rfft(x)| for real x[512] in double: pack even/odd into a 256-point complex FFT */
+static void rfft_mag(const double *x, float *mag) {
+  double zr[WIN / 2], zi[WIN / 2];
+  for (int i = 0; i < WIN / 2; ++i) {
+    int r = g_tab.rev[i];
+    zr[r] = x[2 * i];
+    zi[r] = x[2 * i + 1];
+  }
+  for (int len = 2; len <= WIN / 2; len <<= 1) {
+    int half = len >> 1, step = WIN / len; /* twiddle e^{-2 pi i j/len} = tw[j*step] */
+    for (int s = 0; s < WIN / 2; s += len) {
+      for (int j = 0; j < half; ++j) {
+        double wr = g_tab.tw_re[j * step], wi = g_tab.tw_im[j * step];
+        double ar = zr[s + j], ai = zi[s + j];
+        double br = zr[s + j + half] * wr - zi[s + j + half] * wi;
+        double bi_ = zr[s + j + half] * wi + zi[s + j + half] * wr;
+        zr[s + j] = ar + br;
+        zi[s + j] = ai + bi_;
+        zr[s + j + half] = ar - br;
+        zi[s + j + half] = ai - bi_;
+      }
+    }
+  }
+  /* X[k] = E[k] + W^k O[k];  E = (Z[k] + conj Z[N-k])/2,  O = (Z[k] - conj Z[N-k])/(2i) */
+  const int N = WIN / 2;
+  for (int k = 0; k <= N; ++k) {
+    int k1 = k % N, k2 = (N - k) % N;
+    double er = 0.5 * (zr[k1] + zr[k2]), ei = 0.5 * (zi[k1] - zi[k2]);
+    double orr = 0.5 * (zi[k1] + zi[k2]), oi = -0.5 * (zr[k1] - zr[k2]);
+    double wr, wi;
+    if (k == N) { wr = -1.0; wi = 0.0; } else { wr = g_tab.tw_re[k]; wi = g_tab.tw_im[k]; }
+    double re = er + orr * wr - oi * wi;
+    double im = ei + orr * wi + oi * wr;
+    mag[k] = (float)sqrt(re * re + im * im);
+  }
+}
+
+static void mel_log(const float *mag, const float *W, const float *b, int n_mel, float floor_v,
+                    float log_off, float scale, float *out) {
+  for (int m = 0; m < n_mel; ++m) {
+    float acc = 0.f;
+    const float *w = W + (size_t)m * NBIN;
+    for (int k = 0; k < NBIN; ++k) acc += w[k] * mag[k];
+    acc += b[m];
+    if (acc < floor_v) acc = floor_v;
+    out[m] = (logf(acc) + log_off) * scale;
+  }
+}
+
+/*
+ * One utterance: int16 pcm[n] -> mel[n_frames][n_mel].
+ *   x = clip(f32(pcm) / divisor, -1, 1) (divisor = 32767 streaming, 32768 librosa; the clip only
+ *                                        bites for pcm = -32768 with divisor 32767)
+ *   x[n] -= preemph * x[n-1]             (carry-in = prev_sample)
+ *   frame j = x[hop*j : hop*j + 512]
+ * `prefix` (may be NULL) holds n_prefix float samples that precede pcm[0] in the stream
+ * (quirk C2: the reference never resets the Filter between files).
+ */
+int wwo_logmel(const void *blob, size_t blob_len, const int16_t *pcm, int64_t n, float divisor, int do_clip,
+               float preemph, int hop, const float *prefix, int n_prefix, float *mel, int64_t *n_frames_out) {
+  blob_t b;
+  if (blob_open(blob, blob_len, &b)) return WWO_EBLOB;
+  const int32_t *meta = bi(&b, "filter.meta");
+  const float *cst = bf(&b, "filter.consts");
+  const float *W = bf(&b, "filter.w");
+  const float *bias = bf(&b, "filter.b");
+  if (!meta || !cst || !W || !bias || meta[1] != NBIN) return WWO_EBLOB;
+  int n_mel = meta[0];
+  tab_init();
+  int64_t total = n + n_prefix;
+  float *x = (float *)malloc(sizeof(float) * (size_t)(total > 0 ? total : 1));
+  if (!x) return WWO_EARG;
+  for (int i = 0; i < n_prefix; ++i) x[i] = prefix[i];
+  float carry = 0.f;
+  for (int64_t i = 0; i < n; ++i) {
+    /* reference divides: frame.astype(f32) / 32767 - a true fp32 division */
+    float v = (float)pcm[i] / divisor;
+    if (do_clip) v = v < -1.f ? -1.f : (v > 1.f ? 1.f : v);
+    float cur = v;
+    v = v - preemph * carry;
+    carry = cur;
+    x[n_prefix + i] = v;
+  }
+  int64_t nf = wwo_num_frames(total, hop);
+  if (n_frames_out) *n_frames_out = nf;
+#pragma omp parallel for schedule(static)
+  for (int64_t j = 0; j < nf; ++j) {
+    double fr[WIN];
+    float mag[NBIN];
+    const float *src = x + j * hop;
+    for (int k = 0; k < WIN; ++k) fr[k] = (double)src[k] * g_tab.hann[k];
+    rfft_mag(fr, mag);
+    mel_log(mag, W, bias, n_mel, cst[0], cst[1], cst[2], mel + (size_t)j * n_mel);
+  }
+  free(x);
+  return WWO_OK;
+}
+
+/* float input variant (offline path feeds librosa floats: utils/evaluate_models.py:46,64) */
+int wwo_logmel_f32(const void *blob, size_t blob_len, const float *xin, int64_t n, float preemph, int hop,
+                   float *mel, int64_t *n_frames_out) {
+  blob_t b;
+  if (blob_open(blob, blob_len, &b)) return WWO_EBLOB;
+  const int32_t *meta = bi(&b, "filter.meta");
+  const float *cst = bf(&b, "filter.consts");
+  const float *W = bf(&b, "filter.w");
+  const float *bias = bf(&b, "filter.b");
+  if (!meta || !cst || !W || !bias || meta[1] != NBIN) return WWO_EBLOB;
+  int n_mel = meta[0];
+  tab_init();
+  float *x = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+  float carry = 0.f;
+  for (int64_t i = 0; i < n; ++i) {
+    float cur = xin[i];
+    x[i] = cur - preemph * carry;
+    carry = cur;
+  }
+  int64_t nf = wwo_num_frames(n, hop);
+  if (n_frames_out) *n_frames_out = nf;
+#pragma omp parallel for schedule(static)
+  for (int64_t j = 0; j < nf; ++j) {
+    double fr[WIN];
+    float mag[NBIN];
+    const float *src = x + j * hop;
+    for (int k = 0; k < WIN; ++k) fr[k] = (double)src[k] * g_tab.hann[k];
+    rfft_mag(fr, mag);
+    mel_log(mag, W, bias, n_mel, cst[0], cst[1], cst[2], mel + (size_t)j * n_mel);
+  }
+  free(x);
+  return WWO_OK;
+}
+
+/* STFT magnitude only (for front-end parity tests): frames[nf][512] f32 -> mag[nf][257] */
+int wwo_stft_mag(const float *frames, int64_t nf, float *mag) {
+  tab_init();
+  for (int64_t j = 0; j < nf; ++j) {
+    double fr[WIN];
+    for (int k = 0; k < WIN; ++k) fr[k] = (double)frames[j * WIN + k] * g_tab.hann[k];
+    rfft_mag(fr, mag + j * NBIN);
+  }
+  return WWO_OK;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* CRNN                                                                                 */
+/* ------------------------------------------------------------------------------------ */
+static inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+typedef struct {
+  const float *wx, *bx, *wh, *bh;
+} gru_t;
+
+static void gru_run(const gru_t *g, const float *seq, int T, int in_w, int H, int backward, float *out_seq,
+                    int out_stride, int out_off, float *last) {
+  float h[64], gx[192], gh[192];
+  for (int i = 0; i < H; ++i) h[i] = 0.f;
+  for (int s = 0; s < T; ++s) {
+    int t = backward ? T - 1 - s : s;
+    const float *x = seq + (size_t)t * in_w;
+    for (int o = 0; o < 3 * H; ++o) {
+      float a = 0.f;
+      const float *w = g->wx + (size_t)o * in_w;
+      for (int k = 0; k < in_w; ++k) a += w[k] * x[k];
+      gx[o] = a + g->bx[o];
+      float r = 0.f;
+      const float *u = g->wh + (size_t)o * H;
+      for (int k = 0; k < H; ++k) r += u[k] * h[k];
+      gh[o] = r + g->bh[o];
+    }
+    for (int i = 0; i < H; ++i) {
+      float z = sigmoidf_(gx[i] + gh[i]);
+      float r = sigmoidf_(gx[H + i] + gh[H + i]);
+      float c = tanhf(gx[2 * H + i] + r * gh[2 * H + i]);
+      h[i] = z * h[i] + (1.0f - z) * c;
+    }
+    if (out_seq)
+      for (int i = 0; i < H; ++i) out_seq[(size_t)t * out_stride + out_off + i] = h[i];
+  }
+  if (last)
+    for (int i = 0; i < H; ++i) last[i] = h[i];
+}
+
+/* mel windows [B][T][n_mel] (time-major rows, as the ring buffer holds them) -> out[B][n_out];
+ * optional enc[B][2H] receives the encoder output. */
+int wwo_crnn_forward(const void *blob, size_t blob_len, const float *mel, int B, float *out, float *enc_out) {
+  blob_t b;
+  if (blob_open(blob, blob_len, &b) || b.kind != 1) return WWO_EBLOB;
+  const int32_t *m = bi(&b, "crnn.meta");
+  if (!m) return WWO_EBLOB;
+  const int n_mel = m[0], T = m[1], C = m[2], KF = m[3], KT = m[4], SF = m[5], ST = m[6], PF = m[7], PT = m[8],
+            OF = m[9], OT = m[10], H = m[11], NOUT = m[12], HEAD = m[13];
+  if (H > 64 || OT > 64) return WWO_EARG;
+  const float *cw = bf(&b, "crnn.conv_w"), *cb = bf(&b, "crnn.conv_b");
+  gru_t g1f = {bf(&b, "crnn.g1f.wx"), bf(&b, "crnn.g1f.bx"), bf(&b, "crnn.g1f.wh"), bf(&b, "crnn.g1f.bh")};
+  gru_t g1b = {bf(&b, "crnn.g1b.wx"), bf(&b, "crnn.g1b.bx"), bf(&b, "crnn.g1b.wh"), bf(&b, "crnn.g1b.bh")};
+  gru_t g2f = {bf(&b, "crnn.g2f.wx"), bf(&b, "crnn.g2f.bx"), bf(&b, "crnn.g2f.wh"), bf(&b, "crnn.g2f.bh")};
+  gru_t g2b = {bf(&b, "crnn.g2b.wx"), bf(&b, "crnn.g2b.bx"), bf(&b, "crnn.g2b.wh"), bf(&b, "crnn.g2b.bh")};
+  const float *w1 = bf(&b, "crnn.head_w1"), *b1 = bf(&b, "crnn.head_b1");
+  const float *w2 = bf(&b, "crnn.head_w2"), *b2 = bf(&b, "crnn.head_b2");
+  const int FEAT = OF * C;
+  int rc = WWO_OK;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int n = 0; n < B; ++n) {
+    const float *win = mel + (size_t)n * T * n_mel;
+    float *feat = (float *)malloc(sizeof(float) * (size_t)OT * FEAT);
+    float *seq1 = (float *)malloc(sizeof(float) * (size_t)OT * 2 * H);
+    /* Conv2D over [mel][frame] with SAME padding, stride (SF, ST), ReLU; feature = f*C + c */
+    for (int t = 0; t < OT; ++t)
+      for (int f = 0; f < OF; ++f)
+        for (int c = 0; c < C; ++c) {
+          float a = 0.f;
+          for (int kf = 0; kf < KF; ++kf) {
+            int im = f * SF - PF + kf;
+            if (im < 0 || im >= n_mel) continue;
+            for (int kt = 0; kt < KT; ++kt) {
+              int it = t * ST - PT + kt;
+              if (it < 0 || it >= T) continue;
+              a += win[(size_t)it * n_mel + im] * cw[((size_t)c * KF + kf) * KT + kt];
+            }
+          }
+          a += cb[c];
+          feat[(size_t)t * FEAT + f * C + c] = a > 0.f ? a : 0.f;
+        }
+    gru_run(&g1f, feat, OT, FEAT, H, 0, seq1, 2 * H, 0, NULL);
+    gru_run(&g1b, feat, OT, FEAT, H, 1, seq1, 2 * H, H, NULL);
+    float enc[128];
+    gru_run(&g2f, seq1, OT, 2 * H, H, 0, NULL, 0, 0, enc);
+    gru_run(&g2b, seq1, OT, 2 * H, H, 1, NULL, 0, 0, enc + H);
+    if (enc_out) memcpy(enc_out + (size_t)n * 2 * H, enc, sizeof(float) * 2 * H);
+    float hid[64];
+    for (int o = 0; o < 2 * H; ++o) {
+      float a = 0.f;
+      for (int k = 0; k < 2 * H; ++k) a += w1[(size_t)o * 2 * H + k] * enc[k];
+      a += b1[o];
+      hid[o] = a > 0.f ? a : 0.f;
+    }
+    float y[8];
+    for (int o = 0; o < NOUT; ++o) {
+      float a = 0.f;
+      for (int k = 0; k < 2 * H; ++k) a += w2[(size_t)o * 2 * H + k] * hid[k];
+      y[o] = a + b2[o];
+    }
+    if (HEAD == 0) {
+      for (int o = 0; o < NOUT; ++o) out[(size_t)n * NOUT + o] = sigmoidf_(y[o]);
+    } else {
+      float mx = y[0], s = 0.f;
+      for (int o = 1; o < NOUT; ++o) mx = y[o] > mx ? y[o] : mx;
+      for (int o = 0; o < NOUT; ++o) { y[o] = expf(y[o] - mx); s += y[o]; }
+      for (int o = 0; o < NOUT; ++o) out[(size_t)n * NOUT + o] = y[o] / s;
+    }
+    free(feat);
+    free(seq1);
+  }
+  return rc;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Wavenet                                                                              */
+/* ------------------------------------------------------------------------------------ */
+int wwo_wavenet_forward(const void *blob, size_t blob_len, const float *mel, int B, float *out, float *enc_out) {
+  blob_t b;
+  if (blob_open(blob, blob_len, &b) || b.kind != 2) return WWO_EBLOB;
+  const int32_t *m = bi(&b, "wave.meta");
+  if (!m) return WWO_EBLOB;
+  const int T = m[0], n_mel = m[1], C = m[2], S = m[3], NB = m[4], NOUT = m[5];
+  if (C > 32 || S > 64 || NOUT > 8) return WWO_EARG;
+  const int32_t *dil = bi(&b, "wave.dilations"), *order = bi(&b, "wave.skip_order"), *has_res = bi(&b, "wave.has_res");
+  const float *w_in = bf(&b, "wave.w_in"), *b_in = bf(&b, "wave.b_in");
+  const float *bn_s = bf(&b, "wave.bn_scale"), *bn_t = bf(&b, "wave.bn_shift");
+  const float *w_sig = bf(&b, "wave.w_sig"), *b_sig = bf(&b, "wave.b_sig");
+  const float *w_tanh = bf(&b, "wave.w_tanh"), *b_tanh = bf(&b, "wave.b_tanh");
+  const float *w_res = bf(&b, "wave.w_res"), *b_res = bf(&b, "wave.b_res");
+  const float *w_skip = bf(&b, "wave.w_skip"), *b_skip = bf(&b, "wave.b_skip");
+  const float *d_w1 = bf(&b, "wave.det_w1"), *d_b1 = bf(&b, "wave.det_b1");
+  const float *d_w2 = bf(&b, "wave.det_w2"), *d_b2 = bf(&b, "wave.det_b2");
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int n = 0; n < B; ++n) {
+    const float *win = mel + (size_t)n * T * n_mel;
+    float *x = (float *)malloc(sizeof(float) * (size_t)T * C);
+    float *u = (float *)malloc(sizeof(float) * (size_t)T * C);
+    float *g = (float *)malloc(sizeof(float) * (size_t)T * C);
+    float *skips = (float *)calloc((size_t)NB * T * S, sizeof(float));
+    float *acc = (float *)malloc(sizeof(float) * (size_t)T * S);
+    for (int t = 0; t < T; ++t)
+      for (int o = 0; o < C; ++o) {
+        float a = 0.f;
+        for (int k = 0; k < n_mel; ++k) a += win[(size_t)t * n_mel + k] * w_in[(size_t)k * C + o];
+        a += b_in[o];
+        x[(size_t)t * C + o] = a > 0.f ? a : 0.f;
+      }
+    for (int blk = 0; blk < NB; ++blk) {
+      const int d = dil[blk];
+      const float *ws = w_sig + (size_t)blk * 3 * C * C, *wt = w_tanh + (size_t)blk * 3 * C * C;
+      for (int i = 0; i < T * C; ++i) u[i] = x[i] * bn_s[blk * C + i % C] + bn_t[blk * C + i % C];
+      for (int t = 0; t < T; ++t)
+        for (int o = 0; o < C; ++o) {
+          float as = 0.f, at = 0.f;
+          for (int k = 0; k < 3; ++k) {
+            int tt = t - (2 - k) * d;
+            if (tt < 0) continue; /* causal zero pad is applied AFTER the BN affine */
+            for (int i = 0; i < C; ++i) {
+              float v = u[(size_t)tt * C + i];
+              as += v * ws[((size_t)k * C + i) * C + o];
+              at += v * wt[((size_t)k * C + i) * C + o];
+            }
+          }
+          as += b_sig[blk * C + o];
+          at += b_tanh[blk * C + o];
+          g[(size_t)t * C + o] = tanhf(at) * sigmoidf_(as);
+        }
+      float *sk = skips + (size_t)blk * T * S;
+      for (int t = 0; t < T; ++t) {
+        for (int o = 0; o < S; ++o) {
+          float a = 0.f;
+          for (int i = 0; i < C; ++i) a += g[(size_t)t * C + i] * w_skip[((size_t)blk * C + i) * S + o];
+          a += b_skip[blk * S + o];
+          sk[(size_t)t * S + o] = a > 0.f ? a : 0.f;
+        }
+        if (has_res[blk]) {
+          float r[32];
+          for (int o = 0; o < C; ++o) {
+            float a = 0.f;
+            for (int i = 0; i < C; ++i) a += g[(size_t)t * C + i] * w_res[((size_t)blk * C + i) * C + o];
+            a += b_res[blk * C + o];
+            r[o] = a > 0.f ? a : 0.f;
+          }
+          for (int o = 0; o < C; ++o) x[(size_t)t * C + o] = r[o] + x[(size_t)t * C + o];
+        }
+      }
+    }
+    /* skip sum in the order the graph adds them */
+    memcpy(acc, skips + (size_t)order[0] * T * S, sizeof(float) * (size_t)T * S);
+    for (int j = 1; j < NB; ++j) {
+      const float *sk = skips + (size_t)order[j] * T * S;
+      for (int i = 0; i < T * S; ++i) acc[i] = acc[i] + sk[i];
+    }
+    if (enc_out) memcpy(enc_out + (size_t)n * T * S, acc, sizeof(float) * (size_t)T * S);
+    float best[8];
+    for (int o = 0; o < NOUT; ++o) best[o] = -INFINITY;
+    for (int t = 0; t < T; ++t) {
+      float r[64], h[64];
+      for (int i = 0; i < S; ++i) r[i] = acc[(size_t)t * S + i] > 0.f ? acc[(size_t)t * S + i] : 0.f;
+      for (int o = 0; o < S; ++o) {
+        float a = 0.f;
+        for (int i = 0; i < S; ++i) a += r[i] * d_w1[(size_t)i * S + o];
+        a += d_b1[o];
+        h[o] = a > 0.f ? a : 0.f;
+      }
+      for (int o = 0; o < NOUT; ++o) {
+        float a = 0.f;
+        for (int i = 0; i < S; ++i) a += h[i] * d_w2[(size_t)i * NOUT + o];
+        a += d_b2[o];
+        if (a > best[o]) best[o] = a;
+      }
+    }
+    float mx = best[0], s = 0.f, e[8];
+    for (int o = 1; o < NOUT; ++o) mx = best[o] > mx ? best[o] : mx;
+    for (int o = 0; o < NOUT; ++o) { e[o] = expf(best[o] - mx); s += e[o]; }
+    for (int o = 0; o < NOUT; ++o) out[(size_t)n * NOUT + o] = e[o] / s;
+    free(x); free(u); free(g); free(skips); free(acc);
+  }
+  return WWO_OK;
+}
+
+/* sliding windows over one mel sequence: window i = rows [i*hop, i*hop + T) */
+int wwo_slide_forward(const void *blob, size_t blob_len, const float *mel, int64_t n_rows, int hop, float *out,
+                      int64_t *n_windows) {
+  blob_t b;
+  if (blob_open(blob, blob_len, &b)) return WWO_EBLOB;
+  const int32_t *m = b.kind == 1 ? bi(&b, "crnn.meta") : bi(&b, "wave.meta");
+  if (!m) return WWO_EBLOB;
+  int T = b.kind == 1 ? m[1] : m[0];
+  int n_mel = b.kind == 1 ? m[0] : m[1];
+  int NOUT = b.kind == 1 ? m[12] : m[5];
+  int64_t nw = n_rows >= T ? (n_rows - T) / hop + 1 : 0;
+  if (n_windows) *n_windows = nw;
+  if (nw == 0) return WWO_OK;
+  float *wins = (float *)malloc(sizeof(float) * (size_t)nw * T * n_mel);
+  for (int64_t i = 0; i < nw; ++i) memcpy(wins + (size_t)i * T * n_mel, mel + (size_t)i * hop * n_mel, sizeof(float) * (size_t)T * n_mel);
+  int rc = b.kind == 1 ? wwo_crnn_forward(blob, blob_len, wins, (int)nw, out, NULL)
+                       : wwo_wavenet_forward(blob, blob_len, wins, (int)nw, out, NULL);
+  (void)NOUT;
+  free(wins);
+  return rc;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Posterior smoothing + threshold sweep (utils/evaluate_models.py:185-218)             */
+/* ------------------------------------------------------------------------------------ */
+/* np.convolve(p, ones(w)/w, 'same') for len(p) >= w: out[i] = sum_{j} p[i + (w-1)/2... ] -
+ * 'same' keeps the centre of the full convolution: full[k] = sum_j p[j] v[k-j], out[i] = full[i + (w-1)/2]
+ * => out[i] = (1/w) * sum_{j = i + (w-1)/2 - (w-1)}^{i + (w-1)/2} p[j]   (w=30: j in [i-15, i+14]) */
+int wwo_smooth(const double *p, int64_t n, int w, double *out) {
+  if (w <= 0) return WWO_EARG;
+  const double v = 1.0 / (double)w;
+  /* numpy swaps operands so the longer one is first; for n < w the output length is w */
+  if (n < w) return WWO_EARG;
+  int64_t shift = (w - 1) / 2;
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t hi = i + shift, lo = hi - (w - 1);
+    double a = 0.0;
+    /* numpy's correlate kernel accumulates in index order of the (reversed) kernel over p */
+    for (int64_t j = lo; j <= hi; ++j)
+      if (j >= 0 && j < n) a += p[j] * v;
+    out[i] = a;
+  }
+  return WWO_OK;
+}
+
+int wwo_far_frr(const double *pos, int64_t P, const double *neg_smoothed, int64_t N, const double *thr, int nthr,
+                double num_wakewords, double hours, double *frr, double *fa_per_h, int64_t *fa_count) {
+  for (int k = 0; k < nthr; ++k) {
+    double t = thr[k];
+    int64_t acc = 0;
+    for (int64_t i = 0; i < P; ++i) acc += pos[i] > t;
+    frr[k] = (num_wakewords - (double)acc) / num_wakewords;
+    int64_t fa = 0;
+    int prev = 0;
+    for (int64_t i = 0; i < N; ++i) {
+      int cur = neg_smoothed[i] > t;
+      if (cur && !prev) ++fa;
+      prev = cur;
+    }
+    if (fa_count) fa_count[k] = fa;
+    fa_per_h[k] = (double)fa / hours;
+  }
+  return WWO_OK;
+}
