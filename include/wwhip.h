@@ -1,0 +1,183 @@
+/*
+ * wwhip.h - C ABI of libwwhip.so, the MI355X (gfx950) wake-word inference hot path.
+ *
+ * The reference (MerlinPCarson/WakeWord-Detection) has no FFI of its own: its hot path is
+ * NumPy + the TensorFlow-Lite interpreter behind Python duck-typed classes.  Each entry
+ * point below names the reference interface it replaces (paths relative to the reference
+ * repository root).  The Python host classes in wakeword-detection_amd/wwhip/ bind these
+ * with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative WW_E* code and never throws;
+ *     ww_last_error(ctx) holds a human-readable message for the last failure on that ctx;
+ *   - one ww_ctx per host thread; a ctx owns one HIP stream (or borrows the caller's) and a
+ *     growable device workspace; calls on one ctx are serialised by the caller;
+ *   - "host" entry points take ordinary host pointers, copy through pinned staging and
+ *     return after the result is in the caller's buffer (PCIe inclusive);
+ *   - "_dev" entry points take device pointers (e.g. torch tensor .data_ptr()), enqueue on
+ *     the ctx stream and return without synchronising;
+ *   - the caller owns every buffer it passes; nothing is retained after return except by
+ *     ww_model_load (copies the blob) and the ww_streams object (owns its rings).
+ */
+#ifndef WWHIP_H
+#define WWHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WW_OK 0
+#define WW_EINVAL (-1)    /* bad argument (maps to ValueError) */
+#define WW_EBLOB (-2)     /* malformed weight blob (ValueError) */
+#define WW_EHIP (-3)      /* HIP runtime failure (RuntimeError) */
+#define WW_ENOMEM (-4)    /* allocation failure (MemoryError) */
+#define WW_ESTATE (-5)    /* object used in the wrong state (RuntimeError) */
+#define WW_ENODEVICE (-6) /* no usable gfx950 device (RuntimeError) */
+
+#define WW_KIND_CRNN 1
+#define WW_KIND_WAVENET 2
+
+#define WW_FFT_WINDOW 512 /* (257 - 1) * 2, reference spokestack/wakeword/tflite.py:67 */
+#define WW_FFT_BINS 257
+#define WW_CHUNK 320 /* 20 ms @ 16 kHz, reference spokestack/io/pyaudio.py:24 */
+
+typedef struct ww_ctx ww_ctx;
+typedef struct ww_model ww_model;
+typedef struct ww_streams ww_streams;
+
+typedef struct ww_model_info {
+  int32_t kind;      /* WW_KIND_* */
+  int32_t window;    /* mel frames per inference: 151 (CRNN) / 182 (Wavenet) */
+  int32_t n_mel;     /* 40 */
+  int32_t n_bins;    /* 257 */
+  int32_t n_out;     /* width of the detect output row: 1 (sigmoid) or 2 (softmax) */
+  int32_t enc_rows;  /* encoder output rows: 1 (CRNN) / 182 (Wavenet) */
+  int32_t enc_width; /* encoder output width: 64 (CRNN) / 32 (Wavenet) */
+  int32_t reserved;
+} ww_model_info;
+
+/* Front-end parameters.  Reference: spokestack/wakeword/tflite.py:33-43,150-158 and
+ * utils/tf_lite/filter.py:9-19,42-44. */
+typedef struct ww_frontend_params {
+  float pcm_divisor;  /* 32767 (streaming plugin, tflite.py:150) or 32768 (librosa floats) */
+  int32_t clip;       /* 1: clip to [-1, 1] after the division (tflite.py:151) */
+  float pre_emphasis; /* alpha of x[n] -= alpha * x[n-1]; reference default 0.0 */
+  int32_t hop;        /* samples between frames: 160 (fft_hop_length 10 ms @ 16 kHz) */
+  int32_t precise;    /* 1: Hann product + FFT in fp64 like the reference (tflite.py:175);
+                         0: fp32 butterflies (faster, ~1e-6 relative on the magnitudes) */
+} ww_frontend_params;
+
+/* ---- context ------------------------------------------------------------------------- */
+/* external_stream: NULL -> the ctx creates its own non-blocking stream; otherwise a
+ * hipStream_t owned by the caller (e.g. torch.cuda.current_stream().cuda_stream). */
+int ww_ctx_create(int device, void *external_stream, ww_ctx **out);
+int ww_ctx_destroy(ww_ctx *ctx);
+int ww_ctx_synchronize(ww_ctx *ctx);
+void *ww_ctx_stream(ww_ctx *ctx);
+const char *ww_last_error(const ww_ctx *ctx); /* ctx may be NULL: error of a failed create */
+const char *ww_version(void);
+
+/* Per-kernel timing with HIP events on the ctx stream (bench.py roofline leg).  While
+ * enabled every kernel launch is bracketed by two events; ww_profile_read synchronises and
+ * writes a JSON object {"kernel": {"calls": n, "total_ms": t}, ...}. */
+int ww_profile_enable(ww_ctx *ctx, int on);
+int ww_profile_read(ww_ctx *ctx, char *json, size_t cap);
+/* Event pair on the ctx stream around an arbitrary region. */
+int ww_timer_start(ww_ctx *ctx);
+int ww_timer_stop(ww_ctx *ctx, float *elapsed_ms); /* synchronises on the stop event */
+
+/* ---- model --------------------------------------------------------------------------- */
+/* Replaces TFLiteModel.__init__ for the filter/encode/detect triple
+ * (spokestack/models/tensorflow.py:24-31).  `blob` is the packed weight image produced by
+ * wwhip.weights.pack_blob from the reference's .tflite files:
+ *   u32 magic 'WWHB' | u32 version 1 | u32 kind | u32 n_sections
+ *   n_sections x { char name[24]; u32 offset_bytes; u32 count }   then 16-byte aligned payload
+ * Weights are uploaded once and stay resident in HBM. */
+int ww_model_load(ww_ctx *ctx, const void *blob, size_t len, ww_model **out);
+int ww_model_free(ww_model *model);
+int ww_model_get_info(const ww_model *model, ww_model_info *out);
+
+/* ---- front end: PCM -> log-mel ---------------------------------------------------------
+ * Replaces the per-sample RingBuffer loop + np.fft.rfft + filter.tflite invoke of
+ * Filter.filter_frame / WakewordTrigger._sample/_analyze/_filter
+ * (utils/tf_lite/filter.py:38-75, spokestack/wakeword/tflite.py:148-191).
+ *
+ * Utterance u occupies samples [sample_offs[u], sample_offs[u+1]) of `pcm` and yields
+ * nf(u) = max(0, (len - 512) / hop + 1) frames; frame j covers samples [hop*j, hop*j+512).
+ * Row frame_offs[u] + j of `mel` receives its 40 log-mel values.  frame_offs (n_utt+1
+ * entries) is written by the host variants and read by the device variants. */
+int64_t ww_num_frames(int64_t n_samples, int32_t hop);
+
+int ww_logmel(ww_ctx *ctx, const ww_model *model, const int16_t *pcm, const int64_t *sample_offs, int32_t n_utt,
+              const ww_frontend_params *fp, float *mel, int64_t *frame_offs);
+/* Same, for float samples already scaled to [-1, 1] (the offline path hands librosa floats
+ * to Filter.filter_frame: utils/evaluate_models.py:46,64).  pcm_divisor / clip are ignored. */
+int ww_logmel_f32(ww_ctx *ctx, const ww_model *model, const float *samples, const int64_t *sample_offs,
+                  int32_t n_utt, const ww_frontend_params *fp, float *mel, int64_t *frame_offs);
+/* STFT magnitudes only: frames [n][512] fp32 -> mag [n][257] fp32
+ * (WakewordTrigger._analyze, spokestack/wakeword/tflite.py:174-176). */
+int ww_stft_mag(ww_ctx *ctx, const ww_model *model, const float *frames, int64_t n, int32_t precise, float *mag);
+
+int ww_logmel_dev(ww_ctx *ctx, const ww_model *model, const int16_t *d_pcm, const int64_t *d_sample_offs,
+                  const int64_t *d_frame_offs, int32_t n_utt, int64_t total_frames, int64_t max_frames_per_utt,
+                  const ww_frontend_params *fp, float *d_mel);
+
+/* ---- encode + detect -------------------------------------------------------------------
+ * Replaces encode_model(x) followed by detect_model(x) (two TFLiteModel.__call__,
+ * spokestack/wakeword/tflite.py:193-231; utils/evaluate_models.py:76-86;
+ * utils/evaluate_tf_lite_opts.py:49-69).  `windows` is [B][window][n_mel] fp32, rows in
+ * time order exactly as RingBuffer.read_all returns them (the CRNN transpose to
+ * [1,40,151,1] of tflite.py:199-203 is folded into the kernel's indexing).
+ * `out` receives [B][n_out]: the detect graph's output row. */
+int ww_forward(ww_ctx *ctx, const ww_model *model, const float *windows, int32_t n_windows, float *out);
+/* Optional: also return the encoder output ([B][enc_rows][enc_width]); enc may be NULL. */
+int ww_forward_enc(ww_ctx *ctx, const ww_model *model, const float *windows, int32_t n_windows, float *out,
+                   float *enc);
+
+/* Sliding evaluation of one mel sequence (utils/evaluate_models.py:66-88): window i covers
+ * rows [i*hop, i*hop + window); n_windows = (rows - window) / hop + 1 (0 if rows < window).
+ * The windows are never materialised: kernels index the sequence directly. */
+int ww_slide_forward(ww_ctx *ctx, const ww_model *model, const float *mel, int64_t rows, int32_t hop, float *out,
+                     int64_t *n_windows);
+
+/* Device form.  Window w reads mel rows [d_win_row[w], d_win_row[w] + d_win_valid[w]) and is
+ * zero padded at the end up to `window` rows (evaluate_tf_lite_opts.py:43-45). */
+int ww_forward_windows_dev(ww_ctx *ctx, const ww_model *model, const float *d_mel, int64_t mel_rows,
+                           const int64_t *d_win_row, const int32_t *d_win_valid, int32_t n_windows, float *d_out);
+
+/* Whole hot path for a batch of equal-length clips resident in HBM (BASELINE configs 2/3):
+ * PCM [n_clips][samples_per_clip] -> log-mel -> one zero-padded window per clip ->
+ * encode + detect -> d_out [n_clips][n_out].  d_mel_scratch may be NULL (ctx workspace). */
+int ww_clips_forward_dev(ww_ctx *ctx, const ww_model *model, const int16_t *d_pcm, int32_t n_clips,
+                         int32_t samples_per_clip, const ww_frontend_params *fp, float *d_out);
+
+/* ---- streaming (spokestack/pipeline.py + WakewordTrigger, BASELINE config 5) -------------
+ * S independent 16 kHz streams advanced in lock step, 20 ms per tick.  Device-resident
+ * state per stream: sample ring (512), mel window ring (window x 40), pre-emphasis carry,
+ * running posterior max (tflite.py:96-108).  Per tick and stream: 0..2 new mel frames; for
+ * each new frame while is_speech[s] != 0 one encode+detect (tflite.py:163-168,187-215).
+ * post[s][k] (k < n_post[s] <= 2) are the posteriors produced by this tick, in order. */
+int ww_stream_create(ww_ctx *ctx, const ww_model *model, int32_t n_streams, const ww_frontend_params *fp,
+                     ww_streams **out);
+int ww_stream_destroy(ww_streams *st);
+int ww_stream_step(ww_streams *st, const int16_t *frames, const uint8_t *is_speech, float *post, int32_t *n_post);
+/* WakewordTrigger.reset (tflite.py:241-246) for the listed streams (ids NULL -> all). */
+int ww_stream_reset(ww_streams *st, const int32_t *ids, int32_t n);
+
+/* ---- posterior smoothing + threshold sweep -----------------------------------------------
+ * Replaces plot_FRR_FAR's numeric core (utils/evaluate_models.py:185-218):
+ *   neg' = np.convolve(neg, ones(win)/win, 'same')   (fp64)
+ *   frr[k] = (num_wakewords - #(pos > thr[k])) / num_wakewords
+ *   fa_count[k] = #rising edges of (neg' > thr[k]);  fa_per_h[k] = fa_count[k] / hours
+ * smoothed (may be NULL) receives neg' ([N] fp64).  win <= 0 skips the smoothing. */
+int ww_far_frr(ww_ctx *ctx, const float *pos, int64_t n_pos, const float *neg, int64_t n_neg, int32_t win,
+               const double *thr, int32_t n_thr, double num_wakewords, double hours, double *frr,
+               double *fa_per_h, int64_t *fa_count, double *smoothed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WWHIP_H */

@@ -1,0 +1,313 @@
+"""Generates the committed fixtures under ``tests/golden/``.
+
+Run in the BUILD container only (``python tests/golden/make_golden.py``): it imports the
+parts of the reference that are importable there (pure NumPy: ``spokestack.ring_buffer``,
+``spokestack.pipeline``, ``spokestack.context``) and records their behaviour as data.
+Nothing under ``/root/reference`` is read by the tests themselves - the GPU box does not
+have it.
+
+What each fixture pins
+  ringbuffer_trace.json  scripted op sequence -> observable state of the reference RingBuffer
+  framing.npz            reference RingBuffer driven as utils/tf_lite/filter.py:50-55 drives it,
+                         payload = sample index -> start index of every emitted frame, incl.
+                         carry-over across files
+  pipeline_trace.json    reference SpeechPipeline/SpeechContext event + dispatch order
+  frontend.npz           seeded PCM -> log-mel; framing by the reference RingBuffer, STFT by the
+                         reference's literal NumPy expression, mel graph by oracle/tflite_interp
+  models.npz             seeded mel windows -> encoder output + detect output for every shipped
+                         model dir, from oracle/tflite_interp in fp32 and fp64 ("parity
+                         unpinned": there is no TFLite runtime to produce these)
+  evaluator.npz          seeded posterior streams -> np.convolve smoothing, FRR, FA/h
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "wakeword-detection_amd"))
+sys.path.insert(0, REF)
+
+from spokestack.ring_buffer import RingBuffer  # noqa: E402  (the reference's)
+from spokestack.pipeline import SpeechPipeline  # noqa: E402
+from spokestack.context import SpeechContext  # noqa: E402
+
+from oracle import numpy_ref as NR  # noqa: E402
+from oracle.tflite_interp import ModelDir  # noqa: E402
+
+ASSETS = os.path.join(ROOT, "wakeword-detection_amd", "assets", "tf_lite_models")
+
+
+def ringbuffer_trace():
+    rng = np.random.default_rng(7)
+    script = []
+    for shape in ([4], [3, 2], [1, 2, 3]):
+        rb = RingBuffer(shape=list(shape))
+        ops = []
+        val = 0.0
+
+        def state():
+            return {"empty": bool(rb.is_empty), "full": bool(rb.is_full), "capacity": int(rb.capacity)}
+
+        names = ["write", "read", "rewind", "seek", "reset", "fill", "read_all", "write", "write", "read"]
+        for _ in range(120):
+            name = names[int(rng.integers(len(names)))]
+            rec = {"op": name}
+            try:
+                if name == "write":
+                    val += 1.0
+                    rec["arg"] = val
+                    rb.write(np.full(shape[1:], val, np.float32) if len(shape) > 1 else np.float32(val))
+                elif name == "read":
+                    rec["ret"] = np.asarray(rb.read()).ravel().tolist()
+                elif name == "rewind":
+                    rb.rewind()
+                elif name == "seek":
+                    k = int(rng.integers(0, 3))
+                    rec["arg"] = k
+                    rb.seek(k)
+                elif name == "reset":
+                    rb.reset()
+                elif name == "fill":
+                    v = float(rng.integers(-3, 4))
+                    rec["arg"] = v
+                    rb.fill(v)
+                elif name == "read_all":
+                    if rb.is_empty or ((rb._write + 1) % rb._max_length) == rb._write:
+                        pass
+                    out = rb.read_all()
+                    rec["ret"] = np.asarray(out).ravel().tolist()
+                    rec["ret_shape"] = list(out.shape)
+            except IndexError as e:
+                rec["raises"] = str(e)
+            except ValueError as e:  # np.concatenate of an empty list
+                rec["raises_value_error"] = True
+            rec["state"] = state()
+            ops.append(rec)
+        script.append({"shape": list(shape), "ops": ops})
+    with open(os.path.join(HERE, "ringbuffer_trace.json"), "w") as f:
+        json.dump(script, f)
+
+
+def framing():
+    """Drive the reference ring exactly like filter.py:50-55; the payload is the global
+    sample index so the emitted frame's first element is its start index."""
+    out = {}
+    for name, files in {
+        "single_24000": [24000],
+        "single_short": [500],
+        "single_tiny": [100],
+        "two_files_3200": [3200, 3200],
+        "ragged": [16000, 5000, 777, 12345],
+    }.items():
+        rb = RingBuffer(shape=[512])
+        g = 0
+        starts_per_file = []
+        chunk_counts = []
+        for n in files:
+            n_pad = -(-n // 320) * 320  # files are processed in zero-padded 320-sample chunks
+            starts = []
+            counts = []
+            for c in range(0, n_pad, 320):
+                k = 0
+                for _ in range(320):
+                    rb.write(np.float32(g))
+                    g += 1
+                    if rb.is_full:
+                        fr = rb.read_all()
+                        assert fr.shape == (512,)
+                        assert np.all(np.diff(fr) == 1)
+                        starts.append(int(fr[0]))
+                        k += 1
+                        rb.rewind().seek(160)
+                counts.append(k)
+            starts_per_file.append(starts)
+            chunk_counts.append(counts)
+        out[name + ".files"] = np.array(files, np.int64)
+        out[name + ".starts"] = np.array(sum(starts_per_file, []), np.int64)
+        out[name + ".frames_per_file"] = np.array([len(s) for s in starts_per_file], np.int64)
+        out[name + ".frames_per_chunk"] = np.array(sum(chunk_counts, []), np.int64)
+    np.savez_compressed(os.path.join(HERE, "framing.npz"), **out)
+
+
+def pipeline_trace():
+    trace = []
+
+    class Src:
+        def __init__(self):
+            self.n = 0
+
+        def start(self):
+            trace.append("src.start")
+
+        def stop(self):
+            trace.append("src.stop")
+
+        def close(self):
+            trace.append("src.close")
+
+        def read(self):
+            self.n += 1
+            trace.append(f"src.read{self.n}")
+            return np.zeros(320, np.int16)
+
+    class Stage:
+        def __init__(self, name, pipe_ref):
+            self.name = name
+            self.pipe_ref = pipe_ref
+
+        def __call__(self, ctx, frame):
+            trace.append(f"{self.name}.call active={ctx.is_active} speech={ctx.is_speech}")
+            if self.name == "a" and self.pipe_ref["n"] == 1:
+                ctx.is_speech = True
+            if self.name == "b" and self.pipe_ref["n"] == 2:
+                ctx.is_active = True
+            if self.name == "b" and self.pipe_ref["n"] == 3:
+                ctx.is_active = False
+            if self.name == "b" and self.pipe_ref["n"] == 4:
+                self.pipe_ref["pipe"].stop()
+
+        def close(self):
+            trace.append(f"{self.name}.close")
+
+    ref = {"n": 0}
+    src = Src()
+    pipe = SpeechPipeline(src, [Stage("a", ref), Stage("b", ref)])
+    ref["pipe"] = pipe
+
+    @pipe.event
+    def on_activate(ctx):
+        trace.append("event.activate")
+
+    @pipe.event
+    def on_deactivate(ctx):
+        trace.append("event.deactivate")
+
+    @pipe.event(name="step")
+    def counter(ctx):
+        ref["n"] += 1
+        trace.append(f"event.step{ref['n']}")
+
+    pipe.start()
+    pipe.start()
+    pipe.run()
+    trace.append(f"running={pipe.is_running}")
+    ctx = SpeechContext()
+    ctx.is_active = True
+    ctx.is_active = True
+    ctx.transcript = "x"
+    ctx.confidence = 0.5
+    ctx.reset()
+    trace.append(f"ctx {ctx.is_active} {ctx.is_speech} {ctx.transcript!r} {ctx.confidence}")
+    with open(os.path.join(HERE, "pipeline_trace.json"), "w") as f:
+        json.dump(trace, f)
+
+
+def synth_pcm(rng, n, noise=2000.0, chirp=8000.0):
+    """SURVEY 8(d) cfg-1 generator: Gaussian noise + linear chirp 200->4000 Hz."""
+    t = np.arange(n) / 16000.0
+    dur = max(n / 16000.0, 1e-3)
+    phase = 2 * np.pi * (200.0 * t + 0.5 * (4000.0 - 200.0) / dur * t * t)
+    x = rng.normal(0.0, noise, n) + chirp * np.sin(phase)
+    return np.clip(np.rint(x), -32768, 32767).astype(np.int16)
+
+
+def frontend():
+    m = ModelDir(os.path.join(ASSETS, "CRNN"))
+    rng = np.random.default_rng(1234)
+    out = {}
+    clips = {
+        "noise_chirp": synth_pcm(rng, 24000),
+        "quiet": synth_pcm(rng, 8000, noise=3.0, chirp=0.0),
+        "silence": np.zeros(4000, np.int16),
+        "fullscale": np.where(np.arange(6000) % 2 == 0, 32767, -32768).astype(np.int16),
+        "ragged": synth_pcm(rng, 12345),
+    }
+    for name, pcm in clips.items():
+        for div, clip, pre in ((32767.0, True, 0.0), (32768.0, False, 0.97)):
+            x = pcm.astype(np.float32) / np.float32(div)
+            if clip:
+                x = np.clip(x, -1.0, 1.0)
+            # framing through the REFERENCE ring buffer, STFT by the reference's expression
+            rb = RingBuffer(shape=[512])
+            hann = np.hanning(512)
+            prev = 0.0
+            mags = []
+            for c in range(0, len(x) - len(x) % 320 if False else len(x), 320):
+                fr = x[c : c + 320].copy()
+                p = fr[-1]
+                fr -= pre * np.append(prev, fr[:-1])
+                prev = p
+                for s in fr:
+                    rb.write(s)
+                    if rb.is_full:
+                        w = rb.read_all()
+                        mags.append(np.abs(np.fft.rfft(w * hann, n=512)).astype(np.float32))
+                        rb.rewind().seek(160)
+            mags = np.array(mags, np.float32).reshape(-1, 257)
+            mel = np.array([m.filter(g[None])[0][0] for g in mags], np.float32).reshape(-1, 40)
+            key = f"{name}.div{int(div)}"
+            out[key + ".mag"] = mags
+            out[key + ".mel"] = mel
+        out[name + ".pcm"] = pcm
+    np.savez_compressed(os.path.join(HERE, "frontend.npz"), **out)
+
+
+def models():
+    rng = np.random.default_rng(99)
+    out = {}
+    for d in ("CRNN", "CRNN_softmax", "Wavenet", "Wavenet_alt"):
+        m32 = ModelDir(os.path.join(ASSETS, d), np.float32)
+        m64 = ModelDir(os.path.join(ASSETS, d), np.float64)
+        T = 151 if m32.is_crnn else 182
+        wins = rng.uniform(0.0, 6.0, (5, T, 40)).astype(np.float32)
+        wins[0] = 0.0
+        wins[1] = 3.0
+        wins[2, T // 2 :] = 0.0  # clip zero-padded at the end (evaluate_tf_lite_opts.py:43-45)
+        enc32, det32, det64 = [], [], []
+        for w in wins:
+            x = w.T[None, :, :, None] if m32.is_crnn else w[None]
+            e = m32.encode(x)[0]
+            enc32.append(e[0])
+            det32.append(m32.detect(e)[0][0])
+            det64.append(m64.detect(m64.encode(x)[0])[0][0])
+        out[d + ".windows"] = wins
+        out[d + ".enc32"] = np.array(enc32, np.float32)
+        out[d + ".det32"] = np.array(det32, np.float32)
+        out[d + ".det64"] = np.array(det64, np.float64)
+    np.savez_compressed(os.path.join(HERE, "models.npz"), **out)
+
+
+def evaluator():
+    rng = np.random.default_rng(5)
+    out = {}
+    for name, n in (("short", 64), ("long", 20000), ("exact30", 30)):
+        base = rng.beta(0.3, 3.0, n)
+        bumps = (rng.random(n) < 0.01).astype(float)
+        neg = np.clip(base + np.convolve(bumps, np.ones(25), "same") * rng.uniform(0.4, 1.0, n), 0, 1)
+        neg = neg.astype(np.float32)
+        pos = rng.beta(5.0, 1.0, 200).astype(np.float32)
+        frr, far, cnt, sm = NR.far_frr(pos, neg, 200, hours=n * 0.02 / 3600.0)
+        out[name + ".neg"] = neg
+        out[name + ".pos"] = pos
+        out[name + ".smoothed"] = sm
+        out[name + ".frr"] = frr
+        out[name + ".far"] = far
+        out[name + ".cnt"] = cnt
+        out[name + ".hours"] = np.array([n * 0.02 / 3600.0])
+    np.savez_compressed(os.path.join(HERE, "evaluator.npz"), **out)
+
+
+if __name__ == "__main__":
+    ringbuffer_trace()
+    framing()
+    pipeline_trace()
+    frontend()
+    models()
+    evaluator()
+    for f in sorted(os.listdir(HERE)):
+        print(f, os.path.getsize(os.path.join(HERE, f)))

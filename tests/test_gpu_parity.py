@@ -1,0 +1,187 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the
+committed golden fixtures.  Tolerances follow BASELINE.json: posteriors within 1e-4 (fp32);
+integer results (frame counts, FA counts) exact."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MODELS = ["CRNN", "CRNN_softmax", "Wavenet", "Wavenet_alt"]
+TOL_POST = 1e-4   # north_star: per-frame posteriors within 1e-4 fp32
+TOL_MEL = 1e-4    # log-mel (SURVEY 7 minimum slice)
+
+
+@pytest.fixture(scope="module")
+def engines(assets):
+    from wwhip.engine import Engine
+    out = {m: Engine(os.path.join(assets, m)) for m in MODELS}
+    yield out
+    for e in out.values():
+        e.close()
+
+
+@pytest.fixture(scope="module")
+def oracles(engines):
+    from oracle.cpu import CpuOracle
+    return {m: CpuOracle(e.blob) for m, e in engines.items()}
+
+
+def test_native_library_is_the_path(engines):
+    from wwhip import _lib
+    assert os.path.isfile(_lib.LIB_PATH)
+    with open("/proc/self/maps") as f:
+        assert "libwwhip.so" in f.read()
+
+
+# ---------------------------------------------------------------- front end
+def test_stft_magnitude_vs_numpy(engines):
+    rng = np.random.default_rng(3)
+    frames = rng.normal(0, 0.2, (37, 512)).astype(np.float32)
+    frames[0] = 0.0
+    frames[1] = 0.5 * np.sin(2 * np.pi * 1000 * np.arange(512) / 16000)
+    want = np.abs(np.fft.rfft(frames.astype(np.float64) * np.hanning(512), n=512)).astype(np.float32)
+    got = engines["CRNN"].stft_mag(frames, precise=True)
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-9)
+    fast = engines["CRNN"].stft_mag(frames, precise=False)
+    assert np.abs(fast - want).max() < 2e-4 * max(1.0, float(want.max()))
+
+
+@pytest.mark.parametrize("div,clip,pre", [(32767.0, True, 0.0), (32768.0, False, 0.97)])
+def test_logmel_golden(engines, golden, div, clip, pre):
+    from wwhip.engine import frontend_params
+    z = np.load(os.path.join(golden, "frontend.npz"))
+    names = ["noise_chirp", "quiet", "silence", "fullscale", "ragged"]
+    pcm = [z[n + ".pcm"] for n in names]
+    mels = engines["CRNN"].logmel(pcm, frontend_params(div, clip, pre, 160, True))
+    for n, got in zip(names, mels):
+        want = z[f"{n}.div{int(div)}.mel"]
+        assert got.shape == want.shape, n
+        assert np.abs(got - want).max() < TOL_MEL, (n, np.abs(got - want).max())
+
+
+def test_logmel_vs_oracle_ragged_batch(engines, oracles):
+    rng = np.random.default_rng(11)
+    lens = [24000, 511, 512, 513, 100, 0, 671, 672, 40000, 8000]
+    pcm = [np.clip(rng.normal(0, 3000, n), -32768, 32767).astype(np.int16) for n in lens]
+    mels = engines["Wavenet"].logmel(pcm)
+    for n, p, got in zip(lens, pcm, mels):
+        want = oracles["Wavenet"].logmel(p)
+        assert got.shape == want.shape == (max(0, (n - 512) // 160 + 1) if n >= 512 else 0, 40)
+        if len(want):
+            assert np.abs(got - want).max() < TOL_MEL
+
+
+def test_logmel_float_input_matches_int16(engines):
+    from wwhip.engine import frontend_params
+    rng = np.random.default_rng(12)
+    pcm = np.clip(rng.normal(0, 3000, 9000), -32768, 32767).astype(np.int16)
+    a = engines["CRNN"].logmel([pcm], frontend_params(32768.0, False, 0.5))[0]
+    b = engines["CRNN"].logmel([pcm.astype(np.float32) / np.float32(32768.0)], frontend_params(32768.0, False, 0.5))[0]
+    np.testing.assert_array_equal(a, b)
+
+
+# ---------------------------------------------------------------- models
+@pytest.mark.parametrize("name", MODELS)
+def test_forward_golden(engines, golden, name):
+    z = np.load(os.path.join(golden, "models.npz"))
+    out, enc = engines[name].forward(z[name + ".windows"], want_enc=True)
+    assert np.abs(out - z[name + ".det64"]).max() < TOL_POST
+    assert np.abs(out - z[name + ".det32"]).max() < TOL_POST
+    want_enc = z[name + ".enc32"]
+    assert np.abs(enc.reshape(want_enc.shape) - want_enc).max() < 1e-4
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_forward_vs_oracle_batch(engines, oracles, name):
+    rng = np.random.default_rng(21)
+    e = engines[name]
+    wins = rng.uniform(0, 6.5, (70, e.window, 40)).astype(np.float32)
+    wins[3] = 0
+    wins[4, 100:] = 0
+    got = e.forward(wins)
+    want = oracles[name].forward(wins)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < TOL_POST
+
+
+@pytest.mark.parametrize("name", ["CRNN", "Wavenet"])
+def test_slide_forward_vs_oracle(engines, oracles, name):
+    rng = np.random.default_rng(22)
+    e = engines[name]
+    mel = rng.uniform(0, 6.5, (e.window + 61, 40)).astype(np.float32)
+    got = e.slide_forward(mel, hop=2)
+    want = oracles[name].slide_forward(mel, 2)
+    assert got.shape == want.shape == (31, e.n_out)
+    assert np.abs(got - want).max() < TOL_POST
+    assert e.slide_forward(mel[: e.window - 1], hop=2).shape == (0, e.n_out)
+
+
+def test_forward_rejects_bad_shape(engines):
+    with pytest.raises(ValueError):
+        engines["CRNN"].forward(np.zeros((2, 150, 40), np.float32))
+
+
+# ---------------------------------------------------------------- evaluator
+@pytest.mark.parametrize("case", ["short", "long", "exact30"])
+def test_far_frr_golden(engines, golden, case):
+    z = np.load(os.path.join(golden, "evaluator.npz"))
+    thr = np.arange(0.5, 0.99999, 0.005)
+    frr, fa, cnt, sm = engines["CRNN"].far_frr(z[case + ".pos"], z[case + ".neg"], thr, 200, float(z[case + ".hours"][0]),
+                                               want_smoothed=True)
+    np.testing.assert_allclose(sm, z[case + ".smoothed"], rtol=0, atol=1e-15)
+    np.testing.assert_array_equal(cnt, z[case + ".cnt"])
+    np.testing.assert_allclose(fa, z[case + ".far"], rtol=1e-15)
+    np.testing.assert_allclose(frr, z[case + ".frr"], rtol=0, atol=1e-15)
+
+
+# ---------------------------------------------------------------- whole path, device resident
+@pytest.mark.parametrize("name", ["CRNN", "Wavenet"])
+def test_clips_forward_dev(engines, oracles, name):
+    import torch
+    from wwhip.engine import frontend_params
+    rng = np.random.default_rng(31)
+    e = engines[name]
+    B, S = 33, 24000
+    pcm = np.clip(rng.normal(0, 2500, (B, S)), -32768, 32767).astype(np.int16)
+    d_pcm = torch.from_numpy(pcm).cuda()
+    d_out = torch.zeros((B, e.n_out), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(3):  # first call captures the graph, later calls replay it
+        e.clips_forward_dev(d_pcm.data_ptr(), B, S, d_out.data_ptr(), frontend_params())
+    e.ctx.synchronize()
+    got = d_out.cpu().numpy()
+    want = []
+    for c in pcm:
+        mel = oracles[name].logmel(c)
+        win = np.zeros((e.window, 40), np.float32)
+        win[: min(len(mel), e.window)] = mel[: e.window]
+        want.append(oracles[name].forward(win)[0])
+    assert np.abs(got - np.array(want)).max() < TOL_POST
+
+
+# ---------------------------------------------------------------- streaming
+@pytest.mark.parametrize("name", ["CRNN", "Wavenet"])
+def test_stream_bank_matches_batch_path(engines, oracles, name):
+    from wwhip.engine import StreamBank
+    rng = np.random.default_rng(41)
+    e = engines[name]
+    S, ticks = 5, 90
+    pcm = np.clip(rng.normal(0, 2500, (S, ticks * 320)), -32768, 32767).astype(np.int16)
+    bank = StreamBank(e, S)
+    posts = [[] for _ in range(S)]
+    speech = np.ones(S, np.uint8)
+    for t in range(ticks):
+        p, n = bank.step(pcm[:, t * 320:(t + 1) * 320], speech)
+        for s in range(S):
+            posts[s] += [float(p[s, k]) for k in range(n[s])]
+    bank.close()
+    pidx = e.posterior_index
+    for s in range(S):
+        mel = oracles[name].logmel(pcm[s])
+        # streaming semantics (tflite.py:96-97,187-188): window starts as zeros, slides by 1
+        hist = np.concatenate([np.zeros((e.window, 40), np.float32), mel])
+        want = oracles[name].slide_forward(hist, 1)[1:, pidx]
+        assert len(posts[s]) == len(mel) == len(want)
+        assert np.abs(np.array(posts[s]) - want).max() < TOL_POST

@@ -1,0 +1,734 @@
+// C ABI of libwwhip.so: context, model upload, host/device entry points (see include/wwhip.h).
+#include "common.h"
+
+#include <cmath>
+#include <mutex>
+
+static char g_err[512] = {0};
+
+int ww_fail(ww_ctx *ctx, int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  char *dst = ctx ? ctx->err : g_err;
+  vsnprintf(dst, 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int ww_ensure(ww_ctx *ctx, ww_arena &a, size_t bytes, bool pinned) {
+  if (bytes <= a.cap) return WW_OK;
+  // growing invalidates pointers baked into a cached graph
+  if (!pinned && ctx->clip_graph.exec) {
+    hipStreamSynchronize(ctx->stream);
+    hipGraphExecDestroy(ctx->clip_graph.exec);
+    ctx->clip_graph.exec = nullptr;
+  }
+  if (a.ptr) {
+    hipStreamSynchronize(ctx->stream);
+    if (pinned) hipHostFree(a.ptr); else hipFree(a.ptr);
+    a.ptr = nullptr;
+    a.cap = 0;
+  }
+  size_t want = bytes + bytes / 4 + (1 << 20);
+  hipError_t e = pinned ? hipHostMalloc(&a.ptr, want, hipHostMallocDefault) : hipMalloc(&a.ptr, want);
+  if (e != hipSuccess) {
+    a.ptr = nullptr;
+    return ww_fail(ctx, WW_ENOMEM, "cannot allocate %zu bytes of %s memory: %s", want, pinned ? "pinned host" : "device",
+                   hipGetErrorString(e));
+  }
+  a.cap = want;
+  return WW_OK;
+}
+
+extern "C" {
+
+const char *ww_version(void) { return "wwhip 0.1 (gfx950)"; }
+
+const char *ww_last_error(const ww_ctx *ctx) { return ctx ? ctx->err : g_err; }
+
+int ww_ctx_create(int device, void *external_stream, ww_ctx **out) {
+  if (!out) return ww_fail(nullptr, WW_EINVAL, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return ww_fail(nullptr, WW_ENODEVICE, "no HIP device visible");
+  if (device < 0 || device >= n) return ww_fail(nullptr, WW_EINVAL, "device %d out of range (0..%d)", device, n - 1);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return ww_fail(nullptr, WW_EHIP, "hipGetDeviceProperties failed");
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return ww_fail(nullptr, WW_ENODEVICE, "device %d is %s; libwwhip.so carries gfx950 code only", device, prop.gcnArchName);
+  if (hipSetDevice(device) != hipSuccess) return ww_fail(nullptr, WW_EHIP, "hipSetDevice(%d) failed", device);
+  ww_ctx *c = new ww_ctx();
+  c->device = device;
+  if (external_stream) {
+    c->stream = (hipStream_t)external_stream;
+  } else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete c;
+      return ww_fail(nullptr, WW_EHIP, "hipStreamCreate failed");
+    }
+    c->own_stream = true;
+  }
+  hipEventCreate(&c->t0);
+  hipEventCreate(&c->t1);
+  *out = c;
+  return WW_OK;
+}
+
+int ww_ctx_destroy(ww_ctx *ctx) {
+  if (!ctx) return WW_OK;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  if (ctx->clip_graph.exec) hipGraphExecDestroy(ctx->clip_graph.exec);
+  for (auto &kv : ctx->prof)
+    for (auto &p : kv.second.pending) {
+      hipEventDestroy(p.first);
+      hipEventDestroy(p.second);
+    }
+  if (ctx->dev.ptr) hipFree(ctx->dev.ptr);
+  if (ctx->pinned.ptr) hipHostFree(ctx->pinned.ptr);
+  hipEventDestroy(ctx->t0);
+  hipEventDestroy(ctx->t1);
+  if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return WW_OK;
+}
+
+int ww_ctx_synchronize(ww_ctx *ctx) {
+  if (!ctx) return WW_EINVAL;
+  WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return WW_OK;
+}
+
+void *ww_ctx_stream(ww_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int ww_profile_enable(ww_ctx *ctx, int on) {
+  if (!ctx) return WW_EINVAL;
+  ctx->profiling = on != 0;
+  return WW_OK;
+}
+
+int ww_profile_read(ww_ctx *ctx, char *json, size_t cap) {
+  if (!ctx || !json || cap < 8) return WW_EINVAL;
+  WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::string s = "{";
+  bool first = true;
+  for (auto &kv : ctx->prof) {
+    for (auto &p : kv.second.pending) {
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, p.first, p.second);
+      kv.second.total_ms += ms;
+      hipEventDestroy(p.first);
+      hipEventDestroy(p.second);
+    }
+    kv.second.pending.clear();
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s\"%s\": {\"calls\": %d, \"total_ms\": %.6f}", first ? "" : ", ", kv.first.c_str(),
+             kv.second.calls, kv.second.total_ms);
+    s += buf;
+    first = false;
+  }
+  s += "}";
+  ctx->prof.clear();
+  if (s.size() + 1 > cap) return ww_fail(ctx, WW_EINVAL, "profile buffer too small (%zu needed)", s.size() + 1);
+  memcpy(json, s.c_str(), s.size() + 1);
+  return WW_OK;
+}
+
+int ww_timer_start(ww_ctx *ctx) {
+  if (!ctx) return WW_EINVAL;
+  WW_HIP(ctx, hipEventRecord(ctx->t0, ctx->stream));
+  return WW_OK;
+}
+
+int ww_timer_stop(ww_ctx *ctx, float *ms) {
+  if (!ctx || !ms) return WW_EINVAL;
+  WW_HIP(ctx, hipEventRecord(ctx->t1, ctx->stream));
+  WW_HIP(ctx, hipEventSynchronize(ctx->t1));
+  WW_HIP(ctx, hipEventElapsedTime(ms, ctx->t0, ctx->t1));
+  return WW_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// blob parsing + upload
+// ------------------------------------------------------------------------------------------
+struct blob_view {
+  const uint8_t *base;
+  size_t len;
+  uint32_t n, kind;
+  const void *find(const char *name, uint32_t *count) const {
+    for (uint32_t i = 0; i < n; ++i) {
+      const uint8_t *e = base + 16 + 32 * (size_t)i;
+      if (strncmp((const char *)e, name, 24) == 0) {
+        uint32_t off, cnt;
+        memcpy(&off, e + 24, 4);
+        memcpy(&cnt, e + 28, 4);
+        if ((size_t)off + (size_t)cnt * 4 > len) return nullptr;
+        if (count) *count = cnt;
+        return base + off;
+      }
+    }
+    return nullptr;
+  }
+};
+
+template <typename T>
+static T *upload(ww_model *m, const std::vector<T> &v) {
+  void *d = nullptr;
+  size_t bytes = (v.size() ? v.size() : 1) * sizeof(T);
+  if (hipMalloc(&d, bytes) != hipSuccess) return nullptr;
+  m->allocs.push_back(d);
+  if (v.size() && hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  return (T *)d;
+}
+
+#define NEED_F(var, name, cnt_expect)                                                                       \
+  uint32_t var##_n = 0;                                                                                     \
+  const float *var = (const float *)bv.find(name, &var##_n);                                                \
+  if (!var || (size_t)var##_n != (size_t)(cnt_expect))                                                      \
+    return ww_fail(ctx, WW_EBLOB, "blob section %s missing or has %u elements (expected %zu)", name, var##_n, \
+                   (size_t)(cnt_expect));
+
+static int load_filter(ww_ctx *ctx, ww_model *m, const blob_view &bv) {
+  uint32_t cnt = 0;
+  const int32_t *meta = (const int32_t *)bv.find("filter.meta", &cnt);
+  if (!meta || cnt != 2) return ww_fail(ctx, WW_EBLOB, "blob lacks filter.meta");
+  const int n_mel = meta[0], n_bins = meta[1];
+  if (n_mel < 1 || n_mel > 40 || n_bins != WW_FFT_BINS)
+    return ww_fail(ctx, WW_EBLOB, "unsupported filter geometry %d x %d (need <= 40 x 257)", n_mel, n_bins);
+  NEED_F(cst, "filter.consts", 3);
+  NEED_F(w, "filter.w", (size_t)n_mel * n_bins);
+  NEED_F(b, "filter.b", n_mel);
+  ww_filter_dev &f = m->filt;
+  f.n_mel = n_mel; f.n_bins = n_bins; f.floor_v = cst[0]; f.log_off = cst[1]; f.scale = cst[2];
+  std::vector<int> start(n_mel), len(n_mel), woff(n_mel);
+  std::vector<float> taps;
+  for (int i = 0; i < n_mel; ++i) {
+    int lo = -1, hi = -1;
+    for (int k = 0; k < n_bins; ++k)
+      if (w[(size_t)i * n_bins + k] != 0.0f) {
+        if (lo < 0) lo = k;
+        hi = k;
+      }
+    start[i] = lo < 0 ? 0 : lo;
+    len[i] = lo < 0 ? 0 : hi - lo + 1;
+    woff[i] = (int)taps.size();
+    for (int k = 0; k < len[i]; ++k) taps.push_back(w[(size_t)i * n_bins + start[i] + k]);
+    if (len[i] > f.max_len) f.max_len = len[i];
+  }
+  f.total_taps = (int)taps.size();
+  std::vector<float> bias(b, b + n_mel);
+  std::vector<double> hann(WW_FFT_WINDOW), tw256(512), tw512(512);
+  for (int n = 0; n < WW_FFT_WINDOW; ++n) hann[n] = 0.5 - 0.5 * cos(2.0 * M_PI * (double)n / (double)(WW_FFT_WINDOW - 1));
+  for (int k = 0; k < 256; ++k) {
+    tw256[2 * k] = cos(-2.0 * M_PI * k / 256.0);
+    tw256[2 * k + 1] = sin(-2.0 * M_PI * k / 256.0);
+    tw512[2 * k] = cos(-2.0 * M_PI * k / 512.0);
+    tw512[2 * k + 1] = sin(-2.0 * M_PI * k / 512.0);
+  }
+  f.start = upload(m, start); f.len = upload(m, len); f.woff = upload(m, woff);
+  f.w = upload(m, taps); f.bias = upload(m, bias);
+  f.hann = upload(m, hann); f.tw256 = upload(m, tw256); f.tw512 = upload(m, tw512);
+  if (!f.start || !f.len || !f.woff || !f.w || !f.bias || !f.hann || !f.tw256 || !f.tw512)
+    return ww_fail(ctx, WW_ENOMEM, "filter upload failed");
+  return WW_OK;
+}
+
+static int load_crnn(ww_ctx *ctx, ww_model *m, const blob_view &bv) {
+  uint32_t cnt = 0;
+  const int32_t *meta = (const int32_t *)bv.find("crnn.meta", &cnt);
+  if (!meta || cnt != 14) return ww_fail(ctx, WW_EBLOB, "blob lacks crnn.meta");
+  ww_crnn_dev &c = m->crnn;
+  c.n_mel = meta[0]; c.T = meta[1]; c.C = meta[2]; c.KF = meta[3]; c.KT = meta[4]; c.SF = meta[5]; c.ST = meta[6];
+  c.PF = meta[7]; c.PT = meta[8]; c.OF = meta[9]; c.OT = meta[10]; c.H = meta[11]; c.NOUT = meta[12]; c.HEAD = meta[13];
+  const int K = c.KF * c.KT, KP = 112;
+  if (c.C != 32 || c.H != 32 || c.KT % 4 != 0 || K > KP || c.ST % 4 != 0 || c.NOUT < 1 || c.NOUT > 8 ||
+      (c.OF * c.C) % 32 != 0 || c.n_mel != m->filt.n_mel)
+    return ww_fail(ctx, WW_EBLOB, "unsupported CRNN geometry (C=%d H=%d K=%dx%d stride %dx%d)", c.C, c.H, c.KF, c.KT, c.SF, c.ST);
+  const int max_kf = (KP - 1) / c.KT;  // padded k rows touch kf up to this
+  if ((c.OF - 1) * c.SF + max_kf >= 44 || c.n_mel + c.PF > 44 || (c.OT - 1) * c.ST + c.KT > 164 || c.T + c.PT > 164)
+    return ww_fail(ctx, WW_EBLOB, "CRNN window %dx%d does not fit the conv LDS image", c.n_mel, c.T);
+  NEED_F(cw, "crnn.conv_w", (size_t)c.C * K);
+  NEED_F(cb, "crnn.conv_b", c.C);
+  std::vector<float> w4((size_t)KP / 4 * 32 * 4, 0.f);
+  for (int ch = 0; ch < c.C; ++ch)
+    for (int k = 0; k < K; ++k) w4[((size_t)(k / 4) * 32 + ch) * 4 + (k % 4)] = cw[(size_t)ch * K + k];
+  c.conv_w = upload(m, w4);
+  c.conv_b = upload(m, std::vector<float>(cb, cb + c.C));
+  const int G = 3 * c.H;
+  auto cat2 = [&](const char *a, const char *b, size_t each, std::vector<float> &out) -> int {
+    uint32_t na = 0, nb = 0;
+    const float *pa = (const float *)bv.find(a, &na), *pb = (const float *)bv.find(b, &nb);
+    if (!pa || !pb || na != each || nb != each) return ww_fail(ctx, WW_EBLOB, "blob sections %s/%s missing or mis-sized", a, b);
+    out.assign(pa, pa + each);
+    out.insert(out.end(), pb, pb + each);
+    return WW_OK;
+  };
+  std::vector<float> v;
+  int rc;
+  const size_t in1 = (size_t)c.OF * c.C, in2 = 2 * (size_t)c.H;
+  if ((rc = cat2("crnn.g1f.wx", "crnn.g1b.wx", G * in1, v))) return rc; c.wx1 = upload(m, v);
+  if ((rc = cat2("crnn.g1f.bx", "crnn.g1b.bx", G, v))) return rc; c.bx1 = upload(m, v);
+  if ((rc = cat2("crnn.g1f.wh", "crnn.g1b.wh", (size_t)G * c.H, v))) return rc; c.wh1 = upload(m, v);
+  if ((rc = cat2("crnn.g1f.bh", "crnn.g1b.bh", G, v))) return rc; c.bh1 = upload(m, v);
+  if ((rc = cat2("crnn.g2f.wx", "crnn.g2b.wx", G * in2, v))) return rc; c.wx2 = upload(m, v);
+  if ((rc = cat2("crnn.g2f.bx", "crnn.g2b.bx", G, v))) return rc; c.bx2 = upload(m, v);
+  if ((rc = cat2("crnn.g2f.wh", "crnn.g2b.wh", (size_t)G * c.H, v))) return rc; c.wh2 = upload(m, v);
+  if ((rc = cat2("crnn.g2f.bh", "crnn.g2b.bh", G, v))) return rc; c.bh2 = upload(m, v);
+  NEED_F(w1, "crnn.head_w1", in2 * in2);
+  NEED_F(b1, "crnn.head_b1", in2);
+  NEED_F(w2, "crnn.head_w2", (size_t)c.NOUT * in2);
+  NEED_F(b2, "crnn.head_b2", c.NOUT);
+  c.w1 = upload(m, std::vector<float>(w1, w1 + in2 * in2));
+  c.b1 = upload(m, std::vector<float>(b1, b1 + in2));
+  c.w2 = upload(m, std::vector<float>(w2, w2 + c.NOUT * in2));
+  c.b2 = upload(m, std::vector<float>(b2, b2 + c.NOUT));
+  if (!c.conv_w || !c.conv_b || !c.wx1 || !c.bx1 || !c.wh1 || !c.bh1 || !c.wx2 || !c.bx2 || !c.wh2 || !c.bh2 || !c.w1 ||
+      !c.b1 || !c.w2 || !c.b2)
+    return ww_fail(ctx, WW_ENOMEM, "CRNN upload failed");
+  m->info.window = c.T; m->info.n_out = c.NOUT; m->info.enc_rows = 1; m->info.enc_width = 2 * c.H;
+  return WW_OK;
+}
+
+static int load_wave(ww_ctx *ctx, ww_model *m, const blob_view &bv) {
+  uint32_t cnt = 0;
+  const int32_t *meta = (const int32_t *)bv.find("wave.meta", &cnt);
+  if (!meta || cnt != 6) return ww_fail(ctx, WW_EBLOB, "blob lacks wave.meta");
+  ww_wave_dev &v = m->wave;
+  v.T = meta[0]; v.n_mel = meta[1]; v.C = meta[2]; v.S = meta[3]; v.NB = meta[4]; v.NOUT = meta[5];
+  if (v.C != 16 || v.S != 32 || v.T > 192 || v.T < 1 || v.n_mel > 48 || v.NOUT < 1 || v.NOUT > 16 || v.NB < 1 ||
+      v.n_mel != m->filt.n_mel)
+    return ww_fail(ctx, WW_EBLOB, "unsupported Wavenet geometry (T=%d C=%d S=%d)", v.T, v.C, v.S);
+  const int NB = v.NB, C = v.C, S = v.S;
+  const int32_t *dil = (const int32_t *)bv.find("wave.dilations", &cnt);
+  if (!dil || (int)cnt != NB) return ww_fail(ctx, WW_EBLOB, "blob lacks wave.dilations");
+  const int32_t *order = (const int32_t *)bv.find("wave.skip_order", &cnt);
+  if (!order || (int)cnt != NB) return ww_fail(ctx, WW_EBLOB, "blob lacks wave.skip_order");
+  const int32_t *has_res = (const int32_t *)bv.find("wave.has_res", &cnt);
+  if (!has_res || (int)cnt != NB) return ww_fail(ctx, WW_EBLOB, "blob lacks wave.has_res");
+  for (int b = 0; b < NB; ++b) {
+    if (dil[b] < 1 || 2 * dil[b] > 16) return ww_fail(ctx, WW_EBLOB, "dilation %d unsupported (max 8)", dil[b]);
+    if (order[b] != b) return ww_fail(ctx, WW_EBLOB, "skip connections are not summed in block order");
+  }
+  v.dil.assign(dil, dil + NB); v.order.assign(order, order + NB); v.has_res.assign(has_res, has_res + NB);
+  NEED_F(w_in, "wave.w_in", (size_t)v.n_mel * C);
+  NEED_F(b_in, "wave.b_in", C);
+  NEED_F(bn_s, "wave.bn_scale", (size_t)NB * C);
+  NEED_F(bn_t, "wave.bn_shift", (size_t)NB * C);
+  NEED_F(w_sig, "wave.w_sig", (size_t)NB * 3 * C * C);
+  NEED_F(b_sig, "wave.b_sig", (size_t)NB * C);
+  NEED_F(w_tanh, "wave.w_tanh", (size_t)NB * 3 * C * C);
+  NEED_F(b_tanh, "wave.b_tanh", (size_t)NB * C);
+  NEED_F(w_res, "wave.w_res", (size_t)NB * C * C);
+  NEED_F(b_res, "wave.b_res", (size_t)NB * C);
+  NEED_F(w_skip, "wave.w_skip", (size_t)NB * C * S);
+  NEED_F(b_skip, "wave.b_skip", (size_t)NB * S);
+  NEED_F(dw1, "wave.det_w1", (size_t)S * S);
+  NEED_F(db1, "wave.det_b1", S);
+  NEED_F(dw2, "wave.det_w2", (size_t)S * v.NOUT);
+  NEED_F(db2, "wave.det_b2", v.NOUT);
+  // MFMA B-operand order: [k-block][kk][col][q], k = kb*16 + kk*4 + q
+  std::vector<float> in4(3 * 4 * 16 * 4, 0.f);
+  for (int k = 0; k < v.n_mel; ++k)
+    for (int col = 0; col < C; ++col) in4[(((k / 16) * 4 + (k % 16) / 4) * 16 + col) * 4 + (k % 4)] = w_in[(size_t)k * C + col];
+  std::vector<float> g4((size_t)NB * 3 * 4 * 32 * 4), bg((size_t)NB * 32), rs4((size_t)NB * 4 * 48 * 4), brs((size_t)NB * 48);
+  for (int b = 0; b < NB; ++b) {
+    for (int tap = 0; tap < 3; ++tap)
+      for (int ch = 0; ch < C; ++ch)
+        for (int col = 0; col < 32; ++col) {
+          float val = col < 16 ? w_sig[(((size_t)b * 3 + tap) * C + ch) * C + col]
+                               : w_tanh[(((size_t)b * 3 + tap) * C + ch) * C + col - 16];
+          g4[((((size_t)b * 3 + tap) * 4 + ch / 4) * 32 + col) * 4 + (ch % 4)] = val;
+        }
+    for (int col = 0; col < 16; ++col) {
+      bg[(size_t)b * 32 + col] = b_sig[(size_t)b * C + col];
+      bg[(size_t)b * 32 + 16 + col] = b_tanh[(size_t)b * C + col];
+    }
+    for (int ch = 0; ch < C; ++ch)
+      for (int col = 0; col < 48; ++col) {
+        float val = col < 16 ? w_res[((size_t)b * C + ch) * C + col] : w_skip[((size_t)b * C + ch) * S + col - 16];
+        rs4[(((size_t)b * 4 + ch / 4) * 48 + col) * 4 + (ch % 4)] = val;
+      }
+    for (int col = 0; col < 48; ++col) brs[(size_t)b * 48 + col] = col < 16 ? b_res[(size_t)b * C + col] : b_skip[(size_t)b * S + col - 16];
+  }
+  std::vector<float> d1((size_t)2 * 4 * 32 * 4), d2((size_t)2 * 4 * 16 * 4, 0.f), d2b(16, 0.f);
+  for (int k = 0; k < S; ++k) {
+    for (int col = 0; col < S; ++col) d1[(((size_t)(k / 16) * 4 + (k % 16) / 4) * 32 + col) * 4 + (k % 4)] = dw1[(size_t)k * S + col];
+    for (int col = 0; col < v.NOUT; ++col) d2[(((size_t)(k / 16) * 4 + (k % 16) / 4) * 16 + col) * 4 + (k % 4)] = dw2[(size_t)k * v.NOUT + col];
+  }
+  for (int col = 0; col < v.NOUT; ++col) d2b[col] = db2[col];
+  v.d_dil = upload(m, v.dil); v.d_has_res = upload(m, v.has_res);
+  v.w_in = upload(m, in4); v.b_in = upload(m, std::vector<float>(b_in, b_in + C));
+  v.bn_s = upload(m, std::vector<float>(bn_s, bn_s + (size_t)NB * C));
+  v.bn_t = upload(m, std::vector<float>(bn_t, bn_t + (size_t)NB * C));
+  v.w_gate = upload(m, g4); v.b_gate = upload(m, bg); v.w_rs = upload(m, rs4); v.b_rs = upload(m, brs);
+  v.d_w1 = upload(m, d1); v.d_b1 = upload(m, std::vector<float>(db1, db1 + S));
+  v.d_w2 = upload(m, d2); v.d_b2 = upload(m, d2b);
+  if (!v.d_dil || !v.d_has_res || !v.w_in || !v.b_in || !v.bn_s || !v.bn_t || !v.w_gate || !v.b_gate || !v.w_rs ||
+      !v.b_rs || !v.d_w1 || !v.d_b1 || !v.d_w2 || !v.d_b2)
+    return ww_fail(ctx, WW_ENOMEM, "Wavenet upload failed");
+  m->info.window = v.T; m->info.n_out = v.NOUT; m->info.enc_rows = v.T; m->info.enc_width = S;
+  return WW_OK;
+}
+
+extern "C" {
+
+int ww_model_load(ww_ctx *ctx, const void *blob, size_t len, ww_model **out) {
+  if (!ctx || !blob || !out) return ww_fail(ctx, WW_EINVAL, "NULL argument");
+  *out = nullptr;
+  if (len < 16) return ww_fail(ctx, WW_EBLOB, "blob too short");
+  const uint32_t *h = (const uint32_t *)blob;
+  if (h[0] != 0x42485757u || h[1] != 1u) return ww_fail(ctx, WW_EBLOB, "bad blob magic/version");
+  blob_view bv = {(const uint8_t *)blob, len, h[3], h[2]};
+  if (16 + 32 * (size_t)bv.n > len) return ww_fail(ctx, WW_EBLOB, "section table exceeds blob");
+  if (bv.kind != WW_KIND_CRNN && bv.kind != WW_KIND_WAVENET) return ww_fail(ctx, WW_EBLOB, "unknown model kind %u", bv.kind);
+  WW_HIP(ctx, hipSetDevice(ctx->device));
+  ww_model *m = new ww_model();
+  m->ctx = ctx;
+  m->kind = (int)bv.kind;
+  int rc = load_filter(ctx, m, bv);
+  if (rc == WW_OK) rc = bv.kind == WW_KIND_CRNN ? load_crnn(ctx, m, bv) : load_wave(ctx, m, bv);
+  if (rc != WW_OK) {
+    ww_model_free(m);
+    return rc;
+  }
+  m->info.kind = m->kind;
+  m->info.n_mel = m->filt.n_mel;
+  m->info.n_bins = m->filt.n_bins;
+  *out = m;
+  return WW_OK;
+}
+
+int ww_model_free(ww_model *m) {
+  if (!m) return WW_OK;
+  if (m->ctx) {
+    hipSetDevice(m->ctx->device);
+    hipStreamSynchronize(m->ctx->stream);
+    if (m->ctx->clip_graph.model == m && m->ctx->clip_graph.exec) {
+      hipGraphExecDestroy(m->ctx->clip_graph.exec);
+      m->ctx->clip_graph.exec = nullptr;
+    }
+  }
+  for (void *p : m->allocs) hipFree(p);
+  delete m;
+  return WW_OK;
+}
+
+int ww_model_get_info(const ww_model *m, ww_model_info *out) {
+  if (!m || !out) return WW_EINVAL;
+  *out = m->info;
+  return WW_OK;
+}
+
+int64_t ww_num_frames(int64_t n, int32_t hop) {
+  if (hop <= 0 || n < WW_FFT_WINDOW) return 0;
+  return (n - WW_FFT_WINDOW) / hop + 1;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// front end entry points
+// ------------------------------------------------------------------------------------------
+static int check_fp(ww_ctx *ctx, const ww_frontend_params *fp, bool need_div) {
+  if (!fp) return ww_fail(ctx, WW_EINVAL, "frontend params are NULL");
+  if (fp->hop <= 0 || fp->hop > WW_FFT_WINDOW) return ww_fail(ctx, WW_EINVAL, "hop %d out of range (1..512)", fp->hop);
+  if (need_div && !(fp->pcm_divisor > 0.f)) return ww_fail(ctx, WW_EINVAL, "pcm_divisor must be positive");
+  return WW_OK;
+}
+
+static int logmel_host(ww_ctx *ctx, const ww_model *m, const void *samples, size_t elt, const int64_t *sample_offs, int n_utt,
+                       const ww_frontend_params *fp, float *mel, int64_t *frame_offs) {
+  if (!ctx || !m || !sample_offs || !frame_offs) return ww_fail(ctx, WW_EINVAL, "NULL argument");
+  if (n_utt < 0) return ww_fail(ctx, WW_EINVAL, "negative utterance count");
+  int rc = check_fp(ctx, fp, elt == 2);
+  if (rc) return rc;
+  WW_HIP(ctx, hipSetDevice(ctx->device));
+  frame_offs[0] = 0;
+  int64_t max_f = 0;
+  for (int u = 0; u < n_utt; ++u) {
+    const int64_t n = sample_offs[u + 1] - sample_offs[u];
+    if (n < 0) return ww_fail(ctx, WW_EINVAL, "sample_offs not ascending at %d", u);
+    const int64_t nf = ww_num_frames(n, fp->hop);
+    frame_offs[u + 1] = frame_offs[u] + nf;
+    if (nf > max_f) max_f = nf;
+  }
+  const int64_t total_f = frame_offs[n_utt];
+  if (n_utt == 0 || total_f == 0) return WW_OK;
+  if (!samples || !mel) return ww_fail(ctx, WW_EINVAL, "NULL sample or mel buffer");
+  const int64_t base = sample_offs[0], total_s = sample_offs[n_utt] - base;
+  const size_t b_s = ww_bump::need((size_t)total_s + 16, elt), b_o = ww_bump::need((size_t)n_utt + 1, 8);
+  const size_t b_m = ww_bump::need((size_t)total_f * m->filt.n_mel, 4);
+  if ((rc = ww_ensure(ctx, ctx->dev, b_s + 2 * b_o + b_m, false))) return rc;
+  ww_bump bump(ctx->dev.ptr, ctx->dev.cap);
+  char *d_s = bump.take<char>(b_s);
+  int64_t *d_so = bump.take<int64_t>(n_utt + 1), *d_fo = bump.take<int64_t>(n_utt + 1);
+  float *d_mel = bump.take<float>((size_t)total_f * m->filt.n_mel);
+  std::vector<int64_t> so(n_utt + 1);
+  for (int u = 0; u <= n_utt; ++u) so[u] = sample_offs[u] - base;
+  WW_HIP(ctx, hipMemcpyAsync(d_s, (const char *)samples + (size_t)base * elt, (size_t)total_s * elt, hipMemcpyHostToDevice, ctx->stream));
+  WW_HIP(ctx, hipMemcpyAsync(d_so, so.data(), sizeof(int64_t) * (n_utt + 1), hipMemcpyHostToDevice, ctx->stream));
+  WW_HIP(ctx, hipMemcpyAsync(d_fo, frame_offs, sizeof(int64_t) * (n_utt + 1), hipMemcpyHostToDevice, ctx->stream));
+  // utterances go to blockIdx.y (<= 65535): split the batch if needed
+  for (int u0 = 0; u0 < n_utt; u0 += 65535) {
+    const int nu = (n_utt - u0) < 65535 ? (n_utt - u0) : 65535;
+    if (u0 != 0) return ww_fail(ctx, WW_EINVAL, "more than 65535 utterances in one call");
+    rc = ww_k_logmel(ctx, m, elt == 2 ? (const int16_t *)d_s : nullptr, elt == 4 ? (const float *)d_s : nullptr, d_so, d_fo,
+                     nu, total_f, max_f, fp, d_mel);
+    if (rc) return rc;
+  }
+  WW_HIP(ctx, hipMemcpyAsync(mel, d_mel, (size_t)total_f * m->filt.n_mel * 4, hipMemcpyDeviceToHost, ctx->stream));
+  WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return WW_OK;
+}
+
+extern "C" {
+
+int ww_logmel(ww_ctx *ctx, const ww_model *m, const int16_t *pcm, const int64_t *sample_offs, int32_t n_utt,
+              const ww_frontend_params *fp, float *mel, int64_t *frame_offs) {
+  return logmel_host(ctx, m, pcm, 2, sample_offs, n_utt, fp, mel, frame_offs);
+}
+
+int ww_logmel_f32(ww_ctx *ctx, const ww_model *m, const float *samples, const int64_t *sample_offs, int32_t n_utt,
+                  const ww_frontend_params *fp, float *mel, int64_t *frame_offs) {
+  return logmel_host(ctx, m, samples, 4, sample_offs, n_utt, fp, mel, frame_offs);
+}
+
+int ww_logmel_dev(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, const int64_t *d_sample_offs,
+                  const int64_t *d_frame_offs, int32_t n_utt, int64_t total_frames, int64_t max_frames_per_utt,
+                  const ww_frontend_params *fp, float *d_mel) {
+  if (!ctx || !m || !d_pcm || !d_sample_offs || !d_frame_offs || !d_mel) return ww_fail(ctx, WW_EINVAL, "NULL argument");
+  if (((uintptr_t)d_pcm & 15) != 0) return ww_fail(ctx, WW_EINVAL, "d_pcm must be 16-byte aligned");
+  int rc = check_fp(ctx, fp, true);
+  if (rc) return rc;
+  return ww_k_logmel(ctx, m, d_pcm, nullptr, d_sample_offs, d_frame_offs, n_utt, total_frames, max_frames_per_utt, fp, d_mel);
+}
+
+int ww_stft_mag(ww_ctx *ctx, const ww_model *m, const float *frames, int64_t n, int32_t precise, float *mag) {
+  if (!ctx || !m) return ww_fail(ctx, WW_EINVAL, "NULL argument");
+  if (n < 0) return ww_fail(ctx, WW_EINVAL, "negative frame count");
+  if (n == 0) return WW_OK;
+  if (!frames || !mag) return ww_fail(ctx, WW_EINVAL, "NULL buffer");
+  WW_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t b_f = ww_bump::need((size_t)n * WW_FFT_WINDOW, 4), b_m = ww_bump::need((size_t)n * WW_FFT_BINS, 4);
+  int rc = ww_ensure(ctx, ctx->dev, b_f + b_m, false);
+  if (rc) return rc;
+  ww_bump bump(ctx->dev.ptr, ctx->dev.cap);
+  float *d_f = bump.take<float>((size_t)n * WW_FFT_WINDOW), *d_m = bump.take<float>((size_t)n * WW_FFT_BINS);
+  WW_HIP(ctx, hipMemcpyAsync(d_f, frames, (size_t)n * WW_FFT_WINDOW * 4, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = ww_k_stft_mag(ctx, m, d_f, n, precise, d_m))) return rc;
+  WW_HIP(ctx, hipMemcpyAsync(mag, d_m, (size_t)n * WW_FFT_BINS * 4, hipMemcpyDeviceToHost, ctx->stream));
+  WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return WW_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// encode + detect entry points
+// ------------------------------------------------------------------------------------------
+static size_t model_ws(const ww_model *m, int nw) {
+  return m->kind == WW_KIND_CRNN ? ww_crnn_workspace(m, nw) : ww_wave_workspace(m, nw);
+}
+
+static int model_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *d_row,
+                         const int32_t *d_valid, int64_t row0, int hop, int valid_const, int nw, void *ws, float *d_out,
+                         float *d_enc) {
+  return m->kind == WW_KIND_CRNN
+             ? ww_k_crnn_forward(ctx, m, d_mel, mel_rows, d_row, d_valid, row0, hop, valid_const, nw, ws, d_out, d_enc)
+             : ww_k_wave_forward(ctx, m, d_mel, mel_rows, d_row, d_valid, row0, hop, valid_const, nw, ws, d_out, d_enc);
+}
+
+// windows are processed in chunks so that the workspace stays bounded
+#define WW_MAX_CHUNK 16384
+
+static int forward_host(ww_ctx *ctx, const ww_model *m, const float *mel, int64_t rows, int hop, int64_t nw, float *out,
+                        float *enc) {
+  const int T = m->info.window, F = m->info.n_mel, NO = m->info.n_out;
+  const size_t enc_per = (size_t)m->info.enc_rows * m->info.enc_width;
+  WW_HIP(ctx, hipSetDevice(ctx->device));
+  const int chunk = nw < WW_MAX_CHUNK ? (int)nw : WW_MAX_CHUNK;
+  const size_t b_mel = ww_bump::need((size_t)rows * F, 4), b_out = ww_bump::need((size_t)nw * NO, 4);
+  const size_t b_enc = enc ? ww_bump::need((size_t)chunk * enc_per, 4) : 0;
+  const size_t b_ws = model_ws(m, chunk);
+  int rc = ww_ensure(ctx, ctx->dev, b_mel + b_out + b_enc + b_ws + 1024, false);
+  if (rc) return rc;
+  ww_bump bump(ctx->dev.ptr, ctx->dev.cap);
+  float *d_mel = bump.take<float>((size_t)rows * F);
+  float *d_out = bump.take<float>((size_t)nw * NO);
+  float *d_enc = enc ? bump.take<float>((size_t)chunk * enc_per) : nullptr;
+  void *ws = bump.take<char>(b_ws);
+  WW_HIP(ctx, hipMemcpyAsync(d_mel, mel, (size_t)rows * F * 4, hipMemcpyHostToDevice, ctx->stream));
+  for (int64_t w0 = 0; w0 < nw; w0 += chunk) {
+    const int n = (int)((nw - w0) < chunk ? (nw - w0) : chunk);
+    rc = model_forward(ctx, m, d_mel, rows, nullptr, nullptr, w0 * hop, hop, T, n, ws, d_out + (size_t)w0 * NO, d_enc);
+    if (rc) return rc;
+    if (enc) {
+      WW_HIP(ctx, hipMemcpyAsync(enc + (size_t)w0 * enc_per, d_enc, (size_t)n * enc_per * 4, hipMemcpyDeviceToHost, ctx->stream));
+      WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+  }
+  WW_HIP(ctx, hipMemcpyAsync(out, d_out, (size_t)nw * NO * 4, hipMemcpyDeviceToHost, ctx->stream));
+  WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return WW_OK;
+}
+
+__global__ void iota_offs_kernel(int64_t *sample_offs, int64_t *frame_offs, int n, int64_t samples, int64_t frames) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= n) {
+    sample_offs[i] = (int64_t)i * samples;
+    frame_offs[i] = (int64_t)i * frames;
+  }
+}
+
+extern "C" {
+
+int ww_forward_enc(ww_ctx *ctx, const ww_model *m, const float *windows, int32_t nw, float *out, float *enc) {
+  if (!ctx || !m) return ww_fail(ctx, WW_EINVAL, "NULL argument");
+  if (nw < 0) return ww_fail(ctx, WW_EINVAL, "negative window count");
+  if (nw == 0) return WW_OK;
+  if (!windows || !out) return ww_fail(ctx, WW_EINVAL, "NULL buffer");
+  // B stacked windows are one mel sequence of B*T rows read with hop = T
+  return forward_host(ctx, m, windows, (int64_t)nw * m->info.window, m->info.window, nw, out, enc);
+}
+
+int ww_forward(ww_ctx *ctx, const ww_model *m, const float *windows, int32_t nw, float *out) {
+  return ww_forward_enc(ctx, m, windows, nw, out, nullptr);
+}
+
+int ww_slide_forward(ww_ctx *ctx, const ww_model *m, const float *mel, int64_t rows, int32_t hop, float *out,
+                     int64_t *n_windows) {
+  if (!ctx || !m || !n_windows) return ww_fail(ctx, WW_EINVAL, "NULL argument");
+  if (hop <= 0) return ww_fail(ctx, WW_EINVAL, "hop must be positive");
+  if (rows < 0) return ww_fail(ctx, WW_EINVAL, "negative row count");
+  const int T = m->info.window;
+  const int64_t nw = rows >= T ? (rows - T) / hop + 1 : 0;
+  *n_windows = nw;
+  if (nw == 0) return WW_OK;
+  if (!mel || !out) return ww_fail(ctx, WW_EINVAL, "NULL buffer");
+  return forward_host(ctx, m, mel, rows, hop, nw, out, nullptr);
+}
+
+int ww_forward_windows_dev(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *d_win_row,
+                           const int32_t *d_win_valid, int32_t nw, float *d_out) {
+  if (!ctx || !m || !d_mel || !d_out) return ww_fail(ctx, WW_EINVAL, "NULL argument");
+  if (nw < 0) return ww_fail(ctx, WW_EINVAL, "negative window count");
+  if (nw == 0) return WW_OK;
+  if (!d_win_row || !d_win_valid) return ww_fail(ctx, WW_EINVAL, "window descriptors are NULL");
+  const int NO = m->info.n_out;
+  const int chunk = nw < WW_MAX_CHUNK ? nw : WW_MAX_CHUNK;
+  int rc = ww_ensure(ctx, ctx->dev, model_ws(m, chunk) + 1024, false);
+  if (rc) return rc;
+  for (int w0 = 0; w0 < nw; w0 += chunk) {
+    const int n = (nw - w0) < chunk ? (nw - w0) : chunk;
+    rc = model_forward(ctx, m, d_mel, mel_rows, d_win_row + w0, d_win_valid + w0, 0, 0, 0, n, ctx->dev.ptr,
+                       d_out + (size_t)w0 * NO, nullptr);
+    if (rc) return rc;
+  }
+  return WW_OK;
+}
+
+int ww_clips_forward_dev(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, int32_t n_clips, int32_t samples,
+                         const ww_frontend_params *fp, float *d_out) {
+  if (!ctx || !m || !d_pcm || !d_out) return ww_fail(ctx, WW_EINVAL, "NULL argument");
+  if (n_clips < 0 || samples < 0) return ww_fail(ctx, WW_EINVAL, "negative size");
+  if (n_clips == 0) return WW_OK;
+  if (n_clips > 65535) return ww_fail(ctx, WW_EINVAL, "at most 65535 clips per call");
+  if (((uintptr_t)d_pcm & 15) != 0) return ww_fail(ctx, WW_EINVAL, "d_pcm must be 16-byte aligned");
+  int rc = check_fp(ctx, fp, true);
+  if (rc) return rc;
+  const int64_t nf = ww_num_frames(samples, fp->hop);
+  const int F = m->info.n_mel, T = m->info.window;
+  // workspace: offs | mel | model scratch
+  const size_t b_o = ww_bump::need((size_t)n_clips + 1, 8);
+  const size_t b_mel = ww_bump::need((size_t)n_clips * (nf > 0 ? nf : 1) * F, 4);
+  const size_t b_ws = model_ws(m, n_clips);
+  if ((rc = ww_ensure(ctx, ctx->dev, 2 * b_o + b_mel + b_ws + 1024, false))) return rc;
+  auto &cg = ctx->clip_graph;
+  const bool same = cg.exec && cg.model == m && cg.pcm == d_pcm && cg.out == d_out && cg.n_clips == n_clips &&
+                    cg.samples == samples && cg.ws == ctx->dev.ptr && memcmp(&cg.fp, fp, sizeof *fp) == 0;
+  if (same && !ctx->profiling) {
+    WW_HIP(ctx, hipGraphLaunch(cg.exec, ctx->stream));
+    return WW_OK;
+  }
+  auto enqueue = [&]() -> int {
+    ww_bump bump(ctx->dev.ptr, ctx->dev.cap);
+    int64_t *d_so = bump.take<int64_t>(n_clips + 1), *d_fo = bump.take<int64_t>(n_clips + 1);
+    float *d_mel = bump.take<float>((size_t)n_clips * (nf > 0 ? nf : 1) * F);
+    void *ws = bump.take<char>(b_ws);
+    {
+      ww_launch_scope scope(ctx, "iota_offs_kernel");
+      hipLaunchKernelGGL(iota_offs_kernel, dim3((n_clips + 256) / 256), dim3(256), 0, ctx->stream, d_so, d_fo, n_clips,
+                         (int64_t)samples, nf);
+    }
+    int r = ww_k_logmel(ctx, m, d_pcm, nullptr, d_so, d_fo, n_clips, (int64_t)n_clips * nf, nf, fp, d_mel);
+    if (r) return r;
+    // one window per clip: rows [c*nf, c*nf + min(nf, T)), zero padded to T
+    return model_forward(ctx, m, d_mel, (int64_t)n_clips * nf, nullptr, nullptr, 0, (int)nf, (int)(nf < T ? nf : T),
+                         n_clips, ws, d_out, nullptr);
+  };
+  if (ctx->profiling) return enqueue();
+  // capture the launch chain once, replay afterwards (the chain is launch-latency bound)
+  if (cg.exec) {
+    hipGraphExecDestroy(cg.exec);
+    cg.exec = nullptr;
+  }
+  hipGraph_t graph = nullptr;
+  WW_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+  rc = enqueue();
+  hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+  if (rc) {
+    if (graph) hipGraphDestroy(graph);
+    return rc;
+  }
+  if (e != hipSuccess) return ww_fail(ctx, WW_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+  e = hipGraphInstantiate(&cg.exec, graph, nullptr, nullptr, 0);
+  hipGraphDestroy(graph);
+  if (e != hipSuccess) {
+    cg.exec = nullptr;
+    return ww_fail(ctx, WW_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+  }
+  cg.model = m; cg.pcm = d_pcm; cg.out = d_out; cg.n_clips = n_clips; cg.samples = samples; cg.fp = *fp; cg.ws = ctx->dev.ptr;
+  WW_HIP(ctx, hipGraphLaunch(cg.exec, ctx->stream));
+  return WW_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// posterior smoothing + sweep
+// ------------------------------------------------------------------------------------------
+int ww_far_frr(ww_ctx *ctx, const float *pos, int64_t n_pos, const float *neg, int64_t n_neg, int32_t win,
+               const double *thr, int32_t n_thr, double num_wakewords, double hours, double *frr, double *fa_per_h,
+               int64_t *fa_count, double *smoothed) {
+  if (!ctx || !thr || !frr || !fa_per_h) return ww_fail(ctx, WW_EINVAL, "NULL argument");
+  if (n_pos < 0 || n_neg < 0 || n_thr <= 0) return ww_fail(ctx, WW_EINVAL, "bad sizes");
+  if ((n_pos && !pos) || (n_neg && !neg)) return ww_fail(ctx, WW_EINVAL, "NULL posterior buffer");
+  if (win > 0 && n_neg > 0 && n_neg < win)
+    return ww_fail(ctx, WW_EINVAL, "negative stream shorter than the smoothing window (np.convolve 'same' would change its length)");
+  WW_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t b_p = ww_bump::need((size_t)n_pos + 1, 4), b_n = ww_bump::need((size_t)n_neg + 1, 4);
+  const size_t b_s = ww_bump::need((size_t)n_neg + 1, 8), b_t = ww_bump::need((size_t)n_thr, 8);
+  int rc = ww_ensure(ctx, ctx->dev, b_p + b_n + b_s + 3 * b_t + 1024, false);
+  if (rc) return rc;
+  ww_bump bump(ctx->dev.ptr, ctx->dev.cap);
+  float *d_pos = bump.take<float>(n_pos + 1), *d_neg = bump.take<float>(n_neg + 1);
+  double *d_sm = bump.take<double>(n_neg + 1), *d_thr = bump.take<double>(n_thr);
+  unsigned long long *d_pc = bump.take<unsigned long long>(n_thr), *d_fc = bump.take<unsigned long long>(n_thr);
+  if (n_pos) WW_HIP(ctx, hipMemcpyAsync(d_pos, pos, (size_t)n_pos * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (n_neg) WW_HIP(ctx, hipMemcpyAsync(d_neg, neg, (size_t)n_neg * 4, hipMemcpyHostToDevice, ctx->stream));
+  WW_HIP(ctx, hipMemcpyAsync(d_thr, thr, (size_t)n_thr * 8, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = ww_k_far_frr(ctx, d_pos, n_pos, d_neg, n_neg, win, d_thr, n_thr, d_sm, d_pc, d_fc))) return rc;
+  std::vector<unsigned long long> pc(n_thr), fc(n_thr);
+  WW_HIP(ctx, hipMemcpyAsync(pc.data(), d_pc, (size_t)n_thr * 8, hipMemcpyDeviceToHost, ctx->stream));
+  WW_HIP(ctx, hipMemcpyAsync(fc.data(), d_fc, (size_t)n_thr * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (smoothed && n_neg) WW_HIP(ctx, hipMemcpyAsync(smoothed, d_sm, (size_t)n_neg * 8, hipMemcpyDeviceToHost, ctx->stream));
+  WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < n_thr; ++k) {
+    frr[k] = (num_wakewords - (double)pc[k]) / num_wakewords;
+    fa_per_h[k] = (double)fc[k] / hours;
+    if (fa_count) fa_count[k] = (int64_t)fc[k];
+  }
+  return WW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,166 @@
+// Internal declarations shared by the libwwhip.so translation units (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/wwhip.h"
+
+#define WW_WAVE 64
+
+struct ww_prof_entry {
+  int calls = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  double total_ms = 0.0;
+};
+
+// Growable device / pinned-host arenas.  Never (re)allocated inside a captured region:
+// ensure() is called by the entry points before they start enqueueing.
+struct ww_arena {
+  void *ptr = nullptr;
+  size_t cap = 0;
+};
+
+struct ww_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  char err[512] = {0};
+  ww_arena dev;     // device workspace
+  ww_arena pinned;  // pinned host staging
+  bool profiling = false;
+  std::map<std::string, ww_prof_entry> prof;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  // cached graph for ww_clips_forward_dev
+  struct {
+    hipGraphExec_t exec = nullptr;
+    const void *model = nullptr;
+    const void *pcm = nullptr;
+    void *out = nullptr;
+    int n_clips = 0, samples = 0;
+    ww_frontend_params fp = {};
+    void *ws = nullptr;
+  } clip_graph;
+};
+
+// Device-resident mel filterbank in banded form: band m covers bins [start[m], start[m]+len[m])
+// with weights w[woff[m] .. woff[m]+len[m]).
+struct ww_filter_dev {
+  int n_mel = 0, n_bins = 0;
+  float floor_v = 0, log_off = 0, scale = 0;
+  int *start = nullptr, *len = nullptr, *woff = nullptr;
+  float *w = nullptr, *bias = nullptr;
+  int total_taps = 0, max_len = 0;
+  double *hann = nullptr;    // [512] np.hanning(512) in fp64
+  double *tw256 = nullptr;   // [256][2] e^{-2 pi i k / 256}
+  double *tw512 = nullptr;   // [256][2] e^{-2 pi i k / 512}
+};
+
+struct ww_crnn_dev {
+  int n_mel, T, C, KF, KT, SF, ST, PF, PT, OF, OT, H, NOUT, HEAD;
+  float *conv_w = nullptr;   // [KF*KT][C]  (k-major for the implicit GEMM)
+  float *conv_b = nullptr;   // [C]
+  float *wx1 = nullptr;      // [2*3H][OF*C]  rows: fwd z,r,h then bwd z,r,h
+  float *bx1 = nullptr;      // [2*3H]
+  float *wh1 = nullptr;      // [2][3H][H]
+  float *bh1 = nullptr;      // [2][3H]
+  float *wx2 = nullptr;      // [2*3H][2H]
+  float *bx2 = nullptr;
+  float *wh2 = nullptr;
+  float *bh2 = nullptr;
+  float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
+};
+
+struct ww_wave_dev {
+  int T, n_mel, C, S, NB, NOUT;
+  std::vector<int> dil, order, has_res;
+  int *d_dil = nullptr, *d_has_res = nullptr;
+  float *w_in = nullptr, *b_in = nullptr;          // [n_mel][C], [C]
+  float *bn_s = nullptr, *bn_t = nullptr;          // [NB][C]
+  float *w_gate = nullptr, *b_gate = nullptr;      // [NB][3*C][2C] (cols: sig 0..C-1, tanh C..2C-1), [NB][2C]
+  float *w_rs = nullptr, *b_rs = nullptr;          // [NB][C][C+S] (cols: res 0..C-1, skip C..), [NB][C+S]
+  float *d_w1 = nullptr, *d_b1 = nullptr, *d_w2 = nullptr, *d_b2 = nullptr;
+  bool order_is_natural = true;
+};
+
+struct ww_model {
+  ww_ctx *ctx = nullptr;
+  int kind = 0;
+  ww_model_info info = {};
+  ww_filter_dev filt;
+  ww_crnn_dev crnn;
+  ww_wave_dev wave;
+  std::vector<void *> allocs;
+};
+
+int ww_fail(ww_ctx *ctx, int code, const char *fmt, ...);
+int ww_ensure(ww_ctx *ctx, ww_arena &a, size_t bytes, bool pinned);
+
+#define WW_HIP(ctx, expr)                                                                       \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return ww_fail((ctx), WW_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+// Bracket a kernel launch with profiling events when enabled.
+struct ww_launch_scope {
+  ww_ctx *ctx;
+  const char *name;
+  hipEvent_t a = nullptr, b = nullptr;
+  ww_launch_scope(ww_ctx *c, const char *n) : ctx(c), name(n) {
+    if (ctx->profiling) {
+      hipEventCreate(&a);
+      hipEventCreate(&b);
+      hipEventRecord(a, ctx->stream);
+    }
+  }
+  ~ww_launch_scope() {
+    if (ctx->profiling) {
+      hipEventRecord(b, ctx->stream);
+      auto &e = ctx->prof[name];
+      e.calls++;
+      e.pending.emplace_back(a, b);
+    }
+  }
+};
+
+// bump allocator over the ctx workspace
+struct ww_bump {
+  char *base;
+  size_t off = 0, cap;
+  ww_bump(void *p, size_t c) : base((char *)p), cap(c) {}
+  template <typename T>
+  T *take(size_t n) {
+    size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);
+    T *r = (T *)(base + off);
+    off += bytes;
+    return r;
+  }
+  static size_t need(size_t n, size_t elem) { return (n * elem + 255) & ~size_t(255); }
+};
+
+// ---- kernel-side entry points implemented in the .hip files ------------------------------
+int ww_k_logmel(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, const float *d_f32, const int64_t *d_sample_offs,
+                const int64_t *d_frame_offs, int n_utt, int64_t total_frames, int64_t max_frames_per_utt,
+                const ww_frontend_params *fp, float *d_mel);
+int ww_k_stft_mag(ww_ctx *ctx, const ww_model *m, const float *d_frames, int64_t n, int precise, float *d_mag);
+
+size_t ww_crnn_workspace(const ww_model *m, int n_windows);
+int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *d_win_row,
+                      const int32_t *d_win_valid, int64_t row0, int hop, int valid_const, int n_windows, void *ws,
+                      float *d_out, float *d_enc);
+size_t ww_wave_workspace(const ww_model *m, int n_windows);
+int ww_k_wave_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *d_win_row,
+                      const int32_t *d_win_valid, int64_t row0, int hop, int valid_const, int n_windows, void *ws,
+                      float *d_out, float *d_enc);
+int ww_k_far_frr(ww_ctx *ctx, const float *d_pos, int64_t n_pos, const float *d_neg, int64_t n_neg, int win,
+                 const double *d_thr, int n_thr, double *d_smoothed, unsigned long long *d_pos_cnt,
+                 unsigned long long *d_fa_cnt);

@@ -1,0 +1,320 @@
+// Streaming mode: S concurrent 16 kHz streams advanced 20 ms per tick (BASELINE config 5).
+//
+// Device-resident replacement for the per-stream state of WakewordTrigger
+// (spokestack/wakeword/tflite.py:92-108): sample ring, mel frame window, pre-emphasis carry.
+// Per tick and stream the reference runs a 320-iteration Python loop that emits a frame
+// whenever 512 samples are buffered and then drops the oldest 160 (tflite.py:163-168); with a
+// ring that holds f <= 511 samples before the tick, that is exactly
+//     n_frames = (f + 320 >= 512) ? (f + 320 - 512) / 160 + 1 : 0      (0, 1 or 2)
+// frames at offsets 0, 160 of the concatenation [ring | new samples], and f' = f + 320 -
+// 160 * n_frames samples kept.  The host mirrors f per stream (pure integer bookkeeping) so it
+// knows the number of posteriors a tick will produce and can size the launch exactly; all
+// sample and mel data stay in HBM.
+//
+//   stream_frontend_kernel  one workgroup (2 waves) per stream: shift the mel history by the
+//                           rows appended last tick, normalise + pre-emphasise the 320 new
+//                           samples, FFT + mel for each new frame (one wave per frame) when
+//                           the stream's is_speech bit is set, keep the ring tail.
+//   then the regular CRNN / Wavenet kernels run on the compacted list of new windows.
+#include "common.h"
+#include "fft_device.h"
+
+#define ST_RING 832  // 511 + 320 rounded up
+
+struct ww_streams {
+  ww_ctx *ctx = nullptr;
+  const ww_model *model = nullptr;
+  int S = 0;
+  ww_frontend_params fp = {};
+  int T = 0, F = 0, NO = 0, HR = 0;  // HR = history rows per stream = T + 2
+  // device state
+  float *ring = nullptr;      // [S][ST_RING]
+  float *hist[2] = {nullptr, nullptr};  // [S][T + 2][F], ping-pong
+  float *prev = nullptr;      // [S] pre-emphasis carry (raw previous sample)
+  int cur = 0;
+  // per-tick device buffers
+  int16_t *d_frames = nullptr;   // [S][320]
+  int32_t *d_ctl = nullptr;      // [S][4]: fill, n_frames, flags, appended_last_tick
+  int64_t *d_win_row = nullptr;  // [2S]
+  int32_t *d_win_valid = nullptr;
+  float *d_out = nullptr;        // [2S][NO]
+  void *ws = nullptr;
+  // host mirrors (pinned)
+  int32_t *h_ctl = nullptr;
+  int64_t *h_win_row = nullptr;
+  int32_t *h_win_valid = nullptr;
+  float *h_out = nullptr;
+  int16_t *h_frames = nullptr;
+  std::vector<int> fill, appended;
+};
+
+struct stream_fe_args {
+  const int16_t *frames;
+  const int32_t *ctl;
+  float *ring;
+  const float *hist_in;
+  float *hist_out;
+  float *prev;
+  int T, F, HR;
+  float divisor;
+  int clip;
+  float preemph;
+  int hop;
+  const int *start, *len, *woff;
+  const float *w, *bias;
+  int n_mel, total_taps;
+  float floor_v, log_off, scale;
+  const double *hann, *tw256, *tw512;
+};
+
+template <typename R>
+__global__ __launch_bounds__(128) void stream_frontend_kernel(stream_fe_args a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s = blockIdx.x;
+  const int fill = a.ctl[s * 4 + 0], n_frames = a.ctl[s * 4 + 1], flags = a.ctl[s * 4 + 2], shift_rows = a.ctl[s * 4 + 3];
+  const bool speech = flags & 1, skip = flags & 2;
+
+  size_t off = 0;
+  cplx<R> *tw256 = (cplx<R> *)(smem + off); off += 256 * sizeof(cplx<R>);
+  cplx<R> *tw512 = (cplx<R> *)(smem + off); off += 256 * sizeof(cplx<R>);
+  cplx<R> *fbuf = (cplx<R> *)(smem + off); off += 2 * 256 * sizeof(cplx<R>);
+  float *mag = (float *)(smem + off); off += 2 * 260 * sizeof(float);
+  float *fw = (float *)(smem + off); off += ((a.total_taps + 3) & ~3) * sizeof(float);
+  float *x = (float *)(smem + off);  // [ST_RING]
+
+  // ---- mel history: drop the rows that were appended last tick (hist_out[0..T) = hist_in[shift..shift+T))
+  {
+    const float *src = a.hist_in + ((size_t)s * a.HR + shift_rows) * a.F;
+    float *dst = a.hist_out + (size_t)s * a.HR * a.F;
+    for (int i = tid; i < a.T * a.F; i += 128) dst[i] = src[i];
+  }
+  if (skip) return;  // context.is_active: the frame is not sampled at all (tflite.py:139-140)
+
+  for (int i = tid; i < 256; i += 128) {
+    tw256[i] = {(R)a.tw256[2 * i], (R)a.tw256[2 * i + 1]};
+    tw512[i] = {(R)a.tw512[2 * i], (R)a.tw512[2 * i + 1]};
+  }
+  for (int i = tid; i < a.total_taps; i += 128) fw[i] = a.w[i];
+  // ---- [ring | new samples] in LDS
+  float *ring = a.ring + (size_t)s * ST_RING;
+  for (int i = tid; i < fill; i += 128) x[i] = ring[i];
+  const float carry = a.prev[s];
+  for (int i = tid; i < WW_CHUNK; i += 128) {
+    float v = __fdiv_rn((float)a.frames[(size_t)s * WW_CHUNK + i], a.divisor);
+    if (a.clip) v = fminf(fmaxf(v, -1.0f), 1.0f);
+    float p;
+    if (i == 0) {
+      p = carry;
+    } else {
+      p = __fdiv_rn((float)a.frames[(size_t)s * WW_CHUNK + i - 1], a.divisor);
+      if (a.clip) p = fminf(fmaxf(p, -1.0f), 1.0f);
+    }
+    x[fill + i] = (a.preemph != 0.0f) ? __fsub_rn(v, __fmul_rn(a.preemph, p)) : v;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float v = __fdiv_rn((float)a.frames[(size_t)s * WW_CHUNK + WW_CHUNK - 1], a.divisor);
+    if (a.clip) v = fminf(fmaxf(v, -1.0f), 1.0f);
+    a.prev[s] = v;  // tflite.py:156-158: carry is the un-emphasised last sample
+  }
+  // ---- new frames (wave k handles frame k); only analysed while is_speech (tflite.py:166)
+  if (speech && wave < n_frames) {
+    const float *src = x + wave * a.hop;
+    auto xs = [&](int i) -> float { return src[i]; };
+    float *mg = mag + wave * 260;
+    frame_fft_mag<R>(xs, a.hann, tw256, tw512, fbuf + wave * 256, mg, lane);
+    if (lane < a.n_mel) {
+      const int st = a.start[lane], ln = a.len[lane], wo = a.woff[lane];
+      float acc = 0.0f;
+      for (int i = 0; i < ln; ++i) acc = fmaf(fw[wo + i], mg[st + i], acc);
+      acc += a.bias[lane];
+      acc = fmaxf(acc, a.floor_v);
+      a.hist_out[((size_t)s * a.HR + a.T + wave) * a.F + lane] = (logf(acc) + a.log_off) * a.scale;
+    }
+  }
+  __syncthreads();
+  // ---- keep the ring tail
+  const int keep = fill + WW_CHUNK - n_frames * a.hop;
+  for (int i = tid; i < keep; i += 128) ring[i] = x[n_frames * a.hop + i];
+}
+
+__global__ void stream_reset_kernel(float *ring, float *hist0, float *hist1, const int32_t *ids, int n, int S, int HR, int F) {
+  const int b = blockIdx.x;
+  const int s = ids ? ids[b] : b;
+  if (s < 0 || s >= S) return;
+  for (int i = threadIdx.x; i < HR * F; i += blockDim.x) {
+    hist0[(size_t)s * HR * F + i] = 0.f;
+    hist1[(size_t)s * HR * F + i] = 0.f;
+  }
+  (void)ring;
+  (void)n;
+}
+
+extern "C" {
+
+int ww_stream_destroy(ww_streams *st) {
+  if (!st) return WW_OK;
+  hipSetDevice(st->ctx->device);
+  hipStreamSynchronize(st->ctx->stream);
+  void *dev[] = {st->ring, st->hist[0], st->hist[1], st->prev, st->d_frames, st->d_ctl, st->d_win_row, st->d_win_valid, st->d_out, st->ws};
+  for (void *p : dev)
+    if (p) hipFree(p);
+  void *host[] = {st->h_ctl, st->h_win_row, st->h_win_valid, st->h_out, st->h_frames};
+  for (void *p : host)
+    if (p) hipHostFree(p);
+  delete st;
+  return WW_OK;
+}
+
+int ww_stream_create(ww_ctx *ctx, const ww_model *model, int32_t S, const ww_frontend_params *fp, ww_streams **out) {
+  if (!ctx || !model || !fp || !out) return ww_fail(ctx, WW_EINVAL, "NULL argument");
+  *out = nullptr;
+  if (S <= 0 || S > 65535) return ww_fail(ctx, WW_EINVAL, "stream count %d out of range (1..65535)", S);
+  if (fp->hop != 160) return ww_fail(ctx, WW_EINVAL, "streaming mode supports hop 160 (10 ms @ 16 kHz) only, got %d", fp->hop);
+  if (!(fp->pcm_divisor > 0.f)) return ww_fail(ctx, WW_EINVAL, "pcm_divisor must be positive");
+  WW_HIP(ctx, hipSetDevice(ctx->device));
+  ww_streams *st = new ww_streams();
+  st->ctx = ctx; st->model = model; st->S = S; st->fp = *fp;
+  st->T = model->info.window; st->F = model->info.n_mel; st->NO = model->info.n_out; st->HR = st->T + 2;
+  const size_t hist_elems = (size_t)S * st->HR * st->F;
+  size_t ws_bytes = (model->kind == WW_KIND_CRNN ? ww_crnn_workspace(model, 2 * S) : ww_wave_workspace(model, 2 * S));
+  bool ok = hipMalloc((void **)&st->ring, (size_t)S * ST_RING * 4) == hipSuccess &&
+            hipMalloc((void **)&st->hist[0], hist_elems * 4) == hipSuccess &&
+            hipMalloc((void **)&st->hist[1], hist_elems * 4) == hipSuccess &&
+            hipMalloc((void **)&st->prev, (size_t)S * 4) == hipSuccess &&
+            hipMalloc((void **)&st->d_frames, (size_t)S * WW_CHUNK * 2) == hipSuccess &&
+            hipMalloc((void **)&st->d_ctl, (size_t)S * 16) == hipSuccess &&
+            hipMalloc((void **)&st->d_win_row, (size_t)2 * S * 8) == hipSuccess &&
+            hipMalloc((void **)&st->d_win_valid, (size_t)2 * S * 4) == hipSuccess &&
+            hipMalloc((void **)&st->d_out, (size_t)2 * S * st->NO * 4) == hipSuccess &&
+            hipMalloc(&st->ws, ws_bytes) == hipSuccess &&
+            hipHostMalloc((void **)&st->h_ctl, (size_t)S * 16) == hipSuccess &&
+            hipHostMalloc((void **)&st->h_win_row, (size_t)2 * S * 8) == hipSuccess &&
+            hipHostMalloc((void **)&st->h_win_valid, (size_t)2 * S * 4) == hipSuccess &&
+            hipHostMalloc((void **)&st->h_out, (size_t)2 * S * st->NO * 4) == hipSuccess &&
+            hipHostMalloc((void **)&st->h_frames, (size_t)S * WW_CHUNK * 2) == hipSuccess;
+  if (!ok) {
+    ww_stream_destroy(st);
+    return ww_fail(ctx, WW_ENOMEM, "cannot allocate state for %d streams", S);
+  }
+  hipMemsetAsync(st->ring, 0, (size_t)S * ST_RING * 4, ctx->stream);
+  hipMemsetAsync(st->hist[0], 0, hist_elems * 4, ctx->stream);
+  hipMemsetAsync(st->hist[1], 0, hist_elems * 4, ctx->stream);
+  hipMemsetAsync(st->prev, 0, (size_t)S * 4, ctx->stream);
+  WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  st->fill.assign(S, 0);
+  st->appended.assign(S, 0);
+  *out = st;
+  return WW_OK;
+}
+
+int ww_stream_reset(ww_streams *st, const int32_t *ids, int32_t n) {
+  if (!st) return WW_EINVAL;
+  ww_ctx *ctx = st->ctx;
+  if (ids && n < 0) return ww_fail(ctx, WW_EINVAL, "negative id count");
+  const int count = ids ? n : st->S;
+  if (count == 0) return WW_OK;
+  WW_HIP(ctx, hipSetDevice(ctx->device));
+  int32_t *d_ids = nullptr;
+  if (ids) {
+    for (int i = 0; i < n; ++i)
+      if (ids[i] < 0 || ids[i] >= st->S) return ww_fail(ctx, WW_EINVAL, "stream id %d out of range", ids[i]);
+    // reuse the window-valid buffer (2S ints) as id staging
+    if (n > 2 * st->S) return ww_fail(ctx, WW_EINVAL, "more ids than streams");
+    memcpy(st->h_win_valid, ids, (size_t)n * 4);
+    WW_HIP(ctx, hipMemcpyAsync(st->d_win_valid, st->h_win_valid, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    d_ids = st->d_win_valid;
+  }
+  hipLaunchKernelGGL(stream_reset_kernel, dim3(count), dim3(256), 0, ctx->stream, st->ring, st->hist[0], st->hist[1], d_ids,
+                     count, st->S, st->HR, st->F);
+  WW_HIP(ctx, hipGetLastError());
+  WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // WakewordTrigger.reset (tflite.py:241-246): sample window emptied, frame window zeroed;
+  // _prev_sample is NOT reset by the reference and is not reset here.
+  for (int i = 0; i < count; ++i) {
+    const int s = ids ? ids[i] : i;
+    st->fill[s] = 0;
+    st->appended[s] = 0;
+  }
+  return WW_OK;
+}
+
+int ww_stream_step(ww_streams *st, const int16_t *frames, const uint8_t *is_speech, float *post, int32_t *n_post) {
+  if (!st) return WW_EINVAL;
+  ww_ctx *ctx = st->ctx;
+  if (!frames || !is_speech || !post || !n_post) return ww_fail(ctx, WW_EINVAL, "NULL argument");
+  WW_HIP(ctx, hipSetDevice(ctx->device));
+  const int S = st->S, hop = st->fp.hop;
+  int nw = 0;
+  for (int s = 0; s < S; ++s) {
+    const int flags = is_speech[s] & 3;
+    int nf = 0;
+    if (!(flags & 2)) {
+      const int tot = st->fill[s] + WW_CHUNK;
+      nf = tot >= WW_FFT_WINDOW ? (tot - WW_FFT_WINDOW) / hop + 1 : 0;
+    }
+    st->h_ctl[s * 4 + 0] = st->fill[s];
+    st->h_ctl[s * 4 + 1] = nf;
+    st->h_ctl[s * 4 + 2] = flags;
+    st->h_ctl[s * 4 + 3] = st->appended[s];
+    const int np = (flags & 1) && !(flags & 2) ? nf : 0;
+    n_post[s] = np;
+    for (int k = 0; k < np; ++k) {
+      st->h_win_row[nw] = (int64_t)s * st->HR + k + 1;
+      st->h_win_valid[nw] = st->T;
+      ++nw;
+    }
+    if (!(flags & 2)) st->fill[s] = st->fill[s] + WW_CHUNK - nf * hop;
+    st->appended[s] = np;
+  }
+  memcpy(st->h_frames, frames, (size_t)S * WW_CHUNK * 2);
+  WW_HIP(ctx, hipMemcpyAsync(st->d_frames, st->h_frames, (size_t)S * WW_CHUNK * 2, hipMemcpyHostToDevice, ctx->stream));
+  WW_HIP(ctx, hipMemcpyAsync(st->d_ctl, st->h_ctl, (size_t)S * 16, hipMemcpyHostToDevice, ctx->stream));
+  if (nw) {
+    WW_HIP(ctx, hipMemcpyAsync(st->d_win_row, st->h_win_row, (size_t)nw * 8, hipMemcpyHostToDevice, ctx->stream));
+    WW_HIP(ctx, hipMemcpyAsync(st->d_win_valid, st->h_win_valid, (size_t)nw * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
+  const ww_model *m = st->model;
+  const ww_filter_dev &f = m->filt;
+  stream_fe_args a = {};
+  a.frames = st->d_frames; a.ctl = st->d_ctl; a.ring = st->ring;
+  a.hist_in = st->hist[st->cur]; a.hist_out = st->hist[st->cur ^ 1]; a.prev = st->prev;
+  a.T = st->T; a.F = st->F; a.HR = st->HR;
+  a.divisor = st->fp.pcm_divisor; a.clip = st->fp.clip; a.preemph = st->fp.pre_emphasis; a.hop = hop;
+  a.start = f.start; a.len = f.len; a.woff = f.woff; a.w = f.w; a.bias = f.bias;
+  a.n_mel = f.n_mel; a.total_taps = f.total_taps; a.floor_v = f.floor_v; a.log_off = f.log_off; a.scale = f.scale;
+  a.hann = f.hann; a.tw256 = f.tw256; a.tw512 = f.tw512;
+  {
+    ww_launch_scope scope(ctx, "stream_frontend_kernel");
+    if (st->fp.precise) {
+      size_t sm = 256 * 16 * 2 + 2 * 256 * 16 + 2 * 260 * 4 + ((f.total_taps + 3) & ~3) * 4 + ST_RING * 4;
+      hipLaunchKernelGGL((stream_frontend_kernel<double>), dim3(S), dim3(128), sm, ctx->stream, a);
+    } else {
+      size_t sm = 256 * 8 * 2 + 2 * 256 * 8 + 2 * 260 * 4 + ((f.total_taps + 3) & ~3) * 4 + ST_RING * 4;
+      hipLaunchKernelGGL((stream_frontend_kernel<float>), dim3(S), dim3(128), sm, ctx->stream, a);
+    }
+  }
+  WW_HIP(ctx, hipGetLastError());
+  st->cur ^= 1;
+  if (nw) {
+    const float *d_hist = st->hist[st->cur];
+    int rc = m->kind == WW_KIND_CRNN
+                 ? ww_k_crnn_forward(ctx, m, d_hist, (int64_t)S * st->HR, st->d_win_row, st->d_win_valid, 0, 0, 0, nw, st->ws, st->d_out, nullptr)
+                 : ww_k_wave_forward(ctx, m, d_hist, (int64_t)S * st->HR, st->d_win_row, st->d_win_valid, 0, 0, 0, nw, st->ws, st->d_out, nullptr);
+    if (rc) return rc;
+    WW_HIP(ctx, hipMemcpyAsync(st->h_out, st->d_out, (size_t)nw * st->NO * 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // posterior element: width-1 head -> [0]; width-2 head -> [1]  
+  const int pidx = st->NO == 1 ? 0 : 1;
+  int w = 0;
+  for (int s = 0; s < S; ++s) {
+    post[s * 2] = 0.f;
+    post[s * 2 + 1] = 0.f;
+    for (int k = 0; k < n_post[s]; ++k, ++w) post[s * 2 + k] = st->h_out[(size_t)w * st->NO + pidx];
+  }
+  return WW_OK;
+}
+
+}  // extern "C"

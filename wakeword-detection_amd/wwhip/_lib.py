@@ -1,0 +1,169 @@
+"""ctypes binding of ``libwwhip.so`` (the C ABI declared in ``include/wwhip.h``).
+
+There is no CPU fallback: if the shared object is missing, or no gfx950 device is visible
+when a context is requested, the call raises.  Status codes map to the exception types the
+reference's callers see from TFLite/NumPy (``ValueError`` for bad shapes and arguments,
+``RuntimeError`` for runtime failures).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import threading
+from typing import Dict, Optional
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libwwhip.so")
+
+WW_OK, WW_EINVAL, WW_EBLOB, WW_EHIP, WW_ENOMEM, WW_ESTATE, WW_ENODEVICE = 0, -1, -2, -3, -4, -5, -6
+KIND_CRNN, KIND_WAVENET = 1, 2
+
+
+class ModelInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("kind", "window", "n_mel", "n_bins", "n_out", "enc_rows", "enc_width", "reserved")]
+
+
+class FrontendParams(C.Structure):
+    _fields_ = [("pcm_divisor", C.c_float), ("clip", C.c_int32), ("pre_emphasis", C.c_float),
+                ("hop", C.c_int32), ("precise", C.c_int32)]
+
+
+# name -> (restype, argtypes); every symbol include/wwhip.h declares
+_vp, _i32, _i64, _f32, _f64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_size_t
+_P = C.POINTER
+SYMBOLS: Dict[str, tuple] = {
+    "ww_ctx_create": (C.c_int, [C.c_int, _vp, _P(_vp)]),
+    "ww_ctx_destroy": (C.c_int, [_vp]),
+    "ww_ctx_synchronize": (C.c_int, [_vp]),
+    "ww_ctx_stream": (_vp, [_vp]),
+    "ww_last_error": (C.c_char_p, [_vp]),
+    "ww_version": (C.c_char_p, []),
+    "ww_profile_enable": (C.c_int, [_vp, C.c_int]),
+    "ww_profile_read": (C.c_int, [_vp, C.c_char_p, _sz]),
+    "ww_timer_start": (C.c_int, [_vp]),
+    "ww_timer_stop": (C.c_int, [_vp, _P(_f32)]),
+    "ww_model_load": (C.c_int, [_vp, _vp, _sz, _P(_vp)]),
+    "ww_model_free": (C.c_int, [_vp]),
+    "ww_model_get_info": (C.c_int, [_vp, _P(ModelInfo)]),
+    "ww_num_frames": (_i64, [_i64, _i32]),
+    "ww_logmel": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _P(FrontendParams), _vp, _vp]),
+    "ww_logmel_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _P(FrontendParams), _vp, _vp]),
+    "ww_stft_mag": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "ww_logmel_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _P(FrontendParams), _vp]),
+    "ww_forward": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
+    "ww_forward_enc": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp]),
+    "ww_slide_forward": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _P(_i64)]),
+    "ww_forward_windows_dev": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp]),
+    "ww_clips_forward_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _P(FrontendParams), _vp]),
+    "ww_stream_create": (C.c_int, [_vp, _vp, _i32, _P(FrontendParams), _P(_vp)]),
+    "ww_stream_destroy": (C.c_int, [_vp]),
+    "ww_stream_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "ww_stream_reset": (C.c_int, [_vp, _vp, _i32]),
+    "ww_far_frr": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _f64, _f64, _vp, _vp, _vp, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+_lock = threading.Lock()
+
+
+def load() -> C.CDLL:
+    """Load ``libwwhip.so``; raises ``RuntimeError`` if it has not been built."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
+                "There is no CPU fallback for the wake-word hot path.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def raise_for(rc: int, ctx_handle) -> None:
+    if rc == WW_OK:
+        return
+    msg = load().ww_last_error(ctx_handle)
+    text = msg.decode("utf-8", "replace") if msg else f"libwwhip error {rc}"
+    if rc in (WW_EINVAL, WW_EBLOB):
+        raise ValueError(text)
+    if rc == WW_ENOMEM:
+        raise MemoryError(text)
+    raise RuntimeError(text)
+
+
+class Context:
+    """One ``ww_ctx``: a HIP stream + workspace on one gfx950 device."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None) -> None:
+        lib = load()
+        h = C.c_void_p()
+        rc = lib.ww_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc != WW_OK:
+            raise_for(rc, None)
+        self._h = h
+        self.device = device
+
+    @property
+    def handle(self):
+        return self._h
+
+    def synchronize(self) -> None:
+        raise_for(load().ww_ctx_synchronize(self._h), self._h)
+
+    @property
+    def stream(self) -> int:
+        return int(load().ww_ctx_stream(self._h) or 0)
+
+    def profile(self, on: bool) -> None:
+        raise_for(load().ww_profile_enable(self._h, int(on)), self._h)
+
+    def profile_read(self) -> dict:
+        buf = C.create_string_buffer(1 << 16)
+        raise_for(load().ww_profile_read(self._h, buf, len(buf)), self._h)
+        return json.loads(buf.value.decode())
+
+    def timer_start(self) -> None:
+        raise_for(load().ww_timer_start(self._h), self._h)
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        raise_for(load().ww_timer_stop(self._h, C.byref(ms)), self._h)
+        return float(ms.value)
+
+    def close(self) -> None:
+        if self._h:
+            load().ww_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx: Dict[int, Context] = {}
+
+
+def default_context(device: int = 0) -> Context:
+    """Process-wide context per device for the drop-in classes (single-threaded callers,
+    like the reference: SURVEY 8b 'Threading / ownership')."""
+    ctx = _default_ctx.get(device)
+    if ctx is None:
+        ctx = Context(device)
+        _default_ctx[device] = ctx
+    return ctx

@@ -1,0 +1,210 @@
+"""Host-side handle on one uploaded model: thin, typed wrappers over the C ABI.
+
+Everything here forwards to ``libwwhip.so``; nothing is computed in Python/NumPy apart from
+argument marshalling.  The reference-shaped classes (``Filter``, ``TFLiteModel``,
+``WakewordTrigger``, ``get_posterior`` ...) are built on top of this in the sibling modules.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from . import weights as W
+
+
+def frontend_params(pcm_divisor: float = 32767.0, clip: bool = True, pre_emphasis: float = 0.0,
+                    hop: int = 160, precise: bool = True) -> _lib.FrontendParams:
+    return _lib.FrontendParams(float(pcm_divisor), int(bool(clip)), float(pre_emphasis), int(hop), int(bool(precise)))
+
+
+class Engine:
+    """A model directory (filter/encode/detect ``.tflite``) resident on one MI355X."""
+
+    def __init__(self, model_dir: str, device: int = 0, ctx: Optional[_lib.Context] = None) -> None:
+        self.bundle = W.load_model_dir(model_dir)
+        self.blob = W.pack_blob(self.bundle)
+        self.ctx = ctx if ctx is not None else _lib.default_context(device)
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        buf = np.frombuffer(self.blob, dtype=np.uint8)
+        _lib.raise_for(self._lib.ww_model_load(self.ctx.handle, _lib.ptr(buf), buf.size, C.byref(h)), self.ctx.handle)
+        self._model = h
+        info = _lib.ModelInfo()
+        _lib.raise_for(self._lib.ww_model_get_info(h, C.byref(info)), self.ctx.handle)
+        self.kind = info.kind
+        self.window = info.window
+        self.n_mel = info.n_mel
+        self.n_bins = info.n_bins
+        self.n_out = info.n_out
+        self.enc_shape = (info.enc_rows, info.enc_width)
+        self.model_dir = model_dir
+
+    # ------------------------------------------------------------------ properties
+    @property
+    def handle(self):
+        return self._model
+
+    @property
+    def posterior_index(self) -> int:
+        return self.bundle.posterior_index
+
+    @property
+    def is_crnn(self) -> bool:
+        return self.kind == _lib.KIND_CRNN
+
+    def close(self) -> None:
+        if self._model:
+            self._lib.ww_model_free(self._model)
+            self._model = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc: int) -> None:
+        _lib.raise_for(rc, self.ctx.handle)
+
+    # ------------------------------------------------------------------ front end
+    def num_frames(self, n_samples: int, hop: int = 160) -> int:
+        return int(self._lib.ww_num_frames(int(n_samples), int(hop)))
+
+    def logmel(self, pcm: Sequence[np.ndarray], fp: Optional[_lib.FrontendParams] = None) -> List[np.ndarray]:
+        """List of int16 (or float32) utterances -> list of ``[frames, 40]`` log-mel arrays."""
+        fp = fp or frontend_params()
+        if len(pcm) == 0:
+            return []
+        is_f32 = np.asarray(pcm[0]).dtype != np.int16
+        dt = np.float32 if is_f32 else np.int16
+        arrs = [np.ascontiguousarray(p, dtype=dt).ravel() for p in pcm]
+        # pad every utterance start to a multiple of 8 samples so device loads stay aligned
+        offs = np.zeros(len(arrs) + 1, np.int64)
+        for i, a in enumerate(arrs):
+            offs[i + 1] = offs[i] + a.size
+        flat = np.concatenate(arrs) if arrs else np.zeros(0, dt)
+        foffs = np.zeros(len(arrs) + 1, np.int64)
+        total = sum(self.num_frames(a.size, fp.hop) for a in arrs)
+        mel = np.empty((total, self.n_mel), np.float32)
+        fn = self._lib.ww_logmel_f32 if is_f32 else self._lib.ww_logmel
+        self._chk(fn(self.ctx.handle, self._model, _lib.ptr(flat), _lib.ptr(offs), len(arrs), C.byref(fp),
+                     _lib.ptr(mel), _lib.ptr(foffs)))
+        return [mel[foffs[i]:foffs[i + 1]] for i in range(len(arrs))]
+
+    def stft_mag(self, frames: np.ndarray, precise: bool = True) -> np.ndarray:
+        f = np.ascontiguousarray(frames, dtype=np.float32).reshape(-1, 512)
+        mag = np.empty((f.shape[0], self.n_bins), np.float32)
+        self._chk(self._lib.ww_stft_mag(self.ctx.handle, self._model, _lib.ptr(f), f.shape[0], int(precise), _lib.ptr(mag)))
+        return mag
+
+    # ------------------------------------------------------------------ models
+    def forward(self, windows: np.ndarray, want_enc: bool = False):
+        """``[B, window, 40]`` -> detect rows ``[B, n_out]`` (and encoder output)."""
+        w = np.ascontiguousarray(windows, dtype=np.float32)
+        if w.ndim == 2:
+            w = w[None]
+        if w.ndim != 3 or w.shape[1] != self.window or w.shape[2] != self.n_mel:
+            raise ValueError(f"Cannot set tensor: Dimension mismatch. Got {tuple(w.shape[1:])} but expected "
+                             f"{(self.window, self.n_mel)} per window")
+        out = np.empty((w.shape[0], self.n_out), np.float32)
+        enc = np.empty((w.shape[0],) + self.enc_shape, np.float32) if want_enc else None
+        self._chk(self._lib.ww_forward_enc(self.ctx.handle, self._model, _lib.ptr(w), w.shape[0], _lib.ptr(out), _lib.ptr(enc)))
+        return (out, enc) if want_enc else out
+
+    def slide_forward(self, mel: np.ndarray, hop: int = 2) -> np.ndarray:
+        m = np.ascontiguousarray(mel, dtype=np.float32)
+        if m.ndim != 2 or m.shape[1] != self.n_mel:
+            raise ValueError(f"mel must be [rows, {self.n_mel}]")
+        rows = m.shape[0]
+        nw = (rows - self.window) // hop + 1 if rows >= self.window else 0
+        out = np.empty((nw, self.n_out), np.float32)
+        got = C.c_int64(0)
+        self._chk(self._lib.ww_slide_forward(self.ctx.handle, self._model, _lib.ptr(m), rows, int(hop), _lib.ptr(out), C.byref(got)))
+        assert got.value == nw
+        return out
+
+    # ------------------------------------------------------------------ evaluator
+    def far_frr(self, pos: np.ndarray, neg: np.ndarray, thresholds: np.ndarray, num_wakewords: float, hours: float,
+                window: int = 30, want_smoothed: bool = False):
+        pos = np.ascontiguousarray(pos, dtype=np.float32).ravel()
+        neg = np.ascontiguousarray(neg, dtype=np.float32).ravel()
+        thr = np.ascontiguousarray(thresholds, dtype=np.float64).ravel()
+        frr = np.empty(thr.size, np.float64)
+        fa = np.empty(thr.size, np.float64)
+        cnt = np.empty(thr.size, np.int64)
+        sm = np.empty(neg.size, np.float64) if want_smoothed else None
+        self._chk(self._lib.ww_far_frr(self.ctx.handle, _lib.ptr(pos), pos.size, _lib.ptr(neg), neg.size, int(window),
+                                       _lib.ptr(thr), thr.size, float(num_wakewords), float(hours), _lib.ptr(frr),
+                                       _lib.ptr(fa), _lib.ptr(cnt), _lib.ptr(sm)))
+        return (frr, fa, cnt, sm) if want_smoothed else (frr, fa, cnt)
+
+    # ------------------------------------------------------------------ device-resident paths (torch plumbing)
+    def clips_forward_dev(self, d_pcm_ptr: int, n_clips: int, samples_per_clip: int, d_out_ptr: int,
+                          fp: Optional[_lib.FrontendParams] = None) -> None:
+        fp = fp or frontend_params()
+        self._chk(self._lib.ww_clips_forward_dev(self.ctx.handle, self._model, C.c_void_p(d_pcm_ptr), int(n_clips),
+                                                 int(samples_per_clip), C.byref(fp), C.c_void_p(d_out_ptr)))
+
+    def logmel_dev(self, d_pcm_ptr: int, d_sample_offs_ptr: int, d_frame_offs_ptr: int, n_utt: int, total_frames: int,
+                   max_frames: int, d_mel_ptr: int, fp: Optional[_lib.FrontendParams] = None) -> None:
+        fp = fp or frontend_params()
+        self._chk(self._lib.ww_logmel_dev(self.ctx.handle, self._model, C.c_void_p(d_pcm_ptr), C.c_void_p(d_sample_offs_ptr),
+                                          C.c_void_p(d_frame_offs_ptr), int(n_utt), int(total_frames), int(max_frames),
+                                          C.byref(fp), C.c_void_p(d_mel_ptr)))
+
+    def forward_windows_dev(self, d_mel_ptr: int, mel_rows: int, d_win_row_ptr: int, d_win_valid_ptr: int,
+                            n_windows: int, d_out_ptr: int) -> None:
+        self._chk(self._lib.ww_forward_windows_dev(self.ctx.handle, self._model, C.c_void_p(d_mel_ptr), int(mel_rows),
+                                                   C.c_void_p(d_win_row_ptr), C.c_void_p(d_win_valid_ptr), int(n_windows),
+                                                   C.c_void_p(d_out_ptr)))
+
+
+class StreamBank:
+    """S device-resident streams advanced 20 ms per :meth:`step` (``ww_stream_*``)."""
+
+    def __init__(self, engine: Engine, n_streams: int, fp: Optional[_lib.FrontendParams] = None) -> None:
+        self.engine = engine
+        self.S = int(n_streams)
+        self._lib = _lib.load()
+        fp = fp or frontend_params()
+        h = C.c_void_p()
+        _lib.raise_for(self._lib.ww_stream_create(engine.ctx.handle, engine.handle, self.S, C.byref(fp), C.byref(h)),
+                       engine.ctx.handle)
+        self._h = h
+        self._post = np.zeros((self.S, 2), np.float32)
+        self._n = np.zeros(self.S, np.int32)
+
+    def step(self, frames: np.ndarray, is_speech: np.ndarray, is_active: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
+        f = np.ascontiguousarray(frames, dtype=np.int16)
+        if f.shape != (self.S, 320):
+            raise ValueError(f"frames must be [{self.S}, 320] int16")
+        flags = np.ascontiguousarray(is_speech, dtype=np.uint8).ravel() & 1
+        if is_active is not None:
+            flags = flags | ((np.ascontiguousarray(is_active, dtype=np.uint8).ravel() & 1) << 1)
+        flags = np.ascontiguousarray(flags, dtype=np.uint8)
+        if flags.size != self.S:
+            raise ValueError("is_speech must have one entry per stream")
+        _lib.raise_for(self._lib.ww_stream_step(self._h, _lib.ptr(f), _lib.ptr(flags), _lib.ptr(self._post), _lib.ptr(self._n)),
+                       self.engine.ctx.handle)
+        return self._post, self._n
+
+    def reset(self, ids: Optional[Sequence[int]] = None) -> None:
+        if ids is None:
+            _lib.raise_for(self._lib.ww_stream_reset(self._h, None, 0), self.engine.ctx.handle)
+        else:
+            a = np.ascontiguousarray(ids, dtype=np.int32)
+            _lib.raise_for(self._lib.ww_stream_reset(self._h, _lib.ptr(a), a.size), self.engine.ctx.handle)
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.ww_stream_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
