@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio frames/s of the wake-word hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--model crnn|wavenet] [--clips 256]
+
+One step = one pass of the whole hot path over one batch of synthetic 16 kHz clips that is
+already resident in HBM: int16 PCM [clips, 24000] -> log-mel -> one zero-padded window per
+clip -> encode + detect -> posteriors [clips, n_out]   (BASELINE.json configs[1] for CRNN,
+configs[2] for Wavenet; 1 audio frame = one 10 ms hop = 160 samples, 150 per 1.5 s clip).
+
+N > 1: launched by torch.distributed.run, one rank per GPU; every rank owns its own shard of
+clips (weak scaling, no data-path collective).  The only exchange is the posterior gather
+(RCCL all_gather of the K*clips*n_out floats each rank produced), done once at the end of the
+timed region, as the offline evaluator would do after its shard is finished.
+
+Rank 0 prints ONE JSON line (schema in the task contract) including
+  roofline     - dominant kernel, measured with HIP events around every launch in a separate
+                 pass of the same K steps (ww_profile_enable), priced against the fp32 MFMA
+                 peak (157.3 TFLOP/s) or HBM (8 TB/s) - figures in DESIGN.md section 4
+  cpu_baseline - the C restatement in oracle/ (NOT TFLite) timed on this box's host cores on
+                 a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "wakeword-detection_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+SAMPLES = 24000          # 1.5 s @ 16 kHz
+FRAMES_PER_CLIP = 150    # audio frames (10 ms hops) per clip
+PEAK_F32_MFMA = 157.3e12  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, 256 CUs
+PEAK_HBM = 8.0e12
+
+
+def synth_pcm(rng, n_clips):
+    """Gaussian noise sigma=2000 LSB + linear chirp 200->4000 Hz at 8000 LSB."""
+    t = np.arange(SAMPLES) / 16000.0
+    phase = 2 * np.pi * (200.0 * t + 0.5 * (4000.0 - 200.0) / 1.5 * t * t)
+    x = rng.normal(0.0, 2000.0, (n_clips, SAMPLES)) + 8000.0 * np.sin(phase)[None, :]
+    return np.clip(np.rint(x), -32768, 32767).astype(np.int16)
+
+
+def kernel_flops(eng, n_clips):
+    """Algorithmic FLOPs (2*MAC) and HBM bytes per launch of each kernel for one step."""
+    nf = (SAMPLES - 512) // 160 + 1
+    out = {}
+    fe_bytes = n_clips * (SAMPLES * 2 + nf * 40 * 4)
+    fe_flops = n_clips * nf * 13.9e3
+    out["logmel_kernel<f64>"] = ("hbm", fe_bytes, fe_flops)
+    out["logmel_kernel<f32>"] = ("hbm", fe_bytes, fe_flops)
+    if eng.is_crnn:
+        c = eng.bundle.crnn
+        M = c.out_t * c.out_f
+        K = c.conv_w.shape[1] * c.conv_w.shape[2]
+        H = c.units
+        out["conv5x20_kernel"] = ("mfma", n_clips * (eng.window * 40 * 4 + M * 32 * 4), n_clips * 2.0 * M * K * 32)
+        out["gemm_nt_kernel<gru1>"] = ("mfma", n_clips * c.out_t * (M // c.out_t * 32 + 6 * H) * 4 + 6 * H * c.out_f * 32 * 4,
+                                       n_clips * 2.0 * c.out_t * (c.out_f * 32) * 6 * H)
+        out["gemm_nt_kernel<gru2>"] = ("mfma", n_clips * c.out_t * (2 * H + 6 * H) * 4, n_clips * 2.0 * c.out_t * 2 * H * 6 * H)
+        out["gru_kernel<seq>"] = ("latency", n_clips * c.out_t * (6 * H + 2 * H) * 4, n_clips * 2.0 * c.out_t * 2 * 3 * H * H)
+        out["gru_kernel<last+head>"] = ("latency", n_clips * c.out_t * 6 * H * 4,
+                                        n_clips * (2.0 * c.out_t * 2 * 3 * H * H + 2 * (64 * 64 + 64 * c.n_out)))
+    else:
+        w = eng.bundle.wavenet
+        macs = w.n_frames * (w.n_mel * w.channels) + sum(
+            w.n_frames * (3 * w.channels * 2 * w.channels + w.channels * ((w.channels if b.w_res is not None else 0) + w.skip_channels))
+            for b in w.blocks) + w.n_frames * (w.skip_channels * w.skip_channels + w.skip_channels * eng.n_out)
+        out["wavenet_kernel"] = ("mfma", n_clips * (eng.window * 40 * 4 + eng.n_out * 4), n_clips * 2.0 * macs)
+    return out
+
+
+def cpu_baseline(eng, pcm_sample, budget_s=12.0):
+    """Time the C restatement (oracle/ww_oracle.c, all host threads) on a bounded sample."""
+    from oracle import cpu as ocpu
+    ora = ocpu.CpuOracle(eng.blob)
+    threads = ocpu.num_threads()
+
+    def one_pass(clips):
+        wins = np.zeros((len(clips), eng.window, 40), np.float32)
+        for i, c in enumerate(clips):
+            mel = ora.logmel(c)
+            n = min(len(mel), eng.window)
+            wins[i, :n] = mel[:n]
+        return ora.forward(wins)
+
+    one_pass(pcm_sample[:threads])  # warm up (thread pool, tables)
+    t0 = time.perf_counter()
+    done = 0
+    n = len(pcm_sample)
+    while True:
+        one_pass(pcm_sample)
+        done += n
+        el = time.perf_counter() - t0
+        if el > budget_s or done >= 8 * n:
+            break
+    return {
+        "value": done * FRAMES_PER_CLIP / el,
+        "unit": "audio frames/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{done} clips x 1.5 s ({n}-clip sample of the same synthetic batch, repeated), "
+                  f"{el:.1f} s wall; C restatement oracle/ww_oracle.c with OpenMP over clips, NOT TFLite",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--model", choices=["crnn", "wavenet"], default="crnn")
+    ap.add_argument("--clips", type=int, default=256)
+    ap.add_argument("--rotate", type=int, default=24, help="distinct resident input batches to rotate over")
+    ap.add_argument("--fast-frontend", action="store_true", help="fp32 FFT instead of the reference's fp64")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; no CPU fallback exists for the hot path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from wwhip.engine import Engine, frontend_params
+    from wwhip import _lib
+    ctx = _lib.Context(local_rank)
+    model_dir = os.path.join(PKG, "assets", "tf_lite_models", "CRNN" if args.model == "crnn" else "Wavenet")
+    eng = Engine(model_dir, device=local_rank, ctx=ctx)
+    fp = frontend_params(32767.0, True, 0.0, 160, not args.fast_frontend)
+
+    # R distinct resident input batches, rotated step by step: R * 12.3 MB exceeds the 256 MiB
+    # Infinity Cache, so every step's PCM comes from HBM rather than from a cache-warm copy.
+    rng = np.random.default_rng(1000 + rank)
+    R = max(1, min(args.rotate, args.steps))
+    pcm0 = synth_pcm(rng, args.clips)
+    d_pcm = []
+    for r in range(R):
+        if r == 0:
+            d_pcm.append(torch.from_numpy(pcm0).cuda())
+        else:  # cheap decorrelated variants: roll + sign flip, generated on the device
+            d_pcm.append(torch.roll(d_pcm[0], shifts=37 * r, dims=1) * (1 if r % 2 == 0 else -1))
+    K = args.steps
+    d_outs = [torch.zeros((args.clips, eng.n_out), dtype=torch.float32, device="cuda") for _ in range(R)]
+    d_all = torch.zeros((K, args.clips, eng.n_out), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+
+    def step(k):
+        r = k % R
+        eng.clips_forward_dev(d_pcm[r].data_ptr(), args.clips, SAMPLES, d_outs[r].data_ptr(), fp)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(max(args.warmup, R)):  # at least one pass over every batch: graphs captured
+        step(k)
+    ctx.synchronize()
+    if dist is not None:  # warm up the communicator outside the timed region
+        tmp = [torch.empty_like(d_all) for _ in range(world)]
+        dist.all_gather(tmp, d_all)
+        del tmp
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(K):
+        step(k)
+    ctx.synchronize()
+    if dist is not None:
+        # posterior gather, once per job: every rank contributes the K*clips*n_out floats it produced
+        for k in range(K):
+            d_all[k] = d_outs[k % R]
+        gathered = [torch.empty_like(d_all) for _ in range(world)]
+        dist.all_gather(gathered, d_all)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- per-kernel pass (HIP events around every launch), same K steps
+    ctx.profile(True)
+    for k in range(K):
+        step(k)
+    prof = ctx.profile_read()
+    ctx.profile(False)
+    posts = d_outs[0].cpu().numpy()
+
+    if rank == 0:
+        total_frames = world * K * args.clips * FRAMES_PER_CLIP
+        kf = kernel_flops(eng, args.clips)
+        per_kernel = {}
+        dom, dom_ms = None, -1.0
+        for name, rec in prof.items():
+            avg = rec["total_ms"] / max(rec["calls"], 1)
+            per_kernel[name] = round(avg * 1e3, 3)  # microseconds
+            if name in kf and avg > dom_ms:
+                dom, dom_ms = name, avg
+        bound, nbytes, flops = kf[dom]
+        if bound == "hbm":
+            roof = {"bound": "hbm", "achieved": nbytes / (dom_ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s"}
+        else:
+            roof = {"bound": "mfma", "achieved": flops / (dom_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s"}
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["traffic"] = None
+        roof["kernel"] = dom
+        roof["kernel_avg_us"] = round(dom_ms * 1e3, 3)
+        roof["all_kernels_avg_us"] = per_kernel
+        roof["method"] = "HIP events around each launch (ww_profile_enable), K steps right after the timed region"
+        line = {
+            "metric": "audio frames/sec (16 kHz, 40-mel, 10 ms hop)",
+            "value": total_frames / elapsed,
+            "unit": "audio frames/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": (f"{'CRNN' if args.model == 'crnn' else 'Wavenet'} forward, batch={args.clips}x1.5 s synthetic "
+                             f"16 kHz clips per GPU, PCM resident in HBM -> log-mel ({'fp32' if args.fast_frontend else 'fp64'} FFT) "
+                             f"-> {eng.window}x40 window -> encode+detect, fp32"),
+                "clips_per_gpu": args.clips,
+                "samples_per_clip": SAMPLES,
+                "resident_input_batches_rotated": R,
+                "weights": "reference tf_lite_models (shipped fp32 weights)",
+                "parallelism": f"utterance-sharded x{world}, posterior all_gather once per job" if world > 1 else "single GPU",
+            },
+            "roofline": roof,
+            "posterior_checksum": float(np.sum(posts, dtype=np.float64)),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(eng, pcm0[:64])
+        elif not args.no_cpu_baseline:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -18,10 +18,9 @@ int ww_fail(ww_ctx *ctx, int code, const char *fmt, ...) {
 int ww_ensure(ww_ctx *ctx, ww_arena &a, size_t bytes, bool pinned) {
   if (bytes <= a.cap) return WW_OK;
   // growing invalidates pointers baked into a cached graph
-  if (!pinned && ctx->clip_graph.exec) {
+  if (!pinned && !ctx->clip_graphs.empty()) {
     hipStreamSynchronize(ctx->stream);
-    hipGraphExecDestroy(ctx->clip_graph.exec);
-    ctx->clip_graph.exec = nullptr;
+    ctx->drop_graphs(nullptr);
   }
   if (a.ptr) {
     hipStreamSynchronize(ctx->stream);
@@ -78,7 +77,7 @@ int ww_ctx_destroy(ww_ctx *ctx) {
   if (!ctx) return WW_OK;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
-  if (ctx->clip_graph.exec) hipGraphExecDestroy(ctx->clip_graph.exec);
+  ctx->drop_graphs(nullptr);
   for (auto &kv : ctx->prof)
     for (auto &p : kv.second.pending) {
       hipEventDestroy(p.first);
@@ -405,10 +404,7 @@ int ww_model_free(ww_model *m) {
   if (m->ctx) {
     hipSetDevice(m->ctx->device);
     hipStreamSynchronize(m->ctx->stream);
-    if (m->ctx->clip_graph.model == m && m->ctx->clip_graph.exec) {
-      hipGraphExecDestroy(m->ctx->clip_graph.exec);
-      m->ctx->clip_graph.exec = nullptr;
-    }
+    m->ctx->drop_graphs(m);
   }
   for (void *p : m->allocs) hipFree(p);
   delete m;
@@ -645,12 +641,14 @@ int ww_clips_forward_dev(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, i
   const size_t b_mel = ww_bump::need((size_t)n_clips * (nf > 0 ? nf : 1) * F, 4);
   const size_t b_ws = model_ws(m, n_clips);
   if ((rc = ww_ensure(ctx, ctx->dev, 2 * b_o + b_mel + b_ws + 1024, false))) return rc;
-  auto &cg = ctx->clip_graph;
-  const bool same = cg.exec && cg.model == m && cg.pcm == d_pcm && cg.out == d_out && cg.n_clips == n_clips &&
-                    cg.samples == samples && cg.ws == ctx->dev.ptr && memcmp(&cg.fp, fp, sizeof *fp) == 0;
-  if (same && !ctx->profiling) {
-    WW_HIP(ctx, hipGraphLaunch(cg.exec, ctx->stream));
-    return WW_OK;
+  if (!ctx->profiling) {
+    for (auto &cg : ctx->clip_graphs) {
+      if (cg.model == m && cg.pcm == d_pcm && cg.out == d_out && cg.n_clips == n_clips && cg.samples == samples &&
+          cg.ws == ctx->dev.ptr && memcmp(&cg.fp, fp, sizeof *fp) == 0) {
+        WW_HIP(ctx, hipGraphLaunch(cg.exec, ctx->stream));
+        return WW_OK;
+      }
+    }
   }
   auto enqueue = [&]() -> int {
     ww_bump bump(ctx->dev.ptr, ctx->dev.cap);
@@ -669,10 +667,11 @@ int ww_clips_forward_dev(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, i
                          n_clips, ws, d_out, nullptr);
   };
   if (ctx->profiling) return enqueue();
-  // capture the launch chain once, replay afterwards (the chain is launch-latency bound)
-  if (cg.exec) {
-    hipGraphExecDestroy(cg.exec);
-    cg.exec = nullptr;
+  // capture the launch chain once per distinct (input, output) pair, replay afterwards: the chain
+  // is launch-latency bound at these batch sizes
+  if (ctx->clip_graphs.size() >= 128) {
+    WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->drop_graphs(nullptr);
   }
   hipGraph_t graph = nullptr;
   WW_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
@@ -683,13 +682,12 @@ int ww_clips_forward_dev(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, i
     return rc;
   }
   if (e != hipSuccess) return ww_fail(ctx, WW_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+  ww_ctx::clip_graph_t cg;
   e = hipGraphInstantiate(&cg.exec, graph, nullptr, nullptr, 0);
   hipGraphDestroy(graph);
-  if (e != hipSuccess) {
-    cg.exec = nullptr;
-    return ww_fail(ctx, WW_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
-  }
+  if (e != hipSuccess) return ww_fail(ctx, WW_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
   cg.model = m; cg.pcm = d_pcm; cg.out = d_out; cg.n_clips = n_clips; cg.samples = samples; cg.fp = *fp; cg.ws = ctx->dev.ptr;
+  ctx->clip_graphs.push_back(cg);
   WW_HIP(ctx, hipGraphLaunch(cg.exec, ctx->stream));
   return WW_OK;
 }

@@ -38,8 +38,8 @@ struct ww_ctx {
   bool profiling = false;
   std::map<std::string, ww_prof_entry> prof;
   hipEvent_t t0 = nullptr, t1 = nullptr;
-  // cached graph for ww_clips_forward_dev
-  struct {
+  // cached graphs for ww_clips_forward_dev, keyed by every pointer/size baked into them
+  struct clip_graph_t {
     hipGraphExec_t exec = nullptr;
     const void *model = nullptr;
     const void *pcm = nullptr;
@@ -47,7 +47,18 @@ struct ww_ctx {
     int n_clips = 0, samples = 0;
     ww_frontend_params fp = {};
     void *ws = nullptr;
-  } clip_graph;
+  };
+  std::vector<clip_graph_t> clip_graphs;
+  void drop_graphs(const void *model_or_null) {
+    for (size_t i = 0; i < clip_graphs.size();) {
+      if (!model_or_null || clip_graphs[i].model == model_or_null) {
+        hipGraphExecDestroy(clip_graphs[i].exec);
+        clip_graphs.erase(clip_graphs.begin() + i);
+      } else {
+        ++i;
+      }
+    }
+  }
 };
 
 // Device-resident mel filterbank in banded form: band m covers bins [start[m], start[m]+len[m])
