@@ -217,6 +217,12 @@ static int load_filter(ww_ctx *ctx, ww_model *m, const blob_view &bv) {
     if (len[i] > f.max_len) f.max_len = len[i];
   }
   f.total_taps = (int)taps.size();
+  const int MEL_TAPS = 36;  // WW_MEL_TAPS in fft_device.h
+  if (f.max_len > MEL_TAPS)
+    return ww_fail(ctx, WW_EBLOB, "mel band of %d taps exceeds the kernel limit of %d", f.max_len, MEL_TAPS);
+  std::vector<float> wpad((size_t)MEL_TAPS * 64, 0.f);
+  for (int i = 0; i < n_mel; ++i)
+    for (int k = 0; k < len[i]; ++k) wpad[(size_t)k * 64 + i] = taps[woff[i] + k];
   std::vector<float> bias(b, b + n_mel);
   std::vector<double> hann(WW_FFT_WINDOW), tw256(512), tw512(512);
   for (int n = 0; n < WW_FFT_WINDOW; ++n) hann[n] = 0.5 - 0.5 * cos(2.0 * M_PI * (double)n / (double)(WW_FFT_WINDOW - 1));
@@ -226,10 +232,43 @@ static int load_filter(ww_ctx *ctx, ww_model *m, const blob_view &bv) {
     tw512[2 * k] = cos(-2.0 * M_PI * k / 512.0);
     tw512[2 * k + 1] = sin(-2.0 * M_PI * k / 512.0);
   }
+  std::vector<double> tw16(512);
+  for (int k1 = 0; k1 < 16; ++k1)
+    for (int jj = 0; jj < 16; ++jj) {
+      tw16[2 * (k1 * 16 + jj)] = cos(-2.0 * M_PI * (double)(jj * k1) / 256.0);
+      tw16[2 * (k1 * 16 + jj) + 1] = sin(-2.0 * M_PI * (double)(jj * k1) / 256.0);
+    }
+  f.tw16 = upload(m, tw16);
+  // mel filter as MFMA B operands (v_mfma_f32_16x16x4_f32: lane (col = l&15, kk = l>>4) holds
+  // B[k = 16 kb + 4 kk + q][col], q = 0..3 as one float4).  Tile nt = bands 16nt..16nt+15; only the
+  // 16-bin blocks that contain a non-zero weight of the tile are stored.
+  f.mel_tiles = (n_mel + 15) / 16;
+  std::vector<float> melB;
+  for (int nt = 0; nt < f.mel_tiles; ++nt) {
+    int lo = 1 << 30, hi = -1;
+    for (int b = nt * 16; b < n_mel && b < nt * 16 + 16; ++b)
+      if (len[b] > 0) {
+        lo = start[b] < lo ? start[b] : lo;
+        hi = start[b] + len[b] - 1 > hi ? start[b] + len[b] - 1 : hi;
+      }
+    if (hi < 0) { lo = 0; hi = 0; }
+    for (int kb = lo / 16; kb <= hi / 16; ++kb) {
+      if (f.mel_entries >= 64) return ww_fail(ctx, WW_EBLOB, "mel filterbank too dense for the MFMA form");
+      f.mel_ent_tile[f.mel_entries] = nt;
+      f.mel_ent_kb[f.mel_entries] = kb;
+      ++f.mel_entries;
+      for (int lane_ = 0; lane_ < 64; ++lane_)
+        for (int q = 0; q < 4; ++q) {
+          const int col = lane_ & 15, kk = lane_ >> 4, k = 16 * kb + 4 * kk + q, band = nt * 16 + col;
+          melB.push_back(band < n_mel && k < n_bins ? w[(size_t)band * n_bins + k] : 0.f);
+        }
+    }
+  }
+  f.melB = upload(m, melB);
   f.start = upload(m, start); f.len = upload(m, len); f.woff = upload(m, woff);
-  f.w = upload(m, taps); f.bias = upload(m, bias);
+  f.w = upload(m, taps); f.bias = upload(m, bias); f.wpad = upload(m, wpad);
   f.hann = upload(m, hann); f.tw256 = upload(m, tw256); f.tw512 = upload(m, tw512);
-  if (!f.start || !f.len || !f.woff || !f.w || !f.bias || !f.hann || !f.tw256 || !f.tw512)
+  if (!f.tw16 || !f.melB || !f.start || !f.len || !f.woff || !f.w || !f.bias || !f.wpad || !f.hann || !f.tw256 || !f.tw512)
     return ww_fail(ctx, WW_ENOMEM, "filter upload failed");
   return WW_OK;
 }

@@ -68,10 +68,15 @@ struct ww_filter_dev {
   float floor_v = 0, log_off = 0, scale = 0;
   int *start = nullptr, *len = nullptr, *woff = nullptr;
   float *w = nullptr, *bias = nullptr;
+  float *wpad = nullptr;     // [WW_MEL_TAPS][64] tap-major zero-padded weights (kernel form)
   int total_taps = 0, max_len = 0;
   double *hann = nullptr;    // [512] np.hanning(512) in fp64
   double *tw256 = nullptr;   // [256][2] e^{-2 pi i k / 256}
   double *tw512 = nullptr;   // [256][2] e^{-2 pi i k / 512}
+  double *tw16 = nullptr;    // [16 k1][16 j][2] e^{-2 pi i j k1 / 256}
+  float *melB = nullptr;     // mel filter as MFMA B operands: [kb][64 lanes][4]
+  int mel_tiles = 0, mel_entries = 0;
+  int mel_ent_tile[64] = {0}, mel_ent_kb[64] = {0};  // entry e of melB -> (band tile, 16-bin block)
 };
 
 struct ww_crnn_dev {

@@ -3,22 +3,30 @@
 // Replaces the reference's per-sample RingBuffer loop, np.fft.rfft and the filter.tflite
 // invoke (utils/tf_lite/filter.py:38-75; spokestack/wakeword/tflite.py:148-191).
 //
-// Kernel shape: one 256-thread workgroup (4 wavefronts) owns FPB=16 consecutive frames of
-// one utterance.  The 512+15*160 samples those frames touch are loaded ONCE with coalesced
-// 16-byte loads into LDS (raw int16, or fp32 for the float entry point); every frame is then
-// produced by one wavefront: Hann product + a 256-point complex radix-4 Stockham FFT (each
-// lane owns one radix-4 butterfly per stage, exchanging through a per-wave LDS buffer),
-// the real-FFT untangling pass, |.|, the banded mel filter (one lane per band) and the
-// log/affine tail.  The 16x40 mel tile leaves through LDS as coalesced float4 stores.
+// Kernel shape: one 256-thread workgroup (4 wavefronts) owns FPB consecutive frames of one
+// utterance.  The 512+(FPB-1)*160 samples those frames touch are loaded ONCE with aligned
+// 16-byte loads, normalised / clipped / pre-emphasised in registers and parked in LDS as
+// fp32.  Every frame is then produced by one wavefront (fft_device.h): Hann product (fp64) +
+// 256-point complex radix-4 Stockham FFT + untangling pass + |.|, then the banded mel filter
+// with one lane per band (weights zero-padded to the longest band and stored tap-major in LDS,
+// so the 36-tap loop is fully unrolled and conflict-free) and the log/affine tail.  The
+// FPBx40 mel tile leaves through LDS as one contiguous coalesced store.
 //
-// REAL = double reproduces the reference numerics (the Hann product and FFT run in float64,
-// spokestack/wakeword/tflite.py:175-176, then cast to float32); REAL = float is the fast mode.
+// REAL = double reproduces the reference numerics (Hann product and FFT in float64,
+// spokestack/wakeword/tflite.py:175-176, result cast to float32); REAL = float is the fast mode.
 #include "common.h"
 
 #include "fft_device.h"
 
-#define FPB 16            // frames per block
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef FPB
+#define FPB 16  // frames per block
+#endif
 #define WAVES 4
+#define MEL_PER_WAVE 6
+#define MEL_MAX_ENT (WAVES * MEL_PER_WAVE)
+static_assert(FPB == WAVES * 4, "each wave transforms exactly one group of 4 frames (mags overlay the transposes)");
 
 struct logmel_args {
   const int16_t *pcm;
@@ -31,11 +39,15 @@ struct logmel_args {
   int clip;
   float preemph;
   // filter
-  const int *start, *len, *woff;
-  const float *w, *bias;
-  int n_mel, total_taps;
+  const int *start;
+  const float *wpad;  // [WW_MEL_TAPS][64] tap-major, zero padded
+  const float *bias;
+  int n_mel;
   float floor_v, log_off, scale;
-  const double *hann, *tw256, *tw512;
+  const double *hann, *tw256, *tw512, *tw16;
+  const float *melB;           // MFMA B operands of the mel filter: [kb][64 lanes] float4
+  int mel_tiles, mel_entries;
+  signed char mel_ent_tile[MEL_MAX_ENT], mel_ent_kb[MEL_MAX_ENT];  // entry e -> (band tile, 16-bin block)
   float *mel;
   // stft-only mode
   const float *frames;
@@ -43,10 +55,66 @@ struct logmel_args {
   int64_t n_frames_direct;
 };
 
+template <bool F32IN>
+__device__ __forceinline__ float norm_sample(const logmel_args &a, int64_t g) {
+  if (F32IN) return a.f32[g];
+  float v = __fdiv_rn((float)a.pcm[g], a.divisor);  // reference: frame.astype(f32) / 32767
+  if (a.clip) v = fminf(fmaxf(v, -1.0f), 1.0f);
+  return v;
+}
+
+// ---- radix-16 DFT in registers ------------------------------------------------------------
+template <typename R>
+__device__ __forceinline__ void radix4(cplx<R> &a0, cplx<R> &a1, cplx<R> &a2, cplx<R> &a3) {
+  const cplx<R> t0 = {a0.re + a2.re, a0.im + a2.im}, t1 = {a0.re - a2.re, a0.im - a2.im};
+  const cplx<R> t2 = {a1.re + a3.re, a1.im + a3.im}, t3 = {a1.im - a3.im, -(a1.re - a3.re)};  // (a1-a3)*(-i)
+  a0 = {t0.re + t2.re, t0.im + t2.im};
+  a1 = {t1.re + t3.re, t1.im + t3.im};
+  a2 = {t0.re - t2.re, t0.im - t2.im};
+  a3 = {t1.re - t3.re, t1.im - t3.im};
+}
+
+template <typename R>
+__device__ __forceinline__ cplx<R> mulc(cplx<R> a, R wr, R wi) {
+  return {a.re * wr - a.im * wi, a.re * wi + a.im * wr};
+}
+
+// Forward 16-point DFT, in place.  Input a[n]; output A[k] is left at position 4*(k%4) + k/4.
+template <typename R>
+__device__ __forceinline__ void dft16(cplx<R> (&a)[16]) {
+  constexpr R C = (R)0.92387953251128675613, S = (R)0.38268343236508977173, H = (R)0.70710678118654752440;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) radix4(a[q], a[q + 4], a[q + 8], a[q + 12]);
+  // a[q + 4p] *= W16^(q p),  W16^m = (cos(2 pi m/16), -sin(2 pi m/16))
+  a[5] = mulc(a[5], C, -S);   a[9] = mulc(a[9], H, -H);                        a[13] = mulc(a[13], S, -C);
+  a[6] = mulc(a[6], H, -H);   a[10] = cplx<R>{a[10].im, -a[10].re};            a[14] = mulc(a[14], -H, -H);
+  a[7] = mulc(a[7], S, -C);   a[11] = mulc(a[11], -H, -H);                     a[15] = mulc(a[15], -C, S);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) radix4(a[4 * p], a[4 * p + 1], a[4 * p + 2], a[4 * p + 3]);
+}
+
+__host__ __device__ constexpr int k_of(int pos) { return (pos >> 2) + 4 * (pos & 3); }
+__host__ __device__ constexpr int pos_of(int k) { return 4 * (k & 3) + (k >> 2); }
+
+template <typename R> __device__ __forceinline__ R shfl_r(R v, int src);
+template <> __device__ __forceinline__ float shfl_r<float>(float v, int src) { return __shfl(v, src); }
+template <> __device__ __forceinline__ double shfl_r<double>(double v, int src) { return __shfl(v, src); }
+
+#define MAG_LD 276  // floats per frame of magnitudes: 257 + zero pad to 17*16, stride = 20 mod 64
+#define TR_LD 17    // padded row of the 16x16 transpose
+
+template <typename R>
+__host__ __device__ constexpr int wbuf_bytes() {
+  // per-wave scratch: 16x16 transposes of 4 frames, later the 4 frames' magnitudes.
+  // Size in floats must be 16 mod 64 so that the 16 frames of a block start on distinct banks.
+  return sizeof(R) == 8 ? (4 * 16 * TR_LD * 8 + 64) : (4 * MAG_LD * 4);
+}
+
 template <typename R, bool F32IN>
 __global__ __launch_bounds__(256) void logmel_kernel(logmel_args a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, sub = lane >> 4;
   const int u = blockIdx.y;
   const int64_t s_begin = a.sample_offs[u], s_end = a.sample_offs[u + 1];
   const int64_t n_samples = s_end - s_begin;
@@ -56,97 +124,195 @@ __global__ __launch_bounds__(256) void logmel_kernel(logmel_args a) {
   const int nfb = (int)((nf - f0) < FPB ? (nf - f0) : FPB);
 
   // ---- LDS carve-up
-  constexpr int ELT = F32IN ? 4 : 2;
   size_t off = 0;
-  cplx<R> *tw256 = (cplx<R> *)(smem + off); off += 256 * sizeof(cplx<R>);
-  cplx<R> *tw512 = (cplx<R> *)(smem + off); off += 256 * sizeof(cplx<R>);
-  cplx<R> *fbuf = (cplx<R> *)(smem + off); off += WAVES * 256 * sizeof(cplx<R>);
-  float *mag = (float *)(smem + off); off += WAVES * 260 * sizeof(float);
-  float *mel_tile = (float *)(smem + off); off += FPB * 40 * sizeof(float);
-  float *fw = (float *)(smem + off); off += ((a.total_taps + 3) & ~3) * sizeof(float);
-  int *fmeta = (int *)(smem + off); off += 3 * 64 * sizeof(int);
-  unsigned char *tile = smem + off;  // [tile_cap + 16] elements of ELT bytes
+  double2 *tb_hann = (double2 *)(smem + off); off += 256 * sizeof(double2);
+  cplx<R> *tb_tw = (cplx<R> *)(smem + off); off += 256 * sizeof(cplx<R>);   // [k1][j] = W256^(j k1)
+  cplx<R> *tb_un = (cplx<R> *)(smem + off); off += 256 * sizeof(cplx<R>);   // W512^k
+  unsigned char *wbuf = smem + off; off += WAVES * wbuf_bytes<R>();
+  float *tile = (float *)(smem + off);  // fp32 samples, [WIN + (FPB-1)*hop + 16]
 
   for (int i = tid; i < 256; i += 256) {
-    tw256[i] = {(R)a.tw256[2 * i], (R)a.tw256[2 * i + 1]};
-    tw512[i] = {(R)a.tw512[2 * i], (R)a.tw512[2 * i + 1]};
-  }
-  for (int i = tid; i < a.total_taps; i += 256) fw[i] = a.w[i];
-  if (tid < a.n_mel) {
-    fmeta[tid] = a.start[tid];
-    fmeta[64 + tid] = a.len[tid];
-    fmeta[128 + tid] = a.woff[tid];
+    tb_hann[i] = *(const double2 *)(a.hann + 2 * i);
+    tb_tw[i] = {(R)a.tw16[2 * i], (R)a.tw16[2 * i + 1]};
+    tb_un[i] = {(R)a.tw512[2 * i], (R)a.tw512[2 * i + 1]};
   }
 
-  // ---- stage the sample tile: element 0 of the tile is the sample BEFORE the first one of
-  // frame f0 (pre-emphasis halo; zero at the start of an utterance).
+  // mel B operands of this wave's (tile, block) entries: issued now, consumed after the FFT
+  float4 melb[MEL_PER_WAVE];
+#pragma unroll
+  for (int i = 0; i < MEL_PER_WAVE; ++i) {
+    const int e = wave + WAVES * i;
+    melb[i] = e < a.mel_entries ? ((const float4 *)a.melB)[(size_t)e * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  // ---- stage the sample tile: aligned 16-byte global loads; tile[i + shift] = x[g_first + i]
+  constexpr int VEC = F32IN ? 4 : 8;                      // elements per 16-byte load
   const int64_t g_first = s_begin + f0 * a.hop;           // first sample of frame f0
   const int n_need = WIN + (nfb - 1) * a.hop;             // samples used by this block
-  const int64_t g_lo = g_first - 1;                       // halo sample (may be < s_begin)
-  constexpr int VEC = 16 / ELT;                           // elements per 16-byte load
-  // tile slot i + shift holds global sample g_lo + i; the tile starts on a 16-byte boundary
-  // of the global buffer so that every lane issues aligned 16-byte loads.
-  const int shift = (int)(((g_lo % VEC) + VEC) % VEC);
+  const int shift = (int)(g_first % VEC);
   {
-    const int64_t ga = g_lo - shift;                      // multiple of VEC (may be -VEC)
-    const int n_vec = (shift + n_need + 1 + VEC - 1) / VEC;
+    const int64_t ga = g_first - shift;                   // multiple of VEC, >= 0
+    const int n_vec = (shift + n_need + VEC - 1) / VEC;
     const int64_t total = a.sample_offs[a.n_utt];
+    const float alpha = a.preemph;
     for (int q = tid; q < n_vec; q += 256) {
       const int64_t g = ga + (int64_t)q * VEC;
-      uint4 v = {0u, 0u, 0u, 0u};
-      if (g >= 0 && g + VEC <= total) {
-        v = F32IN ? *(const uint4 *)(a.f32 + g) : *(const uint4 *)(a.pcm + g);
-      } else {
-        unsigned char *pv = (unsigned char *)&v;
-        for (int e = 0; e < VEC; ++e) {
-          const int64_t ge = g + e;
-          if (ge >= 0 && ge < total) {
-            if (F32IN) ((float *)pv)[e] = a.f32[ge];
-            else ((int16_t *)pv)[e] = a.pcm[ge];
+      float v[VEC + 1];
+      // v[0] = sample g-1 (pre-emphasis carry; 0 at the start of the utterance)
+      v[0] = (alpha != 0.0f && g - 1 >= s_begin) ? norm_sample<F32IN>(a, g - 1) : 0.0f;
+      if (g + VEC <= total) {
+        if (F32IN) {
+          const float4 raw = *(const float4 *)(a.f32 + g);
+          v[1] = raw.x; v[2] = raw.y; v[3] = raw.z; v[4] = raw.w;
+        } else {
+          const uint4 raw = *(const uint4 *)(a.pcm + g);
+          const unsigned int w32[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int16_t s16 = (int16_t)((w32[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+            float f = __fdiv_rn((float)s16, a.divisor);
+            if (a.clip) f = fminf(fmaxf(f, -1.0f), 1.0f);
+            v[1 + e] = f;
           }
         }
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[1 + e] = (g + e < total) ? norm_sample<F32IN>(a, g + e) : 0.0f;
       }
-      *(uint4 *)(tile + (size_t)q * 16) = v;
+      float o[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        // reference: frame -= pre_emphasis * previous  (separate fp32 multiply and subtract).
+        // Slots in front of the utterance start are never read by a frame of this utterance,
+        // except that sample s_begin itself must see a zero carry (v[0] above / guard here).
+        const bool at_start = (g + e == s_begin);
+        const float prev = at_start ? 0.0f : v[e];
+        o[e] = (alpha != 0.0f) ? __fsub_rn(v[1 + e], __fmul_rn(alpha, prev)) : v[1 + e];
+      }
+      float4 *dst = (float4 *)(tile + (size_t)q * VEC);
+      dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+      if (VEC == 8) dst[1] = make_float4(o[4], o[5], o[6], o[7]);
     }
-  }
-  __syncthreads();
-  if (tid == 0 && g_lo < s_begin) {                       // utterance start: carry-in is zero
-    if (F32IN) ((float *)tile)[shift] = 0.0f;
-    else ((int16_t *)tile)[shift] = 0;
   }
   __syncthreads();
 
-  const float alpha = a.preemph;
-  cplx<R> *buf = fbuf + wave * 256;
-  float *mg = mag + wave * 260;
-  for (int f = wave; f < nfb; f += WAVES) {
-    const int base = shift + 1 + f * a.hop;  // tile index of the frame's first sample
-    auto x = [&](int i) -> float {
-      float cur = load_sample<R, F32IN>(tile, base + i, a.divisor, a.clip);
-      if (alpha != 0.0f) {
-        float prev = load_sample<R, F32IN>(tile, base + i - 1, a.divisor, a.clip);
-        // reference: frame -= pre_emphasis * prev  (separate fp32 multiply and subtract)
-        cur = __fsub_rn(cur, __fmul_rn(alpha, prev));
-      }
-      return cur;
-    };
-    frame_fft_mag<R>(x, a.hann, tw256, tw512, buf, mg, lane);
-    // ---- banded mel filter + log tail, one lane per band
-    if (lane < a.n_mel) {
-      const int st = fmeta[lane], ln = fmeta[64 + lane], wo = fmeta[128 + lane];
-      float acc = 0.0f;
-      for (int i = 0; i < ln; ++i) acc = fmaf(fw[wo + i], mg[st + i], acc);
-      acc += a.bias[lane];
-      acc = fmaxf(acc, a.floor_v);
-      mel_tile[f * 40 + lane] = (logf(acc) + a.log_off) * a.scale;
+  // ---- FFT: every 16-lane row of a wave owns one frame (4 frames per wave at a time)
+  R *tr = (R *)(wbuf + (size_t)wave * wbuf_bytes<R>());        // [4][16][TR_LD]
+  float *mg = (float *)(wbuf + (size_t)wave * wbuf_bytes<R>());  // overlay: [4][MAG_LD]
+  for (int fb = wave * 4; fb < nfb; fb += WAVES * 4) {
+    int f = fb + sub;
+    f = f < nfb ? f : nfb - 1;  // surplus rows recompute the last frame (results unused)
+    const float *src = tile + shift + f * a.hop;
+    cplx<R> v[16];
+    // pass 1: lane j holds z[16 n1 + j], n1 = 0..15; Hann product in fp64 (tflite.py:175)
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+      const int n = 16 * n1 + j;
+      const double2 h = tb_hann[n];
+      v[n1].re = (R)((double)src[2 * n] * h.x);
+      v[n1].im = (R)((double)src[2 * n + 1] * h.y);
     }
+    dft16<R>(v);
+#pragma unroll
+    for (int pos = 1; pos < 16; ++pos) v[pos] = cmul(v[pos], tb_tw[k_of(pos) * 16 + j]);
+    // 16x16 transpose through LDS, real parts then imaginary parts (same buffer)
+    cplx<R> w[16];
+    R *trs = tr + sub * 16 * TR_LD;
+#pragma unroll
+    for (int pos = 0; pos < 16; ++pos) trs[k_of(pos) * TR_LD + j] = v[pos].re;
     wave_sync();
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) w[n2].re = trs[j * TR_LD + n2];
+    wave_sync();
+#pragma unroll
+    for (int pos = 0; pos < 16; ++pos) trs[k_of(pos) * TR_LD + j] = v[pos].im;
+    wave_sync();
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) w[n2].im = trs[j * TR_LD + n2];
+    wave_sync();
+    // pass 2: lane j = k1 holds Y[n2][k1]; output w[pos] = Z[k1 + 16 k_of(pos)]
+    dft16<R>(w);
+    // untangle X[k] = E + W512^k O with E,O from Z[k], conj Z[256-k]; partner Z[256-k] lives in
+    // lane (16-k1)%16 at k2' = 15-k2 (k1 > 0) or in the same lane at k2' = (16-k2)%16 (k1 = 0)
+    const int src_lane = (lane & 48) | ((16 - j) & 15);
+    float *mrow = mg + sub * MAG_LD;
+#pragma unroll
+    for (int pos = 0; pos < 16; ++pos) {
+      constexpr int dummy = 0; (void)dummy;
+      const int k2 = k_of(pos);
+      const cplx<R> own = w[pos];
+      const cplx<R> cand_a = w[pos_of(15 - k2)], cand_b = w[pos_of((16 - k2) & 15)];
+      cplx<R> send = {j == 0 ? cand_b.re : cand_a.re, j == 0 ? cand_b.im : cand_a.im};
+      cplx<R> pz = {shfl_r<R>(send.re, src_lane), shfl_r<R>(send.im, src_lane)};
+      const cplx<R> un = tb_un[j + 16 * k2];
+      // b = conj(pz)
+      const R er = (R)0.5 * (own.re + pz.re), ei = (R)0.5 * (own.im - pz.im);
+      const R orr = (R)0.5 * (own.im + pz.im), oi = (R)-0.5 * (own.re - pz.re);
+      const R re = er + orr * un.re - oi * un.im;
+      const R im = ei + orr * un.im + oi * un.re;
+      mrow[j + 16 * k2] = __fsqrt_rn((float)(re * re + im * im));
+    }
+    {
+      // k = 256: X = Re(Z0) - Im(Z0) (lane 0 holds Z[0] at pos 0); bins 257..271 are zero padding
+      const R d = w[0].re - w[0].im;
+      mrow[256 + j] = j == 0 ? __fsqrt_rn((float)(d * d)) : 0.0f;
+    }
   }
   __syncthreads();
-  // ---- coalesced store of the mel tile
-  float *dst = a.mel + (a.frame_offs[u] + f0) * (int64_t)a.n_mel;
-  const int n_out = nfb * a.n_mel;
-  for (int i = tid; i < n_out; i += 256) dst[i] = mel_tile[i];
+
+  // ---- mel filterbank as an MFMA contraction over the 16 frames of the block:
+  //   mel[frame][band] = sum_k mag[frame][k] W[band][k].  Band tile nt = bands 16nt..16nt+15 only
+  //   touches the 16-bin blocks that hold its non-zero weights; the (tile, block) pairs are dealt
+  //   round-robin to the 4 waves (B operands were prefetched before the FFT), partial sums meet in
+  //   LDS (overlaying the dead sample tile) and wave nt finishes tile nt.
+  f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  {
+    const int fr = j;  // A-operand row = frame
+    const float *arow = (const float *)(wbuf + (size_t)(fr >> 2) * wbuf_bytes<R>()) + (fr & 3) * MAG_LD + (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < MEL_PER_WAVE; ++i) {
+      const int e = wave + WAVES * i;
+      if (e < a.mel_entries) {
+        const int nt = a.mel_ent_tile[e], kb = a.mel_ent_kb[e];
+        const float4 av = *(const float4 *)(arow + kb * 16);
+        const float4 bv = melb[i];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+          if (t == nt) {
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[t], 0, 0, 0);
+          }
+      }
+    }
+  }
+  f32x4 *part = (f32x4 *)tile;  // [wave][tile][lane]
+#pragma unroll
+  for (int t = 0; t < 3; ++t) part[(wave * 3 + t) * 64 + lane] = acc[t];
+  __syncthreads();
+  if (wave < a.mel_tiles) {
+    const int nt = wave;
+    f32x4 sum = part[(0 * 3 + nt) * 64 + lane];
+#pragma unroll
+    for (int w2 = 1; w2 < WAVES; ++w2) {
+      const f32x4 p = part[(w2 * 3 + nt) * 64 + lane];
+      sum[0] += p[0]; sum[1] += p[1]; sum[2] += p[2]; sum[3] += p[3];
+    }
+    const int band = nt * 16 + j;
+    if (band < a.n_mel) {
+      const float bias = a.bias[band];
+      float *dst = a.mel + (a.frame_offs[u] + f0) * (int64_t)a.n_mel + band;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int frame = (lane >> 4) * 4 + r;
+        if (frame < nfb) {
+          float v = fmaxf(sum[r] + bias, a.floor_v);
+          dst[(int64_t)frame * a.n_mel] = (logf(v) + a.log_off) * a.scale;
+        }
+      }
+    }
+  }
 }
 
 // STFT magnitude of explicit frames [n][512] -> [n][257]; one wave per frame.
@@ -154,53 +320,52 @@ template <typename R>
 __global__ __launch_bounds__(256) void stft_mag_kernel(logmel_args a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  size_t off = 0;
-  cplx<R> *tw256 = (cplx<R> *)(smem + off); off += 256 * sizeof(cplx<R>);
-  cplx<R> *tw512 = (cplx<R> *)(smem + off); off += 256 * sizeof(cplx<R>);
-  cplx<R> *fbuf = (cplx<R> *)(smem + off); off += WAVES * 256 * sizeof(cplx<R>);
-  float *mag = (float *)(smem + off);
-  for (int i = tid; i < 256; i += 256) {
-    tw256[i] = {(R)a.tw256[2 * i], (R)a.tw256[2 * i + 1]};
-    tw512[i] = {(R)a.tw512[2 * i], (R)a.tw512[2 * i + 1]};
-  }
-  __syncthreads();
+  cplx<R> *fbuf = (cplx<R> *)smem;
+  float *mag = (float *)(smem + WAVES * FFT_LD * sizeof(cplx<R>));
+  fft_consts<R> fc;
+  fft_load_consts<R>(fc, lane, a.hann, a.tw256, a.tw512);
   const int64_t f = (int64_t)blockIdx.x * WAVES + wave;
   if (f >= a.n_frames_direct) return;
   const float *src = a.frames + f * WIN;
-  auto x = [&](int i) -> float { return src[i]; };
+  auto x2 = [&](int n) -> float2 { return *(const float2 *)(src + 2 * n); };
   float *mg = mag + wave * 260;
-  frame_fft_mag<R>(x, a.hann, tw256, tw512, fbuf + wave * 256, mg, lane);
+  frame_fft_mag<R>(x2, fc, fbuf + wave * FFT_LD, mg, lane);
   float *dst = a.mag_out + f * NB;
   for (int k = lane; k < NB; k += 64) dst[k] = mg[k];
 }
 
 template <typename R>
-static size_t logmel_smem(int hop, int total_taps, bool f32in) {
+static size_t logmel_smem(int hop) {
   size_t off = 0;
-  off += 256 * sizeof(cplx<R>) * 2;
-  off += WAVES * 256 * sizeof(cplx<R>);
-  off += WAVES * 260 * sizeof(float);
-  off += FPB * 40 * sizeof(float);
-  off += ((total_taps + 3) & ~3) * sizeof(float);
-  off += 3 * 64 * sizeof(int);
-  off += (size_t)(WIN + (FPB - 1) * hop + 1 + 16) * (f32in ? 4 : 2);
+  off += 256 * sizeof(double2);
+  off += 2 * 256 * sizeof(cplx<R>);
+  off += WAVES * wbuf_bytes<R>();
+  size_t tile_b = (size_t)(WIN + (FPB - 1) * hop + 16) * 4;
+  if (tile_b < WAVES * 3 * 64 * 16) tile_b = WAVES * 3 * 64 * 16;  // the mel partial sums overlay the tile
+  off += tile_b;
   return (off + 15) & ~size_t(15);
 }
 
 static void fill_filter_args(logmel_args &a, const ww_model *m) {
   const ww_filter_dev &f = m->filt;
-  a.start = f.start; a.len = f.len; a.woff = f.woff; a.w = f.w; a.bias = f.bias;
-  a.n_mel = f.n_mel; a.total_taps = f.total_taps;
+  a.start = f.start; a.wpad = f.wpad; a.bias = f.bias;
+  a.n_mel = f.n_mel;
   a.floor_v = f.floor_v; a.log_off = f.log_off; a.scale = f.scale;
-  a.hann = f.hann; a.tw256 = f.tw256; a.tw512 = f.tw512;
+  a.hann = f.hann; a.tw256 = f.tw256; a.tw512 = f.tw512; a.tw16 = f.tw16;
+  a.melB = f.melB; a.mel_tiles = f.mel_tiles; a.mel_entries = f.mel_entries;
+  for (int i = 0; i < MEL_MAX_ENT; ++i) {
+    a.mel_ent_tile[i] = i < f.mel_entries ? (signed char)f.mel_ent_tile[i] : 0;
+    a.mel_ent_kb[i] = i < f.mel_entries ? (signed char)f.mel_ent_kb[i] : 0;
+  }
 }
 
 int ww_k_logmel(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, const float *d_f32, const int64_t *d_sample_offs,
                 const int64_t *d_frame_offs, int n_utt, int64_t total_frames, int64_t max_frames_per_utt,
                 const ww_frontend_params *fp, float *d_mel) {
   if (n_utt <= 0 || total_frames <= 0 || max_frames_per_utt <= 0) return WW_OK;
-  if (m->filt.n_mel > 40 || m->filt.n_bins != NB) return ww_fail(ctx, WW_EINVAL, "front end expects 257 bins and <= 40 bands");
   if (fp->hop <= 0 || fp->hop > 512) return ww_fail(ctx, WW_EINVAL, "hop %d out of range (1..512)", fp->hop);
+  if (m->filt.mel_entries > MEL_MAX_ENT || m->filt.mel_tiles > 3)
+    return ww_fail(ctx, WW_EINVAL, "mel filterbank needs %d (tile, block) entries; kernel limit %d", m->filt.mel_entries, MEL_MAX_ENT);
   if (n_utt > 65535) return ww_fail(ctx, WW_EINVAL, "at most 65535 utterances per call (got %d)", n_utt);
   logmel_args a = {};
   a.pcm = d_pcm; a.f32 = d_f32; a.sample_offs = d_sample_offs; a.frame_offs = d_frame_offs;
@@ -211,11 +376,11 @@ int ww_k_logmel(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, const floa
   dim3 grid((unsigned)((max_frames_per_utt + FPB - 1) / FPB), (unsigned)n_utt);
   ww_launch_scope scope(ctx, fp->precise ? "logmel_kernel<f64>" : "logmel_kernel<f32>");
   if (fp->precise) {
-    size_t sm = logmel_smem<double>(fp->hop, a.total_taps, f32in);
+    size_t sm = logmel_smem<double>(fp->hop);
     if (f32in) hipLaunchKernelGGL((logmel_kernel<double, true>), grid, dim3(256), sm, ctx->stream, a);
     else hipLaunchKernelGGL((logmel_kernel<double, false>), grid, dim3(256), sm, ctx->stream, a);
   } else {
-    size_t sm = logmel_smem<float>(fp->hop, a.total_taps, f32in);
+    size_t sm = logmel_smem<float>(fp->hop);
     if (f32in) hipLaunchKernelGGL((logmel_kernel<float, true>), grid, dim3(256), sm, ctx->stream, a);
     else hipLaunchKernelGGL((logmel_kernel<float, false>), grid, dim3(256), sm, ctx->stream, a);
   }
@@ -231,10 +396,10 @@ int ww_k_stft_mag(ww_ctx *ctx, const ww_model *m, const float *d_frames, int64_t
   dim3 grid((unsigned)((n + WAVES - 1) / WAVES));
   ww_launch_scope scope(ctx, "stft_mag_kernel");
   if (precise) {
-    size_t sm = 256 * sizeof(cplx<double>) * 2 + WAVES * 256 * sizeof(cplx<double>) + WAVES * 260 * sizeof(float);
+    size_t sm = WAVES * FFT_LD * sizeof(cplx<double>) + WAVES * 260 * sizeof(float);
     hipLaunchKernelGGL((stft_mag_kernel<double>), grid, dim3(256), sm, ctx->stream, a);
   } else {
-    size_t sm = 256 * sizeof(cplx<float>) * 2 + WAVES * 256 * sizeof(cplx<float>) + WAVES * 260 * sizeof(float);
+    size_t sm = WAVES * FFT_LD * sizeof(cplx<float>) + WAVES * 260 * sizeof(float);
     hipLaunchKernelGGL((stft_mag_kernel<float>), grid, dim3(256), sm, ctx->stream, a);
   }
   WW_HIP(ctx, hipGetLastError());

@@ -60,9 +60,9 @@ struct stream_fe_args {
   int clip;
   float preemph;
   int hop;
-  const int *start, *len, *woff;
-  const float *w, *bias;
-  int n_mel, total_taps;
+  const int *start;
+  const float *wpad, *bias;
+  int n_mel;
   float floor_v, log_off, scale;
   const double *hann, *tw256, *tw512;
 };
@@ -76,11 +76,9 @@ __global__ __launch_bounds__(128) void stream_frontend_kernel(stream_fe_args a) 
   const bool speech = flags & 1, skip = flags & 2;
 
   size_t off = 0;
-  cplx<R> *tw256 = (cplx<R> *)(smem + off); off += 256 * sizeof(cplx<R>);
-  cplx<R> *tw512 = (cplx<R> *)(smem + off); off += 256 * sizeof(cplx<R>);
-  cplx<R> *fbuf = (cplx<R> *)(smem + off); off += 2 * 256 * sizeof(cplx<R>);
+  cplx<R> *fbuf = (cplx<R> *)(smem + off); off += 2 * FFT_LD * sizeof(cplx<R>);
   float *mag = (float *)(smem + off); off += 2 * 260 * sizeof(float);
-  float *fw = (float *)(smem + off); off += ((a.total_taps + 3) & ~3) * sizeof(float);
+  float *wl = (float *)(smem + off); off += WW_MEL_TAPS * 64 * sizeof(float);
   float *x = (float *)(smem + off);  // [ST_RING]
 
   // ---- mel history: drop the rows that were appended last tick (hist_out[0..T) = hist_in[shift..shift+T))
@@ -91,11 +89,7 @@ __global__ __launch_bounds__(128) void stream_frontend_kernel(stream_fe_args a) 
   }
   if (skip) return;  // context.is_active: the frame is not sampled at all (tflite.py:139-140)
 
-  for (int i = tid; i < 256; i += 128) {
-    tw256[i] = {(R)a.tw256[2 * i], (R)a.tw256[2 * i + 1]};
-    tw512[i] = {(R)a.tw512[2 * i], (R)a.tw512[2 * i + 1]};
-  }
-  for (int i = tid; i < a.total_taps; i += 128) fw[i] = a.w[i];
+  for (int i = tid; i < WW_MEL_TAPS * 64 / 4; i += 128) ((float4 *)wl)[i] = ((const float4 *)a.wpad)[i];
   // ---- [ring | new samples] in LDS
   float *ring = a.ring + (size_t)s * ST_RING;
   for (int i = tid; i < fill; i += 128) x[i] = ring[i];
@@ -120,18 +114,16 @@ __global__ __launch_bounds__(128) void stream_frontend_kernel(stream_fe_args a) 
   }
   // ---- new frames (wave k handles frame k); only analysed while is_speech (tflite.py:166)
   if (speech && wave < n_frames) {
+    fft_consts<R> fc;
+    fft_load_consts<R>(fc, lane, a.hann, a.tw256, a.tw512);
     const float *src = x + wave * a.hop;
-    auto xs = [&](int i) -> float { return src[i]; };
+    auto x2 = [&](int n) -> float2 { return make_float2(src[2 * n], src[2 * n + 1]); };
     float *mg = mag + wave * 260;
-    frame_fft_mag<R>(xs, a.hann, tw256, tw512, fbuf + wave * 256, mg, lane);
-    if (lane < a.n_mel) {
-      const int st = a.start[lane], ln = a.len[lane], wo = a.woff[lane];
-      float acc = 0.0f;
-      for (int i = 0; i < ln; ++i) acc = fmaf(fw[wo + i], mg[st + i], acc);
-      acc += a.bias[lane];
-      acc = fmaxf(acc, a.floor_v);
-      a.hist_out[((size_t)s * a.HR + a.T + wave) * a.F + lane] = (logf(acc) + a.log_off) * a.scale;
-    }
+    frame_fft_mag<R>(x2, fc, fbuf + wave * FFT_LD, mg, lane);
+    const int st = lane < a.n_mel ? a.start[lane] : 0;
+    const float bias = lane < a.n_mel ? a.bias[lane] : 0.0f;
+    const float mv = mel_band(mg, wl, st, bias, a.floor_v, a.log_off, a.scale, lane);
+    if (lane < a.n_mel) a.hist_out[((size_t)s * a.HR + a.T + wave) * a.F + lane] = mv;
   }
   __syncthreads();
   // ---- keep the ring tail
@@ -282,16 +274,16 @@ int ww_stream_step(ww_streams *st, const int16_t *frames, const uint8_t *is_spee
   a.hist_in = st->hist[st->cur]; a.hist_out = st->hist[st->cur ^ 1]; a.prev = st->prev;
   a.T = st->T; a.F = st->F; a.HR = st->HR;
   a.divisor = st->fp.pcm_divisor; a.clip = st->fp.clip; a.preemph = st->fp.pre_emphasis; a.hop = hop;
-  a.start = f.start; a.len = f.len; a.woff = f.woff; a.w = f.w; a.bias = f.bias;
-  a.n_mel = f.n_mel; a.total_taps = f.total_taps; a.floor_v = f.floor_v; a.log_off = f.log_off; a.scale = f.scale;
+  a.start = f.start; a.wpad = f.wpad; a.bias = f.bias;
+  a.n_mel = f.n_mel; a.floor_v = f.floor_v; a.log_off = f.log_off; a.scale = f.scale;
   a.hann = f.hann; a.tw256 = f.tw256; a.tw512 = f.tw512;
   {
     ww_launch_scope scope(ctx, "stream_frontend_kernel");
     if (st->fp.precise) {
-      size_t sm = 256 * 16 * 2 + 2 * 256 * 16 + 2 * 260 * 4 + ((f.total_taps + 3) & ~3) * 4 + ST_RING * 4;
+      size_t sm = 2 * FFT_LD * 16 + 2 * 260 * 4 + WW_MEL_TAPS * 64 * 4 + ST_RING * 4;
       hipLaunchKernelGGL((stream_frontend_kernel<double>), dim3(S), dim3(128), sm, ctx->stream, a);
     } else {
-      size_t sm = 256 * 8 * 2 + 2 * 256 * 8 + 2 * 260 * 4 + ((f.total_taps + 3) & ~3) * 4 + ST_RING * 4;
+      size_t sm = 2 * FFT_LD * 8 + 2 * 260 * 4 + WW_MEL_TAPS * 64 * 4 + ST_RING * 4;
       hipLaunchKernelGGL((stream_frontend_kernel<float>), dim3(S), dim3(128), sm, ctx->stream, a);
     }
   }

@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libwwhip.so")
 
 SOURCES = ["api.hip", "frontend.hip", "crnn.hip", "wavenet.hip", "posterior.hip", "streams.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
+FLAGS += os.environ.get("WWHIP_DEFS", "").split()  # development only: e.g. WWHIP_DEFS="-DFPB=32"
 
 
 def _hipcc() -> str:
