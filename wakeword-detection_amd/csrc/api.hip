@@ -282,7 +282,7 @@ static int load_crnn(ww_ctx *ctx, ww_model *m, const blob_view &bv) {
   c.PF = meta[7]; c.PT = meta[8]; c.OF = meta[9]; c.OT = meta[10]; c.H = meta[11]; c.NOUT = meta[12]; c.HEAD = meta[13];
   const int K = c.KF * c.KT, KP = 112;
   if (c.C != 32 || c.H != 32 || c.KT % 4 != 0 || K > KP || c.ST % 4 != 0 || c.NOUT < 1 || c.NOUT > 8 ||
-      (c.OF * c.C) % 32 != 0 || c.n_mel != m->filt.n_mel)
+      (c.OF * c.C) % 64 != 0 || c.OT > 20 || c.T * c.n_mel > 6 * 256 * 4 || c.n_mel != m->filt.n_mel)
     return ww_fail(ctx, WW_EBLOB, "unsupported CRNN geometry (C=%d H=%d K=%dx%d stride %dx%d)", c.C, c.H, c.KF, c.KT, c.SF, c.ST);
   const int max_kf = (KP - 1) / c.KT;  // padded k rows touch kf up to this
   if ((c.OF - 1) * c.SF + max_kf >= 44 || c.n_mel + c.PF > 44 || (c.OT - 1) * c.ST + c.KT > 164 || c.T + c.PT > 164)

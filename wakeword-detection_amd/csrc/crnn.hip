@@ -12,10 +12,12 @@
 //   gemm_nt_kernel    C[M][N] = A[M][K] * W[N][K]^T + b, 64x64x32 tiles, fp32 MFMA, register
 //                     prefetch + double-buffered LDS.  Used for the GRU input projections of
 //                     both directions at once (N = 2*3H = 192).
-//   gru_kernel        the 19-step recurrence; one wavefront per (window, direction), W_h held
-//                     in registers (48 VGPRs per lane, K split over the two lane halves),
-//                     h exchanged through LDS.  Layer 2 keeps only the last state and the
-//                     backward wave's partner computes the detect head in the same launch.
+//   gru_head_kernel   one workgroup per window runs everything behind the layer-1 projections:
+//                     layer-1 recurrence (wave 0 forward, wave 1 backward; W_h in registers, K
+//                     split over adjacent lane pairs, partial dots joined by one DPP swap, h
+//                     exchanged through LDS), the layer-2 input projection for both directions
+//                     as an MFMA GEMM out of LDS (all 4 waves), the layer-2 recurrence and the
+//                     detect head.  Waves 2/3 stage the head weights into LDS meanwhile.
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -63,14 +65,38 @@ __global__ __launch_bounds__(256) void conv5x20_kernel(conv_args a) {
   int valid;
   window_span(a.wa, w, a.T, row, valid);
 
+  // the window is one contiguous [valid][n_mel] block: issue all 16-byte loads first, then
+  // zero the image, then scatter the registers into the transposed (mel-major) image
+  constexpr int CV_MAXV = 6;  // 6 * 256 float4 >= 151 * 40 / 4
+  const float *src = a.mel + row * a.n_mel;
+  const int n = valid * a.n_mel;
+  const bool al16 = ((((uintptr_t)src) & 15) == 0);
+  float4 stage[CV_MAXV];
+#pragma unroll
+  for (int q = 0; q < CV_MAXV; ++q) {
+    const int i = (q * 256 + tid) * 4;
+    if (al16 && i + 3 < n) {
+      stage[q] = *(const float4 *)(src + i);
+    } else {
+      stage[q].x = i < n ? src[i] : 0.f;
+      stage[q].y = i + 1 < n ? src[i + 1] : 0.f;
+      stage[q].z = i + 2 < n ? src[i + 2] : 0.f;
+      stage[q].w = i + 3 < n ? src[i + 3] : 0.f;
+    }
+  }
   for (int i = tid; i < CV_ROWS * CV_LDT / 4; i += 256) ((float4 *)img)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
-  {
-    const float *src = a.mel + row * a.n_mel;
-    const int n = valid * a.n_mel;
-    for (int i = tid; i < n; i += 256) {
-      int it = i / a.n_mel, im = i - it * a.n_mel;
-      img[(im + a.PF) * CV_LDT + it + a.PT] = src[i];
+#pragma unroll
+  for (int q = 0; q < CV_MAXV; ++q) {
+    const int i = (q * 256 + tid) * 4;
+    const float e[4] = {stage[q].x, stage[q].y, stage[q].z, stage[q].w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int ii = i + c;
+      if (ii < n) {
+        const int it = ii / a.n_mel, im = ii - it * a.n_mel;
+        img[(im + a.PF) * CV_LDT + it + a.PT] = e[c];
+      }
     }
   }
   // conv weights for this lane: B operand of mfma 16x16x4: lane (j = lane&15, kk = lane>>4)
@@ -123,8 +149,8 @@ __global__ __launch_bounds__(256) void conv5x20_kernel(conv_args a) {
 // ------------------------------------------------------------------------------------------
 #define GB_M 64
 #define GB_N 64
-#define GB_K 32
-#define GB_LD 36
+#define GB_K 64
+#define GB_LD 68
 
 struct gemm_args {
   const float *A;
@@ -140,14 +166,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(gemm_args g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int m0 = blockIdx.x * GB_M, n0 = blockIdx.y * GB_N;
-  const int lrow = tid >> 3, lc4 = tid & 7;  // loader: rows lrow, lrow+32; float4 column lc4
+  const int lrow = tid >> 4, lc4 = tid & 15;  // loader: rows lrow + 16 h (h = 0..3); float4 column lc4
   const int i16 = lane & 15, kk = lane >> 4;
 
-  float4 pa[2], pb[2];
+  float4 pa[4], pb[4];
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int r = lrow + 32 * h;
+    for (int h = 0; h < 4; ++h) {
+      const int r = lrow + 16 * h;
       const int gm = m0 + r;
       pa[h] = gm < g.M ? *(const float4 *)(g.A + (size_t)gm * g.K + k0 + lc4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
       const int gn = n0 + r;
@@ -156,8 +182,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(gemm_args g) {
   };
   auto sstore = [&](int buf) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int r = lrow + 32 * h;
+    for (int h = 0; h < 4; ++h) {
+      const int r = lrow + 16 * h;
       *(float4 *)(&As[buf][r * GB_LD + lc4 * 4]) = pa[h];
       *(float4 *)(&Bs[buf][r * GB_LD + lc4 * 4]) = pb[h];
     }
@@ -177,7 +203,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(gemm_args g) {
     const int cur = kt & 1;
     if (kt + 1 < nk) gload((kt + 1) * GB_K);
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < GB_K / 16; ++kb) {
       float4 av[2], bv[2];
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) av[mi] = *(const float4 *)(&As[cur][(wr * 32 + mi * 16 + i16) * GB_LD + kb * 16 + kk * 4]);
@@ -211,121 +237,225 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(gemm_args g) {
 }
 
 // ------------------------------------------------------------------------------------------
-// GRU recurrence (+ detect head for the last layer)
+// GRU layer 1 -> layer-2 projection -> GRU layer 2 -> detect head, one workgroup per window
 // ------------------------------------------------------------------------------------------
-struct gru_args {
-  const float *gx;   // [Nw][OT][2*3H]  input projections incl. b_x, cols [dir][gate z,r,h][unit]
-  const float *wh;   // [2][3H][H]
-  const float *bh;   // [2][3H]
-  float *seq;        // layer 1: [Nw][OT][2H] (fwd | bwd); layer 2: nullptr
-  float *enc;        // layer 2: optional [Nw][2H] encoder output (fwd_last | bwd_last)
-  const float *w1, *b1, *w2, *b2;  // detect head (layer 2)
+struct gru_head_args {
+  const float *gx1;  // [Nw][OT][2*3H]  layer-1 input projections incl. b_x, cols [dir][gate z,r,h][unit]
+  const float *wh1, *bh1;  // [2][3H][H], [2][3H]
+  const float *wx2, *bx2;  // [2*3H][2H], [2*3H]
+  const float *wh2, *bh2;
+  const float *w1, *b1, *w2, *b2;  // detect head
+  float *enc;        // optional [Nw][2H] encoder output (fwd_last | bwd_last)
   float *out;        // [Nw][NOUT]
   int OT, NOUT, HEAD;
 };
 
-// H == 32.  Block = 128 threads: wave 0 forward, wave 1 backward, one window per block.
-template <bool LAST>
-__global__ __launch_bounds__(128) void gru_kernel(gru_args a) {
-  constexpr int H = 32;
-  __shared__ __align__(16) float hbuf[2][2][H];  // [dir][ping-pong][unit]
+#define GR_H 32
+#define GR_SEQ_LD 68   // seq1 row: 64 values + 4 pad
+#define GR_GX_LD 196   // gx2 row: 192 values + 4 pad
+#define GR_W1_LD 65
+
+// v_exp_f32 / v_rcp_f32 based gates (~1 ulp each): |error| ~ 2e-7, far inside the 1e-4 budget,
+// and several times shorter than the libm expf / tanhf / IEEE-divide sequences that sit on the
+// 38-step serial chain.
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float e = __builtin_amdgcn_exp2f(2.8853900817779268f * x);  // exp(2x): inf -> 1, 0 -> -1
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+__device__ __forceinline__ float swap_pair(float v) {
+  // value of the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2]
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+
+struct gru_w {
+  float z[16], r[16], c[16];
+  float bz, br, bc;
+};
+
+__device__ __forceinline__ void gru_load_w(gru_w &g, const float *wh, const float *bh, int dir, int unit, int half) {
+  const float *base = wh + (size_t)dir * 3 * GR_H * GR_H;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 z = *(const float4 *)(base + (size_t)(0 * GR_H + unit) * GR_H + half * 16 + q * 4);
+    const float4 r = *(const float4 *)(base + (size_t)(1 * GR_H + unit) * GR_H + half * 16 + q * 4);
+    const float4 c = *(const float4 *)(base + (size_t)(2 * GR_H + unit) * GR_H + half * 16 + q * 4);
+    g.z[q * 4 + 0] = z.x; g.z[q * 4 + 1] = z.y; g.z[q * 4 + 2] = z.z; g.z[q * 4 + 3] = z.w;
+    g.r[q * 4 + 0] = r.x; g.r[q * 4 + 1] = r.y; g.r[q * 4 + 2] = r.z; g.r[q * 4 + 3] = r.w;
+    g.c[q * 4 + 0] = c.x; g.c[q * 4 + 1] = c.y; g.c[q * 4 + 2] = c.z; g.c[q * 4 + 3] = c.w;
+  }
+  g.bz = bh[dir * 3 * GR_H + unit];
+  g.br = bh[dir * 3 * GR_H + GR_H + unit];
+  g.bc = bh[dir * 3 * GR_H + 2 * GR_H + unit];
+}
+
+// One GRU step for lane (unit = lane >> 1, half = lane & 1).  hin: this direction's h in LDS.
+// Keras GRU v2 (reset_after): z = s(xz + hz), r = s(xr + hr), c = tanh(xc + r * hc), h' = z h + (1-z) c
+__device__ __forceinline__ float gru_step(const gru_w &g, const float *hin, int half, float gz, float gr, float gc,
+                                          float h_own) {
+  const float4 *hp = (const float4 *)(hin + half * 16);
+  float sz = 0.f, sr = 0.f, sc = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 hv = hp[q];
+    sz = fmaf(g.z[q * 4 + 0], hv.x, sz); sr = fmaf(g.r[q * 4 + 0], hv.x, sr); sc = fmaf(g.c[q * 4 + 0], hv.x, sc);
+    sz = fmaf(g.z[q * 4 + 1], hv.y, sz); sr = fmaf(g.r[q * 4 + 1], hv.y, sr); sc = fmaf(g.c[q * 4 + 1], hv.y, sc);
+    sz = fmaf(g.z[q * 4 + 2], hv.z, sz); sr = fmaf(g.r[q * 4 + 2], hv.z, sr); sc = fmaf(g.c[q * 4 + 2], hv.z, sc);
+    sz = fmaf(g.z[q * 4 + 3], hv.w, sz); sr = fmaf(g.r[q * 4 + 3], hv.w, sr); sc = fmaf(g.c[q * 4 + 3], hv.w, sc);
+  }
+  sz += swap_pair(sz);
+  sr += swap_pair(sr);
+  sc += swap_pair(sc);
+  const float z = fast_sigmoid(gz + (sz + g.bz));
+  const float r = fast_sigmoid(gr + (sr + g.br));
+  const float c = fast_tanh(gc + r * (sc + g.bc));
+  return z * h_own + (1.0f - z) * c;
+}
+
+__device__ __forceinline__ void wsync_g() {
+  // LDS traffic of one wave is processed in order; wait for it only (not for outstanding
+  // global loads, which an acq_rel fence would also drain) and stop compiler reordering
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(256) void gru_head_kernel(gru_head_args a) {
+  constexpr int H = GR_H;
+  __shared__ __align__(16) float hbuf[2][2][H];          // [dir][ping-pong][unit]
+  __shared__ __align__(16) float seq1[32 * GR_SEQ_LD];   // layer-1 outputs [t][fwd | bwd], rows >= OT zero
+  __shared__ __align__(16) float gx2[20 * GR_GX_LD];     // layer-2 input projections [t][dir][gate][unit]
+  __shared__ float w1s[64 * GR_W1_LD];
+  __shared__ float w2s[8 * 64];
   __shared__ float encs[2 * H];
   __shared__ float hid[2 * H];
-  const int tid = threadIdx.x, lane = tid & 63, dir = tid >> 6;
-  const int unit = lane & 31, half = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int w = blockIdx.x;
+  const int OT = a.OT;
+  const int unit = lane >> 1, half = lane & 1;
+  const int j = lane & 15, kk = lane >> 4;
 
-  // recurrent weights of this lane: gates z, r, h of `unit`, columns [16*half, 16*half + 16)
-  float wz[16], wr_[16], wc[16];
-  {
-    const float *base = a.wh + (size_t)dir * 3 * H * H;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float4 z = *(const float4 *)(base + (size_t)(0 * H + unit) * H + half * 16 + q * 4);
-      float4 r = *(const float4 *)(base + (size_t)(1 * H + unit) * H + half * 16 + q * 4);
-      float4 c = *(const float4 *)(base + (size_t)(2 * H + unit) * H + half * 16 + q * 4);
-      wz[q * 4 + 0] = z.x; wz[q * 4 + 1] = z.y; wz[q * 4 + 2] = z.z; wz[q * 4 + 3] = z.w;
-      wr_[q * 4 + 0] = r.x; wr_[q * 4 + 1] = r.y; wr_[q * 4 + 2] = r.z; wr_[q * 4 + 3] = r.w;
-      wc[q * 4 + 0] = c.x; wc[q * 4 + 1] = c.y; wc[q * 4 + 2] = c.z; wc[q * 4 + 3] = c.w;
-    }
+  // ---- prefetch: recurrent weights (waves 0,1), this wave's slice of W_x2 as MFMA B operands
+  gru_w g1, g2;
+  const int dir = wave & 1;
+  if (wave < 2) {
+    gru_load_w(g1, a.wh1, a.bh1, dir, unit, half);
+    gru_load_w(g2, a.wh2, a.bh2, dir, unit, half);
   }
-  const float bz = a.bh[dir * 3 * H + unit], br = a.bh[dir * 3 * H + H + unit], bc = a.bh[dir * 3 * H + 2 * H + unit];
-  if (half == 0) hbuf[dir][0][unit] = 0.f;
-  float h_own = 0.f;
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  float4 bw[3][4];  // n-tiles wave*3 .. wave*3+2, k-blocks 0..3
+  float bb[3];
+#pragma unroll
+  for (int n = 0; n < 3; ++n) {
+    const int col = (wave * 3 + n) * 16 + j;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) bw[n][kb] = *(const float4 *)(a.wx2 + (size_t)col * 2 * H + kb * 16 + kk * 4);
+    bb[n] = a.bx2[col];
+  }
+  for (int i = tid; i < 32 * GR_SEQ_LD; i += 256) seq1[i] = 0.f;
+  if (tid < 2 * H) hbuf[tid >> 5][0][tid & 31] = 0.f;
+  __syncthreads();
 
-  const float *gxw = a.gx + (size_t)w * a.OT * 6 * H + dir * 3 * H + unit;
-  int t = dir ? a.OT - 1 : 0;
-  float gz = gxw[(size_t)t * 6 * H], gr = gxw[(size_t)t * 6 * H + H], gc = gxw[(size_t)t * 6 * H + 2 * H];
-  for (int s = 0; s < a.OT; ++s) {
-    const int cur = s & 1;
-    // prefetch next step's input projection
-    const int tn = dir ? t - 1 : t + 1;
-    float ngz = 0.f, ngr = 0.f, ngc = 0.f;
-    if (s + 1 < a.OT) {
-      ngz = gxw[(size_t)tn * 6 * H];
-      ngr = gxw[(size_t)tn * 6 * H + H];
-      ngc = gxw[(size_t)tn * 6 * H + 2 * H];
+  // ---- layer 1 recurrence (waves 0,1); waves 2,3 stage the detect head weights meanwhile
+  if (wave < 2) {
+    const float *gxw = a.gx1 + (size_t)w * OT * 6 * H + dir * 3 * H + unit;
+    int t = dir ? OT - 1 : 0;
+    float gz = gxw[(size_t)t * 6 * H], gr = gxw[(size_t)t * 6 * H + H], gc = gxw[(size_t)t * 6 * H + 2 * H];
+    float h_own = 0.f;
+    for (int s = 0; s < OT; ++s) {
+      const int cur = s & 1;
+      const int tn = dir ? t - 1 : t + 1;
+      float ngz = 0.f, ngr = 0.f, ngc = 0.f;
+      if (s + 1 < OT) {
+        ngz = gxw[(size_t)tn * 6 * H];
+        ngr = gxw[(size_t)tn * 6 * H + H];
+        ngc = gxw[(size_t)tn * 6 * H + 2 * H];
+      }
+      h_own = gru_step(g1, &hbuf[dir][cur][0], half, gz, gr, gc, h_own);
+      if (half == 0) {
+        hbuf[dir][cur ^ 1][unit] = h_own;
+        seq1[t * GR_SEQ_LD + dir * H + unit] = h_own;
+      }
+      wsync_g();
+      gz = ngz; gr = ngr; gc = ngc;
+      t = tn;
     }
-    const float4 *hp = (const float4 *)(&hbuf[dir][cur][half * 16]);
-    float sz = 0.f, sr = 0.f, sc = 0.f;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 hv = hp[q];
-      sz = fmaf(wz[q * 4 + 0], hv.x, sz); sr = fmaf(wr_[q * 4 + 0], hv.x, sr); sc = fmaf(wc[q * 4 + 0], hv.x, sc);
-      sz = fmaf(wz[q * 4 + 1], hv.y, sz); sr = fmaf(wr_[q * 4 + 1], hv.y, sr); sc = fmaf(wc[q * 4 + 1], hv.y, sc);
-      sz = fmaf(wz[q * 4 + 2], hv.z, sz); sr = fmaf(wr_[q * 4 + 2], hv.z, sr); sc = fmaf(wc[q * 4 + 2], hv.z, sc);
-      sz = fmaf(wz[q * 4 + 3], hv.w, sz); sr = fmaf(wr_[q * 4 + 3], hv.w, sr); sc = fmaf(wc[q * 4 + 3], hv.w, sc);
-    }
-    sz += __shfl_xor(sz, 32);
-    sr += __shfl_xor(sr, 32);
-    sc += __shfl_xor(sc, 32);
-    // Keras GRU v2 (reset_after): z = s(xz + hz), r = s(xr + hr), c = tanh(xc + r * hc), h' = z*h + (1-z)*c
-    const float z = sigmoid_f(gz + (sz + bz));
-    const float r = sigmoid_f(gr + (sr + br));
-    const float c = tanhf(gc + r * (sc + bc));
-    h_own = z * h_own + (1.0f - z) * c;
-    if (half == 0) {
-      hbuf[dir][cur ^ 1][unit] = h_own;
-      if (!LAST) a.seq[((size_t)w * a.OT + t) * 2 * H + dir * H + unit] = h_own;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    gz = ngz; gr = ngr; gc = ngc;
-    t = tn;
+  } else {
+    const int t2 = tid - 128;
+    for (int i = t2; i < 64 * 64; i += 128) w1s[(i >> 6) * GR_W1_LD + (i & 63)] = a.w1[i];
+    for (int i = t2; i < a.NOUT * 64; i += 128) w2s[i] = a.w2[i];
   }
-  if (LAST) {
+  __syncthreads();
+
+  // ---- layer-2 input projection, both directions: gx2[t][n] = seq1[t][:] . Wx2[n][:] + bx2[n]
+  //      M = 32 (19 valid rows), K = 64, N = 192: wave owns 3 n-tiles, 2 m-tiles each
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const float4 av = *(const float4 *)(&seq1[(mt * 16 + j) * GR_SEQ_LD + kb * 16 + kk * 4]);
+#pragma unroll
+      for (int n = 0; n < 3; ++n) {
+        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bw[n][kb].x, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bw[n][kb].y, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bw[n][kb].z, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bw[n][kb].w, acc[n], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < 3; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = mt * 16 + kk * 4 + r;
+        if (t < OT) gx2[t * GR_GX_LD + (wave * 3 + n) * 16 + j] = acc[n][r] + bb[n];
+      }
+  }
+  if (tid < 2 * H) hbuf[tid >> 5][0][tid & 31] = 0.f;
+  __syncthreads();
+
+  // ---- layer 2 recurrence: only the last state of each direction is kept
+  if (wave < 2) {
+    const float *gxl = gx2 + dir * 3 * H + unit;
+    float h_own = 0.f;
+    int t = dir ? OT - 1 : 0;
+    for (int s = 0; s < OT; ++s) {
+      const int cur = s & 1;
+      const float gz = gxl[t * GR_GX_LD], gr = gxl[t * GR_GX_LD + H], gc = gxl[t * GR_GX_LD + 2 * H];
+      h_own = gru_step(g2, &hbuf[dir][cur][0], half, gz, gr, gc, h_own);
+      if (half == 0) hbuf[dir][cur ^ 1][unit] = h_own;
+      wsync_g();
+      t = dir ? t - 1 : t + 1;
+    }
     if (half == 0) {
       encs[dir * H + unit] = h_own;
       if (a.enc) a.enc[(size_t)w * 2 * H + dir * H + unit] = h_own;
     }
-    __syncthreads();
-    // detect head: Dense(64, relu) -> Dense(NOUT) -> sigmoid | softmax   (wave 0)
-    if (dir == 0) {
-      float acc = 0.f;
-      const float *wrow = a.w1 + (size_t)lane * 2 * H;
-#pragma unroll 8
-      for (int k = 0; k < 2 * H; ++k) acc = fmaf(wrow[k], encs[k], acc);
-      hid[lane] = fmaxf(acc + a.b1[lane], 0.f);
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      float y = 0.f;
-      if (lane < a.NOUT) {
-        const float *w2 = a.w2 + (size_t)lane * 2 * H;
-        for (int k = 0; k < 2 * H; ++k) y = fmaf(w2[k], hid[k], y);
-        y += a.b2[lane];
-      }
-      if (a.HEAD == 0) {
-        if (lane < a.NOUT) a.out[(size_t)w * a.NOUT + lane] = sigmoid_f(y);
-      } else {
-        float mx = (lane < a.NOUT) ? y : -INFINITY;
-        for (int o = 1; o < 8; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        float e = (lane < a.NOUT) ? expf(y - mx) : 0.f;
-        float sum = e;
-        for (int o = 1; o < 8; o <<= 1) sum += __shfl_xor(sum, o);
-        if (lane < a.NOUT) a.out[(size_t)w * a.NOUT + lane] = e / sum;
-      }
+  }
+  __syncthreads();
+
+  // ---- detect head: Dense(64, relu) -> Dense(NOUT) -> sigmoid | softmax   (wave 0)
+  if (wave == 0) {
+    float acc = 0.f;
+#pragma unroll 16
+    for (int k = 0; k < 2 * H; ++k) acc = fmaf(w1s[lane * GR_W1_LD + k], encs[k], acc);
+    hid[lane] = fmaxf(acc + a.b1[lane], 0.f);
+    wsync_g();
+    float y = 0.f;
+    if (lane < a.NOUT) {
+      for (int k = 0; k < 2 * H; ++k) y = fmaf(w2s[lane * 64 + k], hid[k], y);
+      y += a.b2[lane];
+    }
+    if (a.HEAD == 0) {
+      if (lane < a.NOUT) a.out[(size_t)w * a.NOUT + lane] = sigmoid_f(y);
+    } else {
+      float mx = (lane < a.NOUT) ? y : -INFINITY;
+      for (int o = 1; o < 8; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      float e = (lane < a.NOUT) ? expf(y - mx) : 0.f;
+      float sum = e;
+      for (int o = 1; o < 8; o <<= 1) sum += __shfl_xor(sum, o);
+      if (lane < a.NOUT) a.out[(size_t)w * a.NOUT + lane] = e / sum;
     }
   }
 }
@@ -334,7 +464,7 @@ __global__ __launch_bounds__(128) void gru_kernel(gru_args a) {
 // host side
 // ------------------------------------------------------------------------------------------
 struct crnn_ws {
-  float *feat, *gx1, *seq1, *gx2;
+  float *feat, *gx1;
 };
 
 static crnn_ws carve(const ww_model *m, int nw, void *ws) {
@@ -343,15 +473,12 @@ static crnn_ws carve(const ww_model *m, int nw, void *ws) {
   crnn_ws r;
   r.feat = b.take<float>((size_t)nw * c.OT * c.OF * c.C);
   r.gx1 = b.take<float>((size_t)nw * c.OT * 6 * c.H);
-  r.seq1 = b.take<float>((size_t)nw * c.OT * 2 * c.H);
-  r.gx2 = b.take<float>((size_t)nw * c.OT * 6 * c.H);
   return r;
 }
 
 size_t ww_crnn_workspace(const ww_model *m, int nw) {
   const ww_crnn_dev &c = m->crnn;
-  return ww_bump::need((size_t)nw * c.OT * c.OF * c.C, 4) + 2 * ww_bump::need((size_t)nw * c.OT * 6 * c.H, 4) +
-         ww_bump::need((size_t)nw * c.OT * 2 * c.H, 4) + 1024;
+  return ww_bump::need((size_t)nw * c.OT * c.OF * c.C, 4) + ww_bump::need((size_t)nw * c.OT * 6 * c.H, 4) + 1024;
 }
 
 int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *d_win_row,
@@ -374,20 +501,9 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
                        ctx->stream, g);
   }
   {
-    gru_args a = {s.gx1, c.wh1, c.bh1, s.seq1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, c.OT, c.NOUT, c.HEAD};
-    ww_launch_scope scope(ctx, "gru_kernel<seq>");
-    hipLaunchKernelGGL((gru_kernel<false>), dim3(nw), dim3(128), 0, ctx->stream, a);
-  }
-  {
-    gemm_args g = {s.seq1, c.wx2, c.bx2, s.gx2, M, 6 * c.H, 2 * c.H};
-    ww_launch_scope scope(ctx, "gemm_nt_kernel<gru2>");
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3((M + GB_M - 1) / GB_M, (6 * c.H + GB_N - 1) / GB_N), dim3(256), 0,
-                       ctx->stream, g);
-  }
-  {
-    gru_args a = {s.gx2, c.wh2, c.bh2, nullptr, d_enc, c.w1, c.b1, c.w2, c.b2, d_out, c.OT, c.NOUT, c.HEAD};
-    ww_launch_scope scope(ctx, "gru_kernel<last+head>");
-    hipLaunchKernelGGL((gru_kernel<true>), dim3(nw), dim3(128), 0, ctx->stream, a);
+    gru_head_args a = {s.gx1, c.wh1, c.bh1, c.wx2, c.bx2, c.wh2, c.bh2, c.w1, c.b1, c.w2, c.b2, d_enc, d_out, c.OT, c.NOUT, c.HEAD};
+    ww_launch_scope scope(ctx, "gru_head_kernel");
+    hipLaunchKernelGGL(gru_head_kernel, dim3(nw), dim3(256), 0, ctx->stream, a);
   }
   WW_HIP(ctx, hipGetLastError());
   return WW_OK;

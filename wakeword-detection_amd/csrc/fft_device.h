@@ -26,7 +26,9 @@ __device__ __forceinline__ cplx<R> cmul(cplx<R> a, cplx<R> b) {
 }
 
 __device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  // LDS traffic of one wave is processed in order; wait for it only (not for outstanding
+  // global loads, which an acq_rel fence would also drain) and stop compiler reordering
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
 }
 

@@ -60,7 +60,9 @@ struct wave_args {
 __device__ __forceinline__ float sigmoid_w(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 __device__ __forceinline__ void wsync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  // LDS traffic of one wave is processed in order; wait for it only (not for outstanding
+  // global loads, which an acq_rel fence would also drain) and stop compiler reordering
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
 }
 
