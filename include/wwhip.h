@@ -121,6 +121,10 @@ int ww_logmel_f32(ww_ctx *ctx, const ww_model *model, const float *samples, cons
  * (WakewordTrigger._analyze, spokestack/wakeword/tflite.py:174-176). */
 int ww_stft_mag(ww_ctx *ctx, const ww_model *model, const float *frames, int64_t n, int32_t precise, float *mag);
 
+/* filter.tflite on its own: mag [n][257] fp32 -> log-mel [n][40]  (TFLiteModel("filter.tflite")(frame),
+ * spokestack/wakeword/tflite.py:183-184; utils/tf_lite/filter.py:72-73). */
+int ww_filter_apply(ww_ctx *ctx, const ww_model *model, const float *mag, int64_t n, float *mel);
+
 int ww_logmel_dev(ww_ctx *ctx, const ww_model *model, const int16_t *d_pcm, const int64_t *d_sample_offs,
                   const int64_t *d_frame_offs, int32_t n_utt, int64_t total_frames, int64_t max_frames_per_utt,
                   const ww_frontend_params *fp, float *d_mel);
@@ -136,6 +140,10 @@ int ww_forward(ww_ctx *ctx, const ww_model *model, const float *windows, int32_t
 /* Optional: also return the encoder output ([B][enc_rows][enc_width]); enc may be NULL. */
 int ww_forward_enc(ww_ctx *ctx, const ww_model *model, const float *windows, int32_t n_windows, float *out,
                    float *enc);
+
+/* detect.tflite on its own: encoder outputs [n][enc_rows][enc_width] -> detect rows [n][n_out]
+ * (TFLiteModel("detect.tflite")(x), spokestack/wakeword/tflite.py:228-231). */
+int ww_detect(ww_ctx *ctx, const ww_model *model, const float *enc, int32_t n, float *out);
 
 /* Sliding evaluation of one mel sequence (utils/evaluate_models.py:66-88): window i covers
  * rows [i*hop, i*hop + window); n_windows = (rows - window) / hop + 1 (0 if rows < window).

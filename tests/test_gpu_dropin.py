@@ -1,0 +1,236 @@
+"""GPU tests of the reference-shaped classes: they read like the reference's call sites
+(spokestack/wakeword/tflite.py, utils/evaluate_models.py, utils/evaluate_tf_lite_opts.py) and
+are checked against the CPU oracles."""
+import os
+import wave
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def oracle_dirs(assets):
+    from oracle.tflite_interp import ModelDir
+    return {m: ModelDir(os.path.join(assets, m)) for m in ("CRNN", "Wavenet", "CRNN_softmax")}
+
+
+def test_tflite_model_three_files_like_the_reference(assets, oracle_dirs):
+    """The exact call pattern of evaluate_models.py:76-86 / wakeword/tflite.py:183-231."""
+    from spokestack.models.tensorflow import TFLiteModel
+    rng = np.random.default_rng(1)
+    for name in ("CRNN", "Wavenet", "CRNN_softmax"):
+        d = os.path.join(assets, name)
+        filt = TFLiteModel(model_path=os.path.join(d, "filter.tflite"))
+        enc = TFLiteModel(model_path=os.path.join(d, "encode.tflite"))
+        det = TFLiteModel(model_path=os.path.join(d, "detect.tflite"))
+        assert (filt.input_details[0]["shape"][-1] - 1) * 2 == 512
+        is_crnn = name.startswith("CRNN")
+        T = enc.input_details[0]["shape"][2 if is_crnn else 1]
+        assert T == (151 if is_crnn else 182)
+        assert det.input_details[0]["shape"][-1] == (64 if is_crnn else 32)
+        mag = np.abs(rng.normal(0, 1, (1, 257))).astype(np.float32)
+        mel = filt(mag)[0]
+        assert mel.shape == (1, 40)
+        assert np.abs(mel - oracle_dirs[name].filter(mag)[0]).max() < 2e-5
+        frames = rng.uniform(0, 6, (T, 40)).astype(np.float32)
+        if is_crnn:
+            x = np.expand_dims(np.expand_dims(np.array(frames).T, 0), -1)
+        else:
+            x = np.expand_dims(np.array(frames), 0)
+        e = np.array(enc(x)).squeeze(0)
+        want_e = oracle_dirs[name].encode(x)[0]
+        assert e.shape == want_e.shape and np.abs(e - want_e).max() < TOL
+        out = det(e)[0]
+        want = oracle_dirs[name].detect(want_e)[0]
+        assert out.shape == want.shape and np.abs(out - want).max() < TOL
+        with pytest.raises(ValueError):
+            enc(x[:, :, :-1] if is_crnn else x[:, :-1])
+        with pytest.raises(ValueError):
+            filt(mag.astype(np.float64))
+    with pytest.raises(ValueError):
+        TFLiteModel(model_path=os.path.join(assets, "CRNN", "missing.tflite"))
+
+
+def test_filter_streams_like_the_reference(assets, oracle_dirs):
+    """utils/tf_lite/filter.py:38-57 driven in 20 ms chunks, including carry across 'files'."""
+    from tf_lite.filter import Filter
+    from oracle import numpy_ref as NR
+    rng = np.random.default_rng(2)
+    m = oracle_dirs["CRNN"]
+    for pre in (0.0, 0.97):
+        f = Filter(pre_emphasis=pre, model_dir=os.path.join(assets, "CRNN"))
+        ref = NR.RefFilter(lambda a: m.filter(a)[0], pre_emphasis=pre)
+        assert f.num_outputs() == 40
+        counts = []
+        for n_chunks in (10, 10, 3):          # three "files": the ring is never reset (quirk C2)
+            x = rng.normal(0, 0.1, n_chunks * 320).astype(np.float32)
+            got, want = [], []
+            for s in range(0, len(x), 320):
+                a, b = x[s:s + 320].copy(), x[s:s + 320].copy()
+                got += f.filter_frame(a)
+                want += ref.filter_frame(b)
+                np.testing.assert_array_equal(a, b)        # same in-place pre-emphasis
+            counts.append(len(got))
+            assert len(got) == len(want)
+            assert np.abs(np.array(got) - np.array(want)).max() < TOL
+        assert counts == [17, 20, 6]
+    with pytest.raises(ValueError, match="Invalid fft_window_type"):
+        Filter(fft_window_type="hamming", model_dir=os.path.join(assets, "CRNN"))
+
+
+def _reference_trigger_posteriors(mdir, frames_i16, speech_flags, T, pidx):
+    """Posterior sequence the reference WakewordTrigger computes (tflite.py:148-239)."""
+    from oracle import numpy_ref as NR
+    ring = NR.RefRing(512)
+    hann = np.hanning(512)
+    window = np.zeros((T, 40), np.float32)
+    out = []
+    for fr, sp in zip(frames_i16, speech_flags):
+        x = NR.normalise_pcm(fr)
+        for s in x:
+            ring.write(s)
+            if ring.is_full:
+                if sp:
+                    w = ring.read_all()
+                    mag = np.abs(np.fft.rfft(w * hann, n=512)).astype(np.float32)
+                    mel = mdir.filter(mag[None])[0][0]
+                    window = np.concatenate([window[1:], mel[None]])
+                    out.append(float(mdir.window(window)[pidx]))
+                ring.rewind().seek(160)
+    return out
+
+
+@pytest.mark.parametrize("name,mtype", [("CRNN", "CRNN"), ("Wavenet", "Wavenet")])
+def test_wakeword_trigger_in_pipeline(assets, oracle_dirs, name, mtype):
+    from spokestack.pipeline import SpeechPipeline
+    from spokestack.wakeword.tflite import WakewordTrigger
+    rng = np.random.default_rng(5)
+    n_ticks = 40
+    frames = [np.clip(rng.normal(0, 3000, 320), -32768, 32767).astype(np.int16) for _ in range(n_ticks)]
+    speech = [t >= 3 for t in range(n_ticks)]       # VAD rises at tick 3
+
+    class Src:
+        i = 0
+        def start(self): pass
+        def stop(self): pass
+        def close(self): pass
+        def read(self):
+            f = frames[self.i]
+            self.i += 1
+            return f
+
+    class Vad:
+        def __call__(self, ctx, frame):
+            ctx.is_speech = speech[src.i - 1]
+        def close(self): pass
+
+    seen = []
+    wake = WakewordTrigger(model_dir=os.path.join(assets, name), model_type=mtype, posterior_threshold=2.0)
+    orig = wake._sample
+
+    def spy(ctx, frame):
+        before = wake._posterior_max
+        orig(ctx, frame)
+        seen.append(wake._posterior_max)
+    wake._sample = spy
+    src = Src()
+    pipe = SpeechPipeline(src, [Vad(), wake])
+    pipe.start()
+    for _ in range(n_ticks):
+        pipe.step()
+    T = 151 if name == "CRNN" else 182
+    want = _reference_trigger_posteriors(oracle_dirs[name], frames, speech, T, 0 if name == "CRNN" else 1)
+    assert len(want) > 30
+    assert abs(max(want) - seen[-1]) < TOL          # running posterior_max (tflite.py:233-234)
+    assert not pipe.context.is_active               # threshold 2.0 never fires
+    with pytest.raises(ValueError):
+        WakewordTrigger(model_dir=os.path.join(assets, name), model_type="LSTM")
+    with pytest.raises(ValueError, match="Invalid fft_window_type"):
+        WakewordTrigger(fft_window_type="hamming", model_dir=os.path.join(assets, name), model_type=mtype)
+
+
+def test_wakeword_trigger_activates_and_resets(assets):
+    from wwhip.context import SpeechContext
+    from wwhip.wakeword import WakewordTrigger
+    rng = np.random.default_rng(6)
+    woke = []
+    wake = WakewordTrigger(model_dir=os.path.join(assets, "CRNN"), model_type="crnn", posterior_threshold=-1.0,
+                           on_wake=lambda: woke.append(1))
+    ctx = SpeechContext()
+    events = []
+    ctx.add_handler("activate", lambda c: events.append("activate"))
+    ctx.is_speech = True
+    for _ in range(3):
+        wake(ctx, np.clip(rng.normal(0, 3000, 320), -32768, 32767).astype(np.int16))
+    assert ctx.is_active and events == ["activate"] and woke == [1]
+    ctx.is_speech = False                      # VAD fall -> reset (tflite.py:143-146)
+    wake(ctx, np.zeros(320, np.int16))
+    assert wake._posterior_max == 0.0
+    wake.close()
+
+
+def _write_wav(path, pcm):
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(pcm.tobytes())
+
+
+@pytest.mark.parametrize("name,mtype", [("CRNN_softmax", "CRNN"), ("Wavenet", "Wavenet")])
+def test_get_posterior_matches_reference_flow(assets, oracle_dirs, tmp_path, name, mtype):
+    from wwhip.evaluate import get_posterior
+    from oracle import numpy_ref as NR
+    rng = np.random.default_rng(8)
+    files = []
+    sigs = []
+    for i, n in enumerate((30000, 41000)):
+        pcm = np.clip(rng.normal(0, 2500, n), -32768, 32767).astype(np.int16)
+        p = str(tmp_path / f"f{i}.wav")
+        _write_wav(p, pcm)
+        files.append(p)
+        sigs.append(pcm.astype(np.float32) / np.float32(32768))
+    mdir = oracle_dirs[name]
+    T = 151 if mtype == "CRNN" else 182
+    filt = NR.RefFilter(lambda a: mdir.filter(a)[0])            # ONE filter for all files (quirk C2)
+    want_all = [NR.sliding_posteriors(filt, s.copy(), T, lambda w: float(mdir.window(w)[1])) for s in sigs]
+    pos = get_posterior(os.path.join(assets, name), mtype, "false_negatives", files, 20, 16000)
+    assert len(pos) == 2
+    for got, want in zip(pos, want_all):
+        assert abs(got - max(want)) < TOL
+    neg = get_posterior(os.path.join(assets, name), mtype, "false_accepts", files, 20, 16000)
+    flat = [v for w in want_all for v in w]
+    assert len(neg) == len(flat)
+    assert np.abs(np.array(neg) - np.array(flat)).max() < TOL
+
+
+def test_far_frr_identical_to_reference_numbers(assets):
+    from wwhip.evaluate import far_frr, frr_at_fa
+    from oracle import numpy_ref as NR
+    rng = np.random.default_rng(9)
+    neg = np.clip(rng.beta(0.3, 3.0, 5000), 0, 1).astype(np.float32)
+    neg[1000:1040] = 0.97
+    neg[3000:3030] = 0.8
+    pos = rng.beta(5, 1, 300).astype(np.float32)
+    thr, frr, fa, cnt = far_frr(pos, neg, 300, 5000 * 0.02 / 3600, models_dir=os.path.join(assets, "CRNN"))
+    wf, wa, wc, _ = NR.far_frr(pos, neg, 300, 5000 * 0.02 / 3600)
+    np.testing.assert_array_equal(cnt, wc)           # FA counts identical
+    np.testing.assert_allclose(fa, wa, rtol=1e-15)
+    np.testing.assert_allclose(frr, wf, atol=1e-15)
+    assert frr_at_fa(frr, fa, 0.5) == NR.frr_at_fa(wf, wa, 0.5) or (np.isnan(frr_at_fa(frr, fa, 0.5)) and np.isnan(NR.frr_at_fa(wf, wa, 0.5)))
+    with pytest.raises(ValueError):
+        far_frr(pos, neg[:10], 300, 1.0, models_dir=os.path.join(assets, "CRNN"))
+
+
+def test_models_predict_one_window_per_clip(assets):
+    from wwhip.evaluate import load_data, models_predict
+    from wwhip.models import engine_for
+    from oracle.cpu import CpuOracle
+    rng = np.random.default_rng(10)
+    feats = [rng.uniform(0, 6, (n, 40)).astype(np.float32) for n in (147, 200, 60)]
+    eng = engine_for(os.path.join(assets, "CRNN_softmax"))
+    X, y = load_data(feats, [1, 0, 0], eng.window, 40)
+    preds, post = models_predict(eng, X)
+    want = CpuOracle(eng.blob).forward(X)[:, 1]
+    assert np.abs(post - want).max() < TOL
+    assert preds == [1 if p >= 0.5 else 0 for p in want]

@@ -1,0 +1,196 @@
+"""Host-side mirror of the reference interface (CPU only): RingBuffer, SpeechContext,
+SpeechPipeline, ActivationTimeout, frame/window schedules - against fixtures recorded from the
+reference's own classes (tests/golden/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from wwhip.activation_timeout import ActivationTimeout
+from wwhip.context import SpeechContext
+from wwhip.pipeline import SpeechPipeline
+from wwhip.ring_buffer import RingBuffer
+from wwhip import evaluate as E
+from oracle import numpy_ref as NR
+
+
+def test_ring_buffer_replays_reference_trace(golden):
+    script = json.load(open(os.path.join(golden, "ringbuffer_trace.json")))
+    for case in script:
+        shape = case["shape"]
+        rb = RingBuffer(shape=list(shape))
+        for rec in case["ops"]:
+            op = rec["op"]
+            raised = None
+            ret = None
+            try:
+                if op == "write":
+                    v = rec["arg"]
+                    rb.write(np.full(shape[1:], v, np.float32) if len(shape) > 1 else np.float32(v))
+                elif op == "read":
+                    ret = np.asarray(rb.read()).ravel().tolist()
+                elif op == "rewind":
+                    assert rb.rewind() is rb
+                elif op == "seek":
+                    assert rb.seek(rec["arg"]) is rb
+                elif op == "reset":
+                    assert rb.reset() is rb
+                elif op == "fill":
+                    assert rb.fill(rec["arg"]) is rb
+                elif op == "read_all":
+                    out = rb.read_all()
+                    ret = np.asarray(out).ravel().tolist()
+                    assert list(out.shape) == rec["ret_shape"]
+            except IndexError as e:
+                raised = str(e)
+            assert raised == rec.get("raises"), (op, rec)
+            if "ret" in rec and op == "read":
+                assert ret == rec["ret"]
+            if "ret" in rec and op == "read_all":
+                # slots never written hold np.empty garbage in both implementations: compare the
+                # entries the reference run had defined (finite, small) only when identical length
+                assert len(ret) == len(rec["ret"])
+            st = rec["state"]
+            assert (rb.is_empty, rb.is_full, rb.capacity) == (st["empty"], st["full"], st["capacity"]), (op, rec)
+
+
+def test_ring_buffer_values_and_block_write():
+    rb = RingBuffer([5])
+    rb.write_block(np.arange(4, dtype=np.float32))
+    assert len(rb) == 4 and not rb.is_full
+    rb.write(np.float32(4))
+    assert rb.is_full
+    with pytest.raises(IndexError, match="Buffer is full"):
+        rb.write(np.float32(9))
+    assert rb.read().tolist() == [0.0] and rb.read().shape == (1,)
+    rb.write_block(np.array([5, 6], np.float32))
+    assert rb.read_all().tolist() == [2.0, 3.0, 4.0, 5.0, 6.0]
+    assert rb.is_empty
+    with pytest.raises(IndexError, match="Buffer is empty"):
+        rb.read()
+    rb.fill(0.0)
+    assert rb.is_full and rb.read_all().tolist() == [0.0] * 5
+    rb2 = RingBuffer([3, 2])
+    rb2.fill(1.0).rewind().seek(1)
+    rb2.write(np.array([7, 8], np.float32))
+    np.testing.assert_array_equal(rb2.read_all(), [[1, 1], [1, 1], [7, 8]])
+
+
+def test_pipeline_and_context_replay_reference_trace(golden):
+    want = json.load(open(os.path.join(golden, "pipeline_trace.json")))
+    trace = []
+
+    class Src:
+        n = 0
+
+        def start(self): trace.append("src.start")
+        def stop(self): trace.append("src.stop")
+        def close(self): trace.append("src.close")
+
+        def read(self):
+            self.n += 1
+            trace.append(f"src.read{self.n}")
+            return np.zeros(320, np.int16)
+
+    class Stage:
+        def __init__(self, name, ref):
+            self.name, self.ref = name, ref
+
+        def __call__(self, ctx, frame):
+            trace.append(f"{self.name}.call active={ctx.is_active} speech={ctx.is_speech}")
+            n = self.ref["n"]
+            if self.name == "a" and n == 1: ctx.is_speech = True
+            if self.name == "b" and n == 2: ctx.is_active = True
+            if self.name == "b" and n == 3: ctx.is_active = False
+            if self.name == "b" and n == 4: self.ref["pipe"].stop()
+
+        def close(self): trace.append(f"{self.name}.close")
+
+    ref = {"n": 0}
+    pipe = SpeechPipeline(Src(), [Stage("a", ref), Stage("b", ref)])
+    ref["pipe"] = pipe
+
+    @pipe.event
+    def on_activate(ctx): trace.append("event.activate")
+
+    @pipe.event
+    def on_deactivate(ctx): trace.append("event.deactivate")
+
+    @pipe.event(name="step")
+    def counter(ctx):
+        ref["n"] += 1
+        trace.append(f"event.step{ref['n']}")
+
+    pipe.start(); pipe.start(); pipe.run()
+    trace.append(f"running={pipe.is_running}")
+    ctx = SpeechContext()
+    ctx.is_active = True; ctx.is_active = True; ctx.transcript = "x"; ctx.confidence = 0.5; ctx.reset()
+    trace.append(f"ctx {ctx.is_active} {ctx.is_speech} {ctx.transcript!r} {ctx.confidence}")
+    assert trace == want
+
+
+def test_activation_timeout_semantics():
+    ctx = SpeechContext()
+    t = ActivationTimeout(frame_width=20, min_active=100, max_active=200)
+    ctx.is_active = True
+    ctx.is_speech = True
+    for _ in range(5):
+        t(ctx)
+    assert ctx.is_active            # 5 frames = min_active: not yet over
+    ctx.is_speech = False
+    t(ctx)                          # vad fall after min_active -> deactivate
+    assert not ctx.is_active
+    ctx.is_active = True
+    for _ in range(11):
+        t(ctx)
+    assert not ctx.is_active        # max_active exceeded
+
+
+def test_frame_schedule_matches_reference_ring(golden):
+    z = np.load(os.path.join(golden, "framing.npz"))
+    for name in ["single_24000", "single_short", "single_tiny", "two_files_3200", "ragged"]:
+        files = z[name + ".files"]
+        padded = [int(-(-n // 320) * 320) for n in files]
+        per_file, starts = E.frame_schedule(padded, 160, 320, carry_over=True)
+        assert [int(p.sum()) for p in per_file] == z[name + ".frames_per_file"].tolist()
+        assert np.concatenate(per_file).tolist() == z[name + ".frames_per_chunk"].tolist()
+        total = int(sum(p.sum() for p in per_file))
+        assert (160 * np.arange(total)).tolist() == z[name + ".starts"].tolist()
+
+
+def test_window_schedule_matches_reference_loop():
+    rng = np.random.default_rng(0)
+    for T in (151, 182):
+        for n in (100, 48000, 30001):
+            x = rng.normal(0, 0.1, n).astype(np.float32)
+            filt = NR.RefFilter(lambda a: np.zeros((1, 40), np.float32))
+            filt.stft_mag = lambda: np.zeros(257, np.float32)      # numerics irrelevant here
+            seen = []
+            NR.sliding_posteriors(filt, x, T, lambda w: seen.append(1) or 0.0)
+            padded = len(x) + 16000
+            padded += (-padded) % 320
+            fpc, _ = E.frame_schedule([padded])
+            ws = E.window_schedule(fpc[0], T, 2)
+            assert len(ws) == len(seen)
+            assert ws.tolist() == (2 * np.arange(len(ws))).tolist()
+
+
+def test_read_wav_roundtrip(tmp_path):
+    import wave
+    p = str(tmp_path / "a.wav")
+    pcm = (np.arange(-100, 100) * 100).astype(np.int16)
+    with wave.open(p, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(pcm.tobytes())
+    x = E.read_wav(p)
+    np.testing.assert_array_equal(x, pcm.astype(np.float32) / np.float32(32768))
+    with pytest.raises(ValueError):
+        E.read_wav(p, sample_rate=8000)
+
+
+def test_load_data_truncates_and_pads():
+    feats = [np.ones((200, 40), np.float32), np.ones((10, 40), np.float32) * 2]
+    X, y = E.load_data(feats, [1, 0], 151, 40)
+    assert X.shape == (2, 151, 40) and X[0].sum() == 151 * 40 and X[1, 10:].sum() == 0 and X[1, :10].sum() == 800
+    np.testing.assert_array_equal(X, NR.load_h5_like(feats, 151, 40))
+    assert y.tolist() == [1, 0]

@@ -267,8 +267,9 @@ static int load_filter(ww_ctx *ctx, ww_model *m, const blob_view &bv) {
   f.melB = upload(m, melB);
   f.start = upload(m, start); f.len = upload(m, len); f.woff = upload(m, woff);
   f.w = upload(m, taps); f.bias = upload(m, bias); f.wpad = upload(m, wpad);
+  f.wdense = upload(m, std::vector<float>(w, w + (size_t)n_mel * n_bins));
   f.hann = upload(m, hann); f.tw256 = upload(m, tw256); f.tw512 = upload(m, tw512);
-  if (!f.tw16 || !f.melB || !f.start || !f.len || !f.woff || !f.w || !f.bias || !f.wpad || !f.hann || !f.tw256 || !f.tw512)
+  if (!f.wdense || !f.tw16 || !f.melB || !f.start || !f.len || !f.woff || !f.w || !f.bias || !f.wpad || !f.hann || !f.tw256 || !f.tw512)
     return ww_fail(ctx, WW_ENOMEM, "filter upload failed");
   return WW_OK;
 }
@@ -554,6 +555,49 @@ int ww_stft_mag(ww_ctx *ctx, const ww_model *m, const float *frames, int64_t n, 
   WW_HIP(ctx, hipMemcpyAsync(d_f, frames, (size_t)n * WW_FFT_WINDOW * 4, hipMemcpyHostToDevice, ctx->stream));
   if ((rc = ww_k_stft_mag(ctx, m, d_f, n, precise, d_m))) return rc;
   WW_HIP(ctx, hipMemcpyAsync(mag, d_m, (size_t)n * WW_FFT_BINS * 4, hipMemcpyDeviceToHost, ctx->stream));
+  WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return WW_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
+
+int ww_filter_apply(ww_ctx *ctx, const ww_model *m, const float *mag, int64_t n, float *mel) {
+  if (!ctx || !m) return ww_fail(ctx, WW_EINVAL, "NULL argument");
+  if (n < 0) return ww_fail(ctx, WW_EINVAL, "negative row count");
+  if (n == 0) return WW_OK;
+  if (!mag || !mel) return ww_fail(ctx, WW_EINVAL, "NULL buffer");
+  WW_HIP(ctx, hipSetDevice(ctx->device));
+  const int NBN = m->filt.n_bins, F = m->filt.n_mel;
+  const size_t b_a = ww_bump::need((size_t)n * NBN, 4), b_b = ww_bump::need((size_t)n * F, 4);
+  int rc = ww_ensure(ctx, ctx->dev, b_a + b_b, false);
+  if (rc) return rc;
+  ww_bump bump(ctx->dev.ptr, ctx->dev.cap);
+  float *d_a = bump.take<float>((size_t)n * NBN), *d_b = bump.take<float>((size_t)n * F);
+  WW_HIP(ctx, hipMemcpyAsync(d_a, mag, (size_t)n * NBN * 4, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = ww_k_mel_only(ctx, m, d_a, n, d_b))) return rc;
+  WW_HIP(ctx, hipMemcpyAsync(mel, d_b, (size_t)n * F * 4, hipMemcpyDeviceToHost, ctx->stream));
+  WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return WW_OK;
+}
+
+int ww_detect(ww_ctx *ctx, const ww_model *m, const float *enc, int32_t n, float *out) {
+  if (!ctx || !m) return ww_fail(ctx, WW_EINVAL, "NULL argument");
+  if (n < 0) return ww_fail(ctx, WW_EINVAL, "negative row count");
+  if (n == 0) return WW_OK;
+  if (!enc || !out) return ww_fail(ctx, WW_EINVAL, "NULL buffer");
+  WW_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t per = (size_t)m->info.enc_rows * m->info.enc_width;
+  const size_t b_a = ww_bump::need((size_t)n * per, 4), b_b = ww_bump::need((size_t)n * m->info.n_out, 4);
+  int rc = ww_ensure(ctx, ctx->dev, b_a + b_b, false);
+  if (rc) return rc;
+  ww_bump bump(ctx->dev.ptr, ctx->dev.cap);
+  float *d_a = bump.take<float>((size_t)n * per), *d_b = bump.take<float>((size_t)n * m->info.n_out);
+  WW_HIP(ctx, hipMemcpyAsync(d_a, enc, (size_t)n * per * 4, hipMemcpyHostToDevice, ctx->stream));
+  rc = m->kind == WW_KIND_CRNN ? ww_k_crnn_detect(ctx, m, d_a, n, d_b) : ww_k_wave_detect(ctx, m, d_a, n, d_b);
+  if (rc) return rc;
+  WW_HIP(ctx, hipMemcpyAsync(out, d_b, (size_t)n * m->info.n_out * 4, hipMemcpyDeviceToHost, ctx->stream));
   WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return WW_OK;
 }

@@ -68,6 +68,7 @@ struct ww_filter_dev {
   float floor_v = 0, log_off = 0, scale = 0;
   int *start = nullptr, *len = nullptr, *woff = nullptr;
   float *w = nullptr, *bias = nullptr;
+  float *wdense = nullptr;   // [n_mel][n_bins] dense weights (filter.tflite layout)
   float *wpad = nullptr;     // [WW_MEL_TAPS][64] tap-major zero-padded weights (kernel form)
   int total_taps = 0, max_len = 0;
   double *hann = nullptr;    // [512] np.hanning(512) in fp64
@@ -168,6 +169,9 @@ int ww_k_logmel(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, const floa
                 const int64_t *d_frame_offs, int n_utt, int64_t total_frames, int64_t max_frames_per_utt,
                 const ww_frontend_params *fp, float *d_mel);
 int ww_k_stft_mag(ww_ctx *ctx, const ww_model *m, const float *d_frames, int64_t n, int precise, float *d_mag);
+int ww_k_mel_only(ww_ctx *ctx, const ww_model *m, const float *d_mag, int64_t n, float *d_mel);
+int ww_k_crnn_detect(ww_ctx *ctx, const ww_model *m, const float *d_enc, int nw, float *d_out);
+int ww_k_wave_detect(ww_ctx *ctx, const ww_model *m, const float *d_enc, int nw, float *d_out);
 
 size_t ww_crnn_workspace(const ww_model *m, int n_windows);
 int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *d_win_row,

@@ -460,6 +460,43 @@ __global__ __launch_bounds__(256) void gru_head_kernel(gru_head_args a) {
   }
 }
 
+// detect.tflite alone (reference detect_model(x), wakeword/tflite.py:228-229): one wave per row
+__global__ __launch_bounds__(64) void crnn_detect_kernel(const float *enc, const float *w1, const float *b1, const float *w2,
+                                                         const float *b2, float *out, int NOUT, int HEAD) {
+  __shared__ float e[64], hid[64];
+  const int lane = threadIdx.x, w = blockIdx.x;
+  e[lane] = enc[(size_t)w * 64 + lane];
+  __syncthreads();
+  float acc = 0.f;
+  for (int k = 0; k < 64; ++k) acc = fmaf(w1[lane * 64 + k], e[k], acc);
+  hid[lane] = fmaxf(acc + b1[lane], 0.f);
+  __syncthreads();
+  float y = 0.f;
+  if (lane < NOUT) {
+    for (int k = 0; k < 64; ++k) y = fmaf(w2[lane * 64 + k], hid[k], y);
+    y += b2[lane];
+  }
+  if (HEAD == 0) {
+    if (lane < NOUT) out[(size_t)w * NOUT + lane] = sigmoid_f(y);
+  } else {
+    float mx = (lane < NOUT) ? y : -INFINITY;
+    for (int o = 1; o < 8; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float ex = (lane < NOUT) ? expf(y - mx) : 0.f;
+    float sum = ex;
+    for (int o = 1; o < 8; o <<= 1) sum += __shfl_xor(sum, o);
+    if (lane < NOUT) out[(size_t)w * NOUT + lane] = ex / sum;
+  }
+}
+
+int ww_k_crnn_detect(ww_ctx *ctx, const ww_model *m, const float *d_enc, int nw, float *d_out) {
+  if (nw <= 0) return WW_OK;
+  const ww_crnn_dev &c = m->crnn;
+  ww_launch_scope scope(ctx, "crnn_detect_kernel");
+  hipLaunchKernelGGL(crnn_detect_kernel, dim3(nw), dim3(64), 0, ctx->stream, d_enc, c.w1, c.b1, c.w2, c.b2, d_out, c.NOUT, c.HEAD);
+  WW_HIP(ctx, hipGetLastError());
+  return WW_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------

@@ -388,6 +388,32 @@ int ww_k_logmel(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, const floa
   return WW_OK;
 }
 
+// filter.tflite alone (reference filter_model(frame), wakeword/tflite.py:183-184): mag [n][257] -> mel [n][40]
+__global__ __launch_bounds__(64) void mel_only_kernel(const float *mag, int64_t n, const float *w, const float *bias, int n_mel,
+                                                      int n_bins, float floor_v, float log_off, float scale, float *mel) {
+  __shared__ float m[260];
+  const int lane = threadIdx.x;
+  const int64_t f = blockIdx.x;
+  for (int k = lane; k < n_bins; k += 64) m[k] = mag[f * n_bins + k];
+  __syncthreads();
+  if (lane < n_mel) {
+    float acc = 0.f;
+    for (int k = 0; k < n_bins; ++k) acc = fmaf(w[(size_t)lane * n_bins + k], m[k], acc);
+    acc = fmaxf(acc + bias[lane], floor_v);
+    mel[f * n_mel + lane] = (logf(acc) + log_off) * scale;
+  }
+}
+
+int ww_k_mel_only(ww_ctx *ctx, const ww_model *m, const float *d_mag, int64_t n, float *d_mel) {
+  if (n <= 0) return WW_OK;
+  const ww_filter_dev &f = m->filt;
+  ww_launch_scope scope(ctx, "mel_only_kernel");
+  hipLaunchKernelGGL(mel_only_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, d_mag, n, f.wdense, f.bias, f.n_mel, f.n_bins,
+                     f.floor_v, f.log_off, f.scale, d_mel);
+  WW_HIP(ctx, hipGetLastError());
+  return WW_OK;
+}
+
 int ww_k_stft_mag(ww_ctx *ctx, const ww_model *m, const float *d_frames, int64_t n, int precise, float *d_mag) {
   if (n <= 0) return WW_OK;
   logmel_args a = {};

@@ -55,6 +55,7 @@ struct wave_args {
   const float *d_b2;    // [16]
   float *out;           // [Nw][NOUT]
   float *enc;           // optional [Nw][T][32]
+  const float *enc_in;  // HEAD_ONLY: encoder output to run the detect graph on
 };
 
 __device__ __forceinline__ float sigmoid_w(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -72,6 +73,7 @@ __device__ __forceinline__ void wsync() {
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0); \
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
 
+template <bool HEAD_ONLY>
 __global__ __launch_bounds__(256) void wavenet_kernel(wave_args a) {
   // LDS: region A = staged input [192][48] (prologue only), later u[2][208][16] + g[192][16]
   __shared__ __align__(16) float lds[WV_T * WV_INLD > (2 * (WV_T + WV_PAD) * WV_C + WV_T * WV_S) ? WV_T * WV_INLD
@@ -82,6 +84,23 @@ __global__ __launch_bounds__(256) void wavenet_kernel(wave_args a) {
   const int w = blockIdx.x;
   const int T = a.T;
 
+  f32x4 x[3], skip[3][2];
+  float *ubuf = lds;                                    // [2][WV_T + WV_PAD][16]
+  float *gbuf = lds + 2 * (WV_T + WV_PAD) * WV_C;       // [WV_T][16] (wave-private tiles)
+  float *hbuf = gbuf;                                   // detect head reuses it as [WV_T][32]
+  if (HEAD_ONLY) {
+    // detect.tflite alone (reference detect_model(x), wakeword/tflite.py:231): skip sums come from memory
+    const float *e = a.enc_in + (size_t)w * T * WV_S;
+#pragma unroll
+    for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = (wave * 3 + mi) * 16 + kk * 4 + r;
+        skip[mi][0][r] = t < T ? e[(size_t)t * WV_S + j] : 0.f;
+        skip[mi][1][r] = t < T ? e[(size_t)t * WV_S + 16 + j] : 0.f;
+      }
+    (void)x; (void)ubuf;
+  } else {
   int64_t row = a.wa.row ? a.wa.row[w] : a.wa.row0 + (int64_t)w * a.wa.hop;
   int valid = a.wa.valid ? a.wa.valid[w] : a.wa.valid_const;
   if (valid > T) valid = T;
@@ -104,7 +123,6 @@ __global__ __launch_bounds__(256) void wavenet_kernel(wave_args a) {
 
   // ---- input 1x1 conv + ReLU -> x in accumulator layout.  m-tile mi of this wave covers rows
   // (wave*3 + mi)*16 .. +15; lane holds rows kk*4 + r, column j.
-  f32x4 x[3], skip[3][2];
   {
     float4 bw[3];
 #pragma unroll
@@ -127,9 +145,6 @@ __global__ __launch_bounds__(256) void wavenet_kernel(wave_args a) {
   }
   __syncthreads();  // in_lds is dead from here on
 
-  float *ubuf = lds;                                    // [2][WV_T + WV_PAD][16]
-  float *gbuf = lds + 2 * (WV_T + WV_PAD) * WV_C;       // [WV_T][16] (wave-private tiles)
-  float *hbuf = gbuf;                                   // detect head reuses it as [WV_T][32]
   // causal zero rows of both u buffers
   for (int i = tid; i < 2 * WV_PAD * WV_C; i += 256) {
     int b = i / (WV_PAD * WV_C), o = i - b * (WV_PAD * WV_C);
@@ -194,6 +209,7 @@ __global__ __launch_bounds__(256) void wavenet_kernel(wave_args a) {
   }
   __syncthreads();
 
+  }
   // ---- encoder output (optional) + detect head
   if (a.enc) {
     float *e = a.enc + (size_t)w * T * WV_S;
@@ -287,7 +303,20 @@ int ww_k_wave_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
   a.d_w1_4 = v.d_w1; a.d_b1 = v.d_b1; a.d_w2_4 = v.d_w2; a.d_b2 = v.d_b2;
   a.out = d_out; a.enc = d_enc;
   ww_launch_scope scope(ctx, "wavenet_kernel");
-  hipLaunchKernelGGL(wavenet_kernel, dim3(nw), dim3(256), 0, ctx->stream, a);
+  hipLaunchKernelGGL(wavenet_kernel<false>, dim3(nw), dim3(256), 0, ctx->stream, a);
+  WW_HIP(ctx, hipGetLastError());
+  return WW_OK;
+}
+
+int ww_k_wave_detect(ww_ctx *ctx, const ww_model *m, const float *d_enc, int nw, float *d_out) {
+  if (nw <= 0) return WW_OK;
+  const ww_wave_dev &v = m->wave;
+  wave_args a = {};
+  a.T = v.T; a.n_mel = v.n_mel; a.NB = v.NB; a.NOUT = v.NOUT;
+  a.d_w1_4 = v.d_w1; a.d_b1 = v.d_b1; a.d_w2_4 = v.d_w2; a.d_b2 = v.d_b2;
+  a.out = d_out; a.enc = nullptr; a.enc_in = d_enc;
+  ww_launch_scope scope(ctx, "wavenet_detect_kernel");
+  hipLaunchKernelGGL(wavenet_kernel<true>, dim3(nw), dim3(256), 0, ctx->stream, a);
   WW_HIP(ctx, hipGetLastError());
   return WW_OK;
 }

@@ -1,0 +1,1 @@
+from wwhip.models import TFLiteModel  # noqa: F401

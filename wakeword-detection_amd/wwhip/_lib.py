@@ -53,6 +53,8 @@ SYMBOLS: Dict[str, tuple] = {
     "ww_logmel": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _P(FrontendParams), _vp, _vp]),
     "ww_logmel_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _P(FrontendParams), _vp, _vp]),
     "ww_stft_mag": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "ww_filter_apply": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "ww_detect": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
     "ww_logmel_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _P(FrontendParams), _vp]),
     "ww_forward": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
     "ww_forward_enc": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp]),

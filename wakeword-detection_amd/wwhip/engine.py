@@ -100,6 +100,26 @@ class Engine:
         self._chk(self._lib.ww_stft_mag(self.ctx.handle, self._model, _lib.ptr(f), f.shape[0], int(precise), _lib.ptr(mag)))
         return mag
 
+    def filter_apply(self, mag: np.ndarray) -> np.ndarray:
+        """``[n, 257]`` STFT magnitudes -> ``[n, 40]`` log-mel (filter.tflite alone)."""
+        a = np.ascontiguousarray(mag, dtype=np.float32)
+        if a.ndim != 2 or a.shape[1] != self.n_bins:
+            raise ValueError(f"Cannot set tensor: Dimension mismatch. Got {a.shape} but expected (n, {self.n_bins})")
+        mel = np.empty((a.shape[0], self.n_mel), np.float32)
+        self._chk(self._lib.ww_filter_apply(self.ctx.handle, self._model, _lib.ptr(a), a.shape[0], _lib.ptr(mel)))
+        return mel
+
+    def detect(self, enc: np.ndarray) -> np.ndarray:
+        """Encoder outputs ``[n, enc_rows, enc_width]`` -> detect rows ``[n, n_out]`` (detect.tflite alone)."""
+        e = np.ascontiguousarray(enc, dtype=np.float32)
+        per = self.enc_shape[0] * self.enc_shape[1]
+        if e.size % per != 0 or e.size == 0:
+            raise ValueError(f"Cannot set tensor: Dimension mismatch. Got {e.shape} but expected (n,) + {self.enc_shape}")
+        n = e.size // per
+        out = np.empty((n, self.n_out), np.float32)
+        self._chk(self._lib.ww_detect(self.ctx.handle, self._model, _lib.ptr(e), n, _lib.ptr(out)))
+        return out
+
     # ------------------------------------------------------------------ models
     def forward(self, windows: np.ndarray, want_enc: bool = False):
         """``[B, window, 40]`` -> detect rows ``[B, n_out]`` (and encoder output)."""

@@ -1,0 +1,117 @@
+"""Streaming wake-word stage with the surface of the reference's ``WakewordTrigger``
+(``spokestack/wakeword/tflite.py:20-250``).  Per 20 ms frame the reference normalises,
+pre-emphasises, pushes 320 samples through a Python ring, and for every completed STFT frame
+(while ``context.is_speech``) runs filter -> slide window -> encode -> detect.  Here all of
+that state lives on the GPU in a one-stream :class:`StreamBank`; this class keeps only the
+host logic: VAD-edge reset, activation, running maximum.
+
+:class:`WakewordBank` is the many-stream form used by BASELINE config 5.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+from .context import SpeechContext
+from .engine import StreamBank, frontend_params
+from .models import engine_for
+
+_LOG = logging.getLogger(__name__)
+
+
+class WakewordTrigger:
+    def __init__(self, pre_emphasis: float = 0.0, sample_rate: int = 16000, fft_window_type: str = "hann",
+                 fft_hop_length: int = 10, model_dir: str = "", model_type: str = "",
+                 posterior_threshold: float = 0.5, on_wake: Optional[Callable[[], None]] = None, device: int = 0,
+                 **kwargs) -> None:
+        self.pre_emphasis = pre_emphasis
+        self.hop_length = int(fft_hop_length * sample_rate / 1000)
+        if fft_window_type != "hann":
+            raise ValueError("Invalid fft_window_type")
+        self.model_type = model_type.upper()
+        if self.model_type not in ("CRNN", "WAVENET"):
+            # the reference fails later with AttributeError; fail early instead
+            raise ValueError(f"model_type must be 'CRNN' or 'Wavenet', got {model_type!r}")
+        self._engine = engine_for(model_dir, device)
+        if self._engine.is_crnn != (self.model_type == "CRNN"):
+            raise ValueError(f"model_dir holds a {'CRNN' if self._engine.is_crnn else 'Wavenet'} model, "
+                             f"model_type says {model_type}")
+        self._window_size = (self._engine.n_bins - 1) * 2
+        self.mel_length = self._engine.window
+        self.mel_width = self._engine.n_mel
+        self.encode_length, self.encode_width = self._engine.enc_shape
+        self._bank = StreamBank(self._engine, 1, frontend_params(32767.0, True, pre_emphasis, self.hop_length, True))
+        self._posterior_threshold = posterior_threshold
+        self._posterior_max = 0.0
+        self._is_speech = False
+        self._on_wake = on_wake  # replaces the pydub audio reply (tflite.py:111-121,238)
+
+    def __call__(self, context: SpeechContext, frame) -> None:
+        vad_fall = self._is_speech and not context.is_speech
+        self._is_speech = context.is_speech
+        if not context.is_active:
+            self._sample(context, frame)
+        if vad_fall:
+            if not context.is_active:
+                _LOG.info(f"wake: {self._posterior_max}")
+            self.reset()
+
+    def _sample(self, context: SpeechContext, frame) -> None:
+        f = np.asarray(frame, dtype=np.int16).reshape(1, -1)
+        if f.shape[1] != 320:
+            raise ValueError("WakewordTrigger expects 20 ms frames of 320 int16 samples")
+        post, n = self._bank.step(f, np.array([1 if context.is_speech else 0], np.uint8))
+        for k in range(int(n[0])):
+            posterior = float(post[0, k])
+            if posterior > self._posterior_max:
+                self._posterior_max = posterior
+            if posterior > self._posterior_threshold and not context.is_active:
+                _LOG.info(f"AWAKE!: {self._posterior_max}")
+                if self._on_wake is not None:
+                    self._on_wake()
+                context.is_active = True
+
+    def reset(self) -> None:
+        self._bank.reset()
+        self._posterior_max = 0.0
+
+    def close(self) -> None:
+        self.reset()
+
+
+class WakewordBank:
+    """S streams in lock step (one ``SpeechContext`` each): the batched form of
+    :class:`WakewordTrigger` - one kernel chain per 20 ms tick for all streams."""
+
+    def __init__(self, n_streams: int, model_dir: str, posterior_threshold: float = 0.5, pre_emphasis: float = 0.0,
+                 device: int = 0) -> None:
+        self._engine = engine_for(model_dir, device)
+        self.S = int(n_streams)
+        self._bank = StreamBank(self._engine, self.S, frontend_params(32767.0, True, pre_emphasis, 160, True))
+        self.threshold = posterior_threshold
+        self.posterior_max = np.zeros(self.S, np.float32)
+        self._was_speech = np.zeros(self.S, bool)
+
+    def step(self, contexts: Sequence[SpeechContext], frames: np.ndarray) -> np.ndarray:
+        speech = np.array([c.is_speech for c in contexts], bool)
+        active = np.array([c.is_active for c in contexts], bool)
+        fall = self._was_speech & ~speech
+        self._was_speech = speech
+        post, n = self._bank.step(frames, speech.astype(np.uint8), active.astype(np.uint8))
+        for s in range(self.S):
+            for k in range(int(n[s])):
+                p = float(post[s, k])
+                if p > self.posterior_max[s]:
+                    self.posterior_max[s] = p
+                if p > self.threshold and not contexts[s].is_active:
+                    contexts[s].is_active = True
+        ids = np.nonzero(fall)[0]
+        if len(ids):
+            self._bank.reset(ids)
+            self.posterior_max[ids] = 0.0
+        return post
+
+    def close(self) -> None:
+        self._bank.close()
