@@ -81,7 +81,8 @@ def cpu_baseline(eng, pcm_sample, budget_s=12.0):
     """Time the C restatement (oracle/ww_oracle.c, all host threads) on a bounded sample."""
     from oracle import cpu as ocpu
     ora = ocpu.CpuOracle(eng.blob)
-    threads = ocpu.num_threads()
+    # a 1-GPU box grants this job 16 CPUs (of many more logical ones): use exactly that share
+    threads = ocpu.set_threads(max(1, min(16, os.cpu_count() or 1)))
 
     def one_pass(clips):
         wins = np.zeros((len(clips), eng.window, 40), np.float32)
@@ -99,7 +100,7 @@ def cpu_baseline(eng, pcm_sample, budget_s=12.0):
         one_pass(pcm_sample)
         done += n
         el = time.perf_counter() - t0
-        if el > budget_s or done >= 8 * n:
+        if el > budget_s or done >= 16 * n:
             break
     return {
         "value": done * FRAMES_PER_CLIP / el,
@@ -119,6 +120,9 @@ def main():
     ap.add_argument("--model", choices=["crnn", "wavenet"], default="crnn")
     ap.add_argument("--clips", type=int, default=256)
     ap.add_argument("--rotate", type=int, default=24, help="distinct resident input batches to rotate over")
+    ap.add_argument("--pipeline", type=int, default=3,
+                    help="independent contexts (HIP streams) the steps are dealt to round-robin; batches are "
+                         "independent, so consecutive steps may overlap on the GPU")
     ap.add_argument("--fast-frontend", action="store_true", help="fp32 FFT instead of the reference's fp64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -140,9 +144,11 @@ def main():
 
     from wwhip.engine import Engine, frontend_params
     from wwhip import _lib
-    ctx = _lib.Context(local_rank)
+    P = max(1, args.pipeline)
+    ctxs = [_lib.Context(local_rank) for _ in range(P)]
     model_dir = os.path.join(PKG, "assets", "tf_lite_models", "CRNN" if args.model == "crnn" else "Wavenet")
-    eng = Engine(model_dir, device=local_rank, ctx=ctx)
+    engs = [Engine(model_dir, device=local_rank, ctx=c) for c in ctxs]
+    ctx, eng = ctxs[0], engs[0]
     fp = frontend_params(32767.0, True, 0.0, 160, not args.fast_frontend)
 
     # R distinct resident input batches, rotated step by step: R * 12.3 MB exceeds the 256 MiB
@@ -161,18 +167,23 @@ def main():
     d_all = torch.zeros((K, args.clips, eng.n_out), dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
 
-    def step(k):
+    def step(k, only0=False):
         r = k % R
-        eng.clips_forward_dev(d_pcm[r].data_ptr(), args.clips, SAMPLES, d_outs[r].data_ptr(), fp)
+        e = eng if only0 else engs[k % P]
+        e.clips_forward_dev(d_pcm[r].data_ptr(), args.clips, SAMPLES, d_outs[r].data_ptr(), fp)
+
+    def sync_all():
+        for c in ctxs:
+            c.synchronize()
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(max(args.warmup, R)):  # at least one pass over every batch: graphs captured
+    for k in range(max(args.warmup, R * P)):  # every (context, batch) pair seen once: graphs captured
         step(k)
-    ctx.synchronize()
+    sync_all()
     if dist is not None:  # warm up the communicator outside the timed region
         tmp = [torch.empty_like(d_all) for _ in range(world)]
         dist.all_gather(tmp, d_all)
@@ -181,7 +192,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(K):
         step(k)
-    ctx.synchronize()
+    sync_all()
     if dist is not None:
         # posterior gather, once per job: every rank contributes the K*clips*n_out floats it produced
         for k in range(K):
@@ -198,7 +209,7 @@ def main():
     # ---- per-kernel pass (HIP events around every launch), same K steps
     ctx.profile(True)
     for k in range(K):
-        step(k)
+        step(k, only0=True)
     prof = ctx.profile_read()
     ctx.profile(False)
     posts = d_outs[0].cpu().numpy()
@@ -244,6 +255,7 @@ def main():
                 "clips_per_gpu": args.clips,
                 "samples_per_clip": SAMPLES,
                 "resident_input_batches_rotated": R,
+                "pipelined_contexts": P,
                 "weights": "reference tf_lite_models (shipped fp32 weights)",
                 "parallelism": f"utterance-sharded x{world}, posterior all_gather once per job" if world > 1 else "single GPU",
             },
@@ -251,7 +263,7 @@ def main():
             "posterior_checksum": float(np.sum(posts, dtype=np.float64)),
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(eng, pcm0[:64])
+            line["cpu_baseline"] = cpu_baseline(eng, pcm0)
         elif not args.no_cpu_baseline:
             line["cpu_baseline"] = None
         print(json.dumps(line))

@@ -72,6 +72,7 @@ def lib() -> C.CDLL:
     i64, i32, f32 = C.c_int64, C.c_int, C.c_float
     vp, sz = C.c_void_p, C.c_size_t
     L.wwo_num_threads.restype = i32
+    L.wwo_set_threads.argtypes = [i32]
     L.wwo_num_frames.restype = i64
     L.wwo_num_frames.argtypes = [i64, i32]
     L.wwo_logmel.argtypes = [vp, sz, vp, i64, f32, i32, f32, i32, vp, i32, vp, vp]
@@ -93,6 +94,13 @@ def lib_path() -> str:
 
 def num_threads() -> int:
     return int(lib().wwo_num_threads())
+
+
+def set_threads(n: int) -> int:
+    """Fix the OpenMP team size (the GPU boxes expose far more logical CPUs than the job's
+    share; oversubscribing them makes the baseline slower, not faster)."""
+    lib().wwo_set_threads(int(n))
+    return num_threads()
 
 
 def _p(a: Optional[np.ndarray]):

@@ -72,6 +72,14 @@ static const void *blob_find(const blob_t *b, const char *name, uint32_t *count)
 static const float *bf(const blob_t *b, const char *n) { return (const float *)blob_find(b, n, NULL); }
 static const int32_t *bi(const blob_t *b, const char *n) { return (const int32_t *)blob_find(b, n, NULL); }
 
+void wwo_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int wwo_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();
@@ -269,25 +277,44 @@ static inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 typedef struct {
   const float *wx, *bx, *wh, *bh;
+  float *wxT, *whT; /* transposed copies [in][3H], [H][3H]: the gate index is the contiguous (vector) axis */
 } gru_t;
+
+static void gru_prepare(gru_t *g, int in_w, int H) {
+  g->wxT = (float *)malloc(sizeof(float) * (size_t)in_w * 3 * H);
+  g->whT = (float *)malloc(sizeof(float) * (size_t)H * 3 * H);
+  for (int o = 0; o < 3 * H; ++o) {
+    for (int k = 0; k < in_w; ++k) g->wxT[(size_t)k * 3 * H + o] = g->wx[(size_t)o * in_w + k];
+    for (int k = 0; k < H; ++k) g->whT[(size_t)k * 3 * H + o] = g->wh[(size_t)o * H + k];
+  }
+}
+
+static void gru_release(gru_t *g) {
+  free(g->wxT);
+  free(g->whT);
+}
 
 static void gru_run(const gru_t *g, const float *seq, int T, int in_w, int H, int backward, float *out_seq,
                     int out_stride, int out_off, float *last) {
   float h[64], gx[192], gh[192];
+  const int G = 3 * H;
   for (int i = 0; i < H; ++i) h[i] = 0.f;
   for (int s = 0; s < T; ++s) {
     int t = backward ? T - 1 - s : s;
     const float *x = seq + (size_t)t * in_w;
-    for (int o = 0; o < 3 * H; ++o) {
-      float a = 0.f;
-      const float *w = g->wx + (size_t)o * in_w;
-      for (int k = 0; k < in_w; ++k) a += w[k] * x[k];
-      gx[o] = a + g->bx[o];
-      float r = 0.f;
-      const float *u = g->wh + (size_t)o * H;
-      for (int k = 0; k < H; ++k) r += u[k] * h[k];
-      gh[o] = r + g->bh[o];
+    /* gx[o] = sum_k W_x[o][k] x[k] (k ascending, as in the scalar form); o is the vector axis */
+    for (int o = 0; o < G; ++o) { gx[o] = 0.f; gh[o] = 0.f; }
+    for (int k = 0; k < in_w; ++k) {
+      const float xv = x[k];
+      const float *w = g->wxT + (size_t)k * G;
+      for (int o = 0; o < G; ++o) gx[o] += w[o] * xv;
     }
+    for (int k = 0; k < H; ++k) {
+      const float hv = h[k];
+      const float *u = g->whT + (size_t)k * G;
+      for (int o = 0; o < G; ++o) gh[o] += u[o] * hv;
+    }
+    for (int o = 0; o < G; ++o) { gx[o] += g->bx[o]; gh[o] += g->bh[o]; }
     for (int i = 0; i < H; ++i) {
       float z = sigmoidf_(gx[i] + gh[i]);
       float r = sigmoidf_(gx[H + i] + gh[H + i]);
@@ -310,38 +337,51 @@ int wwo_crnn_forward(const void *blob, size_t blob_len, const float *mel, int B,
   if (!m) return WWO_EBLOB;
   const int n_mel = m[0], T = m[1], C = m[2], KF = m[3], KT = m[4], SF = m[5], ST = m[6], PF = m[7], PT = m[8],
             OF = m[9], OT = m[10], H = m[11], NOUT = m[12], HEAD = m[13];
-  if (H > 64 || OT > 64) return WWO_EARG;
+  if (H > 64 || OT > 64 || KF * KT > 256 || C > 64) return WWO_EARG;
   const float *cw = bf(&b, "crnn.conv_w"), *cb = bf(&b, "crnn.conv_b");
-  gru_t g1f = {bf(&b, "crnn.g1f.wx"), bf(&b, "crnn.g1f.bx"), bf(&b, "crnn.g1f.wh"), bf(&b, "crnn.g1f.bh")};
-  gru_t g1b = {bf(&b, "crnn.g1b.wx"), bf(&b, "crnn.g1b.bx"), bf(&b, "crnn.g1b.wh"), bf(&b, "crnn.g1b.bh")};
-  gru_t g2f = {bf(&b, "crnn.g2f.wx"), bf(&b, "crnn.g2f.bx"), bf(&b, "crnn.g2f.wh"), bf(&b, "crnn.g2f.bh")};
-  gru_t g2b = {bf(&b, "crnn.g2b.wx"), bf(&b, "crnn.g2b.bx"), bf(&b, "crnn.g2b.wh"), bf(&b, "crnn.g2b.bh")};
+  gru_t g1f = {bf(&b, "crnn.g1f.wx"), bf(&b, "crnn.g1f.bx"), bf(&b, "crnn.g1f.wh"), bf(&b, "crnn.g1f.bh"), 0, 0};
+  gru_t g1b = {bf(&b, "crnn.g1b.wx"), bf(&b, "crnn.g1b.bx"), bf(&b, "crnn.g1b.wh"), bf(&b, "crnn.g1b.bh"), 0, 0};
+  gru_t g2f = {bf(&b, "crnn.g2f.wx"), bf(&b, "crnn.g2f.bx"), bf(&b, "crnn.g2f.wh"), bf(&b, "crnn.g2f.bh"), 0, 0};
+  gru_t g2b = {bf(&b, "crnn.g2b.wx"), bf(&b, "crnn.g2b.bx"), bf(&b, "crnn.g2b.wh"), bf(&b, "crnn.g2b.bh"), 0, 0};
   const float *w1 = bf(&b, "crnn.head_w1"), *b1 = bf(&b, "crnn.head_b1");
   const float *w2 = bf(&b, "crnn.head_w2"), *b2 = bf(&b, "crnn.head_b2");
   const int FEAT = OF * C;
   int rc = WWO_OK;
+  gru_prepare(&g1f, FEAT, H); gru_prepare(&g1b, FEAT, H); gru_prepare(&g2f, 2 * H, H); gru_prepare(&g2b, 2 * H, H);
+  /* conv weights transposed to [k][c] so that the channel index is the vector axis */
+  float *cwT = (float *)malloc(sizeof(float) * (size_t)KF * KT * C);
+  for (int c = 0; c < C; ++c)
+    for (int k = 0; k < KF * KT; ++k) cwT[(size_t)k * C + c] = cw[(size_t)c * KF * KT + k];
 #pragma omp parallel for schedule(dynamic, 1)
   for (int n = 0; n < B; ++n) {
     const float *win = mel + (size_t)n * T * n_mel;
     float *feat = (float *)malloc(sizeof(float) * (size_t)OT * FEAT);
     float *seq1 = (float *)malloc(sizeof(float) * (size_t)OT * 2 * H);
-    /* Conv2D over [mel][frame] with SAME padding, stride (SF, ST), ReLU; feature = f*C + c */
+    /* Conv2D over [mel][frame] with SAME padding, stride (SF, ST), ReLU; feature = f*C + c.
+     * The receptive field is gathered once per output position (zeros outside the window) so
+     * that the channel loop is a plain contiguous dot product the compiler can vectorise. */
     for (int t = 0; t < OT; ++t)
-      for (int f = 0; f < OF; ++f)
-        for (int c = 0; c < C; ++c) {
-          float a = 0.f;
-          for (int kf = 0; kf < KF; ++kf) {
-            int im = f * SF - PF + kf;
-            if (im < 0 || im >= n_mel) continue;
-            for (int kt = 0; kt < KT; ++kt) {
-              int it = t * ST - PT + kt;
-              if (it < 0 || it >= T) continue;
-              a += win[(size_t)it * n_mel + im] * cw[((size_t)c * KF + kf) * KT + kt];
-            }
+      for (int f = 0; f < OF; ++f) {
+        float patch[256];
+        for (int kf = 0; kf < KF; ++kf) {
+          int im = f * SF - PF + kf;
+          for (int kt = 0; kt < KT; ++kt) {
+            int it = t * ST - PT + kt;
+            patch[kf * KT + kt] = (im < 0 || im >= n_mel || it < 0 || it >= T) ? 0.f : win[(size_t)it * n_mel + im];
           }
-          a += cb[c];
+        }
+        float acc[64];
+        for (int c = 0; c < C; ++c) acc[c] = 0.f;
+        for (int k = 0; k < KF * KT; ++k) {
+          const float pv = patch[k];
+          const float *wr = cwT + (size_t)k * C;
+          for (int c = 0; c < C; ++c) acc[c] += pv * wr[c];
+        }
+        for (int c = 0; c < C; ++c) {
+          const float a = acc[c] + cb[c];
           feat[(size_t)t * FEAT + f * C + c] = a > 0.f ? a : 0.f;
         }
+      }
     gru_run(&g1f, feat, OT, FEAT, H, 0, seq1, 2 * H, 0, NULL);
     gru_run(&g1b, feat, OT, FEAT, H, 1, seq1, 2 * H, H, NULL);
     float enc[128];
@@ -372,6 +412,8 @@ int wwo_crnn_forward(const void *blob, size_t blob_len, const float *mel, int B,
     free(feat);
     free(seq1);
   }
+  gru_release(&g1f); gru_release(&g1b); gru_release(&g2f); gru_release(&g2b);
+  free(cwT);
   return rc;
 }
 
@@ -413,39 +455,46 @@ int wwo_wavenet_forward(const void *blob, size_t blob_len, const float *mel, int
       const int d = dil[blk];
       const float *ws = w_sig + (size_t)blk * 3 * C * C, *wt = w_tanh + (size_t)blk * 3 * C * C;
       for (int i = 0; i < T * C; ++i) u[i] = x[i] * bn_s[blk * C + i % C] + bn_t[blk * C + i % C];
-      for (int t = 0; t < T; ++t)
-        for (int o = 0; o < C; ++o) {
-          float as = 0.f, at = 0.f;
-          for (int k = 0; k < 3; ++k) {
-            int tt = t - (2 - k) * d;
-            if (tt < 0) continue; /* causal zero pad is applied AFTER the BN affine */
-            for (int i = 0; i < C; ++i) {
-              float v = u[(size_t)tt * C + i];
-              as += v * ws[((size_t)k * C + i) * C + o];
-              at += v * wt[((size_t)k * C + i) * C + o];
-            }
+      for (int t = 0; t < T; ++t) {
+        float as[32], at[32];
+        for (int o = 0; o < C; ++o) { as[o] = 0.f; at[o] = 0.f; }
+        for (int k = 0; k < 3; ++k) {
+          int tt = t - (2 - k) * d;
+          if (tt < 0) continue; /* causal zero pad is applied AFTER the BN affine */
+          for (int i = 0; i < C; ++i) {
+            const float v = u[(size_t)tt * C + i];
+            const float *wsr = ws + ((size_t)k * C + i) * C, *wtr = wt + ((size_t)k * C + i) * C;
+            for (int o = 0; o < C; ++o) { as[o] += v * wsr[o]; at[o] += v * wtr[o]; }
           }
-          as += b_sig[blk * C + o];
-          at += b_tanh[blk * C + o];
-          g[(size_t)t * C + o] = tanhf(at) * sigmoidf_(as);
         }
+        for (int o = 0; o < C; ++o)
+          g[(size_t)t * C + o] = tanhf(at[o] + b_tanh[blk * C + o]) * sigmoidf_(as[o] + b_sig[blk * C + o]);
+      }
       float *sk = skips + (size_t)blk * T * S;
       for (int t = 0; t < T; ++t) {
+        float a[64];
+        for (int o = 0; o < S; ++o) a[o] = 0.f;
+        for (int i = 0; i < C; ++i) {
+          const float v = g[(size_t)t * C + i];
+          const float *wr = w_skip + ((size_t)blk * C + i) * S;
+          for (int o = 0; o < S; ++o) a[o] += v * wr[o];
+        }
         for (int o = 0; o < S; ++o) {
-          float a = 0.f;
-          for (int i = 0; i < C; ++i) a += g[(size_t)t * C + i] * w_skip[((size_t)blk * C + i) * S + o];
-          a += b_skip[blk * S + o];
-          sk[(size_t)t * S + o] = a > 0.f ? a : 0.f;
+          const float y = a[o] + b_skip[blk * S + o];
+          sk[(size_t)t * S + o] = y > 0.f ? y : 0.f;
         }
         if (has_res[blk]) {
           float r[32];
-          for (int o = 0; o < C; ++o) {
-            float a = 0.f;
-            for (int i = 0; i < C; ++i) a += g[(size_t)t * C + i] * w_res[((size_t)blk * C + i) * C + o];
-            a += b_res[blk * C + o];
-            r[o] = a > 0.f ? a : 0.f;
+          for (int o = 0; o < C; ++o) r[o] = 0.f;
+          for (int i = 0; i < C; ++i) {
+            const float v = g[(size_t)t * C + i];
+            const float *wr = w_res + ((size_t)blk * C + i) * C;
+            for (int o = 0; o < C; ++o) r[o] += v * wr[o];
           }
-          for (int o = 0; o < C; ++o) x[(size_t)t * C + o] = r[o] + x[(size_t)t * C + o];
+          for (int o = 0; o < C; ++o) {
+            const float y = r[o] + b_res[blk * C + o];
+            x[(size_t)t * C + o] = (y > 0.f ? y : 0.f) + x[(size_t)t * C + o];
+          }
         }
       }
     }
