@@ -77,7 +77,7 @@ def kernel_flops(eng, n_clips):
     return out
 
 
-def cpu_baseline(eng, pcm_sample, budget_s=12.0):
+def cpu_baseline(eng, pcm_sample, budget_s=10.0):
     """Time the C restatement (oracle/ww_oracle.c, all host threads) on a bounded sample."""
     from oracle import cpu as ocpu
     ora = ocpu.CpuOracle(eng.blob)
@@ -100,7 +100,7 @@ def cpu_baseline(eng, pcm_sample, budget_s=12.0):
         one_pass(pcm_sample)
         done += n
         el = time.perf_counter() - t0
-        if el > budget_s or done >= 16 * n:
+        if el > budget_s:
             break
     return {
         "value": done * FRAMES_PER_CLIP / el,
