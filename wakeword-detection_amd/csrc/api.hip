@@ -285,6 +285,8 @@ static int load_crnn(ww_ctx *ctx, ww_model *m, const blob_view &bv) {
   if (c.C != 32 || c.H != 32 || c.KT % 4 != 0 || K > KP || c.ST % 4 != 0 || c.NOUT < 1 || c.NOUT > 8 ||
       (c.OF * c.C) % 64 != 0 || c.OT > 20 || c.T * c.n_mel > 6 * 256 * 4 || c.n_mel != m->filt.n_mel)
     return ww_fail(ctx, WW_EBLOB, "unsupported CRNN geometry (C=%d H=%d K=%dx%d stride %dx%d)", c.C, c.H, c.KF, c.KT, c.SF, c.ST);
+  if (c.n_mel != 40 || c.KF != 5 || c.KT != 20 || c.SF != 2 || c.ST != 8 || c.PF != 1 || c.PT != 6 || c.OF != 20 || c.OT != 19)
+    return ww_fail(ctx, WW_EBLOB, "CRNN conv geometry differs from the 40x151 / 5x20 / stride 2x8 the kernels are built for");
   const int max_kf = (KP - 1) / c.KT;  // padded k rows touch kf up to this
   if ((c.OF - 1) * c.SF + max_kf >= 44 || c.n_mel + c.PF > 44 || (c.OT - 1) * c.ST + c.KT > 164 || c.T + c.PT > 164)
     return ww_fail(ctx, WW_EBLOB, "CRNN window %dx%d does not fit the conv LDS image", c.n_mel, c.T);

@@ -47,6 +47,18 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf
 #define CV_ROWS 44   // mel index + PF, 0..43
 #define CV_LDT 164   // time index + PT, 0..163 (multiple of 4; 164 % 32 == 4)
 #define CV_KB 7      // K = 5*20 = 100 padded to 112 = 7 * 16
+#define CV_THREADS 512
+// Geometry of every CRNN the reference ships (wwdetect/CRNN/train.py:27-49; checked against the
+// blob at model load): compile-time constants turn the index divisions into shifts/multiplies.
+#define CV_NMEL 40
+#define CV_KF 5
+#define CV_KT 20
+#define CV_SF 2
+#define CV_ST 8
+#define CV_PF 1
+#define CV_PT 6
+#define CV_OF 20
+#define CV_OT 19
 
 struct conv_args {
   const float *mel;
@@ -57,7 +69,7 @@ struct conv_args {
   int n_mel, T, KF, KT, SF, ST, PF, PT, OF, OT;
 };
 
-__global__ __launch_bounds__(256) void conv5x20_kernel(conv_args a) {
+__global__ __launch_bounds__(CV_THREADS) void conv5x20_kernel(conv_args a) {
   __shared__ __align__(16) float img[CV_ROWS * CV_LDT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int w = blockIdx.x;
@@ -65,16 +77,26 @@ __global__ __launch_bounds__(256) void conv5x20_kernel(conv_args a) {
   int valid;
   window_span(a.wa, w, a.T, row, valid);
 
+  // conv weights for this lane (B operand of mfma 16x16x4: lane (j = lane&15, kk = lane>>4)); issued
+  // first so that their latency hides behind the window staging
+  const int j = lane & 15, kk = lane >> 4;
+  float4 wreg[CV_KB][2];
+#pragma unroll
+  for (int kb = 0; kb < CV_KB; ++kb)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) wreg[kb][n] = *(const float4 *)(a.w4 + ((size_t)(kb * 4 + kk) * 32 + n * 16 + j) * 4);
+  const float b0 = a.bias[j], b1 = a.bias[16 + j];
+
   // the window is one contiguous [valid][n_mel] block: issue all 16-byte loads first, then
   // zero the image, then scatter the registers into the transposed (mel-major) image
-  constexpr int CV_MAXV = 6;  // 6 * 256 float4 >= 151 * 40 / 4
-  const float *src = a.mel + row * a.n_mel;
-  const int n = valid * a.n_mel;
+  constexpr int CV_MAXV = 3;  // 3 * 512 float4 >= 151 * 40 / 4
+  const float *src = a.mel + row * CV_NMEL;
+  const int n = valid * CV_NMEL;
   const bool al16 = ((((uintptr_t)src) & 15) == 0);
   float4 stage[CV_MAXV];
 #pragma unroll
   for (int q = 0; q < CV_MAXV; ++q) {
-    const int i = (q * 256 + tid) * 4;
+    const int i = (q * CV_THREADS + tid) * 4;
     if (al16 && i + 3 < n) {
       stage[q] = *(const float4 *)(src + i);
     } else {
@@ -84,44 +106,36 @@ __global__ __launch_bounds__(256) void conv5x20_kernel(conv_args a) {
       stage[q].w = i + 3 < n ? src[i + 3] : 0.f;
     }
   }
-  for (int i = tid; i < CV_ROWS * CV_LDT / 4; i += 256) ((float4 *)img)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = tid; i < CV_ROWS * CV_LDT / 4; i += CV_THREADS) ((float4 *)img)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < CV_MAXV; ++q) {
-    const int i = (q * 256 + tid) * 4;
+    const int i = (q * CV_THREADS + tid) * 4;
     const float e[4] = {stage[q].x, stage[q].y, stage[q].z, stage[q].w};
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int ii = i + c;
       if (ii < n) {
-        const int it = ii / a.n_mel, im = ii - it * a.n_mel;
-        img[(im + a.PF) * CV_LDT + it + a.PT] = e[c];
+        const int it = ii / CV_NMEL, im = ii - it * CV_NMEL;
+        img[(im + CV_PF) * CV_LDT + it + CV_PT] = e[c];
       }
     }
   }
-  // conv weights for this lane: B operand of mfma 16x16x4: lane (j = lane&15, kk = lane>>4)
-  const int j = lane & 15, kk = lane >> 4;
-  float4 wreg[CV_KB][2];
-#pragma unroll
-  for (int kb = 0; kb < CV_KB; ++kb)
-#pragma unroll
-    for (int n = 0; n < 2; ++n) wreg[kb][n] = *(const float4 *)(a.w4 + ((size_t)(kb * 4 + kk) * 32 + n * 16 + j) * 4);
-  const float b0 = a.bias[j], b1 = a.bias[16 + j];
   __syncthreads();
 
-  const int M = a.OT * a.OF;
-  const int n_mt = (M + 15) / 16;
+  constexpr int M = CV_OT * CV_OF;
+  constexpr int n_mt = (M + 15) / 16;
   float *dst = a.feat + (size_t)w * M * 32;
-  for (int mt = wave; mt < n_mt; mt += 4) {
+  for (int mt = wave; mt < n_mt; mt += CV_THREADS / 64) {
     int m = mt * 16 + j;  // A operand row for this lane (i = lane & 15)
     if (m >= M) m = M - 1;
-    const int t = m / a.OF, f = m - t * a.OF;
-    const float *abase = img + (f * a.SF) * CV_LDT + t * a.ST;
+    const int t = m / CV_OF, f = m - t * CV_OF;
+    const float *abase = img + (f * CV_SF) * CV_LDT + t * CV_ST;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < CV_KB; ++kb) {
       const int k4 = kb * 16 + kk * 4;
-      const int kf = k4 / a.KT, kt = k4 - kf * a.KT;
+      const int kf = k4 / CV_KT, kt = k4 - kf * CV_KT;
       const float4 av = *(const float4 *)(abase + kf * CV_LDT + kt);
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wreg[kb][0].x, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wreg[kb][1].x, acc1, 0, 0, 0);
@@ -160,20 +174,22 @@ struct gemm_args {
   int M, N, K;
 };
 
-__global__ __launch_bounds__(256) void gemm_nt_kernel(gemm_args g) {
+// 512 threads = 8 waves (2 per SIMD, so one wave's LDS/MFMA latencies are covered by its partner);
+// wave (wr, wc) = (wave >> 1, wave & 1) owns rows wr*16..+15, columns wc*32..+31 of the 64x64 tile.
+__global__ __launch_bounds__(512) void gemm_nt_kernel(gemm_args g) {
   __shared__ __align__(16) float As[2][GB_M * GB_LD];
   __shared__ __align__(16) float Bs[2][GB_N * GB_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int m0 = blockIdx.x * GB_M, n0 = blockIdx.y * GB_N;
-  const int lrow = tid >> 4, lc4 = tid & 15;  // loader: rows lrow + 16 h (h = 0..3); float4 column lc4
+  const int lrow = tid >> 4, lc4 = tid & 15;  // loader: rows lrow, lrow + 32; float4 column lc4
   const int i16 = lane & 15, kk = lane >> 4;
 
-  float4 pa[4], pb[4];
+  float4 pa[2], pb[2];
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      const int r = lrow + 16 * h;
+    for (int h = 0; h < 2; ++h) {
+      const int r = lrow + 32 * h;
       const int gm = m0 + r;
       pa[h] = gm < g.M ? *(const float4 *)(g.A + (size_t)gm * g.K + k0 + lc4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
       const int gn = n0 + r;
@@ -182,19 +198,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(gemm_args g) {
   };
   auto sstore = [&](int buf) {
 #pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      const int r = lrow + 16 * h;
+    for (int h = 0; h < 2; ++h) {
+      const int r = lrow + 32 * h;
       *(float4 *)(&As[buf][r * GB_LD + lc4 * 4]) = pa[h];
       *(float4 *)(&Bs[buf][r * GB_LD + lc4 * 4]) = pb[h];
     }
   };
 
-  f32x4 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
+  f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   const int nk = g.K / GB_K;
   gload(0);
   sstore(0);
@@ -204,36 +215,31 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(gemm_args g) {
     if (kt + 1 < nk) gload((kt + 1) * GB_K);
 #pragma unroll
     for (int kb = 0; kb < GB_K / 16; ++kb) {
-      float4 av[2], bv[2];
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) av[mi] = *(const float4 *)(&As[cur][(wr * 32 + mi * 16 + i16) * GB_LD + kb * 16 + kk * 4]);
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) bv[ni] = *(const float4 *)(&Bs[cur][(wc * 32 + ni * 16 + i16) * GB_LD + kb * 16 + kk * 4]);
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi].x, bv[ni].x, acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi].y, bv[ni].y, acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi].z, bv[ni].z, acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi].w, bv[ni].w, acc[mi][ni], 0, 0, 0);
-        }
+      const float4 av = *(const float4 *)(&As[cur][(wr * 16 + i16) * GB_LD + kb * 16 + kk * 4]);
+      const float4 b0 = *(const float4 *)(&Bs[cur][(wc * 32 + i16) * GB_LD + kb * 16 + kk * 4]);
+      const float4 b1 = *(const float4 *)(&Bs[cur][(wc * 32 + 16 + i16) * GB_LD + kb * 16 + kk * 4]);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b0.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b1.x, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b0.y, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b1.y, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b0.z, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b1.z, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b0.w, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b1.w, acc[1], 0, 0, 0);
     }
     if (kt + 1 < nk) sstore(cur ^ 1);
     __syncthreads();
   }
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int ni = 0; ni < 2; ++ni) {
+    const int gn = n0 + wc * 32 + ni * 16 + i16;
+    const float bv = (gn < g.N) ? g.bias[gn] : 0.f;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int gn = n0 + wc * 32 + ni * 16 + i16;
-      const float bv = (gn < g.N) ? g.bias[gn] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int gm = m0 + wr * 32 + mi * 16 + kk * 4 + r;
-        if (gm < g.M && gn < g.N) g.C[(size_t)gm * g.N + gn] = acc[mi][ni][r] + bv;
-      }
+    for (int r = 0; r < 4; ++r) {
+      const int gm = m0 + wr * 16 + kk * 4 + r;
+      if (gm < g.M && gn < g.N) g.C[(size_t)gm * g.N + gn] = acc[ni][r] + bv;
     }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -528,13 +534,13 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
   {
     conv_args a = {d_mel, wa, c.conv_w, c.conv_b, s.feat, c.n_mel, c.T, c.KF, c.KT, c.SF, c.ST, c.PF, c.PT, c.OF, c.OT};
     ww_launch_scope scope(ctx, "conv5x20_kernel");
-    hipLaunchKernelGGL(conv5x20_kernel, dim3(nw), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(conv5x20_kernel, dim3(nw), dim3(CV_THREADS), 0, ctx->stream, a);
   }
   const int M = nw * c.OT;
   {
     gemm_args g = {s.feat, c.wx1, c.bx1, s.gx1, M, 6 * c.H, c.OF * c.C};
     ww_launch_scope scope(ctx, "gemm_nt_kernel<gru1>");
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3((M + GB_M - 1) / GB_M, (6 * c.H + GB_N - 1) / GB_N), dim3(256), 0,
+    hipLaunchKernelGGL(gemm_nt_kernel, dim3((M + GB_M - 1) / GB_M, (6 * c.H + GB_N - 1) / GB_N), dim3(512), 0,
                        ctx->stream, g);
   }
   {
