@@ -194,3 +194,27 @@ def test_load_data_truncates_and_pads():
     assert X.shape == (2, 151, 40) and X[0].sum() == 151 * 40 and X[1, 10:].sum() == 0 and X[1, :10].sum() == 800
     np.testing.assert_array_equal(X, NR.load_h5_like(feats, 151, 40))
     assert y.tolist() == [1, 0]
+
+
+def test_pcm_quotient_sequence_is_exact_for_all_int16():
+    """The front-end kernels form int16/divisor as q0 = a*r, e = fma(-b, q0, a), q = fma(e, r, q0)
+    (csrc/frontend.hip:pcm_quot).  Exhaustive proof with exact rational arithmetic that this equals
+    the correctly rounded fp32 division the reference performs (tflite.py:150) for both divisors."""
+    from fractions import Fraction
+    f32 = np.float32
+
+    def rn32(fr):
+        y = f32(float(fr))
+        cands = [np.nextafter(y, f32(-np.inf)), y, np.nextafter(y, f32(np.inf))]
+        return f32(min(cands, key=lambda c: (abs(Fraction(float(c)) - fr), int(f32(c).view(np.uint32)) & 1)))
+
+    for div in (32767.0, 32768.0):
+        b = f32(div)
+        r = f32(1.0) / b
+        a = np.arange(-32768, 32768).astype(np.float32)
+        q0 = a * r
+        want = a / b
+        for ai, qi, wi in zip(a[::1], q0, want):
+            e = rn32(Fraction(float(ai)) - Fraction(float(b)) * Fraction(float(qi)))
+            q1 = rn32(Fraction(float(qi)) + Fraction(float(e)) * Fraction(float(r)))
+            assert q1 == wi, (div, ai)

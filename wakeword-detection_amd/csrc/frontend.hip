@@ -36,6 +36,8 @@ struct logmel_args {
   int n_utt;
   int hop;
   float divisor;
+  float rdiv;       // RN(1 / divisor)
+  int fast_div;     // divisor is 32767 or 32768: 3-op exact quotient (see pcm_quot)
   int clip;
   float preemph;
   // filter
@@ -55,10 +57,23 @@ struct logmel_args {
   int64_t n_frames_direct;
 };
 
+// int16 / divisor, correctly rounded (reference: frame.astype(np.float32) / 32767, tflite.py:150).
+// For the two divisors in use (32767, 32768) the quotient of ANY int16 is obtained exactly by
+// q0 = a*r, e = fma(-b, q0, a), q = fma(e, r, q0) with r = RN(1/b) (Markstein); verified
+// exhaustively over all 65536 inputs with exact rational arithmetic (tests/test_host_logic.py).
+__device__ __forceinline__ float pcm_quot(float x, const logmel_args &a) {
+  if (a.fast_div) {
+    const float q0 = __fmul_rn(x, a.rdiv);
+    const float e = __fmaf_rn(-a.divisor, q0, x);
+    return __fmaf_rn(e, a.rdiv, q0);
+  }
+  return __fdiv_rn(x, a.divisor);
+}
+
 template <bool F32IN>
 __device__ __forceinline__ float norm_sample(const logmel_args &a, int64_t g) {
   if (F32IN) return a.f32[g];
-  float v = __fdiv_rn((float)a.pcm[g], a.divisor);  // reference: frame.astype(f32) / 32767
+  float v = pcm_quot((float)a.pcm[g], a);
   if (a.clip) v = fminf(fmaxf(v, -1.0f), 1.0f);
   return v;
 }
@@ -100,6 +115,21 @@ template <typename R> __device__ __forceinline__ R shfl_r(R v, int src);
 template <> __device__ __forceinline__ float shfl_r<float>(float v, int src) { return __shfl(v, src); }
 template <> __device__ __forceinline__ double shfl_r<double>(double v, int src) { return __shfl(v, src); }
 
+// W32^m = exp(-2 pi i m / 32), m = 0..15 (compile-time constants of the untangling twiddles)
+__device__ constexpr double W32_RE[16] = {1.00000000000000000000e+00, 9.80785280403230430579e-01, 9.23879532511286738483e-01, 8.31469612302545235671e-01, 7.07106781186547572737e-01, 5.55570233019602288671e-01, 3.82683432365089837290e-01, 1.95090322016128331351e-01, 6.12323399573676603587e-17, -1.95090322016128192573e-01, -3.82683432365089726268e-01, -5.55570233019601955604e-01, -7.07106781186547461715e-01, -8.31469612302545346694e-01, -9.23879532511286738483e-01, -9.80785280403230430579e-01};
+__device__ constexpr double W32_IM[16] = {-0.00000000000000000000e+00, -1.95090322016128248084e-01, -3.82683432365089781779e-01, -5.55570233019602177649e-01, -7.07106781186547461715e-01, -8.31469612302545235671e-01, -9.23879532511286738483e-01, -9.80785280403230430579e-01, -1.00000000000000000000e+00, -9.80785280403230430579e-01, -9.23879532511286738483e-01, -8.31469612302545457716e-01, -7.07106781186547572737e-01, -5.55570233019602177649e-01, -3.82683432365089892802e-01, -1.95090322016128608906e-01};
+
+// lane (16 - j) % 16 of the same 16-lane row: row_mirror, then rotate right by one lane
+__device__ __forceinline__ int dpp_partner_i(int v) {
+  const int m = __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true);   // row_mirror: lane 15 - j
+  return __builtin_amdgcn_mov_dpp(m, 0x121, 0xF, 0xF, true);          // row_ror:1 : lane j - 1
+}
+__device__ __forceinline__ float dpp_partner(float v) { return __int_as_float(dpp_partner_i(__float_as_int(v))); }
+__device__ __forceinline__ double dpp_partner(double v) {
+  const int lo = dpp_partner_i(__double2loint(v)), hi = dpp_partner_i(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
 #define MAG_LD 276  // floats per frame of magnitudes: 257 + zero pad to 17*16, stride = 20 mod 64
 #define TR_LD 17    // padded row of the 16x16 transpose
 
@@ -111,7 +141,7 @@ __host__ __device__ constexpr int wbuf_bytes() {
 }
 
 template <typename R, bool F32IN>
-__global__ __launch_bounds__(256) void logmel_kernel(logmel_args a) {
+__global__ __launch_bounds__(256, sizeof(R) == 8 ? 3 : 4) void logmel_kernel(logmel_args a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, sub = lane >> 4;
@@ -126,15 +156,22 @@ __global__ __launch_bounds__(256) void logmel_kernel(logmel_args a) {
   // ---- LDS carve-up
   size_t off = 0;
   double2 *tb_hann = (double2 *)(smem + off); off += 256 * sizeof(double2);
-  cplx<R> *tb_tw = (cplx<R> *)(smem + off); off += 256 * sizeof(cplx<R>);   // [k1][j] = W256^(j k1)
-  cplx<R> *tb_un = (cplx<R> *)(smem + off); off += 256 * sizeof(cplx<R>);   // W512^k
+  // fp32: twiddle tables in LDS.  fp64: LDS is the occupancy limiter, so the twiddles are
+  // rebuilt from two per-lane constants instead (W256^j and W512^j) - see below.
+  constexpr bool TW_LDS = sizeof(R) == 4;
+  cplx<R> *tb_tw = (cplx<R> *)(smem + off); off += TW_LDS ? 256 * sizeof(cplx<R>) : 0;   // [k1][j] = W256^(j k1)
+  cplx<R> *tb_un = (cplx<R> *)(smem + off); off += TW_LDS ? 256 * sizeof(cplx<R>) : 0;   // W512^k
+  const cplx<R> base_tw = {(R)a.tw16[2 * (16 + j)], (R)a.tw16[2 * (16 + j) + 1]};          // W256^j
+  const cplx<R> base_un = {(R)a.tw512[2 * j], (R)a.tw512[2 * j + 1]};                      // W512^j
   unsigned char *wbuf = smem + off; off += WAVES * wbuf_bytes<R>();
   float *tile = (float *)(smem + off);  // fp32 samples, [WIN + (FPB-1)*hop + 16]
 
   for (int i = tid; i < 256; i += 256) {
     tb_hann[i] = *(const double2 *)(a.hann + 2 * i);
-    tb_tw[i] = {(R)a.tw16[2 * i], (R)a.tw16[2 * i + 1]};
-    tb_un[i] = {(R)a.tw512[2 * i], (R)a.tw512[2 * i + 1]};
+    if (TW_LDS) {
+      tb_tw[i] = {(R)a.tw16[2 * i], (R)a.tw16[2 * i + 1]};
+      tb_un[i] = {(R)a.tw512[2 * i], (R)a.tw512[2 * i + 1]};
+    }
   }
 
   // mel B operands of this wave's (tile, block) entries: issued now, consumed after the FFT
@@ -170,7 +207,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(logmel_args a) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const int16_t s16 = (int16_t)((w32[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
-            float f = __fdiv_rn((float)s16, a.divisor);
+            float f = pcm_quot((float)s16, a);
             if (a.clip) f = fminf(fmaxf(f, -1.0f), 1.0f);
             v[1 + e] = f;
           }
@@ -214,7 +251,19 @@ __global__ __launch_bounds__(256) void logmel_kernel(logmel_args a) {
     }
     dft16<R>(v);
 #pragma unroll
-    for (int pos = 1; pos < 16; ++pos) v[pos] = cmul(v[pos], tb_tw[k_of(pos) * 16 + j]);
+    for (int pos = 1; pos < 16; ++pos)
+      if (TW_LDS) v[pos] = cmul(v[pos], tb_tw[k_of(pos) * 16 + j]);
+    if (!TW_LDS) {
+      // W256^(j k1) for k1 = 1..15 as powers of W256^j (product tree, depth <= 4: a few fp64 ulp)
+      cplx<R> p[16];
+      p[1] = base_tw;
+      p[2] = cmul(p[1], p[1]);   p[3] = cmul(p[2], p[1]);   p[4] = cmul(p[2], p[2]);   p[5] = cmul(p[4], p[1]);
+      p[6] = cmul(p[3], p[3]);   p[7] = cmul(p[4], p[3]);   p[8] = cmul(p[4], p[4]);   p[9] = cmul(p[8], p[1]);
+      p[10] = cmul(p[5], p[5]);  p[11] = cmul(p[8], p[3]);  p[12] = cmul(p[6], p[6]);  p[13] = cmul(p[8], p[5]);
+      p[14] = cmul(p[7], p[7]);  p[15] = cmul(p[8], p[7]);
+#pragma unroll
+      for (int pos = 1; pos < 16; ++pos) v[pos] = cmul(v[pos], p[k_of(pos)]);
+    }
     // 16x16 transpose through LDS, real parts then imaginary parts (same buffer)
     cplx<R> w[16];
     R *trs = tr + sub * 16 * TR_LD;
@@ -232,30 +281,33 @@ __global__ __launch_bounds__(256) void logmel_kernel(logmel_args a) {
     wave_sync();
     // pass 2: lane j = k1 holds Y[n2][k1]; output w[pos] = Z[k1 + 16 k_of(pos)]
     dft16<R>(w);
-    // untangle X[k] = E + W512^k O with E,O from Z[k], conj Z[256-k]; partner Z[256-k] lives in
-    // lane (16-k1)%16 at k2' = 15-k2 (k1 > 0) or in the same lane at k2' = (16-k2)%16 (k1 = 0)
-    const int src_lane = (lane & 48) | ((16 - j) & 15);
+    // untangle: with a = Z[k], b = conj Z[256-k]:  E = (a+b)/2, O = (a-b)/(2i), T = W512^k O and
+    //   X[k] = E + T,   X[256-k] = conj(E - T)   ->  two magnitudes per evaluation, k < 128 only.
+    // Lane j register k2 holds k = j + 16 k2; its partner Z[256-k] lives in lane (16-j)%16 at
+    // k2' = 15-k2 (j > 0) or in the same lane at k2' = (16-k2)%16 (j = 0): the sender picks the
+    // register and two DPP moves (row_mirror, row_ror:1) bring it over - no LDS traffic.
     float *mrow = mg + sub * MAG_LD;
 #pragma unroll
-    for (int pos = 0; pos < 16; ++pos) {
-      constexpr int dummy = 0; (void)dummy;
-      const int k2 = k_of(pos);
-      const cplx<R> own = w[pos];
+    for (int k2 = 0; k2 < 8; ++k2) {
+      const cplx<R> own = w[pos_of(k2)];
       const cplx<R> cand_a = w[pos_of(15 - k2)], cand_b = w[pos_of((16 - k2) & 15)];
-      cplx<R> send = {j == 0 ? cand_b.re : cand_a.re, j == 0 ? cand_b.im : cand_a.im};
-      cplx<R> pz = {shfl_r<R>(send.re, src_lane), shfl_r<R>(send.im, src_lane)};
-      const cplx<R> un = tb_un[j + 16 * k2];
-      // b = conj(pz)
+      const R send_re = j == 0 ? cand_b.re : cand_a.re, send_im = j == 0 ? cand_b.im : cand_a.im;
+      const cplx<R> pz = {dpp_partner(send_re), dpp_partner(send_im)};
+      // W512^(j + 16 k2) = W512^j * W32^k2
+      const cplx<R> un = TW_LDS ? tb_un[j + 16 * k2] : cmul(base_un, cplx<R>{(R)W32_RE[k2], (R)W32_IM[k2]});
       const R er = (R)0.5 * (own.re + pz.re), ei = (R)0.5 * (own.im - pz.im);
       const R orr = (R)0.5 * (own.im + pz.im), oi = (R)-0.5 * (own.re - pz.re);
-      const R re = er + orr * un.re - oi * un.im;
-      const R im = ei + orr * un.im + oi * un.re;
-      mrow[j + 16 * k2] = __fsqrt_rn((float)(re * re + im * im));
+      const R tr_ = orr * un.re - oi * un.im, ti_ = orr * un.im + oi * un.re;
+      const R pr = er + tr_, pi = ei + ti_, qr = er - tr_, qi = ei - ti_;
+      const int k = j + 16 * k2;
+      mrow[k] = __fsqrt_rn((float)(pr * pr + pi * pi));
+      mrow[256 - k] = __fsqrt_rn((float)(qr * qr + qi * qi));  // k = 0 -> bin 256
     }
     {
-      // k = 256: X = Re(Z0) - Im(Z0) (lane 0 holds Z[0] at pos 0); bins 257..271 are zero padding
-      const R d = w[0].re - w[0].im;
-      mrow[256 + j] = j == 0 ? __fsqrt_rn((float)(d * d)) : 0.0f;
+      // k = 128 pairs with itself: X[128] = conj(Z[128]) (lane 0, k2 = 8); bins 257..271 are zero padding
+      const cplx<R> z = w[pos_of(8)];
+      if (j == 0) mrow[128] = __fsqrt_rn((float)(z.re * z.re + z.im * z.im));
+      else mrow[256 + j] = 0.0f;
     }
   }
   __syncthreads();
@@ -338,7 +390,7 @@ template <typename R>
 static size_t logmel_smem(int hop) {
   size_t off = 0;
   off += 256 * sizeof(double2);
-  off += 2 * 256 * sizeof(cplx<R>);
+  off += sizeof(R) == 4 ? 2 * 256 * sizeof(cplx<R>) : 0;
   off += WAVES * wbuf_bytes<R>();
   size_t tile_b = (size_t)(WIN + (FPB - 1) * hop + 16) * 4;
   if (tile_b < WAVES * 3 * 64 * 16) tile_b = WAVES * 3 * 64 * 16;  // the mel partial sums overlay the tile
@@ -370,6 +422,8 @@ int ww_k_logmel(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, const floa
   logmel_args a = {};
   a.pcm = d_pcm; a.f32 = d_f32; a.sample_offs = d_sample_offs; a.frame_offs = d_frame_offs;
   a.n_utt = n_utt; a.hop = fp->hop; a.divisor = fp->pcm_divisor; a.clip = fp->clip; a.preemph = fp->pre_emphasis;
+  a.rdiv = 1.0f / fp->pcm_divisor;
+  a.fast_div = (fp->pcm_divisor == 32767.0f || fp->pcm_divisor == 32768.0f) ? 1 : 0;
   a.mel = d_mel;
   fill_filter_args(a, m);
   const bool f32in = d_f32 != nullptr;
