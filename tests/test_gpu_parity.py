@@ -185,3 +185,27 @@ def test_stream_bank_matches_batch_path(engines, oracles, name):
         want = oracles[name].slide_forward(hist, 1)[1:, pidx]
         assert len(posts[s]) == len(mel) == len(want)
         assert np.abs(np.array(posts[s]) - want).max() < TOL_POST
+
+
+def test_fp32_frontend_mode_meets_posterior_tolerance(engines, oracles, golden):
+    """precise=0 (fp32 butterflies): log-mel within 2e-4 even on full-scale tones, posteriors
+    within the 1e-4 north-star tolerance of the fp64-FFT oracle."""
+    from wwhip.engine import frontend_params
+    z = np.load(os.path.join(golden, "frontend.npz"))
+    for n in ["noise_chirp", "quiet", "silence", "fullscale", "ragged"]:
+        got = engines["CRNN"].logmel([z[n + ".pcm"]], frontend_params(precise=False))[0]
+        assert np.abs(got - z[n + ".div32767.mel"]).max() < 2e-4, n
+    rng = np.random.default_rng(77)
+    t = np.arange(24000) / 16000.0
+    sig = rng.normal(0, 30, (8, 24000)) + 20000 * np.sin(2 * np.pi * 1000 * t)
+    pcm = np.clip(np.rint(sig), -32768, 32767).astype(np.int16)
+    for name in ("CRNN", "Wavenet"):
+        e = engines[name]
+        mels = e.logmel(list(pcm), frontend_params(precise=False))
+        wins = np.zeros((len(pcm), e.window, 40), np.float32)
+        ref = np.zeros_like(wins)
+        for i, (m, p) in enumerate(zip(mels, pcm)):
+            r = oracles[name].logmel(p)
+            wins[i, :min(len(m), e.window)] = m[:e.window]
+            ref[i, :min(len(r), e.window)] = r[:e.window]
+        assert np.abs(e.forward(wins) - oracles[name].forward(ref)).max() < TOL_POST

@@ -78,6 +78,10 @@ int ww_ctx_destroy(ww_ctx *ctx) {
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
   ctx->drop_graphs(nullptr);
+  for (auto &co : ctx->clip_offs) {
+    hipFree(co.d_so);
+    hipFree(co.d_fo);
+  }
   for (auto &kv : ctx->prof)
     for (auto &p : kv.second.pending) {
       hipEventDestroy(p.first);
@@ -721,11 +725,29 @@ int ww_clips_forward_dev(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, i
   if (rc) return rc;
   const int64_t nf = ww_num_frames(samples, fp->hop);
   const int F = m->info.n_mel, T = m->info.window;
-  // workspace: offs | mel | model scratch
-  const size_t b_o = ww_bump::need((size_t)n_clips + 1, 8);
+  // offset tables for this batch geometry: built once, outside any capture
+  int64_t *d_so = nullptr, *d_fo = nullptr;
+  for (auto &co : ctx->clip_offs)
+    if (co.n_clips == n_clips && co.samples == samples && co.hop == fp->hop) {
+      d_so = co.d_so;
+      d_fo = co.d_fo;
+    }
+  if (!d_so) {
+    ww_ctx::clip_offs_t co;
+    co.n_clips = n_clips; co.samples = samples; co.hop = fp->hop;
+    WW_HIP(ctx, hipMalloc((void **)&co.d_so, sizeof(int64_t) * (n_clips + 1)));
+    WW_HIP(ctx, hipMalloc((void **)&co.d_fo, sizeof(int64_t) * (n_clips + 1)));
+    hipLaunchKernelGGL(iota_offs_kernel, dim3((n_clips + 256) / 256), dim3(256), 0, ctx->stream, co.d_so, co.d_fo, n_clips,
+                       (int64_t)samples, nf);
+    WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->clip_offs.push_back(co);
+    d_so = co.d_so;
+    d_fo = co.d_fo;
+  }
+  // workspace: mel | model scratch
   const size_t b_mel = ww_bump::need((size_t)n_clips * (nf > 0 ? nf : 1) * F, 4);
   const size_t b_ws = model_ws(m, n_clips);
-  if ((rc = ww_ensure(ctx, ctx->dev, 2 * b_o + b_mel + b_ws + 1024, false))) return rc;
+  if ((rc = ww_ensure(ctx, ctx->dev, b_mel + b_ws + 1024, false))) return rc;
   if (!ctx->profiling) {
     for (auto &cg : ctx->clip_graphs) {
       if (cg.model == m && cg.pcm == d_pcm && cg.out == d_out && cg.n_clips == n_clips && cg.samples == samples &&
@@ -737,14 +759,8 @@ int ww_clips_forward_dev(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, i
   }
   auto enqueue = [&]() -> int {
     ww_bump bump(ctx->dev.ptr, ctx->dev.cap);
-    int64_t *d_so = bump.take<int64_t>(n_clips + 1), *d_fo = bump.take<int64_t>(n_clips + 1);
     float *d_mel = bump.take<float>((size_t)n_clips * (nf > 0 ? nf : 1) * F);
     void *ws = bump.take<char>(b_ws);
-    {
-      ww_launch_scope scope(ctx, "iota_offs_kernel");
-      hipLaunchKernelGGL(iota_offs_kernel, dim3((n_clips + 256) / 256), dim3(256), 0, ctx->stream, d_so, d_fo, n_clips,
-                         (int64_t)samples, nf);
-    }
     int r = ww_k_logmel(ctx, m, d_pcm, nullptr, d_so, d_fo, n_clips, (int64_t)n_clips * nf, nf, fp, d_mel);
     if (r) return r;
     // one window per clip: rows [c*nf, c*nf + min(nf, T)), zero padded to T

@@ -49,6 +49,12 @@ struct ww_ctx {
     void *ws = nullptr;
   };
   std::vector<clip_graph_t> clip_graphs;
+  // sample/frame offset tables of the equal-length clip batches seen so far (tiny, built once)
+  struct clip_offs_t {
+    int n_clips = 0, samples = 0, hop = 0;
+    int64_t *d_so = nullptr, *d_fo = nullptr;
+  };
+  std::vector<clip_offs_t> clip_offs;
   void drop_graphs(const void *model_or_null) {
     for (size_t i = 0; i < clip_graphs.size();) {
       if (!model_or_null || clip_graphs[i].model == model_or_null) {
