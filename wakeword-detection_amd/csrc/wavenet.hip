@@ -4,8 +4,10 @@
 // architecture wwdetect/wavenet/wavenet_model.py:11-128; call sites
 // spokestack/wakeword/tflite.py:205-231, utils/evaluate_models.py:83-86).
 //
-// A 256-thread workgroup walks all 24 gated residual blocks of one 182x40 window without
-// leaving the CU.  Time is the MFMA M dimension (182 -> 12 tiles of 16 rows, 3 per wave).
+// A 768-thread workgroup (12 wavefronts, 3 per SIMD) walks all 24 gated residual blocks of one
+// 182x40 window without leaving the CU.  Time is the MFMA M dimension: 182 -> 12 tiles of 16
+// rows, one tile per wave, so three waves share each SIMD's matrix pipe and cover each other's
+// LDS round trips (4 waves x 3 tiles measured 10 % slower).
 // The residual stream x[182][16] and the skip accumulator [182][32] never leave registers:
 // they sit in the v_mfma_f32_16x16x4_f32 accumulator layout (lane -> column, 4 rows per
 // register quad), which is also the layout the next block's epilogue needs.  Only the
@@ -27,6 +29,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define WV_S 32
 #define WV_PAD 16     // causal zero rows in front of u
 #define WV_INLD 48    // staged input row stride (40 mel + zero pad to 3 k-blocks)
+#ifndef WV_NW
+#define WV_NW 12      // wavefronts per workgroup (3 per SIMD): 12 row tiles of 16 frames, one per wave
+#endif
+#define WV_MPW (12 / WV_NW)  // row tiles per wave
+#define WV_THREADS (WV_NW * 64)
 
 struct win_addr_w {
   const int64_t *row;
@@ -67,24 +74,60 @@ __device__ __forceinline__ void wsync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// v_exp_f32 / v_rcp_f32 gates (~1 ulp each, |error| ~2e-7): the gate activations are 16x2 values
+// per row and block; with libm tanhf/expf + IEEE division they cost more VALU time than the
+// block's MFMAs.
+__device__ __forceinline__ float fast_sigmoid_w(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float fast_tanh_w(float x) {
+  const float e = __builtin_amdgcn_exp2f(2.8853900817779268f * x);  // exp(2x): inf -> 1, 0 -> -1
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+struct wave_blk {
+  float4 wg[3][2], wrs[3];
+  float bn_s, bn_t, bsig, btanh, bres, bsk0, bsk1;
+  int d, has_res;
+};
+
 #define MFMA4(acc, av, bv)                                              \
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0); \
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0); \
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0); \
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
 
+__device__ __forceinline__ void wave_blk_load(const wave_args &a, int blk, int j, int kk, wave_blk &p) {
+#pragma unroll
+  for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+      p.wg[kb][n] = *(const float4 *)(a.w_gate4 + (((size_t)blk * 3 + kb) * 4 + kk) * 32 * 4 + (n * 16 + j) * 4);
+#pragma unroll
+  for (int n = 0; n < 3; ++n) p.wrs[n] = *(const float4 *)(a.w_rs4 + ((size_t)blk * 4 + kk) * 48 * 4 + (n * 16 + j) * 4);
+  p.bn_s = a.bn_s[blk * WV_C + j];
+  p.bn_t = a.bn_t[blk * WV_C + j];
+  p.bsig = a.b_gate[blk * 32 + j];
+  p.btanh = a.b_gate[blk * 32 + 16 + j];
+  p.bres = a.b_rs[blk * 48 + j];
+  p.bsk0 = a.b_rs[blk * 48 + 16 + j];
+  p.bsk1 = a.b_rs[blk * 48 + 32 + j];
+  p.d = a.dil[blk];
+  p.has_res = a.has_res[blk];
+}
+
 template <bool HEAD_ONLY>
-__global__ __launch_bounds__(256) void wavenet_kernel(wave_args a) {
+__global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
   // LDS: region A = staged input [192][48] (prologue only), later u[2][208][16] + g[192][16]
   __shared__ __align__(16) float lds[WV_T * WV_INLD > (2 * (WV_T + WV_PAD) * WV_C + WV_T * WV_S) ? WV_T * WV_INLD
                                                                                                   : (2 * (WV_T + WV_PAD) * WV_C + WV_T * WV_S)];
-  __shared__ float red[4][16];
+  __shared__ float red[WV_NW][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kk = lane >> 4;
   const int w = blockIdx.x;
   const int T = a.T;
 
-  f32x4 x[3], skip[3][2];
+  f32x4 x[WV_MPW], skip[WV_MPW][2];
   float *ubuf = lds;                                    // [2][WV_T + WV_PAD][16]
   float *gbuf = lds + 2 * (WV_T + WV_PAD) * WV_C;       // [WV_T][16] (wave-private tiles)
   float *hbuf = gbuf;                                   // detect head reuses it as [WV_T][32]
@@ -92,10 +135,10 @@ __global__ __launch_bounds__(256) void wavenet_kernel(wave_args a) {
     // detect.tflite alone (reference detect_model(x), wakeword/tflite.py:231): skip sums come from memory
     const float *e = a.enc_in + (size_t)w * T * WV_S;
 #pragma unroll
-    for (int mi = 0; mi < 3; ++mi)
+    for (int mi = 0; mi < WV_MPW; ++mi)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int t = (wave * 3 + mi) * 16 + kk * 4 + r;
+        const int t = (wave * WV_MPW + mi) * 16 + kk * 4 + r;
         skip[mi][0][r] = t < T ? e[(size_t)t * WV_S + j] : 0.f;
         skip[mi][1][r] = t < T ? e[(size_t)t * WV_S + 16 + j] : 0.f;
       }
@@ -109,12 +152,12 @@ __global__ __launch_bounds__(256) void wavenet_kernel(wave_args a) {
 
   // ---- stage the window: in_lds[t][0..47], zero outside [0,valid) x [0,n_mel)
   float *in_lds = lds;
-  for (int i = tid; i < WV_T * WV_INLD / 4; i += 256) ((float4 *)in_lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = tid; i < WV_T * WV_INLD / 4; i += WV_THREADS) ((float4 *)in_lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
   {
     const float *src = a.mel + row * a.n_mel;
     const int n = valid * a.n_mel;
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += WV_THREADS) {
       int t = i / a.n_mel, c = i - t * a.n_mel;
       in_lds[t * WV_INLD + c] = src[i];
     }
@@ -129,8 +172,8 @@ __global__ __launch_bounds__(256) void wavenet_kernel(wave_args a) {
     for (int kb = 0; kb < 3; ++kb) bw[kb] = *(const float4 *)(a.w_in4 + ((size_t)(kb * 4 + kk) * 16 + j) * 4);
     const float bias = a.b_in[j];
 #pragma unroll
-    for (int mi = 0; mi < 3; ++mi) {
-      const int t0 = (wave * 3 + mi) * 16;
+    for (int mi = 0; mi < WV_MPW; ++mi) {
+      const int t0 = (wave * WV_MPW + mi) * 16;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kb = 0; kb < 3; ++kb) {
@@ -146,58 +189,49 @@ __global__ __launch_bounds__(256) void wavenet_kernel(wave_args a) {
   __syncthreads();  // in_lds is dead from here on
 
   // causal zero rows of both u buffers
-  for (int i = tid; i < 2 * WV_PAD * WV_C; i += 256) {
+  for (int i = tid; i < 2 * WV_PAD * WV_C; i += WV_THREADS) {
     int b = i / (WV_PAD * WV_C), o = i - b * (WV_PAD * WV_C);
     ubuf[b * (WV_T + WV_PAD) * WV_C + o] = 0.f;
   }
 
-  for (int blk = 0; blk < a.NB; ++blk) {
+  // block parameters are prefetched one block ahead (two register sets, loop unrolled by two)
+  wave_blk pb[2];
+  wave_blk_load(a, 0, j, kk, pb[0]);
+  auto run_block = [&](int blk, const wave_blk &P, wave_blk &Pnext) {
     float *u = ubuf + (blk & 1) * (WV_T + WV_PAD) * WV_C + WV_PAD * WV_C;  // row 0 of u
-    const int d = a.dil[blk];
+    const int d = P.d;
     // ---- BatchNorm affine (wavenet_model.py:57) -> LDS
-    {
-      const float s = a.bn_s[blk * WV_C + j], sh = a.bn_t[blk * WV_C + j];
 #pragma unroll
-      for (int mi = 0; mi < 3; ++mi) {
-        const int t0 = (wave * 3 + mi) * 16 + kk * 4;
+    for (int mi = 0; mi < WV_MPW; ++mi) {
+      const int t0 = (wave * WV_MPW + mi) * 16 + kk * 4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) u[(t0 + r) * WV_C + j] = x[mi][r] * s + sh;
-      }
+      for (int r = 0; r < 4; ++r) u[(t0 + r) * WV_C + j] = x[mi][r] * P.bn_s + P.bn_t;
     }
-    // weights of this block for this lane
-    float4 wg[3][2], wrs[3];
-#pragma unroll
-    for (int kb = 0; kb < 3; ++kb)
-#pragma unroll
-      for (int n = 0; n < 2; ++n)
-        wg[kb][n] = *(const float4 *)(a.w_gate4 + (((size_t)blk * 3 + kb) * 4 + kk) * 32 * 4 + (n * 16 + j) * 4);
-#pragma unroll
-    for (int n = 0; n < 3; ++n) wrs[n] = *(const float4 *)(a.w_rs4 + ((size_t)blk * 4 + kk) * 48 * 4 + (n * 16 + j) * 4);
-    const float bsig = a.b_gate[blk * 32 + j], btanh = a.b_gate[blk * 32 + 16 + j];
-    const float bres = a.b_rs[blk * 48 + j], bsk0 = a.b_rs[blk * 48 + 16 + j], bsk1 = a.b_rs[blk * 48 + 32 + j];
-    const int has_res = a.has_res[blk];
+    if (blk + 1 < a.NB) wave_blk_load(a, blk + 1, j, kk, Pnext);
+    const float bsig = P.bsig, btanh = P.btanh, bres = P.bres, bsk0 = P.bsk0, bsk1 = P.bsk1;
+    const int has_res = P.has_res;
     __syncthreads();  // u complete (all rows, all waves)
 
 #pragma unroll
-    for (int mi = 0; mi < 3; ++mi) {
-      const int t0 = (wave * 3 + mi) * 16;
+    for (int mi = 0; mi < WV_MPW; ++mi) {
+      const int t0 = (wave * WV_MPW + mi) * 16;
       f32x4 as = {0.f, 0.f, 0.f, 0.f}, at = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kb = 0; kb < 3; ++kb) {
         // tap kb reads u[t - (2 - kb) * d]; rows < 0 hit the zero pad (d <= 8 -> >= -16)
         const float4 av = *(const float4 *)(u + (t0 + j - (2 - kb) * d) * WV_C + kk * 4);
-        MFMA4(as, av, wg[kb][0]);
-        MFMA4(at, av, wg[kb][1]);
+        MFMA4(as, av, P.wg[kb][0]);
+        MFMA4(at, av, P.wg[kb][1]);
       }
       float *gt = gbuf + t0 * WV_C;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) gt[(kk * 4 + r) * WV_C + j] = tanhf(at[r] + btanh) * sigmoid_w(as[r] + bsig);
+      for (int r = 0; r < 4; ++r) gt[(kk * 4 + r) * WV_C + j] = fast_tanh_w(at[r] + btanh) * fast_sigmoid_w(as[r] + bsig);
       wsync();
       const float4 gv = *(const float4 *)(gt + j * WV_C + kk * 4);
       f32x4 ar = {0.f, 0.f, 0.f, 0.f}, s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-      MFMA4(ar, gv, wrs[0]);
-      MFMA4(s0, gv, wrs[1]);
-      MFMA4(s1, gv, wrs[2]);
+      MFMA4(ar, gv, P.wrs[0]);
+      MFMA4(s0, gv, P.wrs[1]);
+      MFMA4(s1, gv, P.wrs[2]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (has_res) x[mi][r] = fmaxf(ar[r] + bres, 0.f) + x[mi][r];
@@ -206,6 +240,10 @@ __global__ __launch_bounds__(256) void wavenet_kernel(wave_args a) {
       }
       wsync();
     }
+  };
+  for (int blk = 0; blk < a.NB; blk += 2) {
+    run_block(blk, pb[0], pb[1]);
+    if (blk + 1 < a.NB) run_block(blk + 1, pb[1], pb[0]);
   }
   __syncthreads();
 
@@ -214,10 +252,10 @@ __global__ __launch_bounds__(256) void wavenet_kernel(wave_args a) {
   if (a.enc) {
     float *e = a.enc + (size_t)w * T * WV_S;
 #pragma unroll
-    for (int mi = 0; mi < 3; ++mi)
+    for (int mi = 0; mi < WV_MPW; ++mi)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int t = (wave * 3 + mi) * 16 + kk * 4 + r;
+        const int t = (wave * WV_MPW + mi) * 16 + kk * 4 + r;
         if (t < T) {
           e[(size_t)t * WV_S + j] = skip[mi][0][r];
           e[(size_t)t * WV_S + 16 + j] = skip[mi][1][r];
@@ -234,8 +272,8 @@ __global__ __launch_bounds__(256) void wavenet_kernel(wave_args a) {
   const float b1a = a.d_b1[j], b1b = a.d_b1[16 + j], b2 = a.d_b2[j];
   float best = -INFINITY;
 #pragma unroll
-  for (int mi = 0; mi < 3; ++mi) {
-    const int t0 = (wave * 3 + mi) * 16;
+  for (int mi = 0; mi < WV_MPW; ++mi) {
+    const int t0 = (wave * WV_MPW + mi) * 16;
     float *ht = hbuf + t0 * WV_S;  // [16][32] tile, wave-private
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -276,7 +314,9 @@ __global__ __launch_bounds__(256) void wavenet_kernel(wave_args a) {
   if (lane < 16) red[wave][lane] = best;
   __syncthreads();
   if (tid < 16) {
-    float v = fmaxf(fmaxf(red[0][tid], red[1][tid]), fmaxf(red[2][tid], red[3][tid]));
+    float v = red[0][tid];
+#pragma unroll
+    for (int q = 1; q < WV_NW; ++q) v = fmaxf(v, red[q][tid]);
     float mx = (tid < a.NOUT) ? v : -INFINITY;
     for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     float e = (tid < a.NOUT) ? expf(v - mx) : 0.f;
@@ -303,7 +343,7 @@ int ww_k_wave_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
   a.d_w1_4 = v.d_w1; a.d_b1 = v.d_b1; a.d_w2_4 = v.d_w2; a.d_b2 = v.d_b2;
   a.out = d_out; a.enc = d_enc;
   ww_launch_scope scope(ctx, "wavenet_kernel");
-  hipLaunchKernelGGL(wavenet_kernel<false>, dim3(nw), dim3(256), 0, ctx->stream, a);
+  hipLaunchKernelGGL(wavenet_kernel<false>, dim3(nw), dim3(WV_THREADS), 0, ctx->stream, a);
   WW_HIP(ctx, hipGetLastError());
   return WW_OK;
 }
@@ -316,7 +356,7 @@ int ww_k_wave_detect(ww_ctx *ctx, const ww_model *m, const float *d_enc, int nw,
   a.d_w1_4 = v.d_w1; a.d_b1 = v.d_b1; a.d_w2_4 = v.d_w2; a.d_b2 = v.d_b2;
   a.out = d_out; a.enc = nullptr; a.enc_in = d_enc;
   ww_launch_scope scope(ctx, "wavenet_detect_kernel");
-  hipLaunchKernelGGL(wavenet_kernel<true>, dim3(nw), dim3(256), 0, ctx->stream, a);
+  hipLaunchKernelGGL(wavenet_kernel<true>, dim3(nw), dim3(WV_THREADS), 0, ctx->stream, a);
   WW_HIP(ctx, hipGetLastError());
   return WW_OK;
 }
