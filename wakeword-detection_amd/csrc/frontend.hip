@@ -174,14 +174,6 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? 3 : 4) void logmel_kernel(log
     }
   }
 
-  // mel B operands of this wave's (tile, block) entries: issued now, consumed after the FFT
-  float4 melb[MEL_PER_WAVE];
-#pragma unroll
-  for (int i = 0; i < MEL_PER_WAVE; ++i) {
-    const int e = wave + WAVES * i;
-    melb[i] = e < a.mel_entries ? ((const float4 *)a.melB)[(size_t)e * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-
   // ---- stage the sample tile: aligned 16-byte global loads; tile[i + shift] = x[g_first + i]
   constexpr int VEC = F32IN ? 4 : 8;                      // elements per 16-byte load
   const int64_t g_first = s_begin + f0 * a.hop;           // first sample of frame f0
@@ -233,6 +225,15 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? 3 : 4) void logmel_kernel(log
   }
   __syncthreads();
 
+  float4 melb[MEL_PER_WAVE];
+  bool melb_loaded = false;
+  auto load_melb = [&]() {
+#pragma unroll
+    for (int i = 0; i < MEL_PER_WAVE; ++i) {
+      const int e = wave + WAVES * i;
+      melb[i] = e < a.mel_entries ? ((const float4 *)a.melB)[(size_t)e * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
   // ---- FFT: every 16-lane row of a wave owns one frame (4 frames per wave at a time)
   R *tr = (R *)(wbuf + (size_t)wave * wbuf_bytes<R>());        // [4][16][TR_LD]
   float *mg = (float *)(wbuf + (size_t)wave * wbuf_bytes<R>());  // overlay: [4][MAG_LD]
@@ -281,6 +282,11 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? 3 : 4) void logmel_kernel(log
     wave_sync();
     // pass 2: lane j = k1 holds Y[n2][k1]; output w[pos] = Z[k1 + 16 k_of(pos)]
     dft16<R>(w);
+    // mel B operands of this wave's (tile, block) entries: issued here (after the register peak of
+    // the transposes), consumed after the untangling pass
+    load_melb();
+    melb_loaded = true;
+
     // untangle: with a = Z[k], b = conj Z[256-k]:  E = (a+b)/2, O = (a-b)/(2i), T = W512^k O and
     //   X[k] = E + T,   X[256-k] = conj(E - T)   ->  two magnitudes per evaluation, k < 128 only.
     // Lane j register k2 holds k = j + 16 k2; its partner Z[256-k] lives in lane (16-j)%16 at
@@ -310,6 +316,7 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? 3 : 4) void logmel_kernel(log
       else mrow[256 + j] = 0.0f;
     }
   }
+  if (!melb_loaded) load_melb();  // waves without a frame group in a short tile still contract
   __syncthreads();
 
   // ---- mel filterbank as an MFMA contraction over the 16 frames of the block:
@@ -351,18 +358,29 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? 3 : 4) void logmel_kernel(log
       const f32x4 p = part[(w2 * 3 + nt) * 64 + lane];
       sum[0] += p[0]; sum[1] += p[1]; sum[2] += p[2]; sum[3] += p[3];
     }
+    // log tail, then park the 16x40 tile in LDS (the magnitudes are dead) for a coalesced store
     const int band = nt * 16 + j;
     if (band < a.n_mel) {
       const float bias = a.bias[band];
-      float *dst = a.mel + (a.frame_offs[u] + f0) * (int64_t)a.n_mel + band;
+      float *mt = (float *)wbuf;  // [FPB][40]
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int frame = (lane >> 4) * 4 + r;
-        if (frame < nfb) {
-          float v = fmaxf(sum[r] + bias, a.floor_v);
-          dst[(int64_t)frame * a.n_mel] = (logf(v) + a.log_off) * a.scale;
-        }
+        float v = fmaxf(sum[r] + bias, a.floor_v);
+        mt[frame * a.n_mel + band] = (logf(v) + a.log_off) * a.scale;
       }
+    }
+  }
+  __syncthreads();
+  {
+    // the tile's nfb rows are contiguous in the output: 16-byte stores, 2560 B per tile
+    const float4 *mt4 = (const float4 *)wbuf;
+    float *dstf = a.mel + (a.frame_offs[u] + f0) * (int64_t)a.n_mel;
+    const int n4 = nfb * a.n_mel / 4;
+    if ((((uintptr_t)dstf) & 15) == 0 && (a.n_mel & 3) == 0) {
+      for (int i = tid; i < n4; i += 256) ((float4 *)dstf)[i] = mt4[i];
+    } else {
+      for (int i = tid; i < nfb * a.n_mel; i += 256) dstf[i] = ((const float *)wbuf)[i];
     }
   }
 }
