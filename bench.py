@@ -253,6 +253,14 @@ def main():
             roof = {"bound": "mfma", "achieved": flops / (dom_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
         roof["traffic"] = None
+        try:  # HBM-side bytes per launch from the committed PMC passes of the same workload
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))["kernels"].get(dom)
+            if pmc and args.clips == 256:
+                roof["traffic"] = (pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024
+                roof["traffic_note"] = "FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc (profiles/r01/pmc_traffic.json), bytes per launch"
+                roof["algorithmic_bytes"] = nbytes
+        except (OSError, KeyError, ValueError):
+            pass
         roof["kernel"] = dom
         roof["kernel_avg_us"] = round(dom_ms * 1e3, 3)
         roof["all_kernels_avg_us"] = per_kernel
