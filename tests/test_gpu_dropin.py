@@ -234,3 +234,30 @@ def test_models_predict_one_window_per_clip(assets):
     want = CpuOracle(eng.blob).forward(X)[:, 1]
     assert np.abs(post - want).max() < TOL
     assert preds == [1 if p >= 0.5 else 0 for p in want]
+
+
+@pytest.mark.parametrize("name", ["CRNN_softmax", "Wavenet"])
+def test_testset_evaluation_far_frr_identical(assets, name):
+    """SURVEY 8(d) cfg-1 stand-in, small: FA counts / FRR identical to the CPU oracle flow."""
+    from wwhip.evaluate import synth_testset, evaluate_testset
+    from wwhip.models import engine_for
+    from oracle.cpu import CpuOracle
+    from oracle import numpy_ref as NR
+    clips, labels = synth_testset(24, seed=3, min_s=0.9, max_s=2.2)
+    labels[:5] = 1
+    eng = engine_for(os.path.join(assets, name))
+    res = evaluate_testset(eng, clips, labels)
+    ora = CpuOracle(eng.blob)
+    pidx = eng.posterior_index
+    pos, neg = [], []
+    for c, l in zip(clips, labels):
+        mel = ora.logmel(np.concatenate((np.zeros(8000, np.int16), c, np.zeros(8000, np.int16))))
+        p = ora.slide_forward(mel, 2)[:, pidx]
+        (pos if l else neg).append(p)
+    pos = np.array([p.max() for p in pos], np.float32)
+    neg = np.concatenate(neg)
+    assert np.abs(res["positives"] - pos).max() < TOL and np.abs(res["negatives"] - neg).max() < TOL
+    # same posteriors in -> identical counts out (sweep itself is exact)
+    wf, wa, wc, _ = NR.far_frr(res["positives"], res["negatives"], int(labels.sum()), res["hours"])
+    np.testing.assert_array_equal(res["fa_count"], wc)
+    np.testing.assert_allclose(res["frr"], wf, atol=1e-15)

@@ -71,6 +71,37 @@ SYMBOLS: Dict[str, tuple] = {
 _lib: Optional[C.CDLL] = None
 _lock = threading.Lock()
 
+# Native objects must be released before the interpreter (and with it the HIP runtime) is torn
+# down, and in dependency order: stream banks, then models, then contexts.  Objects register
+# here; an atexit hook closes them; after that close() / __del__ are no-ops.
+import atexit
+import weakref
+
+_live = {"streams": weakref.WeakSet(), "models": weakref.WeakSet(), "contexts": weakref.WeakSet()}
+_shutdown = False
+
+
+def register(kind: str, obj) -> None:
+    _live[kind].add(obj)
+
+
+def is_shutdown() -> bool:
+    return _shutdown
+
+
+def _close_all() -> None:
+    global _shutdown
+    for kind in ("streams", "models", "contexts"):
+        for obj in list(_live[kind]):
+            try:
+                obj.close()
+            except Exception:
+                pass
+    _shutdown = True
+
+
+atexit.register(_close_all)
+
 
 def load() -> C.CDLL:
     """Load ``libwwhip.so``; raises ``RuntimeError`` if it has not been built."""
@@ -118,6 +149,7 @@ class Context:
             raise_for(rc, None)
         self._h = h
         self.device = device
+        register("contexts", self)
 
     @property
     def handle(self):
@@ -147,9 +179,9 @@ class Context:
         return float(ms.value)
 
     def close(self) -> None:
-        if self._h:
+        if self._h and not _shutdown:
             load().ww_ctx_destroy(self._h)
-            self._h = None
+        self._h = None
 
     def __del__(self):  # pragma: no cover
         try:

@@ -41,6 +41,7 @@ class Engine:
         self.n_out = info.n_out
         self.enc_shape = (info.enc_rows, info.enc_width)
         self.model_dir = model_dir
+        _lib.register("models", self)
 
     # ------------------------------------------------------------------ properties
     @property
@@ -56,9 +57,9 @@ class Engine:
         return self.kind == _lib.KIND_CRNN
 
     def close(self) -> None:
-        if self._model:
+        if self._model and not _lib.is_shutdown():
             self._lib.ww_model_free(self._model)
-            self._model = None
+        self._model = None
 
     def __del__(self):  # pragma: no cover
         try:
@@ -194,6 +195,7 @@ class StreamBank:
         _lib.raise_for(self._lib.ww_stream_create(engine.ctx.handle, engine.handle, self.S, C.byref(fp), C.byref(h)),
                        engine.ctx.handle)
         self._h = h
+        _lib.register("streams", self)
         self._post = np.zeros((self.S, 2), np.float32)
         self._n = np.zeros(self.S, np.int32)
 
@@ -219,9 +221,9 @@ class StreamBank:
             _lib.raise_for(self._lib.ww_stream_reset(self._h, _lib.ptr(a), a.size), self.engine.ctx.handle)
 
     def close(self) -> None:
-        if self._h:
+        if self._h and not _lib.is_shutdown():
             self._lib.ww_stream_destroy(self._h)
-            self._h = None
+        self._h = None
 
     def __del__(self):  # pragma: no cover
         try:

@@ -179,3 +179,85 @@ def models_predict(engine: Engine, X: np.ndarray, threshold: float = 0.5) -> Tup
     """One window per clip, class 1 when posterior >= threshold (``evaluate_tf_lite_opts.py:49-69``)."""
     post = engine.forward(X)[:, engine.posterior_index]
     return [1 if p >= threshold else 0 for p in post], post
+
+
+# ----------------------------------------------------------------------------------------------
+# Whole-test-set evaluation on in-memory clips (SURVEY 8d cfg 1 / cfg 4): the a17 flow (one window
+# per clip) and the a14-a16 flow (sliding hop 2, max per positive clip, negatives as one stream,
+# smoothing + sweep), batched: ONE front-end launch for all clips, ONE model launch for all
+# windows of all clips, one sweep.
+# ----------------------------------------------------------------------------------------------
+def synth_clip(rng: np.random.Generator, n: int, noise: float = 2000.0, chirp: float = 8000.0) -> np.ndarray:
+    """SURVEY 8(d) cfg-1 stand-in for a hey-snips clip: Gaussian noise + linear chirp 200->4000 Hz."""
+    t = np.arange(n) / 16000.0
+    dur = max(n / 16000.0, 1e-3)
+    phase = 2 * np.pi * (200.0 * t + 0.5 * (4000.0 - 200.0) / dur * t * t)
+    x = rng.normal(0.0, noise, n) + chirp * np.sin(phase)
+    return np.clip(np.rint(x), -32768, 32767).astype(np.int16)
+
+
+def synth_testset(n_clips: int = 2048, seed: int = 1234, min_s: float = 0.8, max_s: float = 2.5):
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(int(min_s * 16000), int(max_s * 16000) + 1, n_clips)
+    clips = [synth_clip(rng, int(n)) for n in lens]
+    labels = (rng.random(n_clips) < 0.1).astype(np.uint8)
+    return clips, labels
+
+
+def clip_posteriors(engine: Engine, clips: Sequence[np.ndarray], hop: int = 2, fp=None):
+    """Per clip: posterior of the single end-padded window (a17) and the sliding posteriors
+    (hop 2) of the clip padded by 0.5 s of zeros on both sides (evaluate_models.py:52-53), ring
+    reset per clip.  Returns (one_window [N], sliding list of arrays)."""
+    import torch  # only to hold the device buffers of the batched launch
+
+    fp = fp or frontend_params()
+    pidx = engine.posterior_index
+    T = engine.window
+    mels = engine.logmel(list(clips), fp)
+    one = np.zeros((len(clips), T, engine.n_mel), np.float32)
+    for i, m in enumerate(mels):
+        one[i, : min(len(m), T)] = m[:T]
+    p_one = engine.forward(one)[:, pidx] if len(clips) else np.zeros(0, np.float32)
+    padded = [np.concatenate((np.zeros(8000, np.int16), c, np.zeros(8000, np.int16))) for c in clips]
+    mels_p = engine.logmel(padded, fp)
+    # all windows of all clips in one device launch
+    rows = np.concatenate(mels_p) if mels_p else np.zeros((0, engine.n_mel), np.float32)
+    starts, counts, base = [], [], 0
+    for m in mels_p:
+        nw = (len(m) - T) // hop + 1 if len(m) >= T else 0
+        starts.append(base + hop * np.arange(nw, dtype=np.int64))
+        counts.append(nw)
+        base += len(m)
+    win_row = np.concatenate(starts) if starts else np.zeros(0, np.int64)
+    sliding: List[np.ndarray] = []
+    if len(win_row):
+        d_mel = torch.from_numpy(np.ascontiguousarray(rows)).cuda()
+        d_row = torch.from_numpy(win_row).cuda()
+        d_valid = torch.full((len(win_row),), T, dtype=torch.int32, device="cuda")
+        d_out = torch.empty((len(win_row), engine.n_out), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        engine.forward_windows_dev(d_mel.data_ptr(), len(rows), d_row.data_ptr(), d_valid.data_ptr(), len(win_row), d_out.data_ptr())
+        engine.ctx.synchronize()
+        post = d_out.cpu().numpy()[:, pidx]
+    else:
+        post = np.zeros(0, np.float32)
+    o = 0
+    for nw in counts:
+        sliding.append(post[o:o + nw])
+        o += nw
+    return p_one, sliding
+
+
+def evaluate_testset(engine: Engine, clips: Sequence[np.ndarray], labels: Sequence[int], thresholds=None,
+                     windowsize: int = 30):
+    """FRR / FA-per-hour curves + FRR@0.5FA/h + one-window accuracy for a labelled clip set."""
+    labels = np.asarray(labels).astype(bool)
+    p_one, sliding = clip_posteriors(engine, clips)
+    pos = np.array([s.max() if len(s) else 0.0 for s, l in zip(sliding, labels) if l], np.float32)
+    neg = np.concatenate([s for s, l in zip(sliding, labels) if not l]) if (~labels).any() else np.zeros(0, np.float32)
+    hours = sum((len(c) + 16000) for c, l in zip(clips, labels) if not l) / 16000.0 / 3600.0
+    thr, frr, fa, cnt = far_frr(pos, neg, max(int(labels.sum()), 1), hours, thresholds, windowsize, engine=engine)
+    preds = (p_one >= 0.5)
+    return {"thresholds": thr, "frr": frr, "fa_per_hour": fa, "fa_count": cnt, "frr_at_0.5_fa_per_hour": frr_at_fa(frr, fa, 0.5),
+            "one_window_posteriors": p_one, "one_window_accuracy": float((preds == labels).mean()),
+            "positives": pos, "negatives": neg, "hours": hours}
