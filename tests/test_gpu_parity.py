@@ -148,7 +148,7 @@ def test_clips_forward_dev(engines, oracles, name):
     d_pcm = torch.from_numpy(pcm).cuda()
     d_out = torch.zeros((B, e.n_out), dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
-    for _ in range(3):  # first call captures the graph, later calls replay it
+    for _ in range(3):
         e.clips_forward_dev(d_pcm.data_ptr(), B, S, d_out.data_ptr(), frontend_params())
     e.ctx.synchronize()
     got = d_out.cpu().numpy()
