@@ -135,12 +135,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; no CPU fallback exists for the hot path")
+    # WW_BENCH_BACKEND=gloo is a rehearsal mode for a one-GPU box (ranks share GPU 0, the gather
+    # goes through host memory); the driver's multi-GPU runs use RCCL ("nccl"), one GPU per rank.
+    backend = os.environ.get("WW_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    comm_dev = "cuda" if backend == "nccl" else "cpu"
 
     from wwhip.engine import Engine, frontend_params
     from wwhip import _lib
@@ -165,6 +174,7 @@ def main():
     K = args.steps
     d_outs = [torch.zeros((args.clips, eng.n_out), dtype=torch.float32, device="cuda") for _ in range(R)]
     d_all = torch.zeros((K, args.clips, eng.n_out), dtype=torch.float32, device="cuda")
+    slot_of_step = torch.arange(K, device="cuda") % R
     torch.cuda.synchronize()
 
     def step(k, only0=False):
@@ -185,9 +195,10 @@ def main():
         step(k)
     sync_all()
     if dist is not None:  # warm up the communicator outside the timed region
-        tmp = [torch.empty_like(d_all) for _ in range(world)]
-        dist.all_gather(tmp, d_all)
-        del tmp
+        src = d_all.to(comm_dev)
+        tmp = [torch.empty_like(src) for _ in range(world)]
+        dist.all_gather(tmp, src)
+        del tmp, src
     barrier()
     t0 = time.perf_counter()
     for k in range(K):
@@ -195,14 +206,14 @@ def main():
     sync_all()
     if dist is not None:
         # posterior gather, once per job: every rank contributes the K*clips*n_out floats it produced
-        for k in range(K):
-            d_all[k] = d_outs[k % R]
-        gathered = [torch.empty_like(d_all) for _ in range(world)]
-        dist.all_gather(gathered, d_all)
+        d_all = torch.stack(d_outs)[slot_of_step]  # two device kernels, not K copies
+        src = d_all.to(comm_dev)
+        gathered = [torch.empty_like(src) for _ in range(world)]
+        dist.all_gather(gathered, src)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
