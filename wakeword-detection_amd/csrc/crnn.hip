@@ -277,8 +277,10 @@ __device__ __forceinline__ float swap_pair(float v) {
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 struct gru_w {
-  float z[16], r[16], c[16];
+  f32x2 z[8], r[8], c[8];  // W_h rows of this lane's unit, columns [16*half, 16*half+16), as pairs
   float bz, br, bc;
 };
 
@@ -289,9 +291,9 @@ __device__ __forceinline__ void gru_load_w(gru_w &g, const float *wh, const floa
     const float4 z = *(const float4 *)(base + (size_t)(0 * GR_H + unit) * GR_H + half * 16 + q * 4);
     const float4 r = *(const float4 *)(base + (size_t)(1 * GR_H + unit) * GR_H + half * 16 + q * 4);
     const float4 c = *(const float4 *)(base + (size_t)(2 * GR_H + unit) * GR_H + half * 16 + q * 4);
-    g.z[q * 4 + 0] = z.x; g.z[q * 4 + 1] = z.y; g.z[q * 4 + 2] = z.z; g.z[q * 4 + 3] = z.w;
-    g.r[q * 4 + 0] = r.x; g.r[q * 4 + 1] = r.y; g.r[q * 4 + 2] = r.z; g.r[q * 4 + 3] = r.w;
-    g.c[q * 4 + 0] = c.x; g.c[q * 4 + 1] = c.y; g.c[q * 4 + 2] = c.z; g.c[q * 4 + 3] = c.w;
+    g.z[2 * q] = (f32x2){z.x, z.y}; g.z[2 * q + 1] = (f32x2){z.z, z.w};
+    g.r[2 * q] = (f32x2){r.x, r.y}; g.r[2 * q + 1] = (f32x2){r.z, r.w};
+    g.c[2 * q] = (f32x2){c.x, c.y}; g.c[2 * q + 1] = (f32x2){c.z, c.w};
   }
   g.bz = bh[dir * 3 * GR_H + unit];
   g.br = bh[dir * 3 * GR_H + GR_H + unit];
@@ -300,18 +302,20 @@ __device__ __forceinline__ void gru_load_w(gru_w &g, const float *wh, const floa
 
 // One GRU step for lane (unit = lane >> 1, half = lane & 1).  hin: this direction's h in LDS.
 // Keras GRU v2 (reset_after): z = s(xz + hz), r = s(xr + hr), c = tanh(xc + r * hc), h' = z h + (1-z) c
+// The three 16-term dot products run as packed fp32 FMAs (v_pk_fma_f32: two terms per instruction,
+// even / odd partial sums), the halves of K meet through one DPP swap.
 __device__ __forceinline__ float gru_step(const gru_w &g, const float *hin, int half, float gz, float gr, float gc,
                                           float h_own) {
   const float4 *hp = (const float4 *)(hin + half * 16);
-  float sz = 0.f, sr = 0.f, sc = 0.f;
+  f32x2 az = {0.f, 0.f}, ar = {0.f, 0.f}, ac = {0.f, 0.f};
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const float4 hv = hp[q];
-    sz = fmaf(g.z[q * 4 + 0], hv.x, sz); sr = fmaf(g.r[q * 4 + 0], hv.x, sr); sc = fmaf(g.c[q * 4 + 0], hv.x, sc);
-    sz = fmaf(g.z[q * 4 + 1], hv.y, sz); sr = fmaf(g.r[q * 4 + 1], hv.y, sr); sc = fmaf(g.c[q * 4 + 1], hv.y, sc);
-    sz = fmaf(g.z[q * 4 + 2], hv.z, sz); sr = fmaf(g.r[q * 4 + 2], hv.z, sr); sc = fmaf(g.c[q * 4 + 2], hv.z, sc);
-    sz = fmaf(g.z[q * 4 + 3], hv.w, sz); sr = fmaf(g.r[q * 4 + 3], hv.w, sr); sc = fmaf(g.c[q * 4 + 3], hv.w, sc);
+    const f32x2 h0 = {hv.x, hv.y}, h1 = {hv.z, hv.w};
+    az = g.z[2 * q] * h0 + az; ar = g.r[2 * q] * h0 + ar; ac = g.c[2 * q] * h0 + ac;
+    az = g.z[2 * q + 1] * h1 + az; ar = g.r[2 * q + 1] * h1 + ar; ac = g.c[2 * q + 1] * h1 + ac;
   }
+  float sz = az.x + az.y, sr = ar.x + ar.y, sc = ac.x + ac.y;
   sz += swap_pair(sz);
   sr += swap_pair(sr);
   sc += swap_pair(sc);
@@ -319,6 +323,13 @@ __device__ __forceinline__ float gru_step(const gru_w &g, const float *hin, int 
   const float r = fast_sigmoid(gr + (sr + g.br));
   const float c = fast_tanh(gc + r * (sc + g.bc));
   return z * h_own + (1.0f - z) * c;
+}
+
+// Between the h write of one step and the h reads of the next: LDS instructions of ONE wave are
+// executed in issue order, so no s_waitcnt is needed - only the compiler must not reorder them.
+__device__ __forceinline__ void wsync_h() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
 }
 
 __device__ __forceinline__ void wsync_g() {
@@ -359,33 +370,34 @@ __global__ __launch_bounds__(256) void gru_head_kernel(gru_head_args a) {
     for (int kb = 0; kb < 4; ++kb) bw[n][kb] = *(const float4 *)(a.wx2 + (size_t)col * 2 * H + kb * 16 + kk * 4);
     bb[n] = a.bx2[col];
   }
+  // layer-1 input projections of this window -> LDS (the gx2 buffer is free until layer 1 is done):
+  // one coalesced 16-byte pass instead of three dependent global loads on every serial step
+  {
+    const float4 *src = (const float4 *)(a.gx1 + (size_t)w * OT * 6 * H);
+    for (int q = tid; q < OT * 6 * H / 4; q += 256) {
+      const int e = q * 4, t = e / (6 * H), c = e - t * 6 * H;
+      *(float4 *)(&gx2[t * GR_GX_LD + c]) = src[q];
+    }
+  }
   for (int i = tid; i < 32 * GR_SEQ_LD; i += 256) seq1[i] = 0.f;
   if (tid < 2 * H) hbuf[tid >> 5][0][tid & 31] = 0.f;
   __syncthreads();
 
   // ---- layer 1 recurrence (waves 0,1); waves 2,3 stage the detect head weights meanwhile
   if (wave < 2) {
-    const float *gxw = a.gx1 + (size_t)w * OT * 6 * H + dir * 3 * H + unit;
-    int t = dir ? OT - 1 : 0;
-    float gz = gxw[(size_t)t * 6 * H], gr = gxw[(size_t)t * 6 * H + H], gc = gxw[(size_t)t * 6 * H + 2 * H];
+    const float *gxl = gx2 + dir * 3 * H + unit;
     float h_own = 0.f;
+    int t = dir ? OT - 1 : 0;
     for (int s = 0; s < OT; ++s) {
       const int cur = s & 1;
-      const int tn = dir ? t - 1 : t + 1;
-      float ngz = 0.f, ngr = 0.f, ngc = 0.f;
-      if (s + 1 < OT) {
-        ngz = gxw[(size_t)tn * 6 * H];
-        ngr = gxw[(size_t)tn * 6 * H + H];
-        ngc = gxw[(size_t)tn * 6 * H + 2 * H];
-      }
+      const float gz = gxl[t * GR_GX_LD], gr = gxl[t * GR_GX_LD + H], gc = gxl[t * GR_GX_LD + 2 * H];
       h_own = gru_step(g1, &hbuf[dir][cur][0], half, gz, gr, gc, h_own);
       if (half == 0) {
         hbuf[dir][cur ^ 1][unit] = h_own;
         seq1[t * GR_SEQ_LD + dir * H + unit] = h_own;
       }
-      wsync_g();
-      gz = ngz; gr = ngr; gc = ngc;
-      t = tn;
+      wsync_h();
+      t = dir ? t - 1 : t + 1;
     }
   } else {
     const int t2 = tid - 128;
@@ -431,7 +443,7 @@ __global__ __launch_bounds__(256) void gru_head_kernel(gru_head_args a) {
       const float gz = gxl[t * GR_GX_LD], gr = gxl[t * GR_GX_LD + H], gc = gxl[t * GR_GX_LD + 2 * H];
       h_own = gru_step(g2, &hbuf[dir][cur][0], half, gz, gr, gc, h_own);
       if (half == 0) hbuf[dir][cur ^ 1][unit] = h_own;
-      wsync_g();
+      wsync_h();
       t = dir ? t - 1 : t + 1;
     }
     if (half == 0) {
