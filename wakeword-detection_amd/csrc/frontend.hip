@@ -119,15 +119,11 @@ template <> __device__ __forceinline__ double shfl_r<double>(double v, int src) 
 __device__ constexpr double W32_RE[16] = {1.00000000000000000000e+00, 9.80785280403230430579e-01, 9.23879532511286738483e-01, 8.31469612302545235671e-01, 7.07106781186547572737e-01, 5.55570233019602288671e-01, 3.82683432365089837290e-01, 1.95090322016128331351e-01, 6.12323399573676603587e-17, -1.95090322016128192573e-01, -3.82683432365089726268e-01, -5.55570233019601955604e-01, -7.07106781186547461715e-01, -8.31469612302545346694e-01, -9.23879532511286738483e-01, -9.80785280403230430579e-01};
 __device__ constexpr double W32_IM[16] = {-0.00000000000000000000e+00, -1.95090322016128248084e-01, -3.82683432365089781779e-01, -5.55570233019602177649e-01, -7.07106781186547461715e-01, -8.31469612302545235671e-01, -9.23879532511286738483e-01, -9.80785280403230430579e-01, -1.00000000000000000000e+00, -9.80785280403230430579e-01, -9.23879532511286738483e-01, -8.31469612302545457716e-01, -7.07106781186547572737e-01, -5.55570233019602177649e-01, -3.82683432365089892802e-01, -1.95090322016128608906e-01};
 
-// lane (16 - j) % 16 of the same 16-lane row: row_mirror, then rotate right by one lane
-__device__ __forceinline__ int dpp_partner_i(int v) {
-  const int m = __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true);   // row_mirror: lane 15 - j
-  return __builtin_amdgcn_mov_dpp(m, 0x121, 0xF, 0xF, true);          // row_ror:1 : lane j - 1
-}
-__device__ __forceinline__ float dpp_partner(float v) { return __int_as_float(dpp_partner_i(__float_as_int(v))); }
-__device__ __forceinline__ double dpp_partner(double v) {
-  const int lo = dpp_partner_i(__double2loint(v)), hi = dpp_partner_i(__double2hiint(v));
-  return __hiloint2double(hi, lo);
+// One wave's LDS instructions are executed in issue order, so a write followed by another
+// lane's read (or a read followed by an overwrite) needs no s_waitcnt - only a scheduling fence.
+__device__ __forceinline__ void lds_fence() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
 }
 
 #define MAG_LD 276  // floats per frame of magnitudes: 257 + zero pad to 17*16, stride = 20 mod 64
@@ -140,7 +136,7 @@ __host__ __device__ constexpr int wbuf_bytes() {
   return sizeof(R) == 8 ? (4 * 16 * TR_LD * 8 + 64) : (4 * MAG_LD * 4);
 }
 
-template <typename R, bool F32IN>
+template <typename R, bool F32IN, bool SIMPLE>
 __global__ __launch_bounds__(256, sizeof(R) == 8 ? 3 : 4) void logmel_kernel(logmel_args a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -166,20 +162,66 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? 3 : 4) void logmel_kernel(log
   unsigned char *wbuf = smem + off; off += WAVES * wbuf_bytes<R>();
   float *tile = (float *)(smem + off);  // fp32 samples, [WIN + (FPB-1)*hop + 16]
 
-  for (int i = tid; i < 256; i += 256) {
-    tb_hann[i] = *(const double2 *)(a.hann + 2 * i);
-    if (TW_LDS) {
-      tb_tw[i] = {(R)a.tw16[2 * i], (R)a.tw16[2 * i + 1]};
-      tb_un[i] = {(R)a.tw512[2 * i], (R)a.tw512[2 * i + 1]};
-    }
-  }
-
   // ---- stage the sample tile: aligned 16-byte global loads; tile[i + shift] = x[g_first + i]
   constexpr int VEC = F32IN ? 4 : 8;                      // elements per 16-byte load
   const int64_t g_first = s_begin + f0 * a.hop;           // first sample of frame f0
   const int n_need = WIN + (nfb - 1) * a.hop;             // samples used by this block
   const int shift = (int)(g_first % VEC);
-  {
+  auto fill_tables = [&](const double2 hv) {
+    tb_hann[tid] = hv;
+    if (TW_LDS) {
+      tb_tw[tid] = {(R)a.tw16[2 * tid], (R)a.tw16[2 * tid + 1]};
+      tb_un[tid] = {(R)a.tw512[2 * tid], (R)a.tw512[2 * tid + 1]};
+    }
+  };
+  if (SIMPLE) {
+    // No pre-emphasis, divisor 32767/32768, at most two 16-byte vectors per thread (host checks):
+    // straight-line code - both sample loads and the table load are in flight together, so the
+    // block pays one memory latency before its first barrier instead of four in a row.
+    const int64_t ga = g_first - shift;                   // multiple of VEC, >= 0
+    const int n_vec = (shift + n_need + VEC - 1) / VEC;
+    const int64_t total = a.sample_offs[a.n_utt];
+    const int64_t last = (total - VEC) & ~(int64_t)(VEC - 1);  // last full aligned vector (total >= WIN here)
+    int64_t gq[2];
+    uint4 raw[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      gq[h] = ga + (int64_t)(tid + 256 * h) * VEC;
+      const int64_t gl = gq[h] < last ? gq[h] : last;     // clamped: always a full vector inside the buffer
+      raw[h] = F32IN ? *(const uint4 *)(a.f32 + gl) : *(const uint4 *)(a.pcm + gl);
+    }
+    const double2 hv = *(const double2 *)(a.hann + 2 * tid);
+    const float lim = a.clip ? 1.0f : __builtin_inff();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int q = tid + 256 * h;
+      if (q < n_vec) {
+        float o[VEC];
+        if (gq[h] <= last) {
+          const unsigned int w32[4] = {raw[h].x, raw[h].y, raw[h].z, raw[h].w};
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            if (F32IN) {
+              o[e] = __uint_as_float(w32[e]);
+            } else {
+              const float x = (float)(int)(short)(w32[e >> 1] >> ((e & 1) * 16));
+              const float q0 = __fmul_rn(x, a.rdiv);
+              const float er = __fmaf_rn(-a.divisor, q0, x);
+              o[e] = __builtin_amdgcn_fmed3f(__fmaf_rn(er, a.rdiv, q0), -lim, lim);
+            }
+          }
+        } else {  // ragged end of the whole buffer: element-wise, zero beyond it
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) o[e] = (gq[h] + e < total) ? norm_sample<F32IN>(a, gq[h] + e) : 0.0f;
+        }
+        float4 *dst = (float4 *)(tile + (size_t)q * VEC);
+        dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+        if (VEC == 8) dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+      }
+    }
+    fill_tables(hv);
+  } else {
+    fill_tables(*(const double2 *)(a.hann + 2 * tid));
     const int64_t ga = g_first - shift;                   // multiple of VEC, >= 0
     const int n_vec = (shift + n_need + VEC - 1) / VEC;
     const int64_t total = a.sample_offs[a.n_utt];
@@ -270,16 +312,16 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? 3 : 4) void logmel_kernel(log
     R *trs = tr + sub * 16 * TR_LD;
 #pragma unroll
     for (int pos = 0; pos < 16; ++pos) trs[k_of(pos) * TR_LD + j] = v[pos].re;
-    wave_sync();
+    lds_fence();
 #pragma unroll
     for (int n2 = 0; n2 < 16; ++n2) w[n2].re = trs[j * TR_LD + n2];
-    wave_sync();
+    lds_fence();
 #pragma unroll
     for (int pos = 0; pos < 16; ++pos) trs[k_of(pos) * TR_LD + j] = v[pos].im;
-    wave_sync();
+    lds_fence();
 #pragma unroll
     for (int n2 = 0; n2 < 16; ++n2) w[n2].im = trs[j * TR_LD + n2];
-    wave_sync();
+    lds_fence();
     // pass 2: lane j = k1 holds Y[n2][k1]; output w[pos] = Z[k1 + 16 k_of(pos)]
     dft16<R>(w);
     // mel B operands of this wave's (tile, block) entries: issued here (after the register peak of
@@ -287,32 +329,51 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? 3 : 4) void logmel_kernel(log
     load_melb();
     melb_loaded = true;
 
-    // untangle: with a = Z[k], b = conj Z[256-k]:  E = (a+b)/2, O = (a-b)/(2i), T = W512^k O and
-    //   X[k] = E + T,   X[256-k] = conj(E - T)   ->  two magnitudes per evaluation, k < 128 only.
+    // untangle: with a = Z[k], b = conj Z[256-k]:  2E = a+b, 2O = (a-b)/i, 2T = W512^k 2O and
+    //   2X[k] = 2E + 2T,   2X[256-k] = conj(2E - 2T)   ->  two magnitudes per evaluation, k < 128 only;
+    //   the factor 2 leaves as an exact 0.5 after the fp32 square root.
     // Lane j register k2 holds k = j + 16 k2; its partner Z[256-k] lives in lane (16-j)%16 at
-    // k2' = 15-k2 (j > 0) or in the same lane at k2' = (16-k2)%16 (j = 0): the sender picks the
-    // register and two DPP moves (row_mirror, row_ror:1) bring it over - no LDS traffic.
+    // k2' = 15-k2 (j > 0) or in the same lane at k2' = (16-k2)%16 (j = 0).  The partners travel
+    // through the (dead) transpose buffer: rows 8..15 <- registers k2' = 8..15, row 7 <- k2' = 0
+    // (only lane 0 reads that one), so lane j reads row 15-k2 (+1 for j = 0; row 7 for k2 = 0).
+    const int pj = (16 - j) & 15;
+    const R *prow0 = trs + (j == 0 ? 7 : 15) * TR_LD + pj;
+    const R *prow = trs + (j == 0 ? 16 : 15) * TR_LD + pj;
+    cplx<R> pz[8];
+    trs[7 * TR_LD + j] = w[pos_of(0)].re;
+#pragma unroll
+    for (int r = 8; r < 16; ++r) trs[r * TR_LD + j] = w[pos_of(r)].re;
+    lds_fence();
+    pz[0].re = prow0[0];
+#pragma unroll
+    for (int k2 = 1; k2 < 8; ++k2) pz[k2].re = prow[-k2 * TR_LD];
+    lds_fence();
+    trs[7 * TR_LD + j] = w[pos_of(0)].im;
+#pragma unroll
+    for (int r = 8; r < 16; ++r) trs[r * TR_LD + j] = w[pos_of(r)].im;
+    lds_fence();
+    pz[0].im = prow0[0];
+#pragma unroll
+    for (int k2 = 1; k2 < 8; ++k2) pz[k2].im = prow[-k2 * TR_LD];
+    lds_fence();
     float *mrow = mg + sub * MAG_LD;
 #pragma unroll
     for (int k2 = 0; k2 < 8; ++k2) {
       const cplx<R> own = w[pos_of(k2)];
-      const cplx<R> cand_a = w[pos_of(15 - k2)], cand_b = w[pos_of((16 - k2) & 15)];
-      const R send_re = j == 0 ? cand_b.re : cand_a.re, send_im = j == 0 ? cand_b.im : cand_a.im;
-      const cplx<R> pz = {dpp_partner(send_re), dpp_partner(send_im)};
       // W512^(j + 16 k2) = W512^j * W32^k2
       const cplx<R> un = TW_LDS ? tb_un[j + 16 * k2] : cmul(base_un, cplx<R>{(R)W32_RE[k2], (R)W32_IM[k2]});
-      const R er = (R)0.5 * (own.re + pz.re), ei = (R)0.5 * (own.im - pz.im);
-      const R orr = (R)0.5 * (own.im + pz.im), oi = (R)-0.5 * (own.re - pz.re);
+      const R er = own.re + pz[k2].re, ei = own.im - pz[k2].im;
+      const R orr = own.im + pz[k2].im, oi = pz[k2].re - own.re;
       const R tr_ = orr * un.re - oi * un.im, ti_ = orr * un.im + oi * un.re;
       const R pr = er + tr_, pi = ei + ti_, qr = er - tr_, qi = ei - ti_;
       const int k = j + 16 * k2;
-      mrow[k] = __fsqrt_rn((float)(pr * pr + pi * pi));
-      mrow[256 - k] = __fsqrt_rn((float)(qr * qr + qi * qi));  // k = 0 -> bin 256
+      mrow[k] = 0.5f * __builtin_amdgcn_sqrtf((float)(pr * pr + pi * pi));
+      mrow[256 - k] = 0.5f * __builtin_amdgcn_sqrtf((float)(qr * qr + qi * qi));  // k = 0 -> bin 256
     }
     {
       // k = 128 pairs with itself: X[128] = conj(Z[128]) (lane 0, k2 = 8); bins 257..271 are zero padding
       const cplx<R> z = w[pos_of(8)];
-      if (j == 0) mrow[128] = __fsqrt_rn((float)(z.re * z.re + z.im * z.im));
+      if (j == 0) mrow[128] = __builtin_amdgcn_sqrtf((float)(z.re * z.re + z.im * z.im));
       else mrow[256 + j] = 0.0f;
     }
   }
@@ -445,16 +506,28 @@ int ww_k_logmel(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, const floa
   a.mel = d_mel;
   fill_filter_args(a, m);
   const bool f32in = d_f32 != nullptr;
+  // straight-line staging (two vectors per thread) when nothing exotic is asked for
+  const bool simple = fp->pre_emphasis == 0.0f && (f32in || a.fast_div) && WIN + (FPB - 1) * fp->hop + 16 <= 512 * (f32in ? 4 : 8);
   dim3 grid((unsigned)((max_frames_per_utt + FPB - 1) / FPB), (unsigned)n_utt);
   ww_launch_scope scope(ctx, fp->precise ? "logmel_kernel<f64>" : "logmel_kernel<f32>");
   if (fp->precise) {
     size_t sm = logmel_smem<double>(fp->hop);
-    if (f32in) hipLaunchKernelGGL((logmel_kernel<double, true>), grid, dim3(256), sm, ctx->stream, a);
-    else hipLaunchKernelGGL((logmel_kernel<double, false>), grid, dim3(256), sm, ctx->stream, a);
+    if (simple) {
+      if (f32in) hipLaunchKernelGGL((logmel_kernel<double, true, true>), grid, dim3(256), sm, ctx->stream, a);
+      else hipLaunchKernelGGL((logmel_kernel<double, false, true>), grid, dim3(256), sm, ctx->stream, a);
+    } else {
+      if (f32in) hipLaunchKernelGGL((logmel_kernel<double, true, false>), grid, dim3(256), sm, ctx->stream, a);
+      else hipLaunchKernelGGL((logmel_kernel<double, false, false>), grid, dim3(256), sm, ctx->stream, a);
+    }
   } else {
     size_t sm = logmel_smem<float>(fp->hop);
-    if (f32in) hipLaunchKernelGGL((logmel_kernel<float, true>), grid, dim3(256), sm, ctx->stream, a);
-    else hipLaunchKernelGGL((logmel_kernel<float, false>), grid, dim3(256), sm, ctx->stream, a);
+    if (simple) {
+      if (f32in) hipLaunchKernelGGL((logmel_kernel<float, true, true>), grid, dim3(256), sm, ctx->stream, a);
+      else hipLaunchKernelGGL((logmel_kernel<float, false, true>), grid, dim3(256), sm, ctx->stream, a);
+    } else {
+      if (f32in) hipLaunchKernelGGL((logmel_kernel<float, true, false>), grid, dim3(256), sm, ctx->stream, a);
+      else hipLaunchKernelGGL((logmel_kernel<float, false, false>), grid, dim3(256), sm, ctx->stream, a);
+    }
   }
   WW_HIP(ctx, hipGetLastError());
   return WW_OK;
