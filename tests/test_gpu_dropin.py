@@ -261,3 +261,58 @@ def test_testset_evaluation_far_frr_identical(assets, name):
     wf, wa, wc, _ = NR.far_frr(res["positives"], res["negatives"], int(labels.sum()), res["hours"])
     np.testing.assert_array_equal(res["fa_count"], wc)
     np.testing.assert_allclose(res["frr"], wf, atol=1e-15)
+
+
+def test_dataset_filter_writes_the_reference_feature_file(assets, oracle_dirs, tmp_path):
+    """utils/filter_dataset_to_h5.py end to end: wavs + metadata JSON -> test.h5 -> load_h5.
+    Expected features: the reference's per-chunk loop over ONE never-reset Filter (quirk C2)."""
+    import json
+    from wwhip.dataset import DatasetFilter
+    from wwhip.evaluate import load_h5, open_h5
+    from oracle import numpy_ref as NR
+    rng = np.random.default_rng(17)
+    data_dir = tmp_path / "audio"
+    data_dir.mkdir()
+    meta, sigs = [], []
+    for i, n in enumerate((9000, 0, 700, 16321)):
+        pcm = np.clip(rng.normal(0, 2500, n), -32768, 32767).astype(np.int16)
+        _write_wav(str(data_dir / f"utt{i}.wav"), pcm)
+        meta.append({"audio_file_path": f"utt{i}.wav", "is_hotword": int(i == 0), "worker_id": f"w{i % 2}"})
+        sigs.append(pcm.astype(np.float32) / np.float32(32768))
+    (tmp_path / "test.json").write_text(json.dumps(meta))
+
+    def energy_vad(frame_bytes, sr):  # plug-in with webrtcvad's call signature
+        return np.abs(np.frombuffer(frame_bytes, np.int16)).mean() > 1500
+
+    df = DatasetFilter(str(tmp_path / "test.json"), os.path.join(assets, "CRNN"), str(data_dir), str(tmp_path / "out"),
+                       vad=energy_vad)
+    clips = df.filter_dataset_audio()
+    assert df.dataset_file.endswith("test.h5") and os.path.isfile(df.dataset_file)
+
+    # the reference loop (filter_dataset_to_h5.py:63-112), literally
+    mdir = oracle_dirs["CRNN"]
+    filt = NR.RefFilter(lambda a: mdir.filter(a)[0])
+    want = {}
+    for m, s in zip(meta, sigs):
+        if len(s) == 0:
+            continue
+        feats = []
+        for st in range(0, len(s), 320):
+            fr = s[st:st + 320].copy()
+            if len(fr) < 320:
+                fr = np.pad(fr, (0, 320 - len(fr)), mode="constant")
+            feats.extend(filt.filter_frame(fr))
+        if feats:
+            want[m["audio_file_path"].replace(".wav", "")] = np.array(feats)
+    assert [c["file_name"] for c in clips] == list(want)
+    with open_h5(df.dataset_file) as h5:
+        assert list(h5.keys()) == sorted(want)
+        for k, w in want.items():
+            got = h5[k][()]
+            assert got.shape == w.shape and got.dtype == np.float32
+            assert np.abs(got - w).max() < TOL
+        assert int(h5["utt0"].attrs["is_hotword"]) == 1 and int(h5["utt3"].attrs["is_hotword"]) == 0
+        assert int(h5["utt0"].attrs["speaker"]) == 0 and int(h5["utt3"].attrs["speaker"]) == 1
+        assert int(h5["utt0"].attrs["speech_start_ts"]) == 0 and int(h5["utt0"].attrs["speech_end_ts"]) == (8640 + 320) // 160  # the last, mostly padded chunk is below the VAD threshold
+    X, y = load_h5(df.dataset_file, 151, 40)
+    assert X.shape == (len(want), 151, 40) and y.tolist() == [1, 0, 0]

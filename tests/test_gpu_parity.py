@@ -118,6 +118,21 @@ def test_slide_forward_vs_oracle(engines, oracles, name):
     assert e.slide_forward(mel[: e.window - 1], hop=2).shape == (0, e.n_out)
 
 
+def test_forward_vs_keras_checkpoint(engines, golden):
+    """The HIP path against the Keras checkpoint the CRNN_softmax .tflite was converted from,
+    evaluated with Keras-documented layer semantics in float64 (oracle/keras_ref.py)."""
+    from oracle import keras_ref
+    rng = np.random.default_rng(23)
+    wins = rng.uniform(0, 6.5, (9, 151, 40)).astype(np.float32)
+    wins[0] = 0
+    wins[1, 60:] = 0
+    kd = os.path.join(golden, "keras_h5")
+    want, want_enc = keras_ref.crnn_forward(os.path.join(kd, "encode.h5"), os.path.join(kd, "detect.h5"), wins)
+    got, enc = engines["CRNN_softmax"].forward(wins, want_enc=True)
+    assert np.abs(got - want).max() < TOL_POST
+    assert np.abs(enc.reshape(want_enc.shape) - want_enc).max() < 1e-4
+
+
 def test_forward_rejects_bad_shape(engines):
     with pytest.raises(ValueError):
         engines["CRNN"].forward(np.zeros((2, 150, 40), np.float32))

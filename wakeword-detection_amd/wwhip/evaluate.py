@@ -160,17 +160,25 @@ def load_data(features: Sequence[np.ndarray], labels: Sequence[int], timesteps: 
     return X, np.array(labels, dtype=np.uint8)
 
 
-def load_h5(data_file: str, timesteps: int, num_features: int):
-    """The reference's on-disk format (one dataset per clip, attr ``is_hotword``,
-    ``filter_dataset_to_h5.py:136-145``); needs h5py at run time."""
+def open_h5(data_file: str):
+    """h5py when it is installed, otherwise the built-in reader (:mod:`wwhip.h5min`) - both give
+    ``keys()``, ``[name][()]`` and ``.attrs`` for the reference's feature files."""
     try:
         import h5py  # type: ignore
-    except ImportError as e:  # pragma: no cover
-        raise RuntimeError("reading .h5 feature files needs h5py, which is not installed here") from e
+        return h5py.File(data_file, "r")
+    except ImportError:
+        from . import h5min
+        return h5min.File(data_file)
+
+
+def load_h5(data_file: str, timesteps: int, num_features: int):
+    """The reference's on-disk format (one dataset per clip, attr ``is_hotword``,
+    ``filter_dataset_to_h5.py:136-145``) -> ``(X [N, timesteps, F], labels)`` exactly as
+    ``evaluate_tf_lite_opts.py:35-47`` builds them (keys in h5py's name order)."""
     feats, labels = [], []
-    with h5py.File(data_file, "r") as h5:
+    with open_h5(data_file) as h5:
         for key in h5.keys():
-            labels.append(h5[key].attrs["is_hotword"])
+            labels.append(int(h5[key].attrs["is_hotword"]))
             feats.append(h5[key][()])
     return load_data(feats, labels, timesteps, num_features)
 
