@@ -48,7 +48,8 @@ struct wave_args {
   const float *mel;
   win_addr_w wa;
   int T, n_mel, NB, NOUT;
-  const int *dil, *has_res;
+  unsigned long long dil4[2];  // dilation of block b: 4 bits at bit 4*(b%16) of dil4[b/16]  (d <= 8, NB <= 32)
+  unsigned int has_res_mask;   // bit b: block b has a residual 1x1 conv
   const float *w_in4;   // [3 kb][4 kk][16 col][4 q]   (K = 40 padded to 48)
   const float *b_in;    // [16]
   const float *bn_s, *bn_t;  // [NB][16]
@@ -88,7 +89,6 @@ __device__ __forceinline__ float fast_tanh_w(float x) {
 struct wave_blk {
   float4 wg[3][2], wrs[3];
   float bn_s, bn_t, bsig, btanh, bres, bsk0, bsk1;
-  int d, has_res;
 };
 
 #define MFMA4(acc, av, bv)                                              \
@@ -112,8 +112,6 @@ __device__ __forceinline__ void wave_blk_load(const wave_args &a, int blk, int j
   p.bres = a.b_rs[blk * 48 + j];
   p.bsk0 = a.b_rs[blk * 48 + 16 + j];
   p.bsk1 = a.b_rs[blk * 48 + 32 + j];
-  p.d = a.dil[blk];
-  p.has_res = a.has_res[blk];
 }
 
 template <bool HEAD_ONLY>
@@ -199,7 +197,7 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
   wave_blk_load(a, 0, j, kk, pb[0]);
   auto run_block = [&](int blk, const wave_blk &P, wave_blk &Pnext) {
     float *u = ubuf + (blk & 1) * (WV_T + WV_PAD) * WV_C + WV_PAD * WV_C;  // row 0 of u
-    const int d = P.d;
+    const int d = (int)((a.dil4[blk >> 4] >> (4 * (blk & 15))) & 15);  // kernel-argument SGPRs, no load
     // ---- BatchNorm affine (wavenet_model.py:57) -> LDS
 #pragma unroll
     for (int mi = 0; mi < WV_MPW; ++mi) {
@@ -207,9 +205,11 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) u[(t0 + r) * WV_C + j] = x[mi][r] * P.bn_s + P.bn_t;
     }
-    if (blk + 1 < a.NB) wave_blk_load(a, blk + 1, j, kk, Pnext);
+    // next block's parameters: issued unconditionally (index clamped) - a conditional prefetch makes
+    // the compiler drain ALL outstanding loads at the join, i.e. wait for the prefetch it just issued
+    wave_blk_load(a, blk + 1 < a.NB ? blk + 1 : blk, j, kk, Pnext);
     const float bsig = P.bsig, btanh = P.btanh, bres = P.bres, bsk0 = P.bsk0, bsk1 = P.bsk1;
-    const int has_res = P.has_res;
+    const int has_res = (a.has_res_mask >> blk) & 1;
     __syncthreads();  // u complete (all rows, all waves)
 
 #pragma unroll
@@ -337,7 +337,12 @@ int ww_k_wave_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
   a.mel = d_mel;
   a.wa = {d_win_row, d_win_valid, row0, hop, valid_const, mel_rows};
   a.T = v.T; a.n_mel = v.n_mel; a.NB = v.NB; a.NOUT = v.NOUT;
-  a.dil = v.d_dil; a.has_res = v.d_has_res;
+  if (v.NB > 32) return ww_fail(ctx, WW_EINVAL, "Wavenet with %d blocks: kernel limit 32", v.NB);
+  for (int b = 0; b < v.NB; ++b) {
+    if (v.dil[b] < 1 || v.dil[b] > 8) return ww_fail(ctx, WW_EINVAL, "dilation %d of block %d outside 1..8", v.dil[b], b);
+    a.dil4[b >> 4] |= (unsigned long long)v.dil[b] << (4 * (b & 15));
+    if (v.has_res[b]) a.has_res_mask |= 1u << b;
+  }
   a.w_in4 = v.w_in; a.b_in = v.b_in; a.bn_s = v.bn_s; a.bn_t = v.bn_t;
   a.w_gate4 = v.w_gate; a.b_gate = v.b_gate; a.w_rs4 = v.w_rs; a.b_rs = v.b_rs;
   a.d_w1_4 = v.d_w1; a.d_b1 = v.d_b1; a.d_w2_4 = v.d_w2; a.d_b2 = v.d_b2;
