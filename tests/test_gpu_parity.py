@@ -133,6 +133,36 @@ def test_forward_vs_keras_checkpoint(engines, golden):
     assert np.abs(enc.reshape(want_enc.shape) - want_enc).max() < 1e-4
 
 
+@pytest.mark.parametrize("name", ["Wavenet", "Wavenet_alt"])
+def test_wavenet_split_bf16_mode(assets, oracles, golden, name):
+    """ww_model_set_precision(BF16X3): the 24 gated blocks on bf16 MFMA with split operands stay
+    within the north-star tolerance of the fp32 oracle (error model: tools/bf16x3_error.py)."""
+    from wwhip.engine import Engine
+    e = Engine(os.path.join(assets, name), precision="bf16x3")
+    try:
+        rng = np.random.default_rng(29)
+        wins = rng.uniform(0, 6.5, (37, e.window, 40)).astype(np.float32)
+        wins[3] = 0
+        wins[4, 100:] = 0
+        wins[5] = np.clip(rng.normal(3, 1.5, (e.window, 40)), 0, 8)
+        got, enc = e.forward(wins, want_enc=True)
+        want, want_enc = oracles[name].forward(wins, want_enc=True)
+        assert np.abs(got - want).max() < 2e-5          # measured 4e-6; north star 1e-4
+        assert np.abs(enc - want_enc).max() < 1e-3 * max(1.0, float(np.abs(want_enc).max()))
+        z = np.load(os.path.join(golden, "models.npz"))
+        out = e.forward(z[name + ".windows"])
+        assert np.abs(out - z[name + ".det64"]).max() < 2e-5
+        # sliding mode goes through the same kernel
+        mel = rng.uniform(0, 6.5, (e.window + 40, 40)).astype(np.float32)
+        assert np.abs(e.slide_forward(mel, 2) - oracles[name].slide_forward(mel, 2)).max() < 2e-5
+        e.set_precision("fp32")
+        assert np.abs(e.forward(wins) - want).max() < 2e-6
+        with pytest.raises(ValueError):
+            e.set_precision("bf16")
+    finally:
+        e.close()
+
+
 def test_forward_rejects_bad_shape(engines):
     with pytest.raises(ValueError):
         engines["CRNN"].forward(np.zeros((2, 150, 40), np.float32))

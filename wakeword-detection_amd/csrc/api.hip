@@ -403,6 +403,68 @@ static int load_wave(ww_ctx *ctx, ww_model *m, const blob_view &bv) {
     for (int col = 0; col < v.NOUT; ++col) d2[(((size_t)(k / 16) * 4 + (k % 16) / 4) * 16 + col) * 4 + (k % 4)] = dw2[(size_t)k * v.NOUT + col];
   }
   for (int col = 0; col < v.NOUT; ++col) d2b[col] = db2[col];
+  // split-bf16 A operands (wavenet.hip, SPLIT_BF16; transposed formulation: rows = output channels).
+  // slot = (kstep*2 + {sig,tanh})*2 + {hi,lo} for the gate conv (k-step 0 = tap 2 | tap 1, k-step 1 = tap 0 |
+  // zeros), 8 + mtile*2 + {hi,lo} for res | skip (g | zeros).  Lane (i = lane & 15, kg = lane >> 4) holds, in
+  // k-slots 0..3, W[first tap][ch = 4 kg .. 4 kg + 3][out = 16 mtile + i] and in k-slots 4..7 the second tap's.
+  {
+    auto bf16_rne = [](float f) -> uint16_t {
+      uint32_t u;
+      memcpy(&u, &f, 4);
+      u += 0x7FFFu + ((u >> 16) & 1u);
+      return (uint16_t)(u >> 16);
+    };
+    auto bf16_f = [](uint16_t h) -> float {
+      uint32_t u = (uint32_t)h << 16;
+      float f;
+      memcpy(&f, &u, 4);
+      return f;
+    };
+    std::vector<uint16_t> pk((size_t)NB * 14 * 64 * 8, 0);
+    std::vector<float> bv7((size_t)NB * 7 * 16, 0.f);
+    for (int b = 0; b < NB; ++b) {
+      for (int lane = 0; lane < 64; ++lane) {
+        const int i = lane & 15, kg = lane >> 4;
+        for (int q = 0; q < 8; ++q) {
+          const int ch = 4 * kg + (q & 3);
+          for (int ks = 0; ks < 2; ++ks)
+            for (int mt = 0; mt < 2; ++mt) {
+              const int tap = ks == 0 ? (q < 4 ? 2 : 1) : (q < 4 ? 0 : -1);
+              const float wv = tap < 0 ? 0.f : (mt == 0 ? w_sig : w_tanh)[(((size_t)b * 3 + tap) * C + ch) * C + i];
+              const uint16_t hi = bf16_rne(wv), lo = bf16_rne(wv - bf16_f(hi));
+              pk[((((size_t)b * 14 + (ks * 2 + mt) * 2 + 0) * 64) + lane) * 8 + q] = hi;
+              pk[((((size_t)b * 14 + (ks * 2 + mt) * 2 + 1) * 64) + lane) * 8 + q] = lo;
+            }
+          for (int mt = 0; mt < 3; ++mt) {
+            const float wv = q >= 4 ? 0.f
+                                    : (mt == 0 ? w_res[((size_t)b * C + ch) * C + i] : w_skip[((size_t)b * C + ch) * S + (mt - 1) * 16 + i]);
+            const uint16_t hi = bf16_rne(wv), lo = bf16_rne(wv - bf16_f(hi));
+            pk[((((size_t)b * 14 + 8 + mt * 2 + 0) * 64) + lane) * 8 + q] = hi;
+            pk[((((size_t)b * 14 + 8 + mt * 2 + 1) * 64) + lane) * 8 + q] = lo;
+          }
+        }
+      }
+      for (int c = 0; c < 16; ++c) {
+        float *o = &bv7[(size_t)b * 7 * 16];
+        o[0 * 16 + c] = bn_s[(size_t)b * C + c];
+        o[1 * 16 + c] = bn_t[(size_t)b * C + c];
+        o[2 * 16 + c] = b_sig[(size_t)b * C + c];
+        o[3 * 16 + c] = b_tanh[(size_t)b * C + c];
+        o[4 * 16 + c] = b_res[(size_t)b * C + c];
+        o[5 * 16 + c] = b_skip[(size_t)b * S + c];
+        o[6 * 16 + c] = b_skip[(size_t)b * S + 16 + c];
+      }
+    }
+    // one page per block: the operands, then the vectors (wavenet.hip: WV_PAGE_U4 16-byte units)
+    const size_t page_u16 = (size_t)14 * 64 * 8 + 7 * 16 * 2;
+    std::vector<uint16_t> pages((size_t)NB * page_u16);
+    for (int b = 0; b < NB; ++b) {
+      memcpy(&pages[b * page_u16], &pk[(size_t)b * 14 * 64 * 8], (size_t)14 * 64 * 8 * 2);
+      memcpy(&pages[b * page_u16 + (size_t)14 * 64 * 8], &bv7[(size_t)b * 7 * 16], (size_t)7 * 16 * 4);
+    }
+    v.wpk = upload(m, pages);
+    if (!v.wpk) return ww_fail(ctx, WW_ENOMEM, "Wavenet upload failed");
+  }
   v.d_dil = upload(m, v.dil); v.d_has_res = upload(m, v.has_res);
   v.w_in = upload(m, in4); v.b_in = upload(m, std::vector<float>(b_in, b_in + C));
   v.bn_s = upload(m, std::vector<float>(bn_s, bn_s + (size_t)NB * C));
@@ -460,6 +522,14 @@ int ww_model_free(ww_model *m) {
 int ww_model_get_info(const ww_model *m, ww_model_info *out) {
   if (!m || !out) return WW_EINVAL;
   *out = m->info;
+  return WW_OK;
+}
+
+int ww_model_set_precision(ww_model *m, int precision) {
+  if (!m) return WW_EINVAL;
+  if (precision != WW_PRECISION_FP32 && precision != WW_PRECISION_BF16X3)
+    return ww_fail(m->ctx, WW_EINVAL, "unknown precision %d", precision);
+  m->precision = precision;
   return WW_OK;
 }
 

@@ -110,6 +110,7 @@ struct ww_wave_dev {
   float *w_gate = nullptr, *b_gate = nullptr;      // [NB][3*C][2C] (cols: sig 0..C-1, tanh C..2C-1), [NB][2C]
   float *w_rs = nullptr, *b_rs = nullptr;          // [NB][C][C+S] (cols: res 0..C-1, skip C..), [NB][C+S]
   float *d_w1 = nullptr, *d_b1 = nullptr, *d_w2 = nullptr, *d_b2 = nullptr;
+  uint16_t *wpk = nullptr;                         // split-bf16 parameter pages [NB]{[14][64][8] bf16 A operands, [7][16] f32 vectors}
   bool order_is_natural = true;
 };
 
@@ -120,6 +121,7 @@ struct ww_model {
   ww_filter_dev filt;
   ww_crnn_dev crnn;
   ww_wave_dev wave;
+  int precision = 0;  // WW_PRECISION_*
   std::vector<void *> allocs;
 };
 

@@ -64,6 +64,7 @@ struct wave_args {
   float *out;           // [Nw][NOUT]
   float *enc;           // optional [Nw][T][32]
   const float *enc_in;  // HEAD_ONLY: encoder output to run the detect graph on
+  const uint4 *wpk;     // split-bf16 mode: parameter pages [NB][WV_PAGE_U4] (A operands of v_mfma_f32_16x16x32_bf16, then the vectors)
 };
 
 __device__ __forceinline__ float sigmoid_w(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -72,6 +73,13 @@ __device__ __forceinline__ void wsync() {
   // LDS traffic of one wave is processed in order; wait for it only (not for outstanding
   // global loads, which an acq_rel fence would also drain) and stop compiler reordering
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// one wave's LDS operations execute in issue order: a scheduling fence is all a wave-private
+// write -> read (or read -> overwrite) round trip needs
+__device__ __forceinline__ void wsync_fence() {
+  asm volatile("" ::: "memory");
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -114,11 +122,60 @@ __device__ __forceinline__ void wave_blk_load(const wave_args &a, int blk, int j
   p.bsk1 = a.b_rs[blk * 48 + 32 + j];
 }
 
-template <bool HEAD_ONLY>
+
+// ---- split-bf16 contractions ("bf16x3") --------------------------------------------------------
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi) carries 16 mantissa bits; a*b is evaluated as
+// ah*bh + al*bh + ah*bl by three bf16 MFMAs with fp32 accumulate.  Unlike v_mfma_f32_16x16x4_f32,
+// which shares the SIMD's fp32 datapath with the vector ALU (their times add up), the bf16 MFMA
+// runs beside it.  Error model and measurements: tools/bf16x3_error.py, DESIGN.md.
+//
+// The block loop is evaluated TRANSPOSED (channels x time) with v_mfma_f32_16x16x16_bf16: its
+// accumulator layout (lane: column n = lane & 15, rows 4*(lane >> 4) + r) has, per lane, exactly
+// the four k-values (4*kg .. 4*kg + 3, kg = lane >> 4) its B operand wants for the same column.
+// With weights as the A operand (rows = output channels) and activations as B (columns = time),
+// the BatchNorm output of a tile IS the undelayed tap's B operand and the gate product IS the
+// res/skip conv's B operand - both straight out of registers.  Only the two delayed taps read
+// LDS (other time columns, possibly another wave's tile): two 8-byte writes and four 8-byte reads
+// per wave and block, one barrier.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// four fp32 values -> (hi, lo) as the 4 x bf16 operand registers
+__device__ __forceinline__ void split4(const float (&v)[4], s16x4 &hi, s16x4 &lo) {
+  const bf16x2 h01 = __builtin_convertvector((f32x2){v[0], v[1]}, bf16x2);
+  const bf16x2 h23 = __builtin_convertvector((f32x2){v[2], v[3]}, bf16x2);
+  const unsigned u01 = __builtin_bit_cast(unsigned, h01), u23 = __builtin_bit_cast(unsigned, h23);
+  const bf16x2 l01 = __builtin_convertvector((f32x2){v[0] - __uint_as_float(u01 << 16), v[1] - __uint_as_float(u01 & 0xffff0000u)}, bf16x2);
+  const bf16x2 l23 = __builtin_convertvector((f32x2){v[2] - __uint_as_float(u23 << 16), v[3] - __uint_as_float(u23 & 0xffff0000u)}, bf16x2);
+  const uint2 hv = {u01, u23}, lv = {__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+  hi = __builtin_bit_cast(s16x4, hv);
+  lo = __builtin_bit_cast(s16x4, lv);
+}
+
+// v_mfma_f32_16x16x32_bf16 (16 cycles; the K = 16 form costs twice that per MFMA on gfx950, measured):
+// its 8 k-slots per lane are filled with TWO such 4-channel groups - k-slots 0..3 of lane group kg
+// = channels 4 kg .. 4 kg + 3 of one tap, k-slots 4..7 = the same channels of a second tap (or zeros) -
+// which is just a concatenation of two register pairs; the host packs the weights to match.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct s16x4_pair { s16x4 lo, hi; };
+__device__ __forceinline__ bf16x8 cat8(s16x4 first, s16x4 second) {
+  const s16x4_pair p = {first, second};
+  return __builtin_bit_cast(bf16x8, p);
+}
+#define MFMA_BF(acc, av, bv) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc, 0, 0, 0)
+#define WV_SLOTS 14  // A-operand slots per block: gate (2 k-steps x {sig,tanh} x {hi,lo}) = 8, res | skip (3 m-tiles x {hi,lo}) = 6
+#define WV_BVEC 7    // per-channel vectors per block: bn_s, bn_t, b_sig, b_tanh, b_res, b_skip[0:16], b_skip[16:32]
+#define WV_PAGE_U4 (WV_SLOTS * 64 + WV_BVEC * 4)  // one block's parameter page in 16-byte units: operands, then vectors
+
+template <bool HEAD_ONLY, bool SPLIT_BF16>
 __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
   // LDS: region A = staged input [192][48] (prologue only), later u[2][208][16] + g[192][16]
-  __shared__ __align__(16) float lds[WV_T * WV_INLD > (2 * (WV_T + WV_PAD) * WV_C + WV_T * WV_S) ? WV_T * WV_INLD
-                                                                                                  : (2 * (WV_T + WV_PAD) * WV_C + WV_T * WV_S)];
+  // split-bf16: u planes (same bytes as the fp32 u buffers) + two parameter pages (next to / under the head's tile)
+  constexpr int LDS_FP32 = WV_T * WV_INLD > (2 * (WV_T + WV_PAD) * WV_C + WV_T * WV_S) ? WV_T * WV_INLD
+                                                                                       : (2 * (WV_T + WV_PAD) * WV_C + WV_T * WV_S);
+  constexpr int LDS_BF16 = 2 * (WV_T + WV_PAD) * WV_C + 2 * WV_PAGE_U4 * 4;
+  __shared__ __align__(16) float lds[SPLIT_BF16 && LDS_BF16 > LDS_FP32 ? LDS_BF16 : LDS_FP32];
   __shared__ float red[WV_NW][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kk = lane >> 4;
@@ -176,16 +233,21 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
 #pragma unroll
       for (int kb = 0; kb < 3; ++kb) {
         const float4 av = *(const float4 *)(in_lds + (t0 + j) * WV_INLD + kb * 16 + kk * 4);
-        MFMA4(acc, av, bw[kb]);
+        if (SPLIT_BF16) {  // operands swapped: the transposed tile (channels x time)
+          MFMA4(acc, bw[kb], av);
+        } else {
+          MFMA4(acc, av, bw[kb]);
+        }
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) x[mi][r] = fmaxf(acc[r] + bias, 0.f);
+      for (int r = 0; r < 4; ++r) x[mi][r] = fmaxf(acc[r] + (SPLIT_BF16 ? a.b_in[kk * 4 + r] : bias), 0.f);
       skip[mi][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
       skip[mi][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   }
   __syncthreads();  // in_lds is dead from here on
 
+  if (!SPLIT_BF16) {
   // causal zero rows of both u buffers
   for (int i = tid; i < 2 * WV_PAD * WV_C; i += WV_THREADS) {
     int b = i / (WV_PAD * WV_C), o = i - b * (WV_PAD * WV_C);
@@ -247,12 +309,112 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
   }
   __syncthreads();
 
+
+  } else {
+    // ---- split-bf16 block loop (transposed: lane = time column n = lane & 15, rows = channels 4 kk + r).
+    //      LDS: u as two bf16 planes (hi, lo), each [2][WV_T + WV_PAD][16 ch], for the delayed taps only.
+    static_assert(!SPLIT_BF16 || WV_MPW == 1, "the split-bf16 loop handles one row tile per wave");
+    unsigned short *uh = (unsigned short *)lds;                                   // [2][WV_T + WV_PAD][16]
+    unsigned short *ul = uh + 2 * (WV_T + WV_PAD) * WV_C;
+    for (int i = tid; i < 2 * WV_PAD * WV_C; i += WV_THREADS) {                   // causal zero rows, both planes
+      int b = i / (WV_PAD * WV_C), o = i - b * (WV_PAD * WV_C);
+      uh[b * (WV_T + WV_PAD) * WV_C + o] = 0;
+      ul[b * (WV_T + WV_PAD) * WV_C + o] = 0;
+    }
+    const int t0 = wave * 16;
+    // Block parameters (14 A-operand slots + 7 per-channel vectors = one 14.8 KB "page") are identical for
+    // all 12 waves: the workgroup fetches page b+1 with one or two 16-byte loads per thread at the top of
+    // block b, parks it in LDS at the end of the block (double buffered) and every wave reads its operands
+    // from there.  (Per-wave register prefetch of the next page cost 1 us per block: the loads can only be
+    // issued once the registers are free, i.e. late, and the first MFMA of the next block then waits for L2.)
+    uint4 *pages = (uint4 *)(lds + 2 * (WV_T + WV_PAD) * WV_C);                  // [2][WV_PAGE_U4]
+    const uint4 *gpage = a.wpk;
+    const int pi1 = tid + WV_THREADS < WV_PAGE_U4 ? tid + WV_THREADS : WV_PAGE_U4 - 1;
+    pages[tid] = gpage[tid];
+    if (tid + WV_THREADS < WV_PAGE_U4) pages[tid + WV_THREADS] = gpage[pi1];
+    __syncthreads();
+    for (int blk = 0; blk < a.NB; ++blk) {
+      const int boff = (blk & 1) * (WV_T + WV_PAD) * WV_C + WV_PAD * WV_C;      // row 0 of this block's u planes
+      const int d = (int)((a.dil4[blk >> 4] >> (4 * (blk & 15))) & 15);
+      const int has_res = (a.has_res_mask >> blk) & 1;
+      const int nblk = blk + 1 < a.NB ? blk + 1 : blk;                           // unconditional prefetch target
+      const uint4 np0 = gpage[(size_t)nblk * WV_PAGE_U4 + tid], np1 = gpage[(size_t)nblk * WV_PAGE_U4 + pi1];
+      __builtin_amdgcn_sched_barrier(0);  // keep the loads HERE (the scheduler would sink them to their use)
+      const uint4 *pg = pages + (blk & 1) * WV_PAGE_U4;
+      const bf16x8 *wsl = (const bf16x8 *)pg + lane;                             // slot q: wsl[q * 64]
+      const float4 *bvec = (const float4 *)(pg + WV_SLOTS * 64) + kk;           // vector v: bvec[v * 4] (rows 4 kk ..)
+      const float4 bn_s = bvec[0], bn_t = bvec[4];
+      // BatchNorm affine (wavenet_model.py:57): this tile's u = the undelayed tap's B operand
+      const float uv[4] = {x[0][0] * bn_s.x + bn_t.x, x[0][1] * bn_s.y + bn_t.y, x[0][2] * bn_s.z + bn_t.z, x[0][3] * bn_s.w + bn_t.w};
+      s16x4 u2h, u2l;
+      split4(uv, u2h, u2l);
+      const int orow = boff + (t0 + j) * WV_C + 4 * kk;                          // [time t0 + n][ch 4 kk ..]
+      *(s16x4 *)(uh + orow) = u2h;
+      *(s16x4 *)(ul + orow) = u2l;
+      __syncthreads();  // u complete (all rows, all waves); this block's page complete
+      // delayed taps: tap k reads u[t - (2 - k) d]; rows < 0 hit the zero pad (d <= 8)
+      const s16x4 u1h = *(const s16x4 *)(uh + orow - d * WV_C), u1l = *(const s16x4 *)(ul + orow - d * WV_C);
+      const s16x4 u0h = *(const s16x4 *)(uh + orow - 2 * d * WV_C), u0l = *(const s16x4 *)(ul + orow - 2 * d * WV_C);
+      f32x4 as = {0.f, 0.f, 0.f, 0.f}, at = {0.f, 0.f, 0.f, 0.f};
+      // k-step 0 = (tap 2 | tap 1), k-step 1 = (tap 0 | zeros); slot = (kstep * 2 + {sig, tanh}) * 2 + {hi, lo}
+      const s16x4 z4 = {0, 0, 0, 0};
+      const bf16x8 x0h = cat8(u2h, u1h), x0l = cat8(u2l, u1l), x1h = cat8(u0h, z4), x1l = cat8(u0l, z4);
+      {
+        const bf16x8 w0 = wsl[0 * 64], w1 = wsl[1 * 64], w2 = wsl[2 * 64], w3 = wsl[3 * 64];
+        MFMA_BF(as, w0, x0h); MFMA_BF(at, w2, x0h);
+        MFMA_BF(as, w1, x0h); MFMA_BF(at, w3, x0h);
+        MFMA_BF(as, w0, x0l); MFMA_BF(at, w2, x0l);
+        const bf16x8 w4 = wsl[4 * 64], w5 = wsl[5 * 64], w6 = wsl[6 * 64], w7 = wsl[7 * 64];
+        MFMA_BF(as, w4, x1h); MFMA_BF(at, w6, x1h);
+        MFMA_BF(as, w5, x1h); MFMA_BF(at, w7, x1h);
+        MFMA_BF(as, w4, x1l); MFMA_BF(at, w6, x1l);
+      }
+      const float4 bsig = bvec[2 * 4], btanh = bvec[3 * 4];
+      const float gv[4] = {fast_tanh_w(at[0] + btanh.x) * fast_sigmoid_w(as[0] + bsig.x),
+                           fast_tanh_w(at[1] + btanh.y) * fast_sigmoid_w(as[1] + bsig.y),
+                           fast_tanh_w(at[2] + btanh.z) * fast_sigmoid_w(as[2] + bsig.z),
+                           fast_tanh_w(at[3] + btanh.w) * fast_sigmoid_w(as[3] + bsig.w)};
+      s16x4 g_h, g_l;
+      split4(gv, g_h, g_l);  // the gate product is the res / skip conv's B operand as it stands
+      f32x4 ar = {0.f, 0.f, 0.f, 0.f}, s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+      const bf16x8 gh8 = cat8(g_h, z4), gl8 = cat8(g_l, z4);
+      {
+        const bf16x8 r0 = wsl[8 * 64], r1 = wsl[9 * 64], r2 = wsl[10 * 64], r3 = wsl[11 * 64], r4 = wsl[12 * 64], r5 = wsl[13 * 64];
+        MFMA_BF(ar, r0, gh8); MFMA_BF(s0, r2, gh8); MFMA_BF(s1, r4, gh8);
+        MFMA_BF(ar, r1, gh8); MFMA_BF(s0, r3, gh8); MFMA_BF(s1, r5, gh8);
+        MFMA_BF(ar, r0, gl8); MFMA_BF(s0, r2, gl8); MFMA_BF(s1, r4, gl8);
+      }
+      const float4 bres = bvec[4 * 4], bsk0 = bvec[5 * 4], bsk1 = bvec[6 * 4];
+      const float br[4] = {bres.x, bres.y, bres.z, bres.w}, b0[4] = {bsk0.x, bsk0.y, bsk0.z, bsk0.w},
+                  b1[4] = {bsk1.x, bsk1.y, bsk1.z, bsk1.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (has_res) x[0][r] = fmaxf(ar[r] + br[r], 0.f) + x[0][r];
+        skip[0][0][r] = skip[0][0][r] + fmaxf(s0[r] + b0[r], 0.f);
+        skip[0][1][r] = skip[0][1][r] + fmaxf(s1[r] + b1[r], 0.f);
+      }
+      // park the next block's page (loaded a whole block ago); the barrier of the next block publishes it,
+      // and every wave is past its reads of this buffer's previous page (two barriers back)
+      uint4 *pn = pages + ((blk + 1) & 1) * WV_PAGE_U4;
+      pn[tid] = np0;
+      if (tid + WV_THREADS < WV_PAGE_U4) pn[tid + WV_THREADS] = np1;
+    }
+    __syncthreads();
+  }
   }
   // ---- encoder output (optional) + detect head
   if (a.enc) {
     float *e = a.enc + (size_t)w * T * WV_S;
 #pragma unroll
-    for (int mi = 0; mi < WV_MPW; ++mi)
+    for (int mi = 0; mi < WV_MPW; ++mi) {
+      if (SPLIT_BF16) {  // transposed state: lane = time column, four consecutive channels per register quad
+        const int t = (wave * WV_MPW + mi) * 16 + j;
+        if (t < T) {
+          *(float4 *)(e + (size_t)t * WV_S + kk * 4) = make_float4(skip[mi][0][0], skip[mi][0][1], skip[mi][0][2], skip[mi][0][3]);
+          *(float4 *)(e + (size_t)t * WV_S + 16 + kk * 4) = make_float4(skip[mi][1][0], skip[mi][1][1], skip[mi][1][2], skip[mi][1][3]);
+        }
+        continue;
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int t = (wave * WV_MPW + mi) * 16 + kk * 4 + r;
@@ -261,6 +423,7 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
           e[(size_t)t * WV_S + 16 + j] = skip[mi][1][r];
         }
       }
+    }
   }
   float4 w1[2][2], w2[2];
 #pragma unroll
@@ -275,10 +438,17 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
   for (int mi = 0; mi < WV_MPW; ++mi) {
     const int t0 = (wave * WV_MPW + mi) * 16;
     float *ht = hbuf + t0 * WV_S;  // [16][32] tile, wave-private
+    if (SPLIT_BF16) {
+      *(float4 *)(ht + j * WV_S + kk * 4) = make_float4(fmaxf(skip[mi][0][0], 0.f), fmaxf(skip[mi][0][1], 0.f),
+                                                        fmaxf(skip[mi][0][2], 0.f), fmaxf(skip[mi][0][3], 0.f));
+      *(float4 *)(ht + j * WV_S + 16 + kk * 4) = make_float4(fmaxf(skip[mi][1][0], 0.f), fmaxf(skip[mi][1][1], 0.f),
+                                                             fmaxf(skip[mi][1][2], 0.f), fmaxf(skip[mi][1][3], 0.f));
+    } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      ht[(kk * 4 + r) * WV_S + j] = fmaxf(skip[mi][0][r], 0.f);
-      ht[(kk * 4 + r) * WV_S + 16 + j] = fmaxf(skip[mi][1][r], 0.f);
+      for (int r = 0; r < 4; ++r) {
+        ht[(kk * 4 + r) * WV_S + j] = fmaxf(skip[mi][0][r], 0.f);
+        ht[(kk * 4 + r) * WV_S + 16 + j] = fmaxf(skip[mi][1][r], 0.f);
+      }
     }
     wsync();
     f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = {0.f, 0.f, 0.f, 0.f};
@@ -347,8 +517,12 @@ int ww_k_wave_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
   a.w_gate4 = v.w_gate; a.b_gate = v.b_gate; a.w_rs4 = v.w_rs; a.b_rs = v.b_rs;
   a.d_w1_4 = v.d_w1; a.d_b1 = v.d_b1; a.d_w2_4 = v.d_w2; a.d_b2 = v.d_b2;
   a.out = d_out; a.enc = d_enc;
-  ww_launch_scope scope(ctx, "wavenet_kernel");
-  hipLaunchKernelGGL(wavenet_kernel<false>, dim3(nw), dim3(WV_THREADS), 0, ctx->stream, a);
+  ww_launch_scope scope(ctx, m->precision == WW_PRECISION_BF16X3 ? "wavenet_kernel<bf16x3>" : "wavenet_kernel");
+  a.wpk = (const uint4 *)v.wpk;
+  if (m->precision == WW_PRECISION_BF16X3)
+    hipLaunchKernelGGL((wavenet_kernel<false, true>), dim3(nw), dim3(WV_THREADS), 0, ctx->stream, a);
+  else
+    hipLaunchKernelGGL((wavenet_kernel<false, false>), dim3(nw), dim3(WV_THREADS), 0, ctx->stream, a);
   WW_HIP(ctx, hipGetLastError());
   return WW_OK;
 }
@@ -361,7 +535,7 @@ int ww_k_wave_detect(ww_ctx *ctx, const ww_model *m, const float *d_enc, int nw,
   a.d_w1_4 = v.d_w1; a.d_b1 = v.d_b1; a.d_w2_4 = v.d_w2; a.d_b2 = v.d_b2;
   a.out = d_out; a.enc = nullptr; a.enc_in = d_enc;
   ww_launch_scope scope(ctx, "wavenet_detect_kernel");
-  hipLaunchKernelGGL(wavenet_kernel<true>, dim3(nw), dim3(WV_THREADS), 0, ctx->stream, a);
+  hipLaunchKernelGGL((wavenet_kernel<true, false>), dim3(nw), dim3(WV_THREADS), 0, ctx->stream, a);
   WW_HIP(ctx, hipGetLastError());
   return WW_OK;
 }

@@ -20,6 +20,7 @@ LIB_PATH = os.path.join(_PKG, "libwwhip.so")
 
 WW_OK, WW_EINVAL, WW_EBLOB, WW_EHIP, WW_ENOMEM, WW_ESTATE, WW_ENODEVICE = 0, -1, -2, -3, -4, -5, -6
 KIND_CRNN, KIND_WAVENET = 1, 2
+PRECISION_FP32, PRECISION_BF16X3 = 0, 1
 
 
 class ModelInfo(C.Structure):
@@ -49,6 +50,7 @@ SYMBOLS: Dict[str, tuple] = {
     "ww_model_load": (C.c_int, [_vp, _vp, _sz, _P(_vp)]),
     "ww_model_free": (C.c_int, [_vp]),
     "ww_model_get_info": (C.c_int, [_vp, _P(ModelInfo)]),
+    "ww_model_set_precision": (C.c_int, [_vp, C.c_int]),
     "ww_num_frames": (_i64, [_i64, _i32]),
     "ww_logmel": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _P(FrontendParams), _vp, _vp]),
     "ww_logmel_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _P(FrontendParams), _vp, _vp]),

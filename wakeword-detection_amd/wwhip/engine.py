@@ -23,7 +23,8 @@ def frontend_params(pcm_divisor: float = 32767.0, clip: bool = True, pre_emphasi
 class Engine:
     """A model directory (filter/encode/detect ``.tflite``) resident on one MI355X."""
 
-    def __init__(self, model_dir: str, device: int = 0, ctx: Optional[_lib.Context] = None) -> None:
+    def __init__(self, model_dir: str, device: int = 0, ctx: Optional[_lib.Context] = None,
+                 precision: str = "fp32") -> None:
         self.bundle = W.load_model_dir(model_dir)
         self.blob = W.pack_blob(self.bundle)
         self.ctx = ctx if ctx is not None else _lib.default_context(device)
@@ -42,6 +43,18 @@ class Engine:
         self.enc_shape = (info.enc_rows, info.enc_width)
         self.model_dir = model_dir
         _lib.register("models", self)
+        self.precision = "fp32"
+        if precision != "fp32":
+            self.set_precision(precision)
+
+    def set_precision(self, precision: str) -> None:
+        """``"fp32"`` (default, fp32 MFMA) or ``"bf16x3"`` (Wavenet blocks as three bf16 MFMAs on
+        split operands, fp32 accumulate; see ``ww_model_set_precision`` in include/wwhip.h)."""
+        modes = {"fp32": _lib.PRECISION_FP32, "bf16x3": _lib.PRECISION_BF16X3}
+        if precision not in modes:
+            raise ValueError(f"precision must be one of {sorted(modes)}")
+        self._chk(self._lib.ww_model_set_precision(self._model, modes[precision]))
+        self.precision = precision
 
     # ------------------------------------------------------------------ properties
     @property
