@@ -38,6 +38,7 @@ SAMPLES = 24000          # 1.5 s @ 16 kHz
 FRAMES_PER_CLIP = 150    # audio frames (10 ms hops) per clip
 PEAK_F32_MFMA = 157.3e12  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, 256 CUs
 PEAK_HBM = 8.0e12
+PEAK_BF16_MFMA = 2.5e15   # dense bf16, MI355X_MICROARCH.md
 
 
 def synth_pcm(rng, n_clips):
@@ -74,6 +75,7 @@ def kernel_flops(eng, n_clips):
             w.n_frames * (3 * w.channels * 2 * w.channels + w.channels * ((w.channels if b.w_res is not None else 0) + w.skip_channels))
             for b in w.blocks) + w.n_frames * (w.skip_channels * w.skip_channels + w.skip_channels * eng.n_out)
         out["wavenet_kernel"] = ("mfma", n_clips * (eng.window * 40 * 4 + eng.n_out * 4), n_clips * 2.0 * macs)
+        out["wavenet_kernel<bf16x3>"] = out["wavenet_kernel"]
     return out
 
 
@@ -124,6 +126,9 @@ def main():
                     help="independent contexts (HIP streams) the steps are dealt to round-robin; batches are "
                          "independent, so consecutive steps may overlap on the GPU")
     ap.add_argument("--fast-frontend", action="store_true", help="fp32 FFT instead of the reference's fp64")
+    ap.add_argument("--precision", choices=["auto", "fp32", "bf16x3"], default="auto",
+                    help="model contractions: fp32 MFMA, or (Wavenet only) three bf16 MFMAs on split operands with "
+                         "fp32 accumulate; auto = fp32 for CRNN (BASELINE cfg 2), bf16x3 for Wavenet (cfg 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -156,7 +161,10 @@ def main():
     P = max(1, args.pipeline)
     ctxs = [_lib.Context(local_rank) for _ in range(P)]
     model_dir = os.path.join(PKG, "assets", "tf_lite_models", "CRNN" if args.model == "crnn" else "Wavenet")
-    engs = [Engine(model_dir, device=local_rank, ctx=c) for c in ctxs]
+    precision = args.precision if args.precision != "auto" else ("fp32" if args.model == "crnn" else "bf16x3")
+    if args.model == "crnn":
+        precision = "fp32"
+    engs = [Engine(model_dir, device=local_rank, ctx=c, precision=precision) for c in ctxs]
     ctx, eng = ctxs[0], engs[0]
     fp = frontend_params(32767.0, True, 0.0, 160, not args.fast_frontend)
 
@@ -239,6 +247,29 @@ def main():
             step(k)
         sync_all()
 
+    # ---- Wavenet: the same region with fp32 MFMA contractions (parity mode), reported alongside (cfg 3)
+    alt_fp32 = None
+    if precision == "bf16x3":
+        for e in engs:
+            e.set_precision("fp32")
+        for k in range(R * P):
+            step(k)
+        sync_all()
+        barrier()
+        t2 = time.perf_counter()
+        for k in range(K):
+            step(k)
+        sync_all()
+        barrier()
+        alt_fp32 = time.perf_counter() - t2
+        posts_fp32 = torch.stack(d_outs).cpu().numpy()
+        for e in engs:
+            e.set_precision("bf16x3")
+        for k in range(R * P):
+            step(k)
+        sync_all()
+        alt_fp32_maxdiff = float(np.abs(torch.stack(d_outs).cpu().numpy() - posts_fp32).max())
+
     # ---- per-kernel pass (HIP events around every launch), same K steps
     ctx.profile(True)
     for k in range(K):
@@ -260,6 +291,11 @@ def main():
         bound, nbytes, flops = kf[dom]
         if bound == "hbm":
             roof = {"bound": "hbm", "achieved": nbytes / (dom_ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s"}
+        elif dom.endswith("<bf16x3>"):
+            # three bf16 MFMAs per product: priced against the dense bf16 peak with 3x the algorithmic FLOPs
+            roof = {"bound": "mfma", "achieved": 3.0 * flops / (dom_ms * 1e-3) / 1e12, "peak": PEAK_BF16_MFMA / 1e12,
+                    "unit": "TFLOP/s", "note": "split-bf16: 3 bf16 MFMA products per algorithmic product; "
+                    f"algorithmic rate {flops / (dom_ms * 1e-3) / 1e12:.1f} TFLOP/s"}
         else:
             roof = {"bound": "mfma", "achieved": flops / (dom_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
@@ -287,12 +323,12 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if precision == "fp32" else "bf16x3 (split-bf16 products, f32 accumulate)",
             "data": "synthetic",
             "config": {
                 "workload": (f"{'CRNN' if args.model == 'crnn' else 'Wavenet'} forward, batch={args.clips}x1.5 s synthetic "
                              f"16 kHz clips per GPU, PCM resident in HBM -> log-mel ({'fp32' if args.fast_frontend else 'fp64'} FFT) "
-                             f"-> {eng.window}x40 window -> encode+detect, fp32"),
+                             f"-> {eng.window}x40 window -> encode+detect, {'fp32 MFMA' if precision == 'fp32' else 'split-bf16 MFMA (bf16x3), fp32 accumulate'}"),
                 "clips_per_gpu": args.clips,
                 "samples_per_clip": SAMPLES,
                 "resident_input_batches_rotated": R,
@@ -306,6 +342,11 @@ def main():
                 "value": total_frames / alt, "unit": "audio frames/s", "ms_per_step": alt / K * 1e3,
                 "note": "same job with ww_frontend_params.precise=0 (fp32 butterflies); per-rank time, not max-reduced"},
         }
+        if alt_fp32 is not None:
+            line["alt_fp32_mfma_parity_mode"] = {
+                "value": total_frames / alt_fp32, "unit": "audio frames/s", "ms_per_step": alt_fp32 / K * 1e3,
+                "max_abs_posterior_diff_vs_bf16x3": alt_fp32_maxdiff,
+                "note": "same job with ww_model_set_precision(WW_PRECISION_FP32); per-rank time, not max-reduced"}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(eng, pcm0)
         elif not args.no_cpu_baseline:

@@ -157,6 +157,14 @@ def test_wavenet_split_bf16_mode(assets, oracles, golden, name):
         assert np.abs(e.slide_forward(mel, 2) - oracles[name].slide_forward(mel, 2)).max() < 2e-5
         e.set_precision("fp32")
         assert np.abs(e.forward(wins) - want).max() < 2e-6
+        # a chip-filling batch, twice: every workgroup against the fp32 kernel (catches ordering hazards
+        # between waves that a handful of windows never exercises)
+        big = rng.uniform(0, 6.5, (700, e.window, 40)).astype(np.float32)
+        big[::7, 140:] = 0
+        ref = e.forward(big)
+        e.set_precision("bf16x3")
+        for _ in range(2):
+            assert np.abs(e.forward(big) - ref).max() < 2e-5
         with pytest.raises(ValueError):
             e.set_precision("bf16")
     finally:
