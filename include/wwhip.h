@@ -197,6 +197,16 @@ int ww_far_frr(ww_ctx *ctx, const float *pos, int64_t n_pos, const float *neg, i
                const double *thr, int32_t n_thr, double num_wakewords, double hours, double *frr,
                double *fa_per_h, int64_t *fa_count, double *smoothed);
 
+/* ---- superframe shortest-path smoothing -------------------------------------------------
+ * Replaces wwdetect/wfst.py:17-71 `smooth()` (pynini 2-state x T lattice, tropical shortest path) as
+ * wired in utils/CRNN_files/tflite.py:252-263 (superframe of 10 posteriors; trigger if the best path
+ * visits 'wakeword').  in: [n][T][2] = (p_other, p_wakeword) per step, or -ln of them when in_is_cost != 0
+ * (pass NumPy's -np.log for bit-exact reference costs).  stay_bonus = 1 in the reference.  path
+ * (may be NULL) receives the best state sequence [n][T] (0 = other, 1 = wakeword), wake[n] = 1 if it
+ * visits state 1.  T <= 64. */
+int ww_superframe_smooth(ww_ctx *ctx, const float *in, int64_t n, int32_t T, float stay_bonus, int32_t in_is_cost,
+                         uint8_t *path, uint8_t *wake);
+
 #ifdef __cplusplus
 }
 #endif

@@ -173,3 +173,35 @@ def load_h5_like(features: Sequence[np.ndarray], timesteps: int, num_features: i
         f = np.asarray(f)[:timesteps]
         X[i, : f.shape[0], : f.shape[1]] = f
     return X
+
+
+def wfst_smooth(posterior_probs) -> List[int]:
+    """Reference ``wwdetect/wfst.py:17-71`` without pynini: the single shortest path through the
+    2-state lattice it builds, in OpenFst's arithmetic (TropicalWeight = float32; distances relaxed
+    in state order, replaced only when strictly smaller, so ties keep state 0).  Returns the state
+    sequence (0 = 'other', 1 = 'wakeword')."""
+    with np.errstate(divide="ignore"):
+        obs = -np.log(np.asarray(posterior_probs, dtype=np.float32))  # wfst.py:33 (float32 array)
+    T, P = obs.shape
+    d = [np.float32(-np.log(1.0 / P) + obs[0, p]) for p in range(P)]  # :56-57, Arc weight -> float32
+    back = np.zeros((T, P), np.int64)
+    for t in range(1, T):  # :59-66
+        nd = []
+        for p_to in range(P):
+            best, arg = None, 0
+            for p_from in range(P):
+                cost = obs[t, p_to]
+                if p_to == p_from:
+                    cost = np.float32(cost - 1)  # test_transition_matrix == 1 everywhere
+                cand = np.float32(d[p_from] + cost)
+                if best is None or cand < best:
+                    best, arg = cand, p_from
+            nd.append(best)
+            back[t, p_to] = arg
+        d = nd
+    st = 1 if d[1] < d[0] else 0
+    path = [0] * T
+    for t in range(T - 1, -1, -1):
+        path[t] = st
+        st = int(back[t, st])
+    return path

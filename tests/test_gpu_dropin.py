@@ -316,3 +316,33 @@ def test_dataset_filter_writes_the_reference_feature_file(assets, oracle_dirs, t
         assert int(h5["utt0"].attrs["speech_start_ts"]) == 0 and int(h5["utt0"].attrs["speech_end_ts"]) == (8640 + 320) // 160  # the last, mostly padded chunk is below the VAD threshold
     X, y = load_h5(df.dataset_file, 151, 40)
     assert X.shape == (len(want), 151, 40) and y.tolist() == [1, 0, 0]
+
+
+def test_superframe_smoothing_matches_the_reference_lattice(assets):
+    """wwhip.wfst (ww_superframe_smooth) vs the pynini-free restatement of wwdetect/wfst.py."""
+    from wwhip import wfst
+    from oracle import numpy_ref as NR
+    t1 = [[0.8, 0.2], [0.9, 0.1], [0.5, 0.5], [0.4, 0.6], [0.2, 0.8], [0.6, 0.4], [0.3, 0.7], [0.4, 0.6], [0.5, 0.5], [0.9, 0.1]]
+    assert wfst.smooth(t1) == "other other other wakeword wakeword wakeword wakeword wakeword other other"
+    rng = np.random.default_rng(5)
+    p = rng.uniform(0.0, 1.0, (3000, 10)).astype(np.float32)
+    p[::97, 3] = 1.0      # p_other == 0 -> infinite cost
+    p[::89, 5] = 0.0
+    pp = np.stack([np.abs(p - np.float32(1)), p], axis=2)  # as CRNN_files/tflite.py:249-251 builds it
+    paths, wake = wfst.smooth_batch(pp)
+    want = np.array([NR.wfst_smooth(x) for x in pp], np.uint8)
+    np.testing.assert_array_equal(paths, want)
+    np.testing.assert_array_equal(wake, want.any(axis=1))
+    # logarithm on the device: same paths except where two path costs tie within an ulp
+    paths_dev, _ = wfst.smooth_batch(pp, device_log=True)
+    assert (paths_dev != want).any(axis=1).mean() < 2e-3
+    for T in (1, 2, 33, 64):
+        q = rng.uniform(0.01, 0.99, (50, T)).astype(np.float32)
+        qq = np.stack([1 - q, q], axis=2)
+        np.testing.assert_array_equal(wfst.smooth_batch(qq)[0], np.array([NR.wfst_smooth(x) for x in qq], np.uint8))
+    with pytest.raises(ValueError):
+        wfst.smooth_batch(np.zeros((1, 65, 2), np.float32))
+    # detector wiring: ten posteriors per decision
+    det = wfst.SuperframeDetector(10)
+    fired = [det.push(x[1]) for x in t1]
+    assert fired == [False] * 9 + [True]

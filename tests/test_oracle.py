@@ -82,3 +82,32 @@ def test_frr_at_fa_metric():
     far = np.array([3.0, 0.6, 0.5, 0.0])
     assert NR.frr_at_fa(frr, far, 0.5) == 0.2
     assert np.isnan(NR.frr_at_fa(frr, far + 10, 0.5))
+
+
+def test_wfst_smooth_restatement_is_the_shortest_path():
+    """oracle/numpy_ref.wfst_smooth (wwdetect/wfst.py:17-71 without pynini) against brute force over all
+    2^T state sequences, and on the two superframes the reference's __main__ exercises."""
+    import itertools
+    from oracle import numpy_ref as NR
+
+    def brute(pp):
+        obs = -np.log(np.asarray(pp, np.float64))
+        best = None
+        for path in itertools.product((0, 1), repeat=len(obs)):
+            c = np.log(2) + obs[0, path[0]]
+            for t in range(1, len(obs)):
+                c += obs[t, path[t]] - (1 if path[t] == path[t - 1] else 0)
+            if best is None or c < best[0] - 1e-12:
+                best = (c, path)
+        return list(best[1])
+
+    rng = np.random.default_rng(0)
+    for _ in range(120):
+        T = int(rng.integers(1, 11))
+        p = rng.uniform(0.02, 0.98, T)
+        pp = np.stack([1 - p, p], 1)
+        assert NR.wfst_smooth(pp) == brute(pp)
+    t1 = [[0.8, 0.2], [0.9, 0.1], [0.5, 0.5], [0.4, 0.6], [0.2, 0.8], [0.6, 0.4], [0.3, 0.7], [0.4, 0.6], [0.5, 0.5], [0.9, 0.1]]
+    t2 = [[0.8, 0.2], [0.9, 0.1], [0.5, 0.5], [0.55, 0.45], [0.2, 0.8], [0.6, 0.4], [0.7, 0.3], [0.8, 0.2], [0.3, 0.7], [0.9, 0.1]]
+    assert NR.wfst_smooth(t1) == [0, 0, 0, 1, 1, 1, 1, 1, 0, 0]   # stays in 'wakeword' through the 0.6/0.4 dip (wfst.py:83)
+    assert NR.wfst_smooth(t2) == [0] * 10                          # does not enter on one errant frame (wfst.py:94)

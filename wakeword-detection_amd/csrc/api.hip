@@ -904,4 +904,24 @@ int ww_far_frr(ww_ctx *ctx, const float *pos, int64_t n_pos, const float *neg, i
   return WW_OK;
 }
 
+int ww_superframe_smooth(ww_ctx *ctx, const float *in, int64_t n, int32_t T, float stay_bonus, int32_t in_is_cost,
+                         uint8_t *path, uint8_t *wake) {
+  if (!ctx || (n > 0 && (!in || !wake))) return ww_fail(ctx, WW_EINVAL, "NULL argument");
+  if (n < 0) return ww_fail(ctx, WW_EINVAL, "bad sizes");
+  if (n == 0) return WW_OK;
+  WW_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t b_in = ww_bump::need((size_t)n * T * 2, 4), b_p = ww_bump::need((size_t)n * T, 1), b_w = ww_bump::need((size_t)n, 1);
+  int rc = ww_ensure(ctx, ctx->dev, b_in + b_p + b_w + 1024, false);
+  if (rc) return rc;
+  ww_bump bump(ctx->dev.ptr, ctx->dev.cap);
+  float *d_in = bump.take<float>((size_t)n * T * 2);
+  unsigned char *d_p = bump.take<unsigned char>((size_t)n * T), *d_w = bump.take<unsigned char>((size_t)n);
+  WW_HIP(ctx, hipMemcpyAsync(d_in, in, (size_t)n * T * 2 * 4, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = ww_k_viterbi2(ctx, d_in, n, T, stay_bonus, in_is_cost, d_p, d_w))) return rc;
+  if (path) WW_HIP(ctx, hipMemcpyAsync(path, d_p, (size_t)n * T, hipMemcpyDeviceToHost, ctx->stream));
+  WW_HIP(ctx, hipMemcpyAsync(wake, d_w, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return WW_OK;
+}
+
 }  // extern "C"

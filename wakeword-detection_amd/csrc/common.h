@@ -180,6 +180,8 @@ int ww_k_stft_mag(ww_ctx *ctx, const ww_model *m, const float *d_frames, int64_t
 int ww_k_mel_only(ww_ctx *ctx, const ww_model *m, const float *d_mag, int64_t n, float *d_mel);
 int ww_k_crnn_detect(ww_ctx *ctx, const ww_model *m, const float *d_enc, int nw, float *d_out);
 int ww_k_wave_detect(ww_ctx *ctx, const ww_model *m, const float *d_enc, int nw, float *d_out);
+int ww_k_viterbi2(ww_ctx *ctx, const float *d_in, int64_t n, int T, float stay_bonus, int in_is_cost, unsigned char *d_path,
+                  unsigned char *d_wake);
 
 size_t ww_crnn_workspace(const ww_model *m, int n_windows);
 int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *d_win_row,

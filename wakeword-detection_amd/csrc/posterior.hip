@@ -90,3 +90,56 @@ int ww_k_far_frr(ww_ctx *ctx, const float *d_pos, int64_t n_pos, const float *d_
   WW_HIP(ctx, hipGetLastError());
   return WW_OK;
 }
+
+// ---- superframe shortest-path smoothing (wwdetect/wfst.py:17-71; wiring utils/CRNN_files/tflite.py:252-263)
+// The reference builds a 2-state x T lattice with pynini and takes the single shortest path in the
+// tropical semiring (float32 weights): start arcs cost ln 2 + c[0][p]; an arc into state p at time t
+// costs c[t][p], minus the stay bonus (1) when it does not change state; both last states are final.
+// c = -ln(posterior).  That is a 2 x T Viterbi recursion; OpenFst relaxes predecessors in state
+// order and replaces a distance only when strictly smaller, so ties keep state 0 ('other').
+// One thread per superframe; `in` holds either posteriors [n][T][2] or ready-made costs.
+#define VT_MAX_T 64
+__global__ __launch_bounds__(256) void viterbi2_kernel(const float *__restrict__ in, int64_t n, int T, float stay_bonus,
+                                                       int in_is_cost, unsigned char *__restrict__ path,
+                                                       unsigned char *__restrict__ wake) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float *p = in + i * T * 2;
+  auto cost = [&](int t, int q) { return in_is_cost ? p[t * 2 + q] : -logf(p[t * 2 + q]); };
+  unsigned long long back0 = 0, back1 = 0;  // bit t: best predecessor of state 0 / 1 at time t is state 1
+  const float init = (float)0.69314718055994530942;  // float32(-log(1/2)) as the Arc weight conversion yields
+  // the start arc weight is float32(float64(ln 2) + float64(c)) in the reference (float64 + float32 scalar)
+  (void)init;
+  float d0 = (float)(0.6931471805599453 + (double)cost(0, 0));
+  float d1 = (float)(0.6931471805599453 + (double)cost(0, 1));
+  for (int t = 1; t < T; ++t) {
+    const float c0 = cost(t, 0), c1 = cost(t, 1);
+    const float stay0 = c0 - stay_bonus, stay1 = c1 - stay_bonus;  // float32, as `cost -= 1` on a numpy float32
+    const float a00 = d0 + stay0, a10 = d1 + c0;   // into state 0 from 0 / from 1
+    const float a01 = d0 + c1, a11 = d1 + stay1;   // into state 1 from 0 / from 1
+    float n0 = a00, n1 = a01;
+    if (a10 < n0) { n0 = a10; back0 |= 1ull << t; }
+    if (a11 < n1) { n1 = a11; back1 |= 1ull << t; }
+    d0 = n0;
+    d1 = n1;
+  }
+  int st = d1 < d0 ? 1 : 0;
+  int any = 0;
+  for (int t = T - 1; t >= 0; --t) {
+    path[i * T + t] = (unsigned char)st;
+    any |= st;
+    st = (int)(((st ? back1 : back0) >> t) & 1ull);
+  }
+  wake[i] = (unsigned char)any;
+}
+
+int ww_k_viterbi2(ww_ctx *ctx, const float *d_in, int64_t n, int T, float stay_bonus, int in_is_cost, unsigned char *d_path,
+                  unsigned char *d_wake) {
+  if (n <= 0) return WW_OK;
+  if (T < 1 || T > VT_MAX_T) return ww_fail(ctx, WW_EINVAL, "superframe length %d outside 1..%d", T, VT_MAX_T);
+  ww_launch_scope scope(ctx, "viterbi2_kernel");
+  hipLaunchKernelGGL(viterbi2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_in, n, T, stay_bonus,
+                     in_is_cost, d_path, d_wake);
+  WW_HIP(ctx, hipGetLastError());
+  return WW_OK;
+}

@@ -67,6 +67,7 @@ SYMBOLS: Dict[str, tuple] = {
     "ww_stream_destroy": (C.c_int, [_vp]),
     "ww_stream_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "ww_stream_reset": (C.c_int, [_vp, _vp, _i32]),
+    "ww_superframe_smooth": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _i32, _vp, _vp]),
     "ww_far_frr": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _f64, _f64, _vp, _vp, _vp, _vp]),
 }
 

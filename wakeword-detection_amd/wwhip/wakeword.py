@@ -25,7 +25,7 @@ class WakewordTrigger:
     def __init__(self, pre_emphasis: float = 0.0, sample_rate: int = 16000, fft_window_type: str = "hann",
                  fft_hop_length: int = 10, model_dir: str = "", model_type: str = "",
                  posterior_threshold: float = 0.5, on_wake: Optional[Callable[[], None]] = None, device: int = 0,
-                 **kwargs) -> None:
+                 superframe_len: int = 0, **kwargs) -> None:
         self.pre_emphasis = pre_emphasis
         self.hop_length = int(fft_hop_length * sample_rate / 1000)
         if fft_window_type != "hann":
@@ -47,6 +47,10 @@ class WakewordTrigger:
         self._posterior_max = 0.0
         self._is_speech = False
         self._on_wake = on_wake  # replaces the pydub audio reply (tflite.py:111-121,238)
+        # superframe_len > 0 selects the experimental trigger of utils/CRNN_files/tflite.py:252-263
+        # (shortest path over a superframe of posteriors instead of the 0.5 threshold)
+        from .wfst import SuperframeDetector
+        self._superframe = SuperframeDetector(superframe_len) if superframe_len > 0 else None
 
     def __call__(self, context: SpeechContext, frame) -> None:
         vad_fall = self._is_speech and not context.is_speech
@@ -67,7 +71,11 @@ class WakewordTrigger:
             posterior = float(post[0, k])
             if posterior > self._posterior_max:
                 self._posterior_max = posterior
-            if posterior > self._posterior_threshold and not context.is_active:
+            if self._superframe is not None:
+                fire = self._superframe.push(posterior)
+            else:
+                fire = posterior > self._posterior_threshold
+            if fire and not context.is_active:
                 _LOG.info(f"AWAKE!: {self._posterior_max}")
                 if self._on_wake is not None:
                     self._on_wake()
@@ -76,6 +84,8 @@ class WakewordTrigger:
     def reset(self) -> None:
         self._bank.reset()
         self._posterior_max = 0.0
+        if self._superframe is not None:
+            self._superframe.reset()
 
     def close(self) -> None:
         self.reset()
