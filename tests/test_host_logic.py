@@ -218,3 +218,54 @@ def test_pcm_quotient_sequence_is_exact_for_all_int16():
             e = rn32(Fraction(float(ai)) - Fraction(float(b)) * Fraction(float(qi)))
             q1 = rn32(Fraction(float(qi)) + Fraction(float(e)) * Fraction(float(r)))
             assert q1 == wi, (div, ai)
+
+
+def test_vad_hysteresis_and_trigger():
+    """spokestack/vad/webrtc.py:52-77,100-110 with a scripted frame classifier."""
+    from spokestack.vad.webrtc import VoiceActivityDetector, VoiceActivityTrigger
+    from wwhip.context import SpeechContext
+    from wwhip.vad import VadBank
+    script = [0, 1, 1, 0, 1, 1, 1, 1, 0, 0, 1, 0, 0, 0, 0, 1]
+    it = iter(script)
+    vad = VoiceActivityDetector(frame_width=20, vad_rise_delay=60, vad_fall_delay=80, classifier=lambda b, sr: next(it))
+    trig = VoiceActivityTrigger()
+    ctx = SpeechContext()
+    got, active = [], []
+    frame = np.zeros(320, np.int16)
+    for _ in script:
+        vad(ctx, frame)
+        trig(ctx, frame)
+        got.append(bool(ctx.is_speech))
+        active.append(bool(ctx.is_active))
+    # rise needs a run of 3 speech frames (60 // 20), fall a run of 4 non-speech frames (80 // 20)
+    want = [False, False, False, False, False, False, True, True, True, True, True, True, True, True, False, False]
+    assert got == want
+    assert active == [False] * 6 + [True] * 10           # activated on the rising edge, never cleared by the trigger
+    # zero delays: is_speech follows the classifier (run_length >= 0 always holds)
+    it2 = iter(script)
+    vad0 = VoiceActivityDetector(classifier=lambda b, sr: next(it2))
+    ctx0 = SpeechContext()
+    out0 = []
+    for _ in script:
+        vad0(ctx0, frame)
+        out0.append(bool(ctx0.is_speech))
+    assert out0 == [bool(v) for v in script]
+    # the batched form takes the same decisions, stream by stream
+    rng = np.random.default_rng(3)
+    raw = rng.random((200, 7)) < 0.6
+    bank = VadBank(7, 20, 60, 80)
+    singles = []
+    for s in range(7):
+        col = iter(raw[:, s])
+        singles.append((VoiceActivityDetector(frame_width=20, vad_rise_delay=60, vad_fall_delay=80,
+                                              classifier=lambda b, sr, col=col: next(col)), SpeechContext()))
+    for t in range(200):
+        sp = bank.step(raw[t])
+        for s, (v, c) in enumerate(singles):
+            v(c, frame)
+            assert bool(c.is_speech) == bool(sp[s])
+    try:
+        import webrtcvad  # noqa: F401
+    except ImportError:
+        with pytest.raises(RuntimeError):
+            VoiceActivityDetector()                      # no webrtcvad: the classifier must be given

@@ -24,6 +24,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define FPB 16  // frames per block
 #endif
 #define WAVES 4
+#ifndef FE_OCC64
+#define FE_OCC64 3  // fp64 front end: workgroups per CU the register budget is set for
+#endif
 #define MEL_PER_WAVE 6
 #define MEL_MAX_ENT (WAVES * MEL_PER_WAVE)
 static_assert(FPB == WAVES * 4, "each wave transforms exactly one group of 4 frames (mags overlay the transposes)");
@@ -137,7 +140,7 @@ __host__ __device__ constexpr int wbuf_bytes() {
 }
 
 template <typename R, bool F32IN, bool SIMPLE>
-__global__ __launch_bounds__(256, sizeof(R) == 8 ? 3 : 4) void logmel_kernel(logmel_args a) {
+__global__ __launch_bounds__(256, sizeof(R) == 8 ? FE_OCC64 : 4) void logmel_kernel(logmel_args a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, sub = lane >> 4;
