@@ -262,3 +262,45 @@ def test_fp32_frontend_mode_meets_posterior_tolerance(engines, oracles, golden):
             wins[i, :min(len(m), e.window)] = m[:e.window]
             ref[i, :min(len(r), e.window)] = r[:e.window]
         assert np.abs(e.forward(wins) - oracles[name].forward(ref)).max() < TOL_POST
+
+
+# ---------------------------------------------------------------- BASELINE sizes: size-independent properties
+@pytest.mark.parametrize("name,precision", [("CRNN", "fp32"), ("Wavenet", "fp32"), ("Wavenet", "bf16x3")])
+def test_full_config_batch_invariance_and_spot_parity(assets, oracles, name, precision):
+    """configs[1] / configs[2] at full size (256 x 1.5 s clips, PCM resident in HBM): a clip's posterior must
+    not depend on what else is in the batch (bit-exact under chunking and permutation), and a sample of
+    clips must match the oracle."""
+    import torch
+    from wwhip.engine import Engine, frontend_params
+    e = Engine(os.path.join(assets, name), precision=precision)
+    try:
+        rng = np.random.default_rng(101)
+        B, S = 256, 24000
+        t = np.arange(S) / 16000.0
+        chirp = 8000.0 * np.sin(2 * np.pi * (200.0 * t + 0.5 * 3800.0 / 1.5 * t * t))
+        pcm = np.clip(np.rint(rng.normal(0, 2000, (B, S)) + chirp), -32768, 32767).astype(np.int16)
+        fp = frontend_params()
+
+        def run(batch):
+            d_pcm = torch.from_numpy(np.ascontiguousarray(batch)).cuda()
+            d_out = torch.zeros((len(batch), e.n_out), dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            e.clips_forward_dev(d_pcm.data_ptr(), len(batch), S, d_out.data_ptr(), fp)
+            e.ctx.synchronize()
+            return d_out.cpu().numpy()
+
+        full = run(pcm)
+        assert np.isfinite(full).all() and (full >= 0).all() and (full <= 1).all()
+        chunks = np.concatenate([run(pcm[i:i + 64]) for i in range(0, B, 64)])
+        np.testing.assert_array_equal(full, chunks)
+        perm = rng.permutation(B)
+        np.testing.assert_array_equal(run(pcm[perm]), full[perm])
+        np.testing.assert_array_equal(run(pcm), full)      # and it is deterministic run to run
+        tol = TOL_POST if precision == "fp32" else 2e-5
+        for i in rng.choice(B, 6, replace=False):
+            mel = oracles[name].logmel(pcm[i])
+            win = np.zeros((e.window, 40), np.float32)
+            win[: min(len(mel), e.window)] = mel[: e.window]
+            assert np.abs(full[i] - oracles[name].forward(win)[0]).max() < tol
+    finally:
+        e.close()

@@ -8,11 +8,11 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "wakeword-detection_amd")]
 import numpy as np
 from wwhip.engine import Engine, StreamBank
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 10000  # SURVEY 8(d) cfg 5: 10,000 ticks after 100 warm-up
 rng = np.random.default_rng(0)
 out = {}
-for name in ("CRNN", "Wavenet"):
-    eng = Engine(os.path.join(ROOT, "wakeword-detection_amd/assets/tf_lite_models", name))
+for name, prec in (("CRNN", "fp32"), ("Wavenet", "fp32"), ("Wavenet", "bf16x3")):
+    eng = Engine(os.path.join(ROOT, "wakeword-detection_amd/assets/tf_lite_models", name), precision=prec)
     bank = StreamBank(eng, S)
     frames = np.clip(rng.normal(0, 2500, (64, S, 320)), -32768, 32767).astype(np.int16)
     speech = np.ones(S, np.uint8)
@@ -25,7 +25,7 @@ for name in ("CRNN", "Wavenet"):
         p, n = bank.step(frames[t % 64], speech)
         lat[t] = time.perf_counter() - t0
         n_post += int(n.sum())
-    out[name] = {"streams": S, "ticks": ticks, "p50_ms": float(np.percentile(lat, 50) * 1e3),
+    out[name if prec == "fp32" else name + "/" + prec] = {"streams": S, "ticks": ticks, "p50_ms": float(np.percentile(lat, 50) * 1e3),
                  "p99_ms": float(np.percentile(lat, 99) * 1e3), "mean_ms": float(lat.mean() * 1e3),
                  "posteriors_per_tick": n_post / ticks,
                  "realtime_factor": 0.020 / float(lat.mean())}
