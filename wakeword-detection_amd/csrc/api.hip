@@ -421,7 +421,6 @@ static int load_wave(ww_ctx *ctx, ww_model *m, const blob_view &bv) {
       return f;
     };
     std::vector<uint16_t> pk((size_t)NB * 14 * 64 * 8, 0);
-    std::vector<float> bv7((size_t)NB * 7 * 16, 0.f);
     for (int b = 0; b < NB; ++b) {
       for (int lane = 0; lane < 64; ++lane) {
         const int i = lane & 15, kg = lane >> 4;
@@ -430,39 +429,26 @@ static int load_wave(ww_ctx *ctx, ww_model *m, const blob_view &bv) {
           for (int ks = 0; ks < 2; ++ks)
             for (int mt = 0; mt < 2; ++mt) {
               const int tap = ks == 0 ? (q < 4 ? 2 : 1) : (q < 4 ? 0 : -1);
-              const float wv = tap < 0 ? 0.f : (mt == 0 ? w_sig : w_tanh)[(((size_t)b * 3 + tap) * C + ch) * C + i];
+              float wv = tap < 0 ? 0.f : (mt == 0 ? w_sig : w_tanh)[(((size_t)b * 3 + tap) * C + ch) * C + i];
+              if (ks == 1 && q == 4 && kg == 0) wv = (mt == 0 ? b_sig : b_tanh)[(size_t)b * C + i];  // bias slot (B = 1.0)
               const uint16_t hi = bf16_rne(wv), lo = bf16_rne(wv - bf16_f(hi));
               pk[((((size_t)b * 14 + (ks * 2 + mt) * 2 + 0) * 64) + lane) * 8 + q] = hi;
               pk[((((size_t)b * 14 + (ks * 2 + mt) * 2 + 1) * 64) + lane) * 8 + q] = lo;
             }
           for (int mt = 0; mt < 3; ++mt) {
-            const float wv = q >= 4 ? 0.f
-                                    : (mt == 0 ? w_res[((size_t)b * C + ch) * C + i] : w_skip[((size_t)b * C + ch) * S + (mt - 1) * 16 + i]);
+            float wv = q >= 4 ? 0.f
+                              : (mt == 0 ? (has_res[b] ? w_res[((size_t)b * C + ch) * C + i] : 0.f)
+                                         : w_skip[((size_t)b * C + ch) * S + (mt - 1) * 16 + i]);
+            if (q == 4 && kg == 0)  // bias slot (B = 1.0)
+              wv = mt == 0 ? (has_res[b] ? b_res[(size_t)b * C + i] : 0.f) : b_skip[(size_t)b * S + (mt - 1) * 16 + i];
             const uint16_t hi = bf16_rne(wv), lo = bf16_rne(wv - bf16_f(hi));
             pk[((((size_t)b * 14 + 8 + mt * 2 + 0) * 64) + lane) * 8 + q] = hi;
             pk[((((size_t)b * 14 + 8 + mt * 2 + 1) * 64) + lane) * 8 + q] = lo;
           }
         }
       }
-      for (int c = 0; c < 16; ++c) {
-        float *o = &bv7[(size_t)b * 7 * 16];
-        o[0 * 16 + c] = bn_s[(size_t)b * C + c];
-        o[1 * 16 + c] = bn_t[(size_t)b * C + c];
-        o[2 * 16 + c] = b_sig[(size_t)b * C + c];
-        o[3 * 16 + c] = b_tanh[(size_t)b * C + c];
-        o[4 * 16 + c] = b_res[(size_t)b * C + c];
-        o[5 * 16 + c] = b_skip[(size_t)b * S + c];
-        o[6 * 16 + c] = b_skip[(size_t)b * S + 16 + c];
-      }
     }
-    // one page per block: the operands, then the vectors (wavenet.hip: WV_PAGE_U4 16-byte units)
-    const size_t page_u16 = (size_t)14 * 64 * 8 + 7 * 16 * 2;
-    std::vector<uint16_t> pages((size_t)NB * page_u16);
-    for (int b = 0; b < NB; ++b) {
-      memcpy(&pages[b * page_u16], &pk[(size_t)b * 14 * 64 * 8], (size_t)14 * 64 * 8 * 2);
-      memcpy(&pages[b * page_u16 + (size_t)14 * 64 * 8], &bv7[(size_t)b * 7 * 16], (size_t)7 * 16 * 4);
-    }
-    v.wpk = upload(m, pages);
+    v.wpk = upload(m, pk);  // one page per block (wavenet.hip: WV_PAGE_U4 16-byte units)
     if (!v.wpk) return ww_fail(ctx, WW_ENOMEM, "Wavenet upload failed");
   }
   v.d_dil = upload(m, v.dil); v.d_has_res = upload(m, v.has_res);

@@ -165,8 +165,7 @@ __device__ __forceinline__ bf16x8 cat8(s16x4 first, s16x4 second) {
 }
 #define MFMA_BF(acc, av, bv) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc, 0, 0, 0)
 #define WV_SLOTS 14  // A-operand slots per block: gate (2 k-steps x {sig,tanh} x {hi,lo}) = 8, res | skip (3 m-tiles x {hi,lo}) = 6
-#define WV_BVEC 7    // per-channel vectors per block: bn_s, bn_t, b_sig, b_tanh, b_res, b_skip[0:16], b_skip[16:32]
-#define WV_PAGE_U4 (WV_SLOTS * 64 + WV_BVEC * 4)  // one block's parameter page in 16-byte units: operands, then vectors
+#define WV_PAGE_U4 (WV_SLOTS * 64)  // one block's parameter page in 16-byte units (the conv biases sit in padded k-slots)
 
 template <bool HEAD_ONLY, bool SPLIT_BF16>
 __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
@@ -324,7 +323,7 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
       ul[b * (WV_T + WV_PAD) * WV_C + o] = 0;
     }
     const int t0 = wave * 16;
-    // Block parameters (14 A-operand slots + 7 per-channel vectors = one 14.8 KB "page") are identical for
+    // Block parameters (14 A-operand slots = one 14 KB "page") are identical for
     // all 12 waves: the workgroup fetches page b+1 with one or two 16-byte loads per thread at the top of
     // block b, parks it in LDS at the end of the block (double buffered) and every wave reads its operands
     // from there.  (Per-wave register prefetch of the next page cost 1 us per block: the loads can only be
@@ -345,13 +344,11 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
     for (int blk = 0; blk < a.NB; ++blk) {
       const int boff = (blk & 1) * (WV_T + WV_PAD) * WV_C + WV_PAD * WV_C;      // row 0 of this block's u planes
       const int d = (int)((a.dil4[blk >> 4] >> (4 * (blk & 15))) & 15);
-      const int has_res = (a.has_res_mask >> blk) & 1;
       const int nblk = blk + 1 < a.NB ? blk + 1 : blk;                           // unconditional prefetch target
       const uint4 np0 = gpage[(size_t)nblk * WV_PAGE_U4 + tid], np1 = gpage[(size_t)nblk * WV_PAGE_U4 + pi1];
       __builtin_amdgcn_sched_barrier(0);  // keep the loads HERE (the scheduler would sink them to their use)
       const uint4 *pg = pages + (blk & 1) * WV_PAGE_U4;
       const bf16x8 *wsl = (const bf16x8 *)pg + lane;                             // slot q: wsl[q * 64]
-      const float4 *bvec = (const float4 *)(pg + WV_SLOTS * 64) + kk;           // vector v: bvec[v * 4] (rows 4 kk ..)
       const float4 bn_s = bnall[blk * 8 + kk], bn_t = bnall[blk * 8 + 4 + kk];
       // BatchNorm affine (wavenet_model.py:57): this tile's u = the undelayed tap's B operand
       const float uv[4] = {x[0][0] * bn_s.x + bn_t.x, x[0][1] * bn_s.y + bn_t.y, x[0][2] * bn_s.z + bn_t.z, x[0][3] * bn_s.w + bn_t.w};
@@ -366,8 +363,11 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
       const s16x4 u0h = *(const s16x4 *)(uh + orow - 2 * d * WV_C), u0l = *(const s16x4 *)(ul + orow - 2 * d * WV_C);
       f32x4 as = {0.f, 0.f, 0.f, 0.f}, at = {0.f, 0.f, 0.f, 0.f};
       // k-step 0 = (tap 2 | tap 1), k-step 1 = (tap 0 | zeros); slot = (kstep * 2 + {sig, tanh}) * 2 + {hi, lo}
+      // the zero half of k-step 1 carries the conv biases: k-slot 4 of lane group 0 is 1.0 in the hi operand
+      // (0 in the lo operand) and the host put (b_hi, b_lo) into that slot of the weight operands
       const s16x4 z4 = {0, 0, 0, 0};
-      const bf16x8 x0h = cat8(u2h, u1h), x0l = cat8(u2l, u1l), x1h = cat8(u0h, z4), x1l = cat8(u0l, z4);
+      const s16x4 one4 = {(short)(kk == 0 ? 0x3F80 : 0), 0, 0, 0};
+      const bf16x8 x0h = cat8(u2h, u1h), x0l = cat8(u2l, u1l), x1h = cat8(u0h, one4), x1l = cat8(u0l, z4);
       {
         const bf16x8 w0 = wsl[0 * 64], w1 = wsl[1 * 64], w2 = wsl[2 * 64], w3 = wsl[3 * 64];
         MFMA_BF(as, w0, x0h); MFMA_BF(at, w2, x0h);
@@ -378,29 +378,31 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
         MFMA_BF(as, w5, x1h); MFMA_BF(at, w7, x1h);
         MFMA_BF(as, w4, x1l); MFMA_BF(at, w6, x1l);
       }
-      const float4 bsig = bvec[2 * 4], btanh = bvec[3 * 4];
-      const float gv[4] = {fast_tanh_w(at[0] + btanh.x) * fast_sigmoid_w(as[0] + bsig.x),
-                           fast_tanh_w(at[1] + btanh.y) * fast_sigmoid_w(as[1] + bsig.y),
-                           fast_tanh_w(at[2] + btanh.z) * fast_sigmoid_w(as[2] + bsig.z),
-                           fast_tanh_w(at[3] + btanh.w) * fast_sigmoid_w(as[3] + bsig.w)};
+      // gate: tanh(t) * sigmoid(s), biases already inside the accumulators
+      float gv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float et = __builtin_amdgcn_exp2f(2.8853900817779268f * at[r]);    // exp(2 t): inf -> tanh 1, 0 -> -1
+        const float es = __builtin_amdgcn_exp2f(-1.4426950408889634f * as[r]);   // exp(-s)
+        gv[r] = (1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + et)) * __builtin_amdgcn_rcpf(1.0f + es);
+      }
       s16x4 g_h, g_l;
       split4(gv, g_h, g_l);  // the gate product is the res / skip conv's B operand as it stands
       f32x4 ar = {0.f, 0.f, 0.f, 0.f}, s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-      const bf16x8 gh8 = cat8(g_h, z4), gl8 = cat8(g_l, z4);
+      const bf16x8 gh8 = cat8(g_h, one4), gl8 = cat8(g_l, z4);
       {
         const bf16x8 r0 = wsl[8 * 64], r1 = wsl[9 * 64], r2 = wsl[10 * 64], r3 = wsl[11 * 64], r4 = wsl[12 * 64], r5 = wsl[13 * 64];
         MFMA_BF(ar, r0, gh8); MFMA_BF(s0, r2, gh8); MFMA_BF(s1, r4, gh8);
         MFMA_BF(ar, r1, gh8); MFMA_BF(s0, r3, gh8); MFMA_BF(s1, r5, gh8);
         MFMA_BF(ar, r0, gl8); MFMA_BF(s0, r2, gl8); MFMA_BF(s1, r4, gl8);
       }
-      const float4 bres = bvec[4 * 4], bsk0 = bvec[5 * 4], bsk1 = bvec[6 * 4];
-      const float br[4] = {bres.x, bres.y, bres.z, bres.w}, b0[4] = {bsk0.x, bsk0.y, bsk0.z, bsk0.w},
-                  b1[4] = {bsk1.x, bsk1.y, bsk1.z, bsk1.w};
+      // residual / skip update; biases ride in the MFMA, and a block without a residual conv has zero
+      // res weights and bias (relu(0) = 0), so no special case
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (has_res) x[0][r] = fmaxf(ar[r] + br[r], 0.f) + x[0][r];
-        skip[0][0][r] = skip[0][0][r] + fmaxf(s0[r] + b0[r], 0.f);
-        skip[0][1][r] = skip[0][1][r] + fmaxf(s1[r] + b1[r], 0.f);
+        x[0][r] = fmaxf(ar[r], 0.f) + x[0][r];
+        skip[0][0][r] = skip[0][0][r] + fmaxf(s0[r], 0.f);
+        skip[0][1][r] = skip[0][1][r] + fmaxf(s1[r], 0.f);
       }
       // park the next block's page (loaded a whole block ago); the barrier of the next block publishes it,
       // and every wave is past its reads of this buffer's previous page (two barriers back)
