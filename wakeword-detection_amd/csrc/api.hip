@@ -451,14 +451,13 @@ static int load_wave(ww_ctx *ctx, ww_model *m, const blob_view &bv) {
     v.wpk = upload(m, pk);  // one page per block (wavenet.hip: WV_PAGE_U4 16-byte units)
     if (!v.wpk) return ww_fail(ctx, WW_ENOMEM, "Wavenet upload failed");
   }
-  v.d_dil = upload(m, v.dil); v.d_has_res = upload(m, v.has_res);
   v.w_in = upload(m, in4); v.b_in = upload(m, std::vector<float>(b_in, b_in + C));
   v.bn_s = upload(m, std::vector<float>(bn_s, bn_s + (size_t)NB * C));
   v.bn_t = upload(m, std::vector<float>(bn_t, bn_t + (size_t)NB * C));
   v.w_gate = upload(m, g4); v.b_gate = upload(m, bg); v.w_rs = upload(m, rs4); v.b_rs = upload(m, brs);
   v.d_w1 = upload(m, d1); v.d_b1 = upload(m, std::vector<float>(db1, db1 + S));
   v.d_w2 = upload(m, d2); v.d_b2 = upload(m, d2b);
-  if (!v.d_dil || !v.d_has_res || !v.w_in || !v.b_in || !v.bn_s || !v.bn_t || !v.w_gate || !v.b_gate || !v.w_rs ||
+  if (!v.w_in || !v.b_in || !v.bn_s || !v.bn_t || !v.w_gate || !v.b_gate || !v.w_rs ||
       !v.b_rs || !v.d_w1 || !v.d_b1 || !v.d_w2 || !v.d_b2)
     return ww_fail(ctx, WW_ENOMEM, "Wavenet upload failed");
   m->info.window = v.T; m->info.n_out = v.NOUT; m->info.enc_rows = v.T; m->info.enc_width = S;

@@ -104,7 +104,6 @@ struct ww_crnn_dev {
 struct ww_wave_dev {
   int T, n_mel, C, S, NB, NOUT;
   std::vector<int> dil, order, has_res;
-  int *d_dil = nullptr, *d_has_res = nullptr;
   float *w_in = nullptr, *b_in = nullptr;          // [n_mel][C], [C]
   float *bn_s = nullptr, *bn_t = nullptr;          // [NB][C]
   float *w_gate = nullptr, *b_gate = nullptr;      // [NB][3*C][2C] (cols: sig 0..C-1, tanh C..2C-1), [NB][2C]

@@ -3,14 +3,20 @@
 // Replaces the reference's per-sample RingBuffer loop, np.fft.rfft and the filter.tflite
 // invoke (utils/tf_lite/filter.py:38-75; spokestack/wakeword/tflite.py:148-191).
 //
-// Kernel shape: one 256-thread workgroup (4 wavefronts) owns FPB consecutive frames of one
-// utterance.  The 512+(FPB-1)*160 samples those frames touch are loaded ONCE with aligned
-// 16-byte loads, normalised / clipped / pre-emphasised in registers and parked in LDS as
-// fp32.  Every frame is then produced by one wavefront (fft_device.h): Hann product (fp64) +
-// 256-point complex radix-4 Stockham FFT + untangling pass + |.|, then the banded mel filter
-// with one lane per band (weights zero-padded to the longest band and stored tap-major in LDS,
-// so the 36-tap loop is fully unrolled and conflict-free) and the log/affine tail.  The
-// FPBx40 mel tile leaves through LDS as one contiguous coalesced store.
+// Kernel shape: one 256-thread workgroup (4 wavefronts) owns FPB = 16 consecutive frames of one
+// utterance.  The 512 + 15*160 samples those frames touch are loaded ONCE with aligned 16-byte
+// loads (straight-line: every load of the block is in flight before the first wait), normalised /
+// clipped / pre-emphasised in registers and parked in LDS as fp32.  Each wavefront then transforms
+// four frames at once, 16 lanes per frame and 16 points per lane: Hann product (fp64), a radix-16
+// DFT in registers, twiddles, one 16x16 transpose through LDS (real parts, then imaginary parts,
+// same buffer), a second radix-16 DFT - the 256-point complex FFT of the even/odd-packed frame -
+// and the real-FFT untangling, for which lane j fetches its partner Z[256-k] (lane (16-j)%16)
+// through the dead transpose buffer; two magnitudes per evaluation land in LDS.  The mel filter
+// is an MFMA contraction over the block's 16 frames (v_mfma_f32_16x16x4_f32, only the 16-bin blocks
+// that hold non-zero weights, dealt to the four waves, partial sums joined in LDS), then the
+// log/affine tail, and the 16x40 tile leaves through LDS as one contiguous coalesced store.
+// (stft_mag_kernel and the streaming kernel keep the earlier one-wave-per-frame radix-4 Stockham
+// FFT of fft_device.h: they are not on the batched path.)
 //
 // REAL = double reproduces the reference numerics (Hann product and FFT in float64,
 // spokestack/wakeword/tflite.py:175-176, result cast to float32); REAL = float is the fast mode.

@@ -6,20 +6,27 @@
 //
 // A 768-thread workgroup (12 wavefronts, 3 per SIMD) walks all 24 gated residual blocks of one
 // 182x40 window without leaving the CU.  Time is the MFMA M dimension: 182 -> 12 tiles of 16
-// rows, one tile per wave, so three waves share each SIMD's matrix pipe and cover each other's
-// LDS round trips (4 waves x 3 tiles measured 10 % slower).
-// The residual stream x[182][16] and the skip accumulator [182][32] never leave registers:
-// they sit in the v_mfma_f32_16x16x4_f32 accumulator layout (lane -> column, 4 rows per
-// register quad), which is also the layout the next block's epilogue needs.  Only the
-// BatchNorm output u (which the dilated taps of OTHER rows read) and the gate product g
-// (D-layout -> A-layout transpose) go through LDS:
+// rows, one tile per wave.  Two arithmetic modes (ww_model_set_precision):
+//
+// fp32 (default): v_mfma_f32_16x16x4_f32.  The residual stream x[182][16] and the skip accumulator
+// [182][32] never leave registers: they sit in the accumulator layout (lane -> column, 4 rows per
+// register quad), which is also the layout the next block's epilogue needs.  Only the BatchNorm
+// output u (which the dilated taps of OTHER rows read) and the gate product g (D-layout ->
+// A-layout transpose) go through LDS:
 //     u = x*s + t                      -> LDS (double buffered, 16 zero rows in front = causal pad)
 //     [sig|tanh] = u[t-(2-k)d] * Wg    3 taps x 16 ch = K 48, N 32     24 MFMA / 16 rows
 //     g = tanh(.)*sigmoid(.)           -> LDS (wave-private tile)
 //     [res|skip] = g * Wrs             K 16, N 48                      12 MFMA / 16 rows
 //     x += relu(res); skip += relu(skip_b)
-// One __syncthreads per block.  The detect head (ReLU, 1x1 32->32 ReLU, 1x1 32->2, max over
-// time, softmax) runs in the same launch.
+// One __syncthreads per block.  On gfx950 the fp32 MFMA shares the SIMD's fp32 datapath with the
+// vector ALU, so MFMA and VALU time add up (ablations: dropping the 24 gate MFMAs saves exactly their
+// 21.7 us of 77; dropping the gate transcendentals or the barrier saves < 1 us; hand-interleaving
+// VALU into one wave's MFMA gaps made it slower): the kernel runs at ~86 % of that sum.
+//
+// split-bf16 ("bf16x3"): see the block before the kernel - transposed block loop on
+// v_mfma_f32_16x16x32_bf16, operands straight from registers, parameters through LDS pages.
+//
+// The detect head (ReLU, 1x1 32->32 ReLU, 1x1 32->2, max over time, softmax) runs in the same launch.
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
