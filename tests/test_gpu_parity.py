@@ -304,3 +304,27 @@ def test_full_config_batch_invariance_and_spot_parity(assets, oracles, name, pre
             assert np.abs(full[i] - oracles[name].forward(win)[0]).max() < tol
     finally:
         e.close()
+
+
+def test_logmel_parameter_sweep_vs_oracle(engines, oracles):
+    """Both staging paths of the front end (straight-line: no pre-emphasis, divisor 32767/32768; generic:
+    everything else), several hops, ragged lengths incl. ones that end inside a 16-byte vector."""
+    from wwhip.engine import frontend_params
+    rng = np.random.default_rng(57)
+    e, o = engines["CRNN"], oracles["CRNN"]
+    lens = [512, 527, 1000, 5003, 24000, 7, 24001, 16384]
+    pcm = [np.clip(rng.normal(0, 4000, n), -32768, 32767).astype(np.int16) for n in lens]
+    pcm[3][:40] = 32767      # clipping region for divisor 32767 is a no-op, for 30000 it is not
+    cases = [(32767.0, True, 0.0, 160), (32768.0, False, 0.0, 160), (32767.0, True, 0.97, 160), (30000.0, True, 0.0, 160),
+             (32768.0, False, 0.5, 80), (32767.0, False, 0.0, 200), (32767.0, True, 0.0, 512), (1000.0, True, 0.3, 37)]
+    for div, clip, pre, hop in cases:
+        got = e.logmel(pcm, frontend_params(div, clip, pre, hop, True))
+        for n, p, g in zip(lens, pcm, got):
+            want = o.logmel(p, divisor=div, clip=clip, preemph=pre, hop=hop)
+            assert g.shape == want.shape, (div, clip, pre, hop, n)
+            if len(want):
+                assert np.abs(g - want).max() < 2e-5, (div, clip, pre, hop, n, float(np.abs(g - want).max()))
+    with pytest.raises(ValueError):
+        e.logmel(pcm, frontend_params(32767.0, True, 0.0, 0, True))
+    with pytest.raises(ValueError):
+        e.logmel(pcm, frontend_params(32767.0, True, 0.0, 513, True))
