@@ -180,7 +180,7 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
   // split-bf16: u planes (same bytes as the fp32 u buffers) + two parameter pages (next to / under the head's tile)
   constexpr int LDS_FP32 = WV_T * WV_INLD > (2 * (WV_T + WV_PAD) * WV_C + WV_T * WV_S) ? WV_T * WV_INLD
                                                                                        : (2 * (WV_T + WV_PAD) * WV_C + WV_T * WV_S);
-  constexpr int LDS_BF16 = 2 * (WV_T + WV_PAD) * WV_C + 2 * WV_PAGE_U4 * 4 + 32 * 8 * 4;  // + BatchNorm table (NB <= 32)
+  constexpr int LDS_BF16 = 2 * (WV_T + WV_PAD) * WV_C + 3 * WV_PAGE_U4 * 4 + 32 * 8 * 4;  // u planes + 3 pages + BatchNorm table (NB <= 32)
   __shared__ __align__(16) float lds[SPLIT_BF16 && LDS_BF16 > LDS_FP32 ? LDS_BF16 : LDS_FP32];
   __shared__ float red[WV_NW][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -330,32 +330,46 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
       ul[b * (WV_T + WV_PAD) * WV_C + o] = 0;
     }
     const int t0 = wave * 16;
-    // Block parameters (14 A-operand slots = one 14 KB "page") are identical for
-    // all 12 waves: the workgroup fetches page b+1 with one or two 16-byte loads per thread at the top of
-    // block b, parks it in LDS at the end of the block (double buffered) and every wave reads its operands
-    // from there.  (Per-wave register prefetch of the next page cost 1 us per block: the loads can only be
-    // issued once the registers are free, i.e. late, and the first MFMA of the next block then waits for L2.)
-    uint4 *pages = (uint4 *)(lds + 2 * (WV_T + WV_PAD) * WV_C);                  // [2][WV_PAGE_U4]
+    // Block parameters (14 A-operand slots = one 14 KB "page") are identical for all 12 waves: the workgroup
+    // fetches page b+2 with one or two 16-byte loads per thread at the top of block b and parks it in LDS at
+    // the end of the block (three buffers).  The barrier of block b+1 publishes it, so in block b+2 every
+    // wave may read its operands BEFORE that block's barrier - their LDS latency and the burst of 12 waves
+    // reading 14 KB each hide behind the BatchNorm / split / barrier part of the block.  (Per-wave register
+    // prefetch cost 1 us per block: the loads can only be issued once the registers are free, i.e. late;
+    // double-buffered pages read after the barrier left ~1000 cycles of operand reads on the critical path.)
+    uint4 *pages = (uint4 *)(lds + 2 * (WV_T + WV_PAD) * WV_C);                  // [3][WV_PAGE_U4]
     const uint4 *gpage = a.wpk;
     const int pi1 = tid + WV_THREADS < WV_PAGE_U4 ? tid + WV_THREADS : WV_PAGE_U4 - 1;
-    pages[tid] = gpage[tid];
-    if (tid + WV_THREADS < WV_PAGE_U4) pages[tid + WV_THREADS] = gpage[pi1];
+    {
+      const int second = a.NB > 1 ? 1 : 0;
+      pages[tid] = gpage[tid];
+      pages[WV_PAGE_U4 + tid] = gpage[(size_t)second * WV_PAGE_U4 + tid];
+      if (tid + WV_THREADS < WV_PAGE_U4) {
+        pages[tid + WV_THREADS] = gpage[pi1];
+        pages[WV_PAGE_U4 + tid + WV_THREADS] = gpage[(size_t)second * WV_PAGE_U4 + pi1];
+      }
+    }
     // The BatchNorm vectors are needed BEFORE a block's barrier (they produce u), i.e. before that block's
     // page is published: all blocks' copies live in their own small table, filled once.
-    float4 *bnall = (float4 *)(pages + 2 * WV_PAGE_U4);                           // [NB][2][4] float4 = scale, shift
+    float4 *bnall = (float4 *)(pages + 3 * WV_PAGE_U4);                           // [NB][2][4] float4 = scale, shift
     for (int i = tid; i < a.NB * 8; i += WV_THREADS) {
       const int b = i >> 3, v = (i >> 2) & 1, q = i & 3;
       bnall[i] = *(const float4 *)((v ? a.bn_t : a.bn_s) + b * WV_C + 4 * q);
     }
     __syncthreads();
+    int pbuf = 0;  // blk % 3
     for (int blk = 0; blk < a.NB; ++blk) {
       const int boff = (blk & 1) * (WV_T + WV_PAD) * WV_C + WV_PAD * WV_C;      // row 0 of this block's u planes
       const int d = (int)((a.dil4[blk >> 4] >> (4 * (blk & 15))) & 15);
-      const int nblk = blk + 1 < a.NB ? blk + 1 : blk;                           // unconditional prefetch target
+      const int nblk = blk + 2 < a.NB ? blk + 2 : a.NB - 1;                      // unconditional prefetch target
       const uint4 np0 = gpage[(size_t)nblk * WV_PAGE_U4 + tid], np1 = gpage[(size_t)nblk * WV_PAGE_U4 + pi1];
       __builtin_amdgcn_sched_barrier(0);  // keep the loads HERE (the scheduler would sink them to their use)
-      const uint4 *pg = pages + (blk & 1) * WV_PAGE_U4;
+      const uint4 *pg = pages + pbuf * WV_PAGE_U4;
       const bf16x8 *wsl = (const bf16x8 *)pg + lane;                             // slot q: wsl[q * 64]
+      // this block's operands (published one barrier ago): issued now, consumed after the barrier
+      const bf16x8 w0 = wsl[0 * 64], w1 = wsl[1 * 64], w2 = wsl[2 * 64], w3 = wsl[3 * 64];
+      const bf16x8 w4 = wsl[4 * 64], w5 = wsl[5 * 64], w6 = wsl[6 * 64], w7 = wsl[7 * 64];
+      const bf16x8 r0 = wsl[8 * 64], r1 = wsl[9 * 64], r2 = wsl[10 * 64], r3 = wsl[11 * 64], r4 = wsl[12 * 64], r5 = wsl[13 * 64];
       const float4 bn_s = bnall[blk * 8 + kk], bn_t = bnall[blk * 8 + 4 + kk];
       // BatchNorm affine (wavenet_model.py:57): this tile's u = the undelayed tap's B operand
       const float uv[4] = {x[0][0] * bn_s.x + bn_t.x, x[0][1] * bn_s.y + bn_t.y, x[0][2] * bn_s.z + bn_t.z, x[0][3] * bn_s.w + bn_t.w};
@@ -376,11 +390,9 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
       const s16x4 one4 = {(short)(kk == 0 ? 0x3F80 : 0), 0, 0, 0};
       const bf16x8 x0h = cat8(u2h, u1h), x0l = cat8(u2l, u1l), x1h = cat8(u0h, one4), x1l = cat8(u0l, z4);
       {
-        const bf16x8 w0 = wsl[0 * 64], w1 = wsl[1 * 64], w2 = wsl[2 * 64], w3 = wsl[3 * 64];
         MFMA_BF(as, w0, x0h); MFMA_BF(at, w2, x0h);
         MFMA_BF(as, w1, x0h); MFMA_BF(at, w3, x0h);
         MFMA_BF(as, w0, x0l); MFMA_BF(at, w2, x0l);
-        const bf16x8 w4 = wsl[4 * 64], w5 = wsl[5 * 64], w6 = wsl[6 * 64], w7 = wsl[7 * 64];
         MFMA_BF(as, w4, x1h); MFMA_BF(at, w6, x1h);
         MFMA_BF(as, w5, x1h); MFMA_BF(at, w7, x1h);
         MFMA_BF(as, w4, x1l); MFMA_BF(at, w6, x1l);
@@ -398,7 +410,6 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
       f32x4 ar = {0.f, 0.f, 0.f, 0.f}, s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
       const bf16x8 gh8 = cat8(g_h, one4), gl8 = cat8(g_l, z4);
       {
-        const bf16x8 r0 = wsl[8 * 64], r1 = wsl[9 * 64], r2 = wsl[10 * 64], r3 = wsl[11 * 64], r4 = wsl[12 * 64], r5 = wsl[13 * 64];
         MFMA_BF(ar, r0, gh8); MFMA_BF(s0, r2, gh8); MFMA_BF(s1, r4, gh8);
         MFMA_BF(ar, r1, gh8); MFMA_BF(s0, r3, gh8); MFMA_BF(s1, r5, gh8);
         MFMA_BF(ar, r0, gl8); MFMA_BF(s0, r2, gl8); MFMA_BF(s1, r4, gl8);
@@ -411,11 +422,13 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
         skip[0][0][r] = skip[0][0][r] + fmaxf(s0[r], 0.f);
         skip[0][1][r] = skip[0][1][r] + fmaxf(s1[r], 0.f);
       }
-      // park the next block's page (loaded a whole block ago); the barrier of the next block publishes it,
-      // and every wave is past its reads of this buffer's previous page (two barriers back)
-      uint4 *pn = pages + ((blk + 1) & 1) * WV_PAGE_U4;
+      // park page blk+2 (loaded a whole block ago) in the buffer that held page blk-1: every wave is past its
+      // reads of that one (they precede the barrier of block blk, which everyone here has passed)
+      const int nbuf = pbuf == 0 ? 2 : pbuf - 1;  // (blk + 2) % 3
+      uint4 *pn = pages + nbuf * WV_PAGE_U4;
       pn[tid] = np0;
       if (tid + WV_THREADS < WV_PAGE_U4) pn[tid + WV_THREADS] = np1;
+      pbuf = pbuf == 2 ? 0 : pbuf + 1;
     }
     __syncthreads();
   }
