@@ -599,6 +599,7 @@ int ww_logmel_dev(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, const in
   if (((uintptr_t)d_pcm & 15) != 0) return ww_fail(ctx, WW_EINVAL, "d_pcm must be 16-byte aligned");
   int rc = check_fp(ctx, fp, true);
   if (rc) return rc;
+  ww_device_scope dev(ctx->device);
   return ww_k_logmel(ctx, m, d_pcm, nullptr, d_sample_offs, d_frame_offs, n_utt, total_frames, max_frames_per_utt, fp, d_mel);
 }
 
@@ -756,6 +757,7 @@ int ww_forward_windows_dev(ww_ctx *ctx, const ww_model *m, const float *d_mel, i
   if (nw < 0) return ww_fail(ctx, WW_EINVAL, "negative window count");
   if (nw == 0) return WW_OK;
   if (!d_win_row || !d_win_valid) return ww_fail(ctx, WW_EINVAL, "window descriptors are NULL");
+  ww_device_scope dev(ctx->device);
   const int NO = m->info.n_out;
   const int chunk = nw < WW_MAX_CHUNK ? nw : WW_MAX_CHUNK;
   int rc = ww_ensure(ctx, ctx->dev, model_ws(m, chunk) + 1024, false);
@@ -778,6 +780,7 @@ int ww_clips_forward_dev(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, i
   if (((uintptr_t)d_pcm & 15) != 0) return ww_fail(ctx, WW_EINVAL, "d_pcm must be 16-byte aligned");
   int rc = check_fp(ctx, fp, true);
   if (rc) return rc;
+  ww_device_scope dev(ctx->device);
   const int64_t nf = ww_num_frames(samples, fp->hop);
   const int F = m->info.n_mel, T = m->info.window;
   // offset tables for this batch geometry: built once, outside any capture

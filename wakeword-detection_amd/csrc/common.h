@@ -134,6 +134,19 @@ int ww_ensure(ww_ctx *ctx, ww_arena &a, size_t bytes, bool pinned);
       return ww_fail((ctx), WW_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
+// The device-pointer entry points enqueue on the context's stream without touching the caller's
+// current device (the caller may be a framework that tracks it): switch only if needed, and restore.
+struct ww_device_scope {
+  int prev = -1;
+  bool changed = false;
+  explicit ww_device_scope(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) changed = hipSetDevice(dev) == hipSuccess;
+  }
+  ~ww_device_scope() {
+    if (changed) (void)hipSetDevice(prev);
+  }
+};
+
 // Bracket a kernel launch with profiling events when enabled.
 struct ww_launch_scope {
   ww_ctx *ctx;
