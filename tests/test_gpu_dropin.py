@@ -346,3 +346,38 @@ def test_superframe_smoothing_matches_the_reference_lattice(assets):
     det = wfst.SuperframeDetector(10)
     fired = [det.push(x[1]) for x in t1]
     assert fired == [False] * 9 + [True]
+
+
+def test_evaluator_command_line_flow(assets, tmp_path):
+    """tools/evaluate_models.py = utils/evaluate_models.py main(): test.json -> concatenated negative wav ->
+    cached posteriors -> FRR / FA-per-hour; second run must come from the pickle caches."""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    data = tmp_path / "snips"
+    (data / "audio_files").mkdir(parents=True)
+    rng = np.random.default_rng(23)
+    meta = []
+    for i in range(6):
+        pcm = np.clip(rng.normal(0, 2500, int(rng.integers(30000, 42000))), -32768, 32767).astype(np.int16)
+        _write_wav(str(data / "audio_files" / f"c{i}.wav"), pcm)
+        meta.append({"audio_file_path": f"audio_files/c{i}.wav", "is_hotword": int(i < 2), "worker_id": "w"})
+    (data / "test.json").write_text(json.dumps(meta))
+    models = tmp_path / "models"
+    shutil.copytree(os.path.join(assets, "CRNN_softmax"), models)
+    cmd = [sys.executable, os.path.join(root, "tools", "evaluate_models.py"), "--model_type", "CRNN", "--models_dir", str(models) + "/",
+           "--data_dir", str(data) + "/", "--eval_dir", str(tmp_path / "evaluation") + "/"]
+    out1 = json.loads(subprocess.run(cmd, capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
+    assert out1["num_wakewords"] == 2 and len(out1["FRR"]) == 100 and len(out1["FA_per_hour"]) == 100
+    assert all(0.0 <= v <= 1.0 for v in out1["FRR"])
+    far = tmp_path / "evaluation" / "not_hey_snips_long.wav"
+    assert far.exists() and (models / "CRNN_all_wakeword.pkl").exists() and (models / "CRNN_no_wakeword.pkl").exists()
+    # the negative wav holds the first num_wakewords (= 2) negative clips joined by 100 ms of silence
+    from wwhip.evaluate import read_wav
+    n_expect = sum(len(read_wav(str(data / "audio_files" / f"c{i}.wav"))) for i in (2, 3)) + 1600
+    assert len(read_wav(str(far))) == n_expect
+    assert abs(out1["fa_hours"] - n_expect / 16000 / 3600) < 1e-12
+    out2 = json.loads(subprocess.run(cmd, capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
+    assert out2 == out1

@@ -269,3 +269,85 @@ def evaluate_testset(engine: Engine, clips: Sequence[np.ndarray], labels: Sequen
     return {"thresholds": thr, "frr": frr, "fa_per_hour": fa, "fa_count": cnt, "frr_at_0.5_fa_per_hour": frr_at_fa(frr, fa, 0.5),
             "one_window_posteriors": p_one, "one_window_accuracy": float((preds == labels).mean()),
             "positives": pos, "negatives": neg, "hours": hours}
+
+
+# ----------------------------------------------------------------------------------------------
+# The evaluator script's own helpers (utils/evaluate_models.py:138-181, 183-253, 281-326), so that
+# tools/evaluate_models.py is the reference's command line on the HIP path.
+# ----------------------------------------------------------------------------------------------
+def testset_files(base_path: str):
+    """``test.json`` of a Hey-Snips style directory -> (wakeword wavs, other wavs) (``:138-147``)."""
+    import json
+    with open(base_path + "test.json", "r") as f:
+        test_data = json.load(f)
+    wake = [base_path + p["audio_file_path"] for p in test_data if p["is_hotword"]]
+    other = [base_path + p["audio_file_path"] for p in test_data if not p["is_hotword"]]
+    return wake, other
+
+
+def concatenate_FA(wav_paths: Sequence[str], num_files: int, FAR_path: str, sample_rate: int = 16000) -> None:
+    """One long negative wav: the first ``num_files`` clips joined by 100 ms of silence (``:150-160``;
+    the reference uses pydub, here the PCM16 payloads are concatenated directly)."""
+    gap = np.zeros(sample_rate // 10, np.int16)
+    parts: List[np.ndarray] = []
+    for i, path in enumerate(wav_paths[:max(num_files, 1)]):
+        with wave.open(path, "rb") as w:
+            if w.getsampwidth() != 2 or w.getnchannels() != 1 or w.getframerate() != sample_rate:
+                raise ValueError(f"{path}: expected mono PCM16 at {sample_rate} Hz")
+            pcm = np.frombuffer(w.readframes(w.getnframes()), np.int16)
+        if i:
+            parts.append(gap)
+        parts.append(pcm)
+    with wave.open(str(FAR_path), "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(sample_rate)
+        w.writeframes(np.concatenate(parts).tobytes() if parts else b"")
+
+
+def duration_test(FAR_path: str, sample_rate: int) -> float:
+    """Duration in seconds of the negative evaluation wav (``:178-181``)."""
+    return len(read_wav(str(FAR_path), sample_rate)) / sample_rate
+
+
+def load_posteriors(models_dir, model_type, frame_width, sample_rate, eval_type, input_path, out_path, examine_audio=False):
+    """Pickle-cached :func:`get_posterior` (``:163-175``)."""
+    import os
+    import pickle
+    if os.path.exists(str(out_path)):
+        with open(str(out_path), "rb") as f:
+            posteriors = pickle.load(f)
+    else:
+        posteriors = get_posterior(models_dir, model_type, eval_type, input_path, frame_width, sample_rate, examine_audio)
+        with open(str(out_path), "wb") as f:
+            pickle.dump(posteriors, f)
+    return np.squeeze(np.array(posteriors))
+
+
+def plot_FRR_FAR(keyword_posteriors, no_keyword_posteriors, num_wakewords, total_duration_hrs, model_type,
+                 models_dir: Optional[str] = None, show: bool = False) -> dict:
+    """The curves ``plot_FRR_FAR`` draws (``:183-253``), returned as arrays (+ the BASELINE metric); they are
+    drawn with matplotlib only when ``show`` is set and matplotlib is importable."""
+    thr, frr, fa, cnt = far_frr(np.atleast_1d(keyword_posteriors), np.atleast_1d(no_keyword_posteriors), num_wakewords,
+                                total_duration_hrs, models_dir=models_dir)
+    out = {"model_type": model_type, "thresholds": thr, "FRR": frr, "FAR": fa, "FA_count": cnt,
+           "frr_at_0.5_fa_per_hour": frr_at_fa(frr, fa, 0.5)}
+    if show:  # pragma: no cover - interactive
+        try:
+            import matplotlib.pyplot as plt
+        except ImportError:
+            return out
+        for x, y, xl, yl in ((thr, frr, "Posterior Threshold", "False Rejection Rate"),
+                             (thr, fa, "Posterior Threshold", "False Accepts per Hour"),
+                             (fa, frr, "False Alarms per Hour", "False Rejection Rate")):
+            fig, ax = plt.subplots(1, 1)
+            ax.set_facecolor("lightgray")
+            plt.plot(x, y, label=model_type)
+            plt.xlabel(xl)
+            plt.ylabel(yl)
+            plt.grid(color="white")
+            plt.legend()
+            plt.tight_layout()
+            plt.show()
+            plt.close()
+    return out
