@@ -381,3 +381,63 @@ def test_evaluator_command_line_flow(assets, tmp_path):
     assert abs(out1["fa_hours"] - n_expect / 16000 / 3600) < 1e-12
     out2 = json.loads(subprocess.run(cmd, capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
     assert out2 == out1
+
+
+def test_fp16_weight_variant_and_opts_script(assets, tmp_path):
+    """the float16-quantised model variant (constants rounded to fp16, fp32 arithmetic) and
+    tools/evaluate_tf_lite_opts.py (= utils/evaluate_tf_lite_opts.py main) over an H5 test set."""
+    import json
+    import subprocess
+    import sys
+    from wwhip import h5min, weights
+    from wwhip.engine import Engine
+    from oracle.cpu import CpuOracle
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(31)
+    for name in ("CRNN_softmax", "Wavenet"):
+        e = Engine(os.path.join(assets, name), weights_fp16=True)
+        ora = CpuOracle(weights.pack_blob(weights.quantize_fp16(weights.load_model_dir(os.path.join(assets, name)))))
+        ref32 = CpuOracle(weights.pack_blob(weights.load_model_dir(os.path.join(assets, name))))
+        wins = rng.uniform(0, 6.5, (12, e.window, 40)).astype(np.float32)
+        got = e.forward(wins)
+        assert np.abs(got - ora.forward(wins)).max() < TOL
+        d = np.abs(got - ref32.forward(wins)).max()
+        assert 1e-7 < d < 5e-2      # a different model (fp16 constants), but a close one
+        e.close()
+    # H5 test set -> the script
+    clips = {f"clip{i:03d}": (rng.uniform(0, 6.5, (int(rng.integers(60, 220)), 40)).astype(np.float32),
+                              {"is_hotword": int(i % 3 == 0), "speaker": i % 5, "speech_start_ts": -1, "speech_end_ts": -1})
+             for i in range(40)}
+    (tmp_path / "ds").mkdir()
+    h5min.write_datasets(str(tmp_path / "ds" / "test.h5"), clips)
+    import shutil
+    models = tmp_path / "models"
+    shutil.copytree(os.path.join(assets, "CRNN_softmax"), models)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "evaluate_tf_lite_opts.py"), "--tf_models_dir", str(models),
+                        "--dataset_dir", str(tmp_path / "ds"), "--testset", "test.h5", "--model_type", "CRNN"],
+                       capture_output=True, text=True, check=True)
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    for k in ("float32", "float16"):
+        m = res[k]
+        assert m["true_negative"] + m["false_positive"] + m["true_positive"] + m["false_negative"] == 40
+    assert (models / "tf_lite_results.npy").exists()
+    # expected float32 predictions straight from the engine
+    from wwhip.evaluate import load_h5, models_predict
+    X, y = load_h5(str(tmp_path / "ds" / "test.h5"), 151, 40)
+    e = Engine(os.path.join(assets, "CRNN_softmax"))
+    preds, _ = models_predict(e, X)
+    e.close()
+    assert res["float32"]["true_positive"] == int(((np.array(preds) == 1) & (y == 1)).sum())
+
+
+def test_demo_pipeline_on_a_wav(assets, tmp_path):
+    """tools/demo.py: the reference's demo.py stage list (VAD, wake word, activation timeout) over a wav."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(2)
+    pcm = np.clip(rng.normal(0, 3000, 48000), -32768, 32767).astype(np.int16)
+    _write_wav(str(tmp_path / "in.wav"), pcm)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "demo.py"), "--models_dir", os.path.join(assets, "Wavenet"),
+                        "--model_type", "Wavenet", "--wav", str(tmp_path / "in.wav")], capture_output=True, text=True, check=True)
+    assert "wake events at (s):" in r.stdout and "Script completed" in r.stdout

@@ -24,8 +24,10 @@ class Engine:
     """A model directory (filter/encode/detect ``.tflite``) resident on one MI355X."""
 
     def __init__(self, model_dir: str, device: int = 0, ctx: Optional[_lib.Context] = None,
-                 precision: str = "fp32") -> None:
+                 precision: str = "fp32", weights_fp16: bool = False) -> None:
         self.bundle = W.load_model_dir(model_dir)
+        if weights_fp16:  # the reference's float16-quantised model variant (weights.quantize_fp16)
+            self.bundle = W.quantize_fp16(self.bundle)
         self.blob = W.pack_blob(self.bundle)
         self.ctx = ctx if ctx is not None else _lib.default_context(device)
         self._lib = _lib.load()

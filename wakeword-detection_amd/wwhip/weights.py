@@ -564,6 +564,33 @@ def load_model_dir(model_dir: str) -> ModelBundle:
     return b
 
 
+def quantize_fp16(bundle: ModelBundle) -> ModelBundle:
+    """The float16 post-training-quantised variant the reference also builds and evaluates
+    (``wwdetect/CRNN/model.py:165-179``, ``wavenet_model.py:149-163``: ``supported_types = [tf.float16]``;
+    compared in ``utils/evaluate_tf_lite_opts.py:107-125``): every constant of encode / detect is stored as
+    float16 and dequantised to float32 when the model is loaded - the arithmetic stays float32.  The
+    ``-quant.tflite`` files are not shipped, so the same rounding is applied to the extracted constants here
+    (filter.tflite is a separate, unquantised graph and is left alone)."""
+    import copy
+    import dataclasses
+
+    def rnd(obj):
+        if isinstance(obj, np.ndarray) and obj.dtype == np.float32:
+            return obj.astype(np.float16).astype(np.float32)
+        if dataclasses.is_dataclass(obj) and not isinstance(obj, type):
+            return dataclasses.replace(obj, **{f.name: rnd(getattr(obj, f.name)) for f in dataclasses.fields(obj)})
+        if isinstance(obj, tuple):
+            return tuple(rnd(x) for x in obj)
+        if isinstance(obj, list):
+            return [rnd(x) for x in obj]
+        return obj
+
+    out = copy.copy(bundle)
+    out.crnn = rnd(bundle.crnn) if bundle.crnn is not None else None
+    out.wavenet = rnd(bundle.wavenet) if bundle.wavenet is not None else None
+    return out
+
+
 def _sections(bundle: ModelBundle) -> List[Tuple[str, np.ndarray]]:
     f = bundle.filt
     sec: List[Tuple[str, np.ndarray]] = [
