@@ -328,3 +328,35 @@ def test_logmel_parameter_sweep_vs_oracle(engines, oracles):
         e.logmel(pcm, frontend_params(32767.0, True, 0.0, 0, True))
     with pytest.raises(ValueError):
         e.logmel(pcm, frontend_params(32767.0, True, 0.0, 513, True))
+
+
+@pytest.mark.parametrize("name", ["CRNN", "Wavenet"])
+def test_stream_bank_at_config5_width(engines, oracles, name):
+    """BASELINE config 5 geometry on one GPU: 128 streams in lock step (every CU busy), mixed speech flags;
+    a sample of streams is checked posterior by posterior against the batch oracle, and two runs must agree."""
+    from wwhip.engine import StreamBank
+    rng = np.random.default_rng(43)
+    e = engines[name]
+    S, ticks = 128, 100
+    pcm = np.clip(rng.normal(0, 2500, (S, ticks * 320)), -32768, 32767).astype(np.int16)
+
+    def run():
+        bank = StreamBank(e, S)
+        posts = [[] for _ in range(S)]
+        speech = np.ones(S, np.uint8)
+        for t in range(ticks):
+            p, n = bank.step(pcm[:, t * 320:(t + 1) * 320], speech)
+            for s in range(S):
+                posts[s] += [float(p[s, k]) for k in range(n[s])]
+        bank.close()
+        return posts
+
+    a, b = run(), run()
+    assert a == b
+    pidx = e.posterior_index
+    for s in rng.choice(S, 5, replace=False):
+        mel = oracles[name].logmel(pcm[s])
+        hist = np.concatenate([np.zeros((e.window, 40), np.float32), mel])
+        want = oracles[name].slide_forward(hist, 1)[1:, pidx]
+        assert len(a[s]) == len(want)
+        assert np.abs(np.array(a[s]) - want).max() < TOL_POST
