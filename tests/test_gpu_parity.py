@@ -360,3 +360,34 @@ def test_stream_bank_at_config5_width(engines, oracles, name):
         want = oracles[name].slide_forward(hist, 1)[1:, pidx]
         assert len(a[s]) == len(want)
         assert np.abs(np.array(a[s]) - want).max() < TOL_POST
+
+
+def test_context_adopts_a_torch_stream(assets, oracles):
+    """ww_ctx_create(device, stream): work enqueued on a caller-owned HIP stream (here torch's) is ordered with
+    the caller's own work on that stream - no explicit ww_ctx_synchronize needed before torch reads the result."""
+    import torch
+    from wwhip import _lib
+    from wwhip.engine import Engine, frontend_params
+    side = torch.cuda.Stream()
+    ctx = _lib.Context(0, stream=side.cuda_stream)
+    assert ctx.stream == side.cuda_stream
+    e = Engine(os.path.join(assets, "CRNN"), ctx=ctx)
+    try:
+        rng = np.random.default_rng(61)
+        pcm = np.clip(rng.normal(0, 2500, (16, 24000)), -32768, 32767).astype(np.int16)
+        with torch.cuda.stream(side):
+            d_pcm = torch.from_numpy(pcm).cuda(non_blocking=False)
+            d_out = torch.zeros((16, e.n_out), dtype=torch.float32, device="cuda")
+            e.clips_forward_dev(d_pcm.data_ptr(), 16, 24000, d_out.data_ptr(), frontend_params())
+            doubled = d_out * 2.0            # torch kernel on the same stream, after ours
+        side.synchronize()
+        got = d_out.cpu().numpy()
+        np.testing.assert_array_equal(doubled.cpu().numpy(), got * 2.0)
+        for i in (0, 7, 15):
+            mel = oracles["CRNN"].logmel(pcm[i])
+            win = np.zeros((e.window, 40), np.float32)
+            win[: len(mel)] = mel
+            assert np.abs(got[i] - oracles["CRNN"].forward(win)[0]).max() < TOL_POST
+    finally:
+        e.close()
+        ctx.close()
