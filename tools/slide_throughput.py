@@ -11,8 +11,8 @@ rng = np.random.default_rng(0)
 n = int(minutes * 60 * 16000)
 pcm = np.clip(rng.normal(0, 2500, n), -32768, 32767).astype(np.int16)
 out = {}
-for name in ("CRNN", "Wavenet"):
-    eng = Engine(os.path.join(ROOT, "wakeword-detection_amd/assets/tf_lite_models", name))
+for name, prec in (("CRNN", "fp32"), ("Wavenet", "fp32"), ("Wavenet", "bf16x3")):
+    eng = Engine(os.path.join(ROOT, "wakeword-detection_amd/assets/tf_lite_models", name), precision=prec)
     mel = eng.logmel([pcm])[0]
     eng.slide_forward(mel[:4000], 2)
     t0 = time.perf_counter(); mel = eng.logmel([pcm])[0]; t_fe = time.perf_counter() - t0
@@ -23,7 +23,7 @@ for name in ("CRNN", "Wavenet"):
     flop = {"CRNN": 8.04e6, "Wavenet": 20.66e6}[name] * len(post)
     kern_ms = {k: v["total_ms"] for k, v in prof.items()}
     model_ms = sum(v for k, v in kern_ms.items() if not k.startswith("logmel"))
-    out[name] = {"audio_minutes": minutes, "mel_frames": int(len(mel)), "windows": int(len(post)),
+    out[name if prec == "fp32" else name + "/" + prec] = {"posterior_checksum": float(np.sum(post, dtype=np.float64)), "audio_minutes": minutes, "mel_frames": int(len(mel)), "windows": int(len(post)),
                  "frontend_host_s": t_fe, "slide_host_s": t_sl,
                  "audio_frames_per_s_host": (n / 160) / (t_fe + t_sl),
                  "kernel_ms": kern_ms, "model_TFLOPs_device": flop / (model_ms * 1e-3) / 1e12,
