@@ -131,3 +131,56 @@ def test_not_hdf5(tmp_path):
     p.write_bytes(b"not an hdf5 file at all" * 10)
     with pytest.raises(ValueError):
         h5min.File(str(p))
+
+
+def test_crnn_against_pytorch_layers(keras_dir, assets):
+    """A fifth, library-grade reading: the Keras checkpoint's weights loaded into torch.nn.Conv2d /
+    torch.nn.GRU(bidirectional) / torch.nn.Linear (PyTorch's GRU is the same reset-after formulation; gates are
+    ordered r, z, n instead of z, r, h) and run on the CPU, against the C restatement of the flatbuffer."""
+    import torch
+    import torch.nn.functional as F
+    from oracle.cpu import CpuOracle
+    ora = CpuOracle(weights.pack_blob(weights.load_model_dir(os.path.join(assets, "CRNN_softmax"))))
+    with h5min.File(os.path.join(keras_dir, "encode.h5")) as f, h5min.File(os.path.join(keras_dir, "detect.h5")) as g:
+        mw, dw = f["model_weights"], g["model_weights"]
+        k = torch.tensor(mw["conv2d/conv2d/kernel:0"][()]).permute(3, 2, 0, 1).contiguous()   # [out, in, kh, kw]
+        kb = torch.tensor(mw["conv2d/conv2d/bias:0"][()])
+
+        def gru_params(path):
+            K, R, B = (mw[path + "/" + n][()] for n in ("kernel:0", "recurrent_kernel:0", "bias:0"))
+            H = R.shape[0]
+            perm = np.concatenate([np.arange(H, 2 * H), np.arange(0, H), np.arange(2 * H, 3 * H)])  # z,r,h -> r,z,n
+            return (torch.tensor(K.T[perm].copy()), torch.tensor(R.T[perm].copy()), torch.tensor(B[0][perm].copy()),
+                    torch.tensor(B[1][perm].copy()))
+
+        def make_gru(inp, fwd, bwd):
+            m = torch.nn.GRU(inp, 32, batch_first=True, bidirectional=True)
+            with torch.no_grad():
+                for sfx, p in (("", gru_params(fwd)), ("_reverse", gru_params(bwd))):
+                    getattr(m, "weight_ih_l0" + sfx).copy_(p[0])
+                    getattr(m, "weight_hh_l0" + sfx).copy_(p[1])
+                    getattr(m, "bias_ih_l0" + sfx).copy_(p[2])
+                    getattr(m, "bias_hh_l0" + sfx).copy_(p[3])
+            return m.double()
+
+        g1 = make_gru(640, "bidirectional/bidirectional/forward_gru/gru_cell_1", "bidirectional/bidirectional/backward_gru/gru_cell_2")
+        g2 = make_gru(64, "bidirectional_1/bidirectional_1/forward_gru_1/gru_cell_4",
+                      "bidirectional_1/bidirectional_1/backward_gru_1/gru_cell_5")
+        w1, b1 = torch.tensor(dw["dense/dense/kernel:0"][()]).double(), torch.tensor(dw["dense/dense/bias:0"][()]).double()
+        w2, b2 = torch.tensor(dw["dense_1/dense_1/kernel:0"][()]).double(), torch.tensor(dw["dense_1/dense_1/bias:0"][()]).double()
+    rng = np.random.default_rng(9)
+    wins = rng.uniform(0, 6.5, (4, 151, 40)).astype(np.float32)
+    wins[1, 90:] = 0
+    with torch.no_grad():
+        x = torch.tensor(wins).double().permute(0, 2, 1)[:, None]                 # [B, 1, 40 (H), 151 (W)]
+        # TensorFlow SAME padding for kernel (5, 20), strides (2, 8): (1, 2) on H, (6, 7) on W
+        x = F.pad(x, (6, 7, 1, 2))
+        y = F.relu(F.conv2d(x, k.double(), kb.double(), stride=(2, 8)))           # [B, 32, 20, 19]
+        y = y.permute(0, 3, 2, 1).reshape(len(wins), 19, 640)                     # Permute((2,1,3)) + Reshape((19, 640))
+        s1, _ = g1(y)
+        _, h2 = g2(s1)                                                            # h2: [2, B, 32] = fwd last, bwd last
+        enc = torch.cat([h2[0], h2[1]], dim=1)
+        post = torch.softmax(F.relu(enc @ w1 + b1) @ w2 + b2, dim=1).numpy()
+    p_o, e_o = ora.forward(wins, want_enc=True)
+    assert np.abs(post - p_o).max() < 2e-6
+    assert np.abs(enc.numpy() - e_o.reshape(len(wins), 64)).max() < 5e-6
