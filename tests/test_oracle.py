@@ -111,3 +111,47 @@ def test_wfst_smooth_restatement_is_the_shortest_path():
     t2 = [[0.8, 0.2], [0.9, 0.1], [0.5, 0.5], [0.55, 0.45], [0.2, 0.8], [0.6, 0.4], [0.7, 0.3], [0.8, 0.2], [0.3, 0.7], [0.9, 0.1]]
     assert NR.wfst_smooth(t1) == [0, 0, 0, 1, 1, 1, 1, 1, 0, 0]   # stays in 'wakeword' through the 0.6/0.4 dip (wfst.py:83)
     assert NR.wfst_smooth(t2) == [0] * 10                          # does not enter on one errant frame (wfst.py:94)
+
+
+@pytest.mark.parametrize("name", ["Wavenet", "Wavenet_alt"])
+def test_wavenet_against_pytorch_layers(assets, name):
+    """wwdetect/wavenet/wavenet_model.py:11-128 rebuilt from torch.nn.functional (conv1d with dilation on a
+    causally padded input, the inference-mode BatchNorm affine, GlobalMaxPooling1D + softmax), fed with the
+    weights the TFLite reader extracts, float64 - PyTorch's convolution kernels instead of the flatbuffer's
+    PAD / SPACE_TO_BATCH / CONV_2D / BATCH_TO_SPACE chains that the op-by-op interpreter walks."""
+    import torch
+    import torch.nn.functional as F
+    from wwhip import weights
+    from oracle.cpu import CpuOracle
+    bundle = weights.load_model_dir(os.path.join(assets, name))
+    w = bundle.wavenet
+    ora = CpuOracle(weights.pack_blob(bundle))
+    T = lambda a: torch.tensor(np.asarray(a)).double()
+
+    def conv1x1(x, wt, b, act=None):          # x [B, C, T]; wt [C_in, C_out]
+        y = F.conv1d(x, T(wt).t()[:, :, None], T(b))
+        return F.relu(y) if act == "relu" else y
+
+    def causal(x, wt3, b, d):                 # wt3 [3, C_in, C_out], tap k reads x[t - (2 - k) d]
+        k = T(wt3).permute(2, 1, 0).contiguous()   # [C_out, C_in, 3]
+        return F.conv1d(F.pad(x, (2 * d, 0)), k, T(b), dilation=d)
+
+    rng = np.random.default_rng(19)
+    wins = rng.uniform(0, 6.5, (3, w.n_frames, w.n_mel)).astype(np.float32)
+    wins[1, 120:] = 0
+    with torch.no_grad():
+        x = conv1x1(T(wins).permute(0, 2, 1), w.w_in, w.b_in, "relu")
+        skips = []
+        for b in w.blocks:
+            u = x * T(b.bn_scale)[None, :, None] + T(b.bn_shift)[None, :, None]
+            merged = torch.tanh(causal(u, b.w_tanh, b.b_tanh, b.dilation)) * torch.sigmoid(causal(u, b.w_sig, b.b_sig, b.dilation))
+            skips.append(conv1x1(merged, b.w_skip, b.b_skip, "relu"))
+            if b.w_res is not None:
+                x = conv1x1(merged, b.w_res, b.b_res, "relu") + x
+        enc = sum(skips[i] for i in w.skip_order)
+        h = conv1x1(F.relu(enc), w.det_w1, w.det_b1, "relu")
+        y = conv1x1(h, w.det_w2, w.det_b2).max(dim=2).values
+        post = torch.softmax(y, dim=1).numpy()
+    p_o, e_o = ora.forward(wins, want_enc=True)
+    assert np.abs(post - p_o).max() < 2e-6
+    assert np.abs(enc.permute(0, 2, 1).numpy() - e_o).max() < 2e-5 * max(1.0, float(np.abs(e_o).max()))
