@@ -79,3 +79,33 @@ def test_reader_rejects_garbage():
 def test_missing_model_file(tmp_path):
     with pytest.raises(FileNotFoundError):
         W.load_model_dir(str(tmp_path))
+
+
+def test_filter_weights_are_the_slaney_mel_filterbank(assets):
+    """The 40 x 257 matrix read out of filter.tflite is librosa.filters.mel(sr=16000, n_fft=512, n_mels=40,
+    fmin=0, fmax=8000, htk=False, norm='slaney') - restated here from its published formula - to fp32
+    rounding: pins the extraction (orientation, band order) against something the reader did not produce."""
+    from wwhip import weights
+
+    def hz2mel(f):
+        f = np.asarray(f, float)
+        f_sp, min_log_hz, logstep = 200.0 / 3, 1000.0, np.log(6.4) / 27.0
+        return np.where(f >= min_log_hz, min_log_hz / f_sp + np.log(np.maximum(f, 1e-9) / min_log_hz) / logstep, f / f_sp)
+
+    def mel2hz(m):
+        m = np.asarray(m, float)
+        f_sp, min_log_hz, logstep = 200.0 / 3, 1000.0, np.log(6.4) / 27.0
+        return np.where(m >= min_log_hz / f_sp, min_log_hz * np.exp(logstep * (m - min_log_hz / f_sp)), f_sp * m)
+
+    fft = np.linspace(0, 8000.0, 257)
+    mel_f = mel2hz(np.linspace(hz2mel(0.0), hz2mel(8000.0), 42))
+    fdiff, ramps = np.diff(mel_f), mel_f[:, None] - fft[None]
+    M = np.stack([np.maximum(0, np.minimum(-ramps[i] / fdiff[i], ramps[i + 2] / fdiff[i + 1])) for i in range(40)])
+    M *= (2.0 / (mel_f[2:42] - mel_f[:40]))[:, None]
+    for name in ("CRNN", "Wavenet"):
+        f = weights.load_model_dir(os.path.join(assets, name)).filt
+        assert f.weight.shape == (40, 257)
+        assert np.abs(f.weight - M).max() < 2e-9
+        assert not f.bias.any()
+        # y = 0.5 * (ln(max(x, 1e-5)) - ln(1e-5))
+        assert abs(f.floor - 1e-5) < 1e-12 and abs(f.log_offset + np.log(1e-5)) < 1e-6 and f.scale == 0.5
