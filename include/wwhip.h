@@ -179,7 +179,11 @@ int ww_clips_forward_dev(ww_ctx *ctx, const ww_model *model, const int16_t *d_pc
  * state per stream: sample ring (512), mel window ring (window x 40), pre-emphasis carry,
  * running posterior max (tflite.py:96-108).  Per tick and stream: 0..2 new mel frames; for
  * each new frame while is_speech[s] != 0 one encode+detect (tflite.py:163-168,187-215).
- * post[s][k] (k < n_post[s] <= 2) are the posteriors produced by this tick, in order. */
+ * post[s][k] (k < n_post[s] <= 2) are the posteriors produced by this tick, in order.
+ * is_speech[s] is a bit set: bit 0 = the VAD says speech (context.is_speech); bit 1 = the stream is already
+ * active (context.is_active): the reference does not sample an active stream at all (tflite.py:139-140), so its
+ * rings stand still and it yields no posterior until the flag is cleared.  frames = [n_streams][320] int16
+ * (20 ms at 16 kHz). */
 int ww_stream_create(ww_ctx *ctx, const ww_model *model, int32_t n_streams, const ww_frontend_params *fp,
                      ww_streams **out);
 int ww_stream_destroy(ww_streams *st);

@@ -41,7 +41,7 @@ int ww_ensure(ww_ctx *ctx, ww_arena &a, size_t bytes, bool pinned) {
 
 extern "C" {
 
-const char *ww_version(void) { return "wwhip 0.1 (gfx950)"; }
+const char *ww_version(void) { return "wwhip 0.2 (gfx950)"; }
 
 const char *ww_last_error(const ww_ctx *ctx) { return ctx ? ctx->err : g_err; }
 
