@@ -243,6 +243,144 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(gemm_args g) {
 }
 
 // ------------------------------------------------------------------------------------------
+// gemm_nt_bf16x6_kernel (WW_PRECISION_BF16X6): the same C = A W^T + b on the bf16 matrix pipe.
+// Every operand is split three ways, x = h + m + l with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)
+// (24 mantissa bits), and a*b is taken as ah*bh + ah*bm + am*bh + am*bm + ah*bl + al*bh - six
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulate, 96 matrix cycles per K = 32 against 256 for eight
+// v_mfma_f32_16x16x4_f32, and on the pipe that runs beside the vector ALU.  The dropped terms are below
+// 2^-32 of the product: the result differs from the fp32 kernel's at the rounding level (tools/bf16x3_error.py
+// has the error model; tests/test_gpu_parity.py the measurement).
+// 64x64 tile, 4 waves (one per SIMD), each a 32x32 sub-tile = 2x2 MFMA tiles: with three planes per operand the
+// LDS operand traffic per MFMA is what bounds the wave-tile size from below.  A is split while it is staged
+// (VALU work that overlaps the MFMAs), W arrives pre-split from the host.
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#define G6_LD 80  // bf16 per LDS row: 64 k-values + 16 pad = 160 B; row strides of 32 (mod 64) bytes give every lane group of a
+                  // ds_read_b128 sixteen distinct 16-byte slots (144 B would be 2-way conflicted)
+
+struct gemm6_args {
+  const float *A;
+  const unsigned short *W3;  // [3 planes][N][K] bf16 (h, m, l)
+  const float *bias;
+  float *C;
+  int M, N, K;
+};
+
+// two fp32 values -> the three packed bf16 pairs (h, m, l)
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
+  const bf16x2_t hh = __builtin_convertvector((f32x2_t){a, b}, bf16x2_t);
+  h = __builtin_bit_cast(unsigned, hh);
+  const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+  const bf16x2_t mm = __builtin_convertvector((f32x2_t){ra, rb}, bf16x2_t);
+  m = __builtin_bit_cast(unsigned, mm);
+  const bf16x2_t ll = __builtin_convertvector((f32x2_t){ra - __uint_as_float(m << 16), rb - __uint_as_float(m & 0xffff0000u)}, bf16x2_t);
+  l = __builtin_bit_cast(unsigned, ll);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_nt_bf16x6_kernel(gemm6_args g) {
+  extern __shared__ __align__(16) unsigned short g6_smem[];
+  // [buf 2][operand A|W][plane 3][64 rows][G6_LD]
+  auto plane = [&](int buf, int opnd, int p) { return g6_smem + (((size_t)buf * 2 + opnd) * 3 + p) * 64 * G6_LD; };
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  const int lrow = tid >> 2, lk = (tid & 3) * 16;  // loader: one row, 16 consecutive k
+  const int i16 = lane & 15, kg = lane >> 4;
+
+  float4 pa[4];
+  uint4 pw00, pw01, pw10, pw11, pw20, pw21;  // named scalars: as an array this prefetch set was kept in scratch
+  // rows past M / N are clamped, not masked: their products land in accumulator rows / columns that are never stored
+  const float *arow = g.A + (size_t)(m0 + lrow < g.M ? m0 + lrow : g.M - 1) * g.K + lk;
+  const unsigned short *wrow = g.W3 + (size_t)(n0 + lrow < g.N ? n0 + lrow : g.N - 1) * g.K + lk;
+  const size_t wplane = (size_t)g.N * g.K;
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pa[q] = *(const float4 *)(arow + k0 + 4 * q);
+    pw00 = *(const uint4 *)(wrow + k0);
+    pw01 = *(const uint4 *)(wrow + k0 + 8);
+    pw10 = *(const uint4 *)(wrow + wplane + k0);
+    pw11 = *(const uint4 *)(wrow + wplane + k0 + 8);
+    pw20 = *(const uint4 *)(wrow + 2 * wplane + k0);
+    pw21 = *(const uint4 *)(wrow + 2 * wplane + k0 + 8);
+  };
+  auto sstore = [&](int buf) {
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      split3_pair(pa[q].x, pa[q].y, h[2 * q], m[2 * q], l[2 * q]);
+      split3_pair(pa[q].z, pa[q].w, h[2 * q + 1], m[2 * q + 1], l[2 * q + 1]);
+    }
+    const int o = lrow * G6_LD + lk;
+    *(uint4 *)(plane(buf, 0, 0) + o) = make_uint4(h[0], h[1], h[2], h[3]);
+    *(uint4 *)(plane(buf, 0, 0) + o + 8) = make_uint4(h[4], h[5], h[6], h[7]);
+    *(uint4 *)(plane(buf, 0, 1) + o) = make_uint4(m[0], m[1], m[2], m[3]);
+    *(uint4 *)(plane(buf, 0, 1) + o + 8) = make_uint4(m[4], m[5], m[6], m[7]);
+    *(uint4 *)(plane(buf, 0, 2) + o) = make_uint4(l[0], l[1], l[2], l[3]);
+    *(uint4 *)(plane(buf, 0, 2) + o + 8) = make_uint4(l[4], l[5], l[6], l[7]);
+    *(uint4 *)(plane(buf, 1, 0) + o) = pw00;
+    *(uint4 *)(plane(buf, 1, 0) + o + 8) = pw01;
+    *(uint4 *)(plane(buf, 1, 1) + o) = pw10;
+    *(uint4 *)(plane(buf, 1, 1) + o + 8) = pw11;
+    *(uint4 *)(plane(buf, 1, 2) + o) = pw20;
+    *(uint4 *)(plane(buf, 1, 2) + o + 8) = pw21;
+  };
+
+  f32x4 acc[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+  const int nk = g.K / 64;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    gload((kt + 1 < nk ? kt + 1 : kt) * 64);  // unconditional (clamped): no branch, no drain at a join
+    __builtin_amdgcn_sched_barrier(0);        // issued HERE, a whole MFMA section ahead of their use
+#pragma unroll
+    for (int s32 = 0; s32 < 2; ++s32) {
+      bf16x8_t a[2][3], w[2][3];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          a[t][p] = *(const bf16x8_t *)(plane(cur, 0, p) + (wr * 32 + t * 16 + i16) * G6_LD + s32 * 32 + kg * 8);
+          w[t][p] = *(const bf16x8_t *)(plane(cur, 1, p) + (wc * 32 + t * 16 + i16) * G6_LD + s32 * 32 + kg * 8);
+        }
+      // small terms first; the four accumulators take turns so that no MFMA waits on its predecessor
+#define G6_TERM(pa_, pw_)                                                                                        \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][pa_], w[0][pw_], acc[0][0], 0, 0, 0);                  \
+  acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][pa_], w[1][pw_], acc[0][1], 0, 0, 0);                  \
+  acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][pa_], w[0][pw_], acc[1][0], 0, 0, 0);                  \
+  acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][pa_], w[1][pw_], acc[1][1], 0, 0, 0);
+      G6_TERM(0, 2)
+      G6_TERM(2, 0)
+      G6_TERM(1, 1)
+      G6_TERM(0, 1)
+      G6_TERM(1, 0)
+      G6_TERM(0, 0)
+#undef G6_TERM
+    }
+    // keep the split of the NEXT tile behind this tile's MFMAs: hoisted in front of them (which the scheduler
+    // does, to shorten the live range of the raw loads) it waits for the global loads it was meant to hide
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < nk) sstore(cur ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    const int gn = n0 + wc * 32 + tn * 16 + i16;
+    const float bv = (gn < g.N) ? g.bias[gn] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gm = m0 + wr * 32 + tm * 16 + kg * 4 + r;
+        if (gm < g.M && gn < g.N) g.C[(size_t)gm * g.N + gn] = acc[tm][tn][r] + bv;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // GRU layer 1 -> layer-2 projection -> GRU layer 2 -> detect head, one workgroup per window
 // ------------------------------------------------------------------------------------------
 struct gru_head_args {
@@ -549,7 +687,17 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
     hipLaunchKernelGGL(conv5x20_kernel, dim3(nw), dim3(CV_THREADS), 0, ctx->stream, a);
   }
   const int M = nw * c.OT;
-  {
+  if (m->precision == WW_PRECISION_BF16X6) {
+    gemm6_args g = {s.feat, c.wx1_3, c.bx1, s.gx1, M, 6 * c.H, c.OF * c.C};
+    constexpr int smem = 2 * 2 * 3 * 64 * G6_LD * 2;  // 122,880 B
+    static bool attr_set = false;
+    if (!attr_set) {
+      WW_HIP(ctx, hipFuncSetAttribute((const void *)gemm_nt_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+      attr_set = true;
+    }
+    ww_launch_scope scope(ctx, "gemm_nt_kernel<gru1,bf16x6>");
+    hipLaunchKernelGGL(gemm_nt_bf16x6_kernel, dim3((M + 63) / 64, (6 * c.H + 63) / 64), dim3(256), smem, ctx->stream, g);
+  } else {
     gemm_args g = {s.feat, c.wx1, c.bx1, s.gx1, M, 6 * c.H, c.OF * c.C};
     ww_launch_scope scope(ctx, "gemm_nt_kernel<gru1>");
     hipLaunchKernelGGL(gemm_nt_kernel, dim3((M + GB_M - 1) / GB_M, (6 * c.H + GB_N - 1) / GB_N), dim3(512), 0,
