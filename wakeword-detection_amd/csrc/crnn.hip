@@ -336,33 +336,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int cur = kt & 1;
     gload((kt + 1 < nk ? kt + 1 : kt) * 64);  // unconditional (clamped): no branch, no drain at a join
     __builtin_amdgcn_sched_barrier(0);        // issued HERE, a whole MFMA section ahead of their use
-#pragma unroll
-    for (int s32 = 0; s32 < 2; ++s32) {
-      bf16x8_t a[2][3], w[2][3];
+    // both k32-steps' operands are read up front (second set while the first set's MFMAs run): with three planes
+    // per operand the reads are as long as the MFMAs, so they must not sit between them
+    bf16x8_t a[2][2][3], w[2][2][3];
+    auto rd = [&](int s32) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-          a[t][p] = *(const bf16x8_t *)(plane(cur, 0, p) + (wr * 32 + t * 16 + i16) * G6_LD + s32 * 32 + kg * 8);
-          w[t][p] = *(const bf16x8_t *)(plane(cur, 1, p) + (wc * 32 + t * 16 + i16) * G6_LD + s32 * 32 + kg * 8);
+          a[s32][t][p] = *(const bf16x8_t *)(plane(cur, 0, p) + (wr * 32 + t * 16 + i16) * G6_LD + s32 * 32 + kg * 8);
+          w[s32][t][p] = *(const bf16x8_t *)(plane(cur, 1, p) + (wc * 32 + t * 16 + i16) * G6_LD + s32 * 32 + kg * 8);
         }
-      // small terms first; the four accumulators take turns so that no MFMA waits on its predecessor
-#define G6_TERM(pa_, pw_)                                                                                        \
-  acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][pa_], w[0][pw_], acc[0][0], 0, 0, 0);                  \
-  acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][pa_], w[1][pw_], acc[0][1], 0, 0, 0);                  \
-  acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][pa_], w[0][pw_], acc[1][0], 0, 0, 0);                  \
-  acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][pa_], w[1][pw_], acc[1][1], 0, 0, 0);
-      G6_TERM(0, 2)
-      G6_TERM(2, 0)
-      G6_TERM(1, 1)
-      G6_TERM(0, 1)
-      G6_TERM(1, 0)
-      G6_TERM(0, 0)
-#undef G6_TERM
-    }
-    // keep the split of the NEXT tile behind this tile's MFMAs: hoisted in front of them (which the scheduler
-    // does, to shorten the live range of the raw loads) it waits for the global loads it was meant to hide
+    };
+    // small terms first; the four accumulators take turns so that no MFMA waits on its predecessor
+#define G6_TERM(s_, pa_, pw_)                                                                                    \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s_][0][pa_], w[s_][0][pw_], acc[0][0], 0, 0, 0);          \
+  acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s_][0][pa_], w[s_][1][pw_], acc[0][1], 0, 0, 0);          \
+  acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s_][1][pa_], w[s_][0][pw_], acc[1][0], 0, 0, 0);          \
+  acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s_][1][pa_], w[s_][1][pw_], acc[1][1], 0, 0, 0);
+#define G6_STEP(s_) G6_TERM(s_, 0, 2) G6_TERM(s_, 2, 0) G6_TERM(s_, 1, 1) G6_TERM(s_, 0, 1) G6_TERM(s_, 1, 0) G6_TERM(s_, 0, 0)
+    rd(0);
     __builtin_amdgcn_sched_barrier(0);
+    rd(1);
+    G6_STEP(0)
+    __builtin_amdgcn_sched_barrier(0);
+    G6_STEP(1)
+#undef G6_STEP
+#undef G6_TERM
+    // (the split of the NEXT tile is free to mingle with the second step's MFMAs, but not to move in front of
+    // the first step's: there it would wait for the global loads it is meant to hide)
     if (kt + 1 < nk) sstore(cur ^ 1);
     __syncthreads();
   }
