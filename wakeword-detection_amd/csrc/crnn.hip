@@ -172,6 +172,7 @@ struct gemm_args {
   const float *bias;
   float *C;
   int M, N, K;
+  int n_tiles;  // ceil(N / 64)
 };
 
 // 512 threads = 8 waves (2 per SIMD, so one wave's LDS/MFMA latencies are covered by its partner);
@@ -181,7 +182,13 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(gemm_args g) {
   __shared__ __align__(16) float Bs[2][GB_N * GB_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int m0 = blockIdx.x * GB_M, n0 = blockIdx.y * GB_N;
+  // XCD-aware tile order: workgroups go round-robin to the 8 XCDs (id % 8), each with its own L2.  The n-tiles
+  // of one m-tile read the same 64 rows of A, so they are given ids of equal residue: A then crosses the fabric
+  // once instead of once per n-tile (FETCH_SIZE 28.9 -> see profiles/r01/pmc_traffic.json).
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int mt = (slot / g.n_tiles) * 8 + xcd, nt = slot % g.n_tiles;
+  if (mt * GB_M >= g.M) return;
+  const int m0 = mt * GB_M, n0 = nt * GB_N;
   const int lrow = tid >> 4, lc4 = tid & 15;  // loader: rows lrow, lrow + 32; float4 column lc4
   const int i16 = lane & 15, kk = lane >> 4;
 
@@ -700,10 +707,11 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
     ww_launch_scope scope(ctx, "gemm_nt_kernel<gru1,bf16x6>");
     hipLaunchKernelGGL(gemm_nt_bf16x6_kernel, dim3((M + 63) / 64, (6 * c.H + 63) / 64), dim3(256), smem, ctx->stream, g);
   } else {
-    gemm_args g = {s.feat, c.wx1, c.bx1, s.gx1, M, 6 * c.H, c.OF * c.C};
+    const int n_tiles = (6 * c.H + GB_N - 1) / GB_N, m_tiles = (M + GB_M - 1) / GB_M;
+    gemm_args g = {s.feat, c.wx1, c.bx1, s.gx1, M, 6 * c.H, c.OF * c.C, n_tiles};
     ww_launch_scope scope(ctx, "gemm_nt_kernel<gru1>");
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3((M + GB_M - 1) / GB_M, (6 * c.H + GB_N - 1) / GB_N), dim3(512), 0,
-                       ctx->stream, g);
+    // ids: 8 XCDs x (m-tiles of that residue, rounded up) x n-tiles; ids whose m-tile is past the end exit at once
+    hipLaunchKernelGGL(gemm_nt_kernel, dim3(8 * ((m_tiles + 7) / 8) * n_tiles), dim3(512), 0, ctx->stream, g);
   }
   {
     gru_head_args a = {s.gx1, c.wh1, c.bh1, c.wx2, c.bx2, c.wh2, c.bh2, c.w1, c.b1, c.w2, c.b2, d_enc, d_out, c.OT, c.NOUT, c.HEAD};

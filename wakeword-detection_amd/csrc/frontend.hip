@@ -43,6 +43,7 @@ struct logmel_args {
   const int64_t *sample_offs;
   const int64_t *frame_offs;
   int n_utt;
+  int tiles_per_utt;  // ceil(longest utterance's frames / FPB)
   int hop;
   float divisor;
   float rdiv;       // RN(1 / divisor)
@@ -169,11 +170,16 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? FE_OCC64 : 4) void logmel_ker
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, sub = lane >> 4;
-  const int u = blockIdx.y;
+  // XCD-aware order: workgroup ids go round-robin to the 8 XCDs (id % 8), each with its own L2.  Adjacent
+  // tiles of an utterance share 352 of their 2 912 samples, so all tiles of utterance u are given ids of
+  // residue u % 8: the shared lines are then fetched once per utterance instead of once per tile.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int u = (slot / a.tiles_per_utt) * 8 + xcd, tile_idx = slot % a.tiles_per_utt;
+  if (u >= a.n_utt) return;
   const int64_t s_begin = a.sample_offs[u], s_end = a.sample_offs[u + 1];
   const int64_t n_samples = s_end - s_begin;
   const int64_t nf = n_samples >= WIN ? (n_samples - WIN) / a.hop + 1 : 0;
-  const int64_t f0 = (int64_t)blockIdx.x * FPB;
+  const int64_t f0 = (int64_t)tile_idx * FPB;
   if (f0 >= nf) return;
   const int nfb = (int)((nf - f0) < FPB ? (nf - f0) : FPB);
 
@@ -210,12 +216,16 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? FE_OCC64 : 4) void logmel_ker
     const int n_vec = (shift + n_need + VEC - 1) / VEC;
     const int64_t total = a.sample_offs[a.n_utt];
     const int64_t last = (total - VEC) & ~(int64_t)(VEC - 1);  // last full aligned vector (total >= WIN here)
+    const int64_t tile_last = ga + (int64_t)(n_vec - 1) * VEC;
     int64_t gq[2];
     uint4 raw[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       gq[h] = ga + (int64_t)(tid + 256 * h) * VEC;
-      const int64_t gl = gq[h] < last ? gq[h] : last;     // clamped: always a full vector inside the buffer
+      // clamped: always a full vector inside the buffer, and never past this block's last vector (threads
+      // beyond it would otherwise pull the NEXT tile's lines through this XCD's L2: +40 % fabric traffic)
+      int64_t gl = gq[h] < tile_last ? gq[h] : tile_last;
+      gl = gl < last ? gl : last;
       raw[h] = F32IN ? *(const uint4 *)(a.f32 + gl) : *(const uint4 *)(a.pcm + gl);
     }
     const double2 hv = *(const double2 *)(a.hann + 2 * tid);
@@ -553,7 +563,11 @@ int ww_k_logmel(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, const floa
   const bool f32in = d_f32 != nullptr;
   // straight-line staging (two vectors per thread) when nothing exotic is asked for
   const bool simple = fp->pre_emphasis == 0.0f && (f32in || a.fast_div) && WIN + (FPB - 1) * fp->hop + 16 <= 512 * (f32in ? 4 : 8);
-  dim3 grid((unsigned)((max_frames_per_utt + FPB - 1) / FPB), (unsigned)n_utt);
+  const int64_t tiles = (max_frames_per_utt + FPB - 1) / FPB;
+  const int64_t n_ids = 8 * (((int64_t)n_utt + 7) / 8) * tiles;
+  if (n_ids > 0x7fffffff) return ww_fail(ctx, WW_EINVAL, "front-end launch too large (%lld workgroups): split the batch", (long long)n_ids);
+  a.tiles_per_utt = (int)tiles;
+  dim3 grid((unsigned)n_ids);
   ww_launch_scope scope(ctx, fp->precise ? "logmel_kernel<f64>" : "logmel_kernel<f32>");
   if (fp->precise) {
     size_t sm = logmel_smem<double>(fp->hop);
