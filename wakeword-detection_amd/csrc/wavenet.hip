@@ -218,9 +218,18 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
   {
     const float *src = a.mel + row * a.n_mel;
     const int n = valid * a.n_mel;
-    for (int i = tid; i < n; i += WV_THREADS) {
-      int t = i / a.n_mel, c = i - t * a.n_mel;
-      in_lds[t * WV_INLD + c] = src[i];
+    if ((a.n_mel & 3) == 0 && ((((uintptr_t)src) & 15) == 0)) {
+      // the window is one contiguous [valid][n_mel] block and a row is a whole number of float4s:
+      // 16-byte loads (issued back to back), 16-byte LDS stores
+      for (int i = tid; i < n / 4; i += WV_THREADS) {
+        const int e = i * 4, t = e / a.n_mel, c = e - t * a.n_mel;
+        *(float4 *)(in_lds + t * WV_INLD + c) = *(const float4 *)(src + e);
+      }
+    } else {
+      for (int i = tid; i < n; i += WV_THREADS) {
+        int t = i / a.n_mel, c = i - t * a.n_mel;
+        in_lds[t * WV_INLD + c] = src[i];
+      }
     }
   }
   __syncthreads();
