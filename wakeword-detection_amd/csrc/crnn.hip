@@ -9,9 +9,11 @@
 //                     staged once (transposed, zero-bordered) in LDS, conv weights live in
 //                     registers, output is written in the [t][f*32+c] order of the
 //                     Permute+Reshape (model.py:37-39).
-//   gemm_nt_kernel    C[M][N] = A[M][K] * W[N][K]^T + b, 64x64x32 tiles, fp32 MFMA, register
-//                     prefetch + double-buffered LDS.  Used for the GRU input projections of
-//                     both directions at once (N = 2*3H = 192).
+//   gemm_nt_kernel    C[M][N] = A[M][K] * W[N][K]^T + b, 64x64x64 tiles, fp32 MFMA, register
+//                     prefetch + double-buffered LDS, XCD-aware tile order.  Used for the GRU input
+//                     projections of both directions at once (N = 2*3H = 192).  At M = 4864 it is bound by
+//                     moving operands (L2 -> LDS -> registers), not by the matrix pipe: see
+//                     gemm_nt_bf16x6_kernel, whose 3.5x shorter matrix time changes the total by 5 %.
 //   gru_head_kernel   one workgroup per window runs everything behind the layer-1 projections:
 //                     layer-1 recurrence (wave 0 forward, wave 1 backward; W_h in registers, K
 //                     split over adjacent lane pairs, partial dots joined by one DPP swap, h
