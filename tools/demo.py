@@ -9,7 +9,6 @@ import logging
 import os
 import sys
 import time
-import wave
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "wakeword-detection_amd")]
@@ -20,41 +19,10 @@ from spokestack.activation_timeout import ActivationTimeout  # noqa: E402
 from spokestack.pipeline import SpeechPipeline  # noqa: E402
 from spokestack.vad.webrtc import VoiceActivityDetector  # noqa: E402
 from spokestack.wakeword.tflite import WakewordTrigger  # noqa: E402
+from spokestack.io.wav import WavInput  # noqa: E402
 from wwhip.vad import EnergyClassifier  # noqa: E402
 
 logging.basicConfig(level=logging.INFO)
-
-
-class WavInput:
-    """Input stage with PyAudioInput's surface (``read() -> int16 frame``, ``start/stop/close``); stops the
-    pipeline at end of file."""
-
-    def __init__(self, path: str, sample_rate: int = 16000, frame_width: int = 20) -> None:
-        with wave.open(path, "rb") as w:
-            if w.getframerate() != sample_rate or w.getsampwidth() != 2 or w.getnchannels() != 1:
-                raise ValueError(f"{path}: expected mono PCM16 at {sample_rate} Hz")
-            self._pcm = np.frombuffer(w.readframes(w.getnframes()), np.int16)
-        self._n = sample_rate // 1000 * frame_width
-        self._pos = 0
-        self.pipeline = None
-
-    def read(self) -> np.ndarray:
-        fr = self._pcm[self._pos:self._pos + self._n]
-        self._pos += self._n
-        if len(fr) < self._n:
-            fr = np.pad(fr, (0, self._n - len(fr)))
-            if self.pipeline is not None:
-                self.pipeline.stop()
-        return fr
-
-    def start(self) -> None:
-        pass
-
-    def stop(self) -> None:
-        pass
-
-    def close(self) -> None:
-        pass
 
 
 def parse_args():
@@ -76,7 +44,7 @@ def main(args):
     except RuntimeError:
         vad = VoiceActivityDetector(classifier=EnergyClassifier(500.0))
     wakes = []
-    wake = WakewordTrigger(model_dir=args.models_dir, model_type=args.model_type, on_wake=lambda: wakes.append(mic._pos / args.sr))
+    wake = WakewordTrigger(model_dir=args.models_dir, model_type=args.model_type, on_wake=lambda: wakes.append(mic.position_s))
     timeout = ActivationTimeout(frame_width=args.fw)
     pipeline = SpeechPipeline(mic, [vad, wake, timeout])
     mic.pipeline = pipeline
