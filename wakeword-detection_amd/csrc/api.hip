@@ -1,6 +1,7 @@
 // C ABI of libwwhip.so: context, model upload, host/device entry points (see include/wwhip.h).
 #include "common.h"
 
+#include <algorithm>
 #include <cmath>
 #include <mutex>
 
@@ -243,37 +244,39 @@ static int load_filter(ww_ctx *ctx, ww_model *m, const blob_view &bv) {
       tw16[2 * (k1 * 16 + jj) + 1] = sin(-2.0 * M_PI * (double)(jj * k1) / 256.0);
     }
   f.tw16 = upload(m, tw16);
-  // mel filter as MFMA B operands (v_mfma_f32_16x16x4_f32: lane (col = l&15, kk = l>>4) holds
-  // B[k = 16 kb + 4 kk + q][col], q = 0..3 as one float4).  Tile nt = bands 16nt..16nt+15; only the
-  // 16-bin blocks that contain a non-zero weight of the tile are stored.
-  f.mel_tiles = (n_mel + 15) / 16;
-  std::vector<float> melB;
-  for (int nt = 0; nt < f.mel_tiles; ++nt) {
-    int lo = 1 << 30, hi = -1;
-    for (int b = nt * 16; b < n_mel && b < nt * 16 + 16; ++b)
-      if (len[b] > 0) {
-        lo = start[b] < lo ? start[b] : lo;
-        hi = start[b] + len[b] - 1 > hi ? start[b] + len[b] - 1 : hi;
+  // mel filter in lane form (frontend.hip, logmel_kernel): bands sorted by width, widest first, dealt to
+  // groups of 16 slots with 36 / 16 / 12 padded taps.  Weights carry the 0.5 of the real-FFT untangling
+  // (exact), and a band's first bin is pulled back so that its padded taps stay inside the zero-padded
+  // row of 272 magnitudes.
+  {
+    static const int cap[3] = {36, 16, 12}, chunk0[3] = {0, 9, 13};
+    if (n_mel > 48) return ww_fail(ctx, WW_EBLOB, "mel filterbank has %d bands; the lane form holds 48", n_mel);
+    std::vector<int> order(n_mel);
+    for (int i = 0; i < n_mel; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return len[x] > len[y]; });
+    std::vector<float> melV((size_t)WW_MELV_CHUNKS * 16 * 4, 0.f);
+    std::vector<int> meta(3 * 16, 0xffff << 16);
+    for (int r = 0; r < n_mel; ++r) {
+      const int g = r / 16, slot = r % 16, band = order[r];
+      if (len[band] > cap[g])
+        return ww_fail(ctx, WW_EBLOB, "mel band %d spans %d bins; the lane form takes %d for the %d widest, %d for the next 16, %d for the rest",
+                       band, len[band], cap[0], 16, cap[1], cap[2]);
+      int s0 = start[band];
+      if (s0 > 272 - cap[g]) s0 = 272 - cap[g];
+      for (int k = 0; k < len[band]; ++k) {
+        const int t = start[band] - s0 + k;
+        melV[((size_t)(chunk0[g] + t / 4) * 16 + slot) * 4 + t % 4] = 0.5f * w[(size_t)band * n_bins + start[band] + k];
       }
-    if (hi < 0) { lo = 0; hi = 0; }
-    for (int kb = lo / 16; kb <= hi / 16; ++kb) {
-      if (f.mel_entries >= 64) return ww_fail(ctx, WW_EBLOB, "mel filterbank too dense for the MFMA form");
-      f.mel_ent_tile[f.mel_entries] = nt;
-      f.mel_ent_kb[f.mel_entries] = kb;
-      ++f.mel_entries;
-      for (int lane_ = 0; lane_ < 64; ++lane_)
-        for (int q = 0; q < 4; ++q) {
-          const int col = lane_ & 15, kk = lane_ >> 4, k = 16 * kb + 4 * kk + q, band = nt * 16 + col;
-          melB.push_back(band < n_mel && k < n_bins ? w[(size_t)band * n_bins + k] : 0.f);
-        }
+      meta[g * 16 + slot] = s0 | (band << 16);
     }
+    f.melV = upload(m, melV);
+    f.melVmeta = upload(m, meta);
   }
-  f.melB = upload(m, melB);
   f.start = upload(m, start); f.len = upload(m, len); f.woff = upload(m, woff);
   f.w = upload(m, taps); f.bias = upload(m, bias); f.wpad = upload(m, wpad);
   f.wdense = upload(m, std::vector<float>(w, w + (size_t)n_mel * n_bins));
   f.hann = upload(m, hann); f.tw256 = upload(m, tw256); f.tw512 = upload(m, tw512);
-  if (!f.wdense || !f.tw16 || !f.melB || !f.start || !f.len || !f.woff || !f.w || !f.bias || !f.wpad || !f.hann || !f.tw256 || !f.tw512)
+  if (!f.wdense || !f.tw16 || !f.melV || !f.melVmeta || !f.start || !f.len || !f.woff || !f.w || !f.bias || !f.wpad || !f.hann || !f.tw256 || !f.tw512)
     return ww_fail(ctx, WW_ENOMEM, "filter upload failed");
   return WW_OK;
 }

@@ -69,6 +69,7 @@ struct ww_ctx {
 
 // Device-resident mel filterbank in banded form: band m covers bins [start[m], start[m]+len[m])
 // with weights w[woff[m] .. woff[m]+len[m]).
+#define WW_MELV_CHUNKS 16  // 9 + 4 + 3 float4 chunks: groups of 36, 16 and 12 taps
 struct ww_filter_dev {
   int n_mel = 0, n_bins = 0;
   float floor_v = 0, log_off = 0, scale = 0;
@@ -81,9 +82,10 @@ struct ww_filter_dev {
   double *tw256 = nullptr;   // [256][2] e^{-2 pi i k / 256}
   double *tw512 = nullptr;   // [256][2] e^{-2 pi i k / 512}
   double *tw16 = nullptr;    // [16 k1][16 j][2] e^{-2 pi i j k1 / 256}
-  float *melB = nullptr;     // mel filter as MFMA B operands: [kb][64 lanes][4]
-  int mel_tiles = 0, mel_entries = 0;
-  int mel_ent_tile[64] = {0}, mel_ent_kb[64] = {0};  // entry e of melB -> (band tile, 16-bin block)
+  // Mel filter in lane form for the batched front end (frontend.hip): the bands, sorted by width, are dealt
+  // to three groups of 16 "slots"; slot s of group g accumulates one band over WW_MELV_CAP[g] padded taps.
+  float *melV = nullptr;     // [WW_MELV_CHUNKS][16 slots] float4: 0.5 * weight of taps 4c..4c+3 (chunks of group 0, 1, 2)
+  int *melVmeta = nullptr;   // [3][16]: first bin | band << 16 (band 0xffff: empty slot)
 };
 
 struct ww_crnn_dev {

@@ -33,8 +33,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef FE_OCC64
 #define FE_OCC64 3  // fp64 front end: workgroups per CU the register budget is set for
 #endif
-#define MEL_PER_WAVE 6
-#define MEL_MAX_ENT (WAVES * MEL_PER_WAVE)
 static_assert(FPB == WAVES * 4, "each wave transforms exactly one group of 4 frames (mags overlay the transposes)");
 
 struct logmel_args {
@@ -57,9 +55,8 @@ struct logmel_args {
   int n_mel;
   float floor_v, log_off, scale;
   const double *hann, *tw256, *tw512, *tw16;
-  const float *melB;           // MFMA B operands of the mel filter: [kb][64 lanes] float4
-  int mel_tiles, mel_entries;
-  signed char mel_ent_tile[MEL_MAX_ENT], mel_ent_kb[MEL_MAX_ENT];  // entry e -> (band tile, 16-bin block)
+  const float *melV;           // mel filter in lane form: [WW_MELV_CHUNKS][16 slots] float4 (api.hip, load_filter)
+  const int *melVmeta;         // [3 groups][16 slots]: first bin | band << 16
   float *mel;
   // stft-only mode
   const float *frames;
@@ -147,6 +144,14 @@ __device__ __forceinline__ void lds_read16_b64(const double *p, double (&d)[16])
   WW_RD(8); WW_RD(9); WW_RD(10); WW_RD(11); WW_RD(12); WW_RD(13); WW_RD(14); WW_RD(15);
 #undef WW_RD
 }
+// The same with a stride of 128 bytes: lane j's sample pairs (x[32 n1 + 2j], x[32 n1 + 2j + 1]), n1 = 0..15.
+__device__ __forceinline__ void lds_read16_b64_s128(const float *p, double (&d)[16]) {
+  const unsigned a = (unsigned)(uintptr_t)p;
+#define WW_RD(i) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d[i]) : "v"(a), "n"((i) * 128))
+  WW_RD(0); WW_RD(1); WW_RD(2); WW_RD(3); WW_RD(4); WW_RD(5); WW_RD(6); WW_RD(7);
+  WW_RD(8); WW_RD(9); WW_RD(10); WW_RD(11); WW_RD(12); WW_RD(13); WW_RD(14); WW_RD(15);
+#undef WW_RD
+}
 __device__ __forceinline__ void lds_wait_all(double (&d)[16]) {
   asm volatile("s_waitcnt lgkmcnt(0)"
                : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]), "+v"(d[8]),
@@ -155,7 +160,17 @@ __device__ __forceinline__ void lds_wait_all(double (&d)[16]) {
                : "memory");
 }
 
-#define MAG_LD 276  // floats per frame of magnitudes: 257 + zero pad to 17*16, stride = 20 mod 64
+// An LDS pointer the compiler knows nothing about: constant element offsets from it then travel in the
+// instruction's offset field instead of costing one vector add per access.
+typedef __attribute__((address_space(3))) const float lds_cfloat;
+__device__ __forceinline__ lds_cfloat *lds_opaque(const float *p) {
+  unsigned a = (unsigned)(uintptr_t)p;  // low 32 bits of a flat LDS pointer = the LDS byte address
+  asm volatile("" : "+v"(a));
+  return (lds_cfloat *)(uintptr_t)a;
+}
+
+#define MAG_LD 272  // floats per frame of magnitudes: 257 + zero pad to 17*16; 16 mod 32, so the two frames a
+                    // 32-lane write group touches use disjoint banks
 #define TR_LD 17    // padded row of the 16x16 transpose
 
 template <typename R>
@@ -305,30 +320,40 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? FE_OCC64 : 4) void logmel_ker
   }
   __syncthreads();
 
-  float4 melb[MEL_PER_WAVE];
-  bool melb_loaded = false;
-  auto load_melb = [&]() {
-#pragma unroll
-    for (int i = 0; i < MEL_PER_WAVE; ++i) {
-      const int e = wave + WAVES * i;
-      melb[i] = e < a.mel_entries ? ((const float4 *)a.melB)[(size_t)e * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
   // ---- FFT: every 16-lane row of a wave owns one frame (4 frames per wave at a time)
   R *tr = (R *)(wbuf + (size_t)wave * wbuf_bytes<R>());        // [4][16][TR_LD]
   float *mg = (float *)(wbuf + (size_t)wave * wbuf_bytes<R>());  // overlay: [4][MAG_LD]
-  for (int fb = wave * 4; fb < nfb; fb += WAVES * 4) {
+  // From here on the four waves never meet again: each one carries its own 4 frames to the output.
+  const int fb = wave * 4;
+  if (fb >= nfb) return;
+  {
     int f = fb + sub;
     f = f < nfb ? f : nfb - 1;  // surplus rows recompute the last frame (results unused)
     const float *src = tile + shift + f * a.hop;
     cplx<R> v[16];
     // pass 1: lane j holds z[16 n1 + j], n1 = 0..15; Hann product in fp64 (tflite.py:175)
+    if (((shift | a.hop) & 1) == 0) {  // block-uniform
+      // 8-byte aligned pairs: ds_read_b64 (a quarter of the LDS time of the two-dword form, and with hop = 160
+      // the four frames of a wave sit 32 banks apart: conflict-free)
+      double xs[16];
+      lds_read16_b64_s128(src + 2 * j, xs);
+      double2 h[16];
 #pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) {
-      const int n = 16 * n1 + j;
-      const double2 h = tb_hann[n];
-      v[n1].re = (R)((double)src[2 * n] * h.x);
-      v[n1].im = (R)((double)src[2 * n + 1] * h.y);
+      for (int n1 = 0; n1 < 16; ++n1) h[n1] = tb_hann[16 * n1 + j];
+      lds_wait_all(xs);
+#pragma unroll
+      for (int n1 = 0; n1 < 16; ++n1) {
+        v[n1].re = (R)((double)__int_as_float(__double2loint(xs[n1])) * h[n1].x);
+        v[n1].im = (R)((double)__int_as_float(__double2hiint(xs[n1])) * h[n1].y);
+      }
+    } else {
+#pragma unroll
+      for (int n1 = 0; n1 < 16; ++n1) {
+        const int n = 16 * n1 + j;
+        const double2 h = tb_hann[n];
+        v[n1].re = (R)((double)src[2 * n] * h.x);
+        v[n1].im = (R)((double)src[2 * n + 1] * h.y);
+      }
     }
     dft16<R>(v);
 #pragma unroll
@@ -379,11 +404,6 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? FE_OCC64 : 4) void logmel_ker
     }
     // pass 2: lane j = k1 holds Y[n2][k1]; output w[pos] = Z[k1 + 16 k_of(pos)]
     dft16<R>(w);
-    // mel B operands of this wave's (tile, block) entries: issued here (after the register peak of
-    // the transposes), consumed after the untangling pass
-    load_melb();
-    melb_loaded = true;
-
     // untangle: with a = Z[k], b = conj Z[256-k]:  2E = a+b, 2O = (a-b)/i, 2T = W512^k 2O and
     //   2X[k] = 2E + 2T,   2X[256-k] = conj(2E - 2T)   ->  two magnitudes per evaluation, k < 128 only;
     //   the factor 2 leaves as an exact 0.5 after the fp32 square root.
@@ -422,81 +442,70 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? FE_OCC64 : 4) void logmel_ker
       const R tr_ = orr * un.re - oi * un.im, ti_ = orr * un.im + oi * un.re;
       const R pr = er + tr_, pi = ei + ti_, qr = er - tr_, qi = ei - ti_;
       const int k = j + 16 * k2;
-      mrow[k] = 0.5f * __builtin_amdgcn_sqrtf((float)(pr * pr + pi * pi));
-      mrow[256 - k] = 0.5f * __builtin_amdgcn_sqrtf((float)(qr * qr + qi * qi));  // k = 0 -> bin 256
+      mrow[k] = __builtin_amdgcn_sqrtf((float)(pr * pr + pi * pi));  // 2|X[k]|: the mel weights carry the 0.5
+      mrow[256 - k] = __builtin_amdgcn_sqrtf((float)(qr * qr + qi * qi));  // k = 0 -> bin 256
     }
     {
       // k = 128 pairs with itself: X[128] = conj(Z[128]) (lane 0, k2 = 8); bins 257..271 are zero padding
       const cplx<R> z = w[pos_of(8)];
-      if (j == 0) mrow[128] = __builtin_amdgcn_sqrtf((float)(z.re * z.re + z.im * z.im));
+      if (j == 0) mrow[128] = 2.0f * __builtin_amdgcn_sqrtf((float)(z.re * z.re + z.im * z.im));
       else mrow[256 + j] = 0.0f;
     }
   }
-  if (!melb_loaded) load_melb();  // waves without a frame group in a short tile still contract
-  __syncthreads();
 
-  // ---- mel filterbank as an MFMA contraction over the 16 frames of the block:
-  //   mel[frame][band] = sum_k mag[frame][k] W[band][k].  Band tile nt = bands 16nt..16nt+15 only
-  //   touches the 16-bin blocks that hold its non-zero weights; the (tile, block) pairs are dealt
-  //   round-robin to the 4 waves (B operands were prefetched before the FFT), partial sums meet in
-  //   LDS (overlaying the dead sample tile) and wave nt finishes tile nt.
-  f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  // ---- mel filterbank on the vector ALU, per wave: lane (sub, j) owns frame `sub` and slot j of each of the
+  //   three band groups (load_filter, api.hip): 36 + 16 + 12 padded taps, one fused multiply-add per tap with
+  //   the magnitude read straight from this wave's LDS rows.  (The fp32 MFMA form of this contraction kept the
+  //   SIMD's vector ALU idle for 32 cycles per instruction - fp32 MFMA and VALU share a datapath on gfx950 -
+  //   and needed three workgroup barriers for the partial sums; this form needs none.)
+  lds_fence();
   {
-    const int fr = j;  // A-operand row = frame
-    const float *arow = (const float *)(wbuf + (size_t)(fr >> 2) * wbuf_bytes<R>()) + (fr & 3) * MAG_LD + (lane >> 4) * 4;
+    constexpr int CAPQ[3] = {9, 4, 3}, C0[3] = {0, 9, 13};
+    const float4 *wv = (const float4 *)a.melV + j;
+    const float *mrow = mg + sub * MAG_LD;
+    __builtin_amdgcn_sched_barrier(0);  // the 64 weight registers must not be live across the FFT
+    int meta[3];
 #pragma unroll
-    for (int i = 0; i < MEL_PER_WAVE; ++i) {
-      const int e = wave + WAVES * i;
-      if (e < a.mel_entries) {
-        const int nt = a.mel_ent_tile[e], kb = a.mel_ent_kb[e];
-        const float4 av = *(const float4 *)(arow + kb * 16);
-        const float4 bv = melb[i];
+    for (int g = 0; g < 3; ++g) meta[g] = a.melVmeta[g * 16 + j];
+    float4 wq[WW_MELV_CHUNKS];
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
-          if (t == nt) {
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[t], 0, 0, 0);
-          }
+    for (int c = 0; c < WW_MELV_CHUNKS; ++c) wq[c] = wv[c * 16];
+    int band[3];
+    float bias[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      band[g] = (int)((unsigned)meta[g] >> 16);  // 0xffff: empty slot
+      bias[g] = a.bias[band[g] < a.n_mel ? band[g] : 0];
+    }
+    float res[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      __builtin_amdgcn_sched_barrier(0);  // one group's magnitudes in flight at a time
+      lds_cfloat *mb = lds_opaque(mrow + (meta[g] & 0xffff));
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < CAPQ[g]; ++c) {
+        const float4 w4 = wq[C0[g] + c];
+        acc = fmaf(mb[4 * c + 0], w4.x, acc);
+        acc = fmaf(mb[4 * c + 1], w4.y, acc);
+        acc = fmaf(mb[4 * c + 2], w4.z, acc);
+        acc = fmaf(mb[4 * c + 3], w4.w, acc);
       }
+      res[g] = (logf(fmaxf(acc + bias[g], a.floor_v)) + a.log_off) * a.scale;
     }
-  }
-  f32x4 *part = (f32x4 *)tile;  // [wave][tile][lane]
+    // park the wave's 4 x n_mel tile in LDS (its magnitudes are dead) for one contiguous store; empty slots
+    // write to a spare word each so that the code stays straight-line
+    lds_fence();
+    float *mt = mg;
 #pragma unroll
-  for (int t = 0; t < 3; ++t) part[(wave * 3 + t) * 64 + lane] = acc[t];
-  __syncthreads();
-  if (wave < a.mel_tiles) {
-    const int nt = wave;
-    f32x4 sum = part[(0 * 3 + nt) * 64 + lane];
-#pragma unroll
-    for (int w2 = 1; w2 < WAVES; ++w2) {
-      const f32x4 p = part[(w2 * 3 + nt) * 64 + lane];
-      sum[0] += p[0]; sum[1] += p[1]; sum[2] += p[2]; sum[3] += p[3];
-    }
-    // log tail, then park the 16x40 tile in LDS (the magnitudes are dead) for a coalesced store
-    const int band = nt * 16 + j;
-    if (band < a.n_mel) {
-      const float bias = a.bias[band];
-      float *mt = (float *)wbuf;  // [FPB][40]
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int frame = (lane >> 4) * 4 + r;
-        float v = fmaxf(sum[r] + bias, a.floor_v);
-        mt[frame * a.n_mel + band] = (logf(v) + a.log_off) * a.scale;
-      }
-    }
-  }
-  __syncthreads();
-  {
-    // the tile's nfb rows are contiguous in the output: 16-byte stores, 2560 B per tile
-    const float4 *mt4 = (const float4 *)wbuf;
-    float *dstf = a.mel + (a.frame_offs[u] + f0) * (int64_t)a.n_mel;
-    const int n4 = nfb * a.n_mel / 4;
+    for (int g = 0; g < 3; ++g) mt[band[g] < a.n_mel ? sub * a.n_mel + band[g] : 4 * a.n_mel + lane] = res[g];
+    lds_fence();
+    const int nv = (nfb - fb) < 4 ? (nfb - fb) : 4;
+    float *dstf = a.mel + (a.frame_offs[u] + f0 + fb) * (int64_t)a.n_mel;
     if ((((uintptr_t)dstf) & 15) == 0 && (a.n_mel & 3) == 0) {
-      for (int i = tid; i < n4; i += 256) ((float4 *)dstf)[i] = mt4[i];
+      for (int i = lane; i < nv * a.n_mel / 4; i += 64) ((float4 *)dstf)[i] = ((const float4 *)mt)[i];
     } else {
-      for (int i = tid; i < nfb * a.n_mel; i += 256) dstf[i] = ((const float *)wbuf)[i];
+      for (int i = lane; i < nv * a.n_mel; i += 64) dstf[i] = mt[i];
     }
   }
 }
@@ -526,9 +535,7 @@ static size_t logmel_smem(int hop) {
   off += 256 * sizeof(double2);
   off += sizeof(R) == 4 ? 2 * 256 * sizeof(cplx<R>) : 0;
   off += WAVES * wbuf_bytes<R>();
-  size_t tile_b = (size_t)(WIN + (FPB - 1) * hop + 16) * 4;
-  if (tile_b < WAVES * 3 * 64 * 16) tile_b = WAVES * 3 * 64 * 16;  // the mel partial sums overlay the tile
-  off += tile_b;
+  off += (size_t)(WIN + (FPB - 1) * hop + 16) * 4;
   return (off + 15) & ~size_t(15);
 }
 
@@ -538,11 +545,7 @@ static void fill_filter_args(logmel_args &a, const ww_model *m) {
   a.n_mel = f.n_mel;
   a.floor_v = f.floor_v; a.log_off = f.log_off; a.scale = f.scale;
   a.hann = f.hann; a.tw256 = f.tw256; a.tw512 = f.tw512; a.tw16 = f.tw16;
-  a.melB = f.melB; a.mel_tiles = f.mel_tiles; a.mel_entries = f.mel_entries;
-  for (int i = 0; i < MEL_MAX_ENT; ++i) {
-    a.mel_ent_tile[i] = i < f.mel_entries ? (signed char)f.mel_ent_tile[i] : 0;
-    a.mel_ent_kb[i] = i < f.mel_entries ? (signed char)f.mel_ent_kb[i] : 0;
-  }
+  a.melV = f.melV; a.melVmeta = f.melVmeta;
 }
 
 int ww_k_logmel(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, const float *d_f32, const int64_t *d_sample_offs,
@@ -550,8 +553,6 @@ int ww_k_logmel(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, const floa
                 const ww_frontend_params *fp, float *d_mel) {
   if (n_utt <= 0 || total_frames <= 0 || max_frames_per_utt <= 0) return WW_OK;
   if (fp->hop <= 0 || fp->hop > 512) return ww_fail(ctx, WW_EINVAL, "hop %d out of range (1..512)", fp->hop);
-  if (m->filt.mel_entries > MEL_MAX_ENT || m->filt.mel_tiles > 3)
-    return ww_fail(ctx, WW_EINVAL, "mel filterbank needs %d (tile, block) entries; kernel limit %d", m->filt.mel_entries, MEL_MAX_ENT);
   if (n_utt > 65535) return ww_fail(ctx, WW_EINVAL, "at most 65535 utterances per call (got %d)", n_utt);
   logmel_args a = {};
   a.pcm = d_pcm; a.f32 = d_f32; a.sample_offs = d_sample_offs; a.frame_offs = d_frame_offs;
