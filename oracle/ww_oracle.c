@@ -112,8 +112,8 @@ static int g_tab_ready = 0;
 
 static void tab_init(void) {
   if (g_tab_ready) return;
-  /* np.hanning(M): 0.5 - 0.5 cos(2 pi n / (M-1)), symmetric */
-  for (int n = 0; n < WIN; ++n) g_tab.hann[n] = 0.5 - 0.5 * cos(2.0 * M_PI * (double)n / (double)(WIN - 1));
+  /* np.hanning(M) as NumPy evaluates it: 0.5 + 0.5 cos(pi n / (M-1)) for n = 1-M, 3-M, ..., M-1 */
+  for (int n = 0; n < WIN; ++n) g_tab.hann[n] = 0.5 + 0.5 * cos(M_PI * (double)(2 * n - (WIN - 1)) / (double)(WIN - 1));
   for (int k = 0; k < WIN / 2; ++k) {
     g_tab.tw_re[k] = cos(-2.0 * M_PI * (double)k / (double)WIN);
     g_tab.tw_im[k] = sin(-2.0 * M_PI * (double)k / (double)WIN);

@@ -230,7 +230,9 @@ static int load_filter(ww_ctx *ctx, ww_model *m, const blob_view &bv) {
     for (int k = 0; k < len[i]; ++k) wpad[(size_t)k * 64 + i] = taps[woff[i] + k];
   std::vector<float> bias(b, b + n_mel);
   std::vector<double> hann(WW_FFT_WINDOW), tw256(512), tw512(512);
-  for (int n = 0; n < WW_FFT_WINDOW; ++n) hann[n] = 0.5 - 0.5 * cos(2.0 * M_PI * (double)n / (double)(WW_FFT_WINDOW - 1));
+  // np.hanning(M) as NumPy evaluates it: 0.5 + 0.5 cos(pi n / (M-1)), n = 1-M, 3-M, ..., M-1 (exactly symmetric)
+  for (int n = 0; n < WW_FFT_WINDOW; ++n)
+    hann[n] = 0.5 + 0.5 * cos(M_PI * (double)(2 * n - (WW_FFT_WINDOW - 1)) / (double)(WW_FFT_WINDOW - 1));
   for (int k = 0; k < 256; ++k) {
     tw256[2 * k] = cos(-2.0 * M_PI * k / 256.0);
     tw256[2 * k + 1] = sin(-2.0 * M_PI * k / 256.0);
@@ -254,21 +256,30 @@ static int load_filter(ww_ctx *ctx, ww_model *m, const blob_view &bv) {
     std::vector<int> order(n_mel);
     for (int i = 0; i < n_mel; ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return len[x] > len[y]; });
+    // First bins are rounded down to a multiple of 4 when every band still fits its group's taps: the kernel
+    // then reads the magnitudes 16 bytes at a time.
+    bool aligned = true;
+    for (int r = 0; r < n_mel; ++r) {
+      const int g = r / 16, band = order[r];
+      if (len[band] > cap[g])
+        return ww_fail(ctx, WW_EBLOB, "mel band %d spans %d bins; the lane form takes %d for the %d widest, %d for the next 16, %d for the rest",
+                       band, len[band], cap[0], 16, cap[1], cap[2]);
+      int s0 = start[band] < 272 - cap[g] ? start[band] : 272 - cap[g];
+      if (start[band] - (s0 & ~3) + len[band] > cap[g]) aligned = false;
+    }
     std::vector<float> melV((size_t)WW_MELV_CHUNKS * 16 * 4, 0.f);
     std::vector<int> meta(3 * 16, 0xffff << 16);
     for (int r = 0; r < n_mel; ++r) {
       const int g = r / 16, slot = r % 16, band = order[r];
-      if (len[band] > cap[g])
-        return ww_fail(ctx, WW_EBLOB, "mel band %d spans %d bins; the lane form takes %d for the %d widest, %d for the next 16, %d for the rest",
-                       band, len[band], cap[0], 16, cap[1], cap[2]);
-      int s0 = start[band];
-      if (s0 > 272 - cap[g]) s0 = 272 - cap[g];
+      int s0 = start[band] < 272 - cap[g] ? start[band] : 272 - cap[g];
+      if (aligned) s0 &= ~3;
       for (int k = 0; k < len[band]; ++k) {
         const int t = start[band] - s0 + k;
         melV[((size_t)(chunk0[g] + t / 4) * 16 + slot) * 4 + t % 4] = 0.5f * w[(size_t)band * n_bins + start[band] + k];
       }
       meta[g * 16 + slot] = s0 | (band << 16);
     }
+    f.melv_aligned = aligned ? 1 : 0;
     f.melV = upload(m, melV);
     f.melVmeta = upload(m, meta);
   }

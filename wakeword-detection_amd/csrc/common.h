@@ -86,6 +86,7 @@ struct ww_filter_dev {
   // to three groups of 16 "slots"; slot s of group g accumulates one band over WW_MELV_CAP[g] padded taps.
   float *melV = nullptr;     // [WW_MELV_CHUNKS][16 slots] float4: 0.5 * weight of taps 4c..4c+3 (chunks of group 0, 1, 2)
   int *melVmeta = nullptr;   // [3][16]: first bin | band << 16 (band 0xffff: empty slot)
+  int melv_aligned = 0;      // every first bin is a multiple of 4
 };
 
 struct ww_crnn_dev {

@@ -57,6 +57,7 @@ struct logmel_args {
   const double *hann, *tw256, *tw512, *tw16;
   const float *melV;           // mel filter in lane form: [WW_MELV_CHUNKS][16 slots] float4 (api.hip, load_filter)
   const int *melVmeta;         // [3 groups][16 slots]: first bin | band << 16
+  int melv_aligned;            // first bins are multiples of 4: 16-byte magnitude reads
   float *mel;
   // stft-only mode
   const float *frames;
@@ -163,6 +164,7 @@ __device__ __forceinline__ void lds_wait_all(double (&d)[16]) {
 // An LDS pointer the compiler knows nothing about: constant element offsets from it then travel in the
 // instruction's offset field instead of costing one vector add per access.
 typedef __attribute__((address_space(3))) const float lds_cfloat;
+typedef __attribute__((address_space(3))) const f32x4 lds_cfloat4;
 __device__ __forceinline__ lds_cfloat *lds_opaque(const float *p) {
   unsigned a = (unsigned)(uintptr_t)p;  // low 32 bits of a flat LDS pointer = the LDS byte address
   asm volatile("" : "+v"(a));
@@ -478,20 +480,39 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? FE_OCC64 : 4) void logmel_ker
       bias[g] = a.bias[band[g] < a.n_mel ? band[g] : 0];
     }
     float res[3];
+    if (a.melv_aligned) {
 #pragma unroll
-    for (int g = 0; g < 3; ++g) {
-      __builtin_amdgcn_sched_barrier(0);  // one group's magnitudes in flight at a time
-      lds_cfloat *mb = lds_opaque(mrow + (meta[g] & 0xffff));
-      float acc = 0.f;
+      for (int g = 0; g < 3; ++g) {
+        __builtin_amdgcn_sched_barrier(0);  // one group's magnitudes in flight at a time
+        lds_cfloat4 *mb = (lds_cfloat4 *)lds_opaque(mrow + (meta[g] & 0xffff));
+        float acc = 0.f;
 #pragma unroll
-      for (int c = 0; c < CAPQ[g]; ++c) {
-        const float4 w4 = wq[C0[g] + c];
-        acc = fmaf(mb[4 * c + 0], w4.x, acc);
-        acc = fmaf(mb[4 * c + 1], w4.y, acc);
-        acc = fmaf(mb[4 * c + 2], w4.z, acc);
-        acc = fmaf(mb[4 * c + 3], w4.w, acc);
+        for (int c = 0; c < CAPQ[g]; ++c) {
+          const float4 w4 = wq[C0[g] + c];
+          const f32x4 m4 = mb[c];
+          acc = fmaf(m4[0], w4.x, acc);
+          acc = fmaf(m4[1], w4.y, acc);
+          acc = fmaf(m4[2], w4.z, acc);
+          acc = fmaf(m4[3], w4.w, acc);
+        }
+        res[g] = (logf(fmaxf(acc + bias[g], a.floor_v)) + a.log_off) * a.scale;
       }
-      res[g] = (logf(fmaxf(acc + bias[g], a.floor_v)) + a.log_off) * a.scale;
+    } else {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        __builtin_amdgcn_sched_barrier(0);
+        lds_cfloat *mb = lds_opaque(mrow + (meta[g] & 0xffff));
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < CAPQ[g]; ++c) {
+          const float4 w4 = wq[C0[g] + c];
+          acc = fmaf(mb[4 * c + 0], w4.x, acc);
+          acc = fmaf(mb[4 * c + 1], w4.y, acc);
+          acc = fmaf(mb[4 * c + 2], w4.z, acc);
+          acc = fmaf(mb[4 * c + 3], w4.w, acc);
+        }
+        res[g] = (logf(fmaxf(acc + bias[g], a.floor_v)) + a.log_off) * a.scale;
+      }
     }
     // park the wave's 4 x n_mel tile in LDS (its magnitudes are dead) for one contiguous store; empty slots
     // write to a spare word each so that the code stays straight-line
@@ -545,7 +566,7 @@ static void fill_filter_args(logmel_args &a, const ww_model *m) {
   a.n_mel = f.n_mel;
   a.floor_v = f.floor_v; a.log_off = f.log_off; a.scale = f.scale;
   a.hann = f.hann; a.tw256 = f.tw256; a.tw512 = f.tw512; a.tw16 = f.tw16;
-  a.melV = f.melV; a.melVmeta = f.melVmeta;
+  a.melV = f.melV; a.melVmeta = f.melVmeta; a.melv_aligned = f.melv_aligned;
 }
 
 int ww_k_logmel(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, const float *d_f32, const int64_t *d_sample_offs,
