@@ -257,7 +257,12 @@ static int load_filter(ww_ctx *ctx, ww_model *m, const blob_view &bv) {
     for (int i = 0; i < n_mel; ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return len[x] > len[y]; });
     // First bins are rounded down to a multiple of 4 when every band still fits its group's taps: the kernel
-    // then reads the magnitudes 16 bytes at a time.
+    // then reads the magnitudes 16 bytes at a time.  A ds_read_b128 is served in four groups of 16 lanes
+    // ({0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32); with lane = 4 slot + frame those hold the
+    // slots {0,3,5,6}, {1,2,4,7}, {8,11,13,14}, {9,10,12,15}, and the four frames' rows lie 4 sixteen-byte bank
+    // slots apart.  So the four bands of such a quad should start on different bank slots mod 4: where the
+    // taps leave room a band's first bin is pulled back further to get there.
+    static const int quad[4][4] = {{0, 3, 5, 6}, {1, 2, 4, 7}, {8, 11, 13, 14}, {9, 10, 12, 15}};
     bool aligned = true;
     for (int r = 0; r < n_mel; ++r) {
       const int g = r / 16, band = order[r];
@@ -269,15 +274,65 @@ static int load_filter(ww_ctx *ctx, ww_model *m, const blob_view &bv) {
     }
     std::vector<float> melV((size_t)WW_MELV_CHUNKS * 16 * 4, 0.f);
     std::vector<int> meta(3 * 16, 0xffff << 16);
-    for (int r = 0; r < n_mel; ++r) {
-      const int g = r / 16, slot = r % 16, band = order[r];
-      int s0 = start[band] < 272 - cap[g] ? start[band] : 272 - cap[g];
-      if (aligned) s0 &= ~3;
-      for (int k = 0; k < len[band]; ++k) {
-        const int t = start[band] - s0 + k;
-        melV[((size_t)(chunk0[g] + t / 4) * 16 + slot) * 4 + t % 4] = 0.5f * w[(size_t)band * n_bins + start[band] + k];
+    for (int g = 0; g < 3; ++g) {
+      const int nb = n_mel - 16 * g < 0 ? 0 : (n_mel - 16 * g > 16 ? 16 : n_mel - 16 * g);
+      int s0v[16], slotv[16], cls_n[4] = {0, 0, 0, 0};
+      // least flexible bands choose their residue class first
+      std::vector<int> idx(nb);
+      for (int i = 0; i < nb; ++i) idx[i] = i;
+      auto room = [&](int i) {  // how many steps of 4 bins band i can be pulled back beyond the plain rounding
+        const int band = order[16 * g + i];
+        int s0 = start[band] < 272 - cap[g] ? start[band] : 272 - cap[g];
+        if (!aligned) return 0;
+        s0 &= ~3;
+        int n = 0;
+        while (s0 - 4 * (n + 1) >= 0 && start[band] - (s0 - 4 * (n + 1)) + len[band] <= cap[g]) ++n;
+        return n;
+      };
+      std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return room(x) < room(y); });
+      for (int i : idx) {
+        const int band = order[16 * g + i];
+        int s0 = start[band] < 272 - cap[g] ? start[band] : 272 - cap[g];
+        if (aligned) s0 &= ~3;
+        int best = 0, best_n = 1 << 30;
+        for (int n = 0; n <= room(i) && n < 4; ++n) {
+          const int cls = ((s0 - 4 * n) / 4) & 3;
+          if (cls_n[cls] < best_n) { best_n = cls_n[cls]; best = n; }
+        }
+        s0 -= 4 * best;
+        s0v[i] = s0;
+        const int cls = (s0 / 4) & 3;
+        // class member number q goes to quad q (a fifth member of a class takes any free slot below)
+        slotv[i] = cls_n[cls] < 4 ? quad[cls_n[cls]][cls] : -1;
+        ++cls_n[cls];
       }
-      meta[g * 16 + slot] = s0 | (band << 16);
+      bool used[16] = {false};
+      for (int i = 0; i < nb; ++i)
+        if (slotv[i] >= 0) {
+          if (used[slotv[i]]) slotv[i] = -1; else used[slotv[i]] = true;
+        }
+      for (int i = 0; i < nb; ++i)
+        if (slotv[i] < 0)
+          for (int sl = 0; sl < 16; ++sl)
+            if (!used[sl]) { slotv[i] = sl; used[sl] = true; break; }
+      for (int i = 0; i < nb; ++i) {
+        const int band = order[16 * g + i], slot = slotv[i], s0 = s0v[i];
+        for (int k = 0; k < len[band]; ++k) {
+          const int t = start[band] - s0 + k;
+          melV[((size_t)(chunk0[g] + t / 4) * 16 + slot) * 4 + t % 4] = 0.5f * w[(size_t)band * n_bins + start[band] + k];
+        }
+        meta[g * 16 + slot] = s0 | (band << 16);
+      }
+      // empty slots read (zero-weighted) magnitudes too: park each on the bank slot its quad still lacks
+      for (int q = 0; q < 4; ++q) {
+        bool have[4] = {false, false, false, false};
+        for (int c = 0; c < 4; ++c)
+          if (used[quad[q][c]]) have[((meta[g * 16 + quad[q][c]] & 0xffff) / 4) & 3] = true;
+        for (int c = 0; c < 4; ++c)
+          if (!used[quad[q][c]])
+            for (int cls = 0; cls < 4; ++cls)
+              if (!have[cls]) { have[cls] = true; meta[g * 16 + quad[q][c]] = (4 * cls) | (0xffff << 16); break; }
+      }
     }
     f.melv_aligned = aligned ? 1 : 0;
     f.melV = upload(m, melV);

@@ -455,13 +455,17 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? FE_OCC64 : 4) void logmel_ker
     }
   }
 
-  // ---- mel filterbank on the vector ALU, per wave: lane (sub, j) owns frame `sub` and slot j of each of the
-  //   three band groups (load_filter, api.hip): 36 + 16 + 12 padded taps, one fused multiply-add per tap with
-  //   the magnitude read straight from this wave's LDS rows.  (The fp32 MFMA form of this contraction kept the
-  //   SIMD's vector ALU idle for 32 cycles per instruction - fp32 MFMA and VALU share a datapath on gfx950 -
-  //   and needed three workgroup barriers for the partial sums; this form needs none.)
+  // ---- mel filterbank on the vector ALU, per wave: lane 4 s + q owns frame q and slot s of each of the three
+  //   band groups (load_filter, api.hip): 36 + 16 + 12 padded taps, one fused multiply-add per tap with the
+  //   magnitudes read 16 bytes at a time from this wave's LDS rows.  Frame in the low lane bits: the four
+  //   16-lane groups a ds_read_b128 is served in then hold four slots x four frames each, the rows of the four
+  //   frames sit 4 sixteen-byte bank slots apart, and load_filter deals the bands so that the four slots of such
+  //   a group start on different slots mod 4 - conflict-free.  (The fp32 MFMA form of this contraction kept
+  //   the SIMD's vector ALU idle for 32 cycles per instruction - fp32 MFMA and VALU share a datapath on gfx950
+  //   - and needed three workgroup barriers for the partial sums; this form needs none.)
   lds_fence();
   {
+    const int j = lane >> 2, sub = lane & 3;  // mel phase only: (slot, frame) of this lane
     constexpr int CAPQ[3] = {9, 4, 3}, C0[3] = {0, 9, 13};
     const float4 *wv = (const float4 *)a.melV + j;
     const float *mrow = mg + sub * MAG_LD;
