@@ -171,6 +171,13 @@ __device__ __forceinline__ lds_cfloat *lds_opaque(const float *p) {
   return (lds_cfloat *)(uintptr_t)a;
 }
 
+// (h[2n], h[2n+1]) for n = 16 n1 + j from the half table of 128 pairs (h[m] = h[511 - m])
+__device__ __forceinline__ double2 hann_pair(const double2 *tb, int n1, int j) {
+  if (n1 < 8) return tb[16 * n1 + j];
+  const double2 m = tb[16 * (15 - n1) + 15 - j];
+  return make_double2(m.y, m.x);
+}
+
 #define MAG_LD 272  // floats per frame of magnitudes: 257 + zero pad to 17*16; 16 mod 32, so the two frames a
                     // 32-lane write group touches use disjoint banks
 #define TR_LD 17    // padded row of the 16x16 transpose
@@ -202,13 +209,13 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? FE_OCC64 : 4) void logmel_ker
 
   // ---- LDS carve-up
   size_t off = 0;
-  double2 *tb_hann = (double2 *)(smem + off); off += 256 * sizeof(double2);
-  // fp32: twiddle tables in LDS.  fp64: LDS is the occupancy limiter, so the twiddles are
-  // rebuilt from two per-lane constants instead (W256^j and W512^j) - see below.
-  constexpr bool TW_LDS = sizeof(R) == 4;
-  cplx<R> *tb_tw = (cplx<R> *)(smem + off); off += TW_LDS ? 256 * sizeof(cplx<R>) : 0;   // [k1][j] = W256^(j k1)
-  cplx<R> *tb_un = (cplx<R> *)(smem + off); off += TW_LDS ? 256 * sizeof(cplx<R>) : 0;   // W512^k
-  const cplx<R> base_tw = {(R)a.tw16[2 * (16 + j)], (R)a.tw16[2 * (16 + j) + 1]};          // W256^j
+  // Hann table: np.hanning is symmetric (h[n] = h[511 - n]), so the first 256 values serve as 128 pairs
+  double2 *tb_hann = (double2 *)(smem + off); off += 128 * sizeof(double2);
+  // W256^(j k1) comes from LDS in both precisions; W512^k is a table in fp32 only - in fp64 LDS is the
+  // occupancy limiter, and the untangling twiddles are rebuilt from one per-lane constant (W512^j) instead.
+  constexpr bool UN_LDS = sizeof(R) == 4;
+  cplx<R> *tb_tw = (cplx<R> *)(smem + off); off += 256 * sizeof(cplx<R>);                 // [k1][j] = W256^(j k1)
+  cplx<R> *tb_un = (cplx<R> *)(smem + off); off += UN_LDS ? 256 * sizeof(cplx<R>) : 0;   // W512^k
   const cplx<R> base_un = {(R)a.tw512[2 * j], (R)a.tw512[2 * j + 1]};                      // W512^j
   unsigned char *wbuf = smem + off; off += WAVES * wbuf_bytes<R>();
   float *tile = (float *)(smem + off);  // fp32 samples, [WIN + (FPB-1)*hop + 16]
@@ -218,12 +225,10 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? FE_OCC64 : 4) void logmel_ker
   const int64_t g_first = s_begin + f0 * a.hop;           // first sample of frame f0
   const int n_need = WIN + (nfb - 1) * a.hop;             // samples used by this block
   const int shift = (int)(g_first % VEC);
-  auto fill_tables = [&](const double2 hv) {
-    tb_hann[tid] = hv;
-    if (TW_LDS) {
-      tb_tw[tid] = {(R)a.tw16[2 * tid], (R)a.tw16[2 * tid + 1]};
-      tb_un[tid] = {(R)a.tw512[2 * tid], (R)a.tw512[2 * tid + 1]};
-    }
+  auto fill_tables = [&](const double2 hv, const double2 twv) {
+    if (tid < 128) tb_hann[tid] = hv;
+    tb_tw[tid] = {(R)twv.x, (R)twv.y};
+    if (UN_LDS) tb_un[tid] = {(R)a.tw512[2 * tid], (R)a.tw512[2 * tid + 1]};
   };
   if (SIMPLE) {
     // No pre-emphasis, divisor 32767/32768, at most two 16-byte vectors per thread (host checks):
@@ -245,7 +250,8 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? FE_OCC64 : 4) void logmel_ker
       gl = gl < last ? gl : last;
       raw[h] = F32IN ? *(const uint4 *)(a.f32 + gl) : *(const uint4 *)(a.pcm + gl);
     }
-    const double2 hv = *(const double2 *)(a.hann + 2 * tid);
+    const double2 hv = *(const double2 *)(a.hann + 2 * (tid & 127));
+    const double2 twv = *(const double2 *)(a.tw16 + 2 * tid);
     const float lim = a.clip ? 1.0f : __builtin_inff();
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -274,9 +280,9 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? FE_OCC64 : 4) void logmel_ker
         if (VEC == 8) dst[1] = make_float4(o[4], o[5], o[6], o[7]);
       }
     }
-    fill_tables(hv);
+    fill_tables(hv, twv);
   } else {
-    fill_tables(*(const double2 *)(a.hann + 2 * tid));
+    fill_tables(*(const double2 *)(a.hann + 2 * (tid & 127)), *(const double2 *)(a.tw16 + 2 * tid));
     const int64_t ga = g_first - shift;                   // multiple of VEC, >= 0
     const int n_vec = (shift + n_need + VEC - 1) / VEC;
     const int64_t total = a.sample_offs[a.n_utt];
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? FE_OCC64 : 4) void logmel_ker
       lds_read16_b64_s128(src + 2 * j, xs);
       double2 h[16];
 #pragma unroll
-      for (int n1 = 0; n1 < 16; ++n1) h[n1] = tb_hann[16 * n1 + j];
+      for (int n1 = 0; n1 < 16; ++n1) h[n1] = hann_pair(tb_hann, n1, j);
       lds_wait_all(xs);
 #pragma unroll
       for (int n1 = 0; n1 < 16; ++n1) {
@@ -352,26 +358,14 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? FE_OCC64 : 4) void logmel_ker
 #pragma unroll
       for (int n1 = 0; n1 < 16; ++n1) {
         const int n = 16 * n1 + j;
-        const double2 h = tb_hann[n];
+        const double2 h = hann_pair(tb_hann, n1, j);
         v[n1].re = (R)((double)src[2 * n] * h.x);
         v[n1].im = (R)((double)src[2 * n + 1] * h.y);
       }
     }
     dft16<R>(v);
 #pragma unroll
-    for (int pos = 1; pos < 16; ++pos)
-      if (TW_LDS) v[pos] = cmul(v[pos], tb_tw[k_of(pos) * 16 + j]);
-    if (!TW_LDS) {
-      // W256^(j k1) for k1 = 1..15 as powers of W256^j (product tree, depth <= 4: a few fp64 ulp)
-      cplx<R> p[16];
-      p[1] = base_tw;
-      p[2] = cmul(p[1], p[1]);   p[3] = cmul(p[2], p[1]);   p[4] = cmul(p[2], p[2]);   p[5] = cmul(p[4], p[1]);
-      p[6] = cmul(p[3], p[3]);   p[7] = cmul(p[4], p[3]);   p[8] = cmul(p[4], p[4]);   p[9] = cmul(p[8], p[1]);
-      p[10] = cmul(p[5], p[5]);  p[11] = cmul(p[8], p[3]);  p[12] = cmul(p[6], p[6]);  p[13] = cmul(p[8], p[5]);
-      p[14] = cmul(p[7], p[7]);  p[15] = cmul(p[8], p[7]);
-#pragma unroll
-      for (int pos = 1; pos < 16; ++pos) v[pos] = cmul(v[pos], p[k_of(pos)]);
-    }
+    for (int pos = 1; pos < 16; ++pos) v[pos] = cmul(v[pos], tb_tw[k_of(pos) * 16 + j]);
     // 16x16 transpose through LDS, real parts then imaginary parts (same buffer)
     cplx<R> w[16];
     R *trs = tr + sub * 16 * TR_LD;
@@ -438,7 +432,7 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? FE_OCC64 : 4) void logmel_ker
     for (int k2 = 0; k2 < 8; ++k2) {
       const cplx<R> own = w[pos_of(k2)];
       // W512^(j + 16 k2) = W512^j * W32^k2
-      const cplx<R> un = TW_LDS ? tb_un[j + 16 * k2] : cmul(base_un, cplx<R>{(R)W32_RE[k2], (R)W32_IM[k2]});
+      const cplx<R> un = UN_LDS ? tb_un[j + 16 * k2] : cmul(base_un, cplx<R>{(R)W32_RE[k2], (R)W32_IM[k2]});
       const R er = own.re + pz[k2].re, ei = own.im - pz[k2].im;
       const R orr = own.im + pz[k2].im, oi = pz[k2].re - own.re;
       const R tr_ = orr * un.re - oi * un.im, ti_ = orr * un.im + oi * un.re;
@@ -557,8 +551,8 @@ __global__ __launch_bounds__(256) void stft_mag_kernel(logmel_args a) {
 template <typename R>
 static size_t logmel_smem(int hop) {
   size_t off = 0;
-  off += 256 * sizeof(double2);
-  off += sizeof(R) == 4 ? 2 * 256 * sizeof(cplx<R>) : 0;
+  off += 128 * sizeof(double2);
+  off += (sizeof(R) == 4 ? 2 : 1) * 256 * sizeof(cplx<R>);
   off += WAVES * wbuf_bytes<R>();
   off += (size_t)(WIN + (FPB - 1) * hop + 16) * 4;
   return (off + 15) & ~size_t(15);
