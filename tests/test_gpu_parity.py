@@ -414,3 +414,59 @@ def test_context_adopts_a_torch_stream(assets, oracles):
     finally:
         e.close()
         ctx.close()
+
+
+def _engine_with_filter(assets, monkeypatch, weight):
+    """A CRNN engine whose filter.tflite weights are replaced by ``weight`` [40][257]."""
+    import dataclasses
+    from wwhip import weights as W
+    from wwhip.engine import Engine
+    real = W.load_model_dir
+
+    def patched(path):
+        b = real(path)
+        return dataclasses.replace(b, filt=dataclasses.replace(b.filt, weight=np.ascontiguousarray(weight, np.float32)))
+
+    monkeypatch.setattr(W, "load_model_dir", patched)
+    return Engine(os.path.join(assets, "CRNN"))
+
+
+def test_logmel_with_other_filterbanks(assets, monkeypatch):
+    """The lane form of the mel filter (api.hip load_filter) on filterbanks other than the shipped one: a bank
+    whose widest band cannot be moved to a 16-byte boundary (scalar-read path), bands without any weight, bands of
+    one tap, bands at the very top of the spectrum - and a band wider than the form takes (load error)."""
+    from oracle.cpu import CpuOracle
+    rng = np.random.default_rng(91)
+    pcm = [np.clip(rng.normal(0, 3000, n), -32768, 32767).astype(np.int16) for n in (24000, 3000, 700)]
+
+    def bank(spans):
+        w = np.zeros((40, 257), np.float32)
+        for b, (s, n) in enumerate(spans):
+            w[b, s:s + n] = rng.uniform(0.05, 1.0, n).astype(np.float32)
+        return w
+
+    banks = {
+        # widest band 36 taps starting on an odd bin: no room to round its first bin down
+        "unaligned": bank([(217, 36), (181, 34), (150, 31)] + [(3 * i + 1, 5 + i % 7) for i in range(37)]),
+        # dead bands, one-tap bands, bands touching bin 256
+        "sparse": bank([(256, 1), (250, 7), (245, 12), (0, 1), (1, 1)] + [(0, 0)] * 5 + [(5 * i, 3) for i in range(30)]),
+        # sixteen wide bands, sixteen of 16 taps, eight of 12: every group at its limit
+        "full": bank([(7 * i + 1, 36) for i in range(16)] + [(11 * i + 2, 16) for i in range(16)] + [(30 * i + 3, 12) for i in range(8)]),
+    }
+    for name, w in banks.items():
+        e = _engine_with_filter(assets, monkeypatch, w)
+        try:
+            o = CpuOracle(e.blob)
+            for fast in (False, True):
+                from wwhip.engine import frontend_params
+                got = e.logmel(pcm, frontend_params(precise=not fast))
+                for p, g in zip(pcm, got):
+                    want = o.logmel(p)
+                    assert g.shape == want.shape
+                    assert np.abs(g - want).max() < (2e-3 if fast else 2e-5), (name, fast, float(np.abs(g - want).max()))
+        finally:
+            e.close()
+    with pytest.raises(Exception, match="mel band"):
+        _engine_with_filter(assets, monkeypatch, bank([(10, 37)] + [(4 * i, 4) for i in range(39)]))
+    with pytest.raises(Exception, match="mel band"):
+        _engine_with_filter(assets, monkeypatch, bank([(7 * i, 20) for i in range(17)] + [(4 * i, 4) for i in range(23)]))
