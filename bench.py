@@ -127,7 +127,7 @@ def main():
                     help="independent contexts (HIP streams) the steps are dealt to round-robin; batches are "
                          "independent, so consecutive steps may overlap on the GPU")
     ap.add_argument("--fast-frontend", action="store_true", help="fp32 FFT instead of the reference's fp64")
-    ap.add_argument("--precision", choices=["auto", "fp32", "bf16x3"], default="auto",
+    ap.add_argument("--precision", choices=["auto", "fp32", "bf16x3", "bf16x6"], default="auto",
                     help="model contractions: fp32 MFMA, or (Wavenet only) three bf16 MFMAs on split operands with "
                          "fp32 accumulate; auto = fp32 for CRNN (BASELINE cfg 2), bf16x3 for Wavenet (cfg 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -163,7 +163,7 @@ def main():
     ctxs = [_lib.Context(local_rank) for _ in range(P)]
     model_dir = os.path.join(PKG, "assets", "tf_lite_models", "CRNN" if args.model == "crnn" else "Wavenet")
     precision = args.precision if args.precision != "auto" else ("fp32" if args.model == "crnn" else "bf16x3")
-    if args.model == "crnn":
+    if args.model == "crnn" and precision != "bf16x6":
         precision = "fp32"
     engs = [Engine(model_dir, device=local_rank, ctx=c, precision=precision) for c in ctxs]
     ctx, eng = ctxs[0], engs[0]

@@ -1,7 +1,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r01c
+O=$R/gpurun_out/r01e
 mkdir -p $O
 cd $R
 python bench.py > $O/bench_crnn.json 2> $O/bench_crnn.err

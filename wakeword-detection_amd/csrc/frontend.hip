@@ -487,16 +487,17 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? FE_OCC64 : 4) void logmel_ker
       for (int g = 0; g < 3; ++g) {
         __builtin_amdgcn_sched_barrier(0);  // one group's magnitudes in flight at a time
         lds_cfloat4 *mb = (lds_cfloat4 *)lds_opaque(mrow + (meta[g] & 0xffff));
-        float acc = 0.f;
+        float acc = 0.f, acc1 = 0.f;  // two chains: a dependent fp32 FMA does not issue back to back
 #pragma unroll
         for (int c = 0; c < CAPQ[g]; ++c) {
           const float4 w4 = wq[C0[g] + c];
           const f32x4 m4 = mb[c];
           acc = fmaf(m4[0], w4.x, acc);
-          acc = fmaf(m4[1], w4.y, acc);
+          acc1 = fmaf(m4[1], w4.y, acc1);
           acc = fmaf(m4[2], w4.z, acc);
-          acc = fmaf(m4[3], w4.w, acc);
+          acc1 = fmaf(m4[3], w4.w, acc1);
         }
+        acc += acc1;
         res[g] = (logf(fmaxf(acc + bias[g], a.floor_v)) + a.log_off) * a.scale;
       }
     } else {
