@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--model", choices=["crnn", "wavenet"], default="crnn")
     ap.add_argument("--clips", type=int, default=256)
     ap.add_argument("--rotate", type=int, default=24, help="distinct resident input batches to rotate over")
-    ap.add_argument("--pipeline", type=int, default=3,
+    ap.add_argument("--pipeline", type=int, default=4,
                     help="independent contexts (HIP streams) the steps are dealt to round-robin; batches are "
                          "independent, so consecutive steps may overlap on the GPU")
     ap.add_argument("--fast-frontend", action="store_true", help="fp32 FFT instead of the reference's fp64")
