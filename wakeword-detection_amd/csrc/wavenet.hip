@@ -384,13 +384,18 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
       const float uv[4] = {x[0][0] * bn_s.x + bn_t.x, x[0][1] * bn_s.y + bn_t.y, x[0][2] * bn_s.z + bn_t.z, x[0][3] * bn_s.w + bn_t.w};
       s16x4 u2h, u2l;
       split4(uv, u2h, u2l);
-      const int orow = boff + (t0 + j) * WV_C + 4 * kk;                          // [time t0 + n][ch 4 kk ..]
+      // [time t][8-byte chunk (kk + t / 4) % 4]: a row is 32 bytes, so without the rotation the 16 lanes of a
+      // write group (one kk, 16 rows) would share 8 banks (4-way conflict) and a 32-lane read group 2-way
+      const int trow = t0 + j;
+      auto uoff = [&](int t) { return boff + t * WV_C + 4 * ((kk + (t >> 2)) & 3); };  // t may be < 0: zero pad rows
+      const int orow = uoff(trow);
       *(s16x4 *)(uh + orow) = u2h;
       *(s16x4 *)(ul + orow) = u2l;
       __syncthreads();  // u complete (all rows, all waves); this block's page complete
       // delayed taps: tap k reads u[t - (2 - k) d]; rows < 0 hit the zero pad (d <= 8)
-      const s16x4 u1h = *(const s16x4 *)(uh + orow - d * WV_C), u1l = *(const s16x4 *)(ul + orow - d * WV_C);
-      const s16x4 u0h = *(const s16x4 *)(uh + orow - 2 * d * WV_C), u0l = *(const s16x4 *)(ul + orow - 2 * d * WV_C);
+      const int o1 = uoff(trow - d), o0 = uoff(trow - 2 * d);
+      const s16x4 u1h = *(const s16x4 *)(uh + o1), u1l = *(const s16x4 *)(ul + o1);
+      const s16x4 u0h = *(const s16x4 *)(uh + o0), u0l = *(const s16x4 *)(ul + o0);
       f32x4 as = {0.f, 0.f, 0.f, 0.f}, at = {0.f, 0.f, 0.f, 0.f};
       // k-step 0 = (tap 2 | tap 1), k-step 1 = (tap 0 | zeros); slot = (kstep * 2 + {sig, tanh}) * 2 + {hi, lo}
       // the zero half of k-step 1 carries the conv biases: k-slot 4 of lane group 0 is 1.0 in the hi operand
