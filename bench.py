@@ -118,7 +118,7 @@ def cpu_baseline(eng, pcm_sample, budget_s=10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--model", choices=["crnn", "wavenet"], default="crnn")
     ap.add_argument("--clips", type=int, default=256)
