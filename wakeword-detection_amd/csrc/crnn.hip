@@ -166,7 +166,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv5x20_kernel(conv_args a) {
 #define GB_M 64
 #define GB_N 64
 #define GB_K 64
-#define GB_LD 68
+#define GB_LD 72  // 288 B rows (32 mod 64): the operand ds_read_b128s are bank-conflict-free (68 was 2-way conflicted)
 
 struct gemm_args {
   const float *A;
