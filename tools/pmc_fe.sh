@@ -1,3 +1,4 @@
+# SQ counters of the batched log-mel kernel, four counters per pass (development tool; results under gpurun_out/pmcq*)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 i=0
