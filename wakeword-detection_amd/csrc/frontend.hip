@@ -34,9 +34,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define FPB 16  // frames per block
 #endif
 #define WAVES 4
-#ifndef FE_OCC64
-#define FE_OCC64 3  // fp64 front end: workgroups per CU the register budget is set for
-#endif
 static_assert(FPB == WAVES * 4, "each wave transforms exactly one group of 4 frames (mags overlay the transposes)");
 
 struct logmel_args {
@@ -194,7 +191,7 @@ __host__ __device__ constexpr int wbuf_bytes() {
 }
 
 template <typename R, bool F32IN, bool SIMPLE>
-__global__ __launch_bounds__(256, sizeof(R) == 8 ? FE_OCC64 : 4) void logmel_kernel(logmel_args a) {
+__global__ __launch_bounds__(256, 4) void logmel_kernel(logmel_args a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, sub = lane >> 4;
@@ -215,13 +212,17 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? FE_OCC64 : 4) void logmel_ker
   size_t off = 0;
   // Hann table: np.hanning is symmetric (h[n] = h[511 - n]), so the first 256 values serve as 128 pairs
   double2 *tb_hann = (double2 *)(smem + off); off += 128 * sizeof(double2);
-  // W256^(j k1) comes from LDS in both precisions; W512^k is a table in fp32 only - in fp64 LDS is the
-  // occupancy limiter, and the untangling twiddles are rebuilt from one per-lane constant (W512^j) instead.
-  constexpr bool UN_LDS = sizeof(R) == 4;
-  cplx<R> *tb_tw = (cplx<R> *)(smem + off); off += 256 * sizeof(cplx<R>);                 // [k1][j] = W256^(j k1)
-  cplx<R> *tb_un = (cplx<R> *)(smem + off); off += UN_LDS ? 256 * sizeof(cplx<R>) : 0;   // W512^k
+  // fp32: twiddle tables in LDS.  fp64: LDS is the occupancy limiter (4 workgroups per CU need <= 40 KB each),
+  // so the twiddles are rebuilt from two per-lane constants instead (W256^j and W512^j) - see below - and only
+  // three of the four per-wave buffers are allocated: wave 3 uses the sample tile, which is dead once every wave
+  // has formed its Hann products (one extra barrier).
+  constexpr bool TW_LDS = sizeof(R) == 4;
+  cplx<R> *tb_tw = (cplx<R> *)(smem + off); off += TW_LDS ? 256 * sizeof(cplx<R>) : 0;   // [k1][j] = W256^(j k1)
+  cplx<R> *tb_un = (cplx<R> *)(smem + off); off += TW_LDS ? 256 * sizeof(cplx<R>) : 0;   // W512^k
+  const cplx<R> base_tw = {(R)a.tw16[2 * (16 + j)], (R)a.tw16[2 * (16 + j) + 1]};          // W256^j
   const cplx<R> base_un = {(R)a.tw512[2 * j], (R)a.tw512[2 * j + 1]};                      // W512^j
-  unsigned char *wbuf = smem + off; off += WAVES * wbuf_bytes<R>();
+  constexpr int NWB = TW_LDS ? WAVES : WAVES - 1;
+  unsigned char *wbuf = smem + off; off += NWB * wbuf_bytes<R>();
   float *tile = (float *)(smem + off);  // fp32 samples, [WIN + (FPB-1)*hop + 16]
 
   // ---- stage the sample tile: aligned 16-byte global loads; tile[i + shift] = x[g_first + i]
@@ -231,8 +232,10 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? FE_OCC64 : 4) void logmel_ker
   const int shift = (int)(g_first % VEC);
   auto fill_tables = [&](const double2 hv, const double2 twv) {
     if (tid < 128) tb_hann[tid] = hv;
-    tb_tw[tid] = {(R)twv.x, (R)twv.y};
-    if (UN_LDS) tb_un[tid] = {(R)a.tw512[2 * tid], (R)a.tw512[2 * tid + 1]};
+    if (TW_LDS) {
+      tb_tw[tid] = {(R)twv.x, (R)twv.y};
+      tb_un[tid] = {(R)a.tw512[2 * tid], (R)a.tw512[2 * tid + 1]};
+    }
   };
   if (SIMPLE) {
     // No pre-emphasis, divisor 32767/32768, at most two 16-byte vectors per thread (host checks):
@@ -333,16 +336,16 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? FE_OCC64 : 4) void logmel_ker
   __syncthreads();
 
   // ---- FFT: every 16-lane row of a wave owns one frame (4 frames per wave at a time)
-  R *tr = (R *)(wbuf + (size_t)wave * wbuf_bytes<R>());        // [4][16][TR_LD]
-  float *mg = (float *)(wbuf + (size_t)wave * wbuf_bytes<R>());  // overlay: [4][MAG_LD]
-  // From here on the four waves never meet again: each one carries its own 4 frames to the output.
+  unsigned char *wb = (!TW_LDS && wave == WAVES - 1) ? (unsigned char *)tile : wbuf + (size_t)wave * wbuf_bytes<R>();
+  R *tr = (R *)wb;          // [4][16][TR_LD]
+  float *mg = (float *)wb;  // overlay: [4][MAG_LD]
   const int fb = wave * 4;
-  if (fb >= nfb) return;
-  {
+  const bool active = fb < nfb;
+  cplx<R> v[16];
+  if (active) {
     int f = fb + sub;
     f = f < nfb ? f : nfb - 1;  // surplus rows recompute the last frame (results unused)
     const float *src = tile + shift + f * a.hop;
-    cplx<R> v[16];
     // pass 1: lane j holds z[16 n1 + j], n1 = 0..15; Hann product in fp64 (tflite.py:175)
     if (((shift | a.hop) & 1) == 0) {  // block-uniform
       // 8-byte aligned pairs: ds_read_b64 (a quarter of the LDS time of the two-dword form, and with hop = 160
@@ -367,9 +370,26 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? FE_OCC64 : 4) void logmel_ker
         v[n1].im = (R)((double)src[2 * n + 1] * h.y);
       }
     }
+  }
+  if (!TW_LDS) __syncthreads();  // fp64: the sample tile is dead now - wave 3's transposes and magnitudes move in
+  // From here on the four waves never meet again: each one carries its own 4 frames to the output.
+  if (!active) return;
+  {
     dft16<R>(v);
+    if (TW_LDS) {
 #pragma unroll
-    for (int pos = 1; pos < 16; ++pos) v[pos] = cmul(v[pos], tb_tw[k_of(pos) * 16 + j]);
+      for (int pos = 1; pos < 16; ++pos) v[pos] = cmul(v[pos], tb_tw[k_of(pos) * 16 + j]);
+    } else {
+      // W256^(j k1) for k1 = 1..15 as powers of W256^j (product tree, depth <= 4: a few fp64 ulp)
+      cplx<R> p[16];
+      p[1] = base_tw;
+      p[2] = cmul(p[1], p[1]);   p[3] = cmul(p[2], p[1]);   p[4] = cmul(p[2], p[2]);   p[5] = cmul(p[4], p[1]);
+      p[6] = cmul(p[3], p[3]);   p[7] = cmul(p[4], p[3]);   p[8] = cmul(p[4], p[4]);   p[9] = cmul(p[8], p[1]);
+      p[10] = cmul(p[5], p[5]);  p[11] = cmul(p[8], p[3]);  p[12] = cmul(p[6], p[6]);  p[13] = cmul(p[8], p[5]);
+      p[14] = cmul(p[7], p[7]);  p[15] = cmul(p[8], p[7]);
+#pragma unroll
+      for (int pos = 1; pos < 16; ++pos) v[pos] = cmul(v[pos], p[k_of(pos)]);
+    }
     // 16x16 transpose through LDS, real parts then imaginary parts (same buffer)
     cplx<R> w[16];
     R *trs = tr + sub * 16 * TR_LD;
@@ -436,7 +456,7 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? FE_OCC64 : 4) void logmel_ker
     for (int k2 = 0; k2 < 8; ++k2) {
       const cplx<R> own = w[pos_of(k2)];
       // W512^(j + 16 k2) = W512^j * W32^k2
-      const cplx<R> un = UN_LDS ? tb_un[j + 16 * k2] : cmul(base_un, cplx<R>{(R)W32_RE[k2], (R)W32_IM[k2]});
+      const cplx<R> un = TW_LDS ? tb_un[j + 16 * k2] : cmul(base_un, cplx<R>{(R)W32_RE[k2], (R)W32_IM[k2]});
       const R er = own.re + pz[k2].re, ei = own.im - pz[k2].im;
       const R orr = own.im + pz[k2].im, oi = pz[k2].re - own.re;
       const R tr_ = orr * un.re - oi * un.im, ti_ = orr * un.im + oi * un.re;
@@ -557,9 +577,11 @@ template <typename R>
 static size_t logmel_smem(int hop) {
   size_t off = 0;
   off += 128 * sizeof(double2);
-  off += (sizeof(R) == 4 ? 2 : 1) * 256 * sizeof(cplx<R>);
-  off += WAVES * wbuf_bytes<R>();
-  off += (size_t)(WIN + (FPB - 1) * hop + 16) * 4;
+  off += sizeof(R) == 4 ? 2 * 256 * sizeof(cplx<R>) : 0;
+  off += (sizeof(R) == 4 ? WAVES : WAVES - 1) * wbuf_bytes<R>();
+  size_t tile_b = (size_t)(WIN + (FPB - 1) * hop + 16) * 4;
+  if (sizeof(R) == 8 && tile_b < (size_t)wbuf_bytes<R>()) tile_b = wbuf_bytes<R>();  // wave 3's buffer moves into the tile
+  off += tile_b;
   return (off + 15) & ~size_t(15);
 }
 
