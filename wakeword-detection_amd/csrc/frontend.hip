@@ -6,19 +6,21 @@
 // Kernel shape: one 256-thread workgroup (4 wavefronts) stages the samples of FPB = 16 consecutive frames of
 // one utterance: the 512 + 15*160 samples those frames touch are loaded ONCE with aligned 16-byte loads
 // (straight-line: every load of the block is in flight before the first wait), normalised / clipped /
-// pre-emphasised in registers and parked in LDS as fp32.  After that single barrier the four wavefronts never
-// meet again; each carries 4 frames to the output, 16 lanes per frame and 16 points per lane: Hann product
-// (fp64), a radix-16 DFT in registers, twiddles (LDS table), one 16x16 transpose through LDS (real parts, then
+// pre-emphasised in registers and parked in LDS as fp32.  After that barrier (and in fp64 one more behind the
+// Hann products) the four wavefronts never meet again; each carries 4 frames to the output, 16 lanes per frame and 16 points per lane: Hann product
+// (fp64), a radix-16 DFT in registers, twiddles, one 16x16 transpose through LDS (real parts, then
 // imaginary parts, same buffer), a second radix-16 DFT - the 256-point complex FFT of the even/odd-packed
 // frame - and the real-FFT untangling, for which lane j fetches its partner Z[256-k] (lane (16-j)%16) through
 // the dead transpose buffer; two magnitudes per evaluation land in LDS.  The mel filter runs on the vector ALU
 // with the lanes re-dealt as (band slot, frame): 64 fused multiply-adds per lane on magnitudes read 16 bytes
 // at a time (bands dealt so that these reads are bank-conflict-free: load_filter in api.hip), then the
 // log/affine tail, and the wave's 4x40 tile leaves through LDS as one contiguous store.
-// What bounds it (rocprofv3 --pmc, 256 clips): per CU the vector ALUs are busy ~55 % of the kernel and the
-// LDS ~35 %; with 3 workgroups per CU (LDS: 52.9 KB each in fp64) the rest is dependency latency inside a
-// wave's transform.  Halving the transposes' LDS footprint to reach 4 workgroups per CU costs more LDS
-// instructions than the extra occupancy returns (measured: DESIGN.md 7.1).
+// What bounds it (rocprofv3 --pmc, 256 clips): per CU the vector ALUs are busy ~60 % of the kernel and the
+// LDS ~38 %; the rest is dependency latency inside a wave's transform, which is why occupancy pays: 4 workgroups
+// per CU need <= 128 VGPRs and <= 40 KB of LDS each.  In fp64 that is met by giving wave 3 the sample tile as its
+// transpose buffer (the tile is dead once every wave has formed its Hann products: one extra barrier) and by
+// rebuilding the W256 twiddles on the ALU instead of keeping a 4 KB table.  (Halving the transposes' footprint by
+// running them two frames at a time costs more LDS instructions than the occupancy returns: DESIGN.md 7.1.)
 // (stft_mag_kernel and the streaming kernel keep the earlier one-wave-per-frame radix-4 Stockham
 // FFT of fft_device.h: they are not on the batched path.)
 //
