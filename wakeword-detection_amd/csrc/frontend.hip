@@ -193,7 +193,7 @@ __host__ __device__ constexpr int wbuf_bytes() {
 }
 
 template <typename R, bool F32IN, bool SIMPLE>
-__global__ __launch_bounds__(256, 4) void logmel_kernel(logmel_args a) {
+__global__ __launch_bounds__(256, sizeof(R) == 8 ? 4 : 5) void logmel_kernel(logmel_args a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, sub = lane >> 4;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(logmel_args a) {
   cplx<R> *tb_un = (cplx<R> *)(smem + off); off += TW_LDS ? 256 * sizeof(cplx<R>) : 0;   // W512^k
   const cplx<R> base_tw = {(R)a.tw16[2 * (16 + j)], (R)a.tw16[2 * (16 + j) + 1]};          // W256^j
   const cplx<R> base_un = {(R)a.tw512[2 * j], (R)a.tw512[2 * j + 1]};                      // W512^j
-  constexpr int NWB = TW_LDS ? WAVES : WAVES - 1;
+  constexpr int NWB = WAVES - 1;
   unsigned char *wbuf = smem + off; off += NWB * wbuf_bytes<R>();
   float *tile = (float *)(smem + off);  // fp32 samples, [WIN + (FPB-1)*hop + 16]
 
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(logmel_args a) {
   __syncthreads();
 
   // ---- FFT: every 16-lane row of a wave owns one frame (4 frames per wave at a time)
-  unsigned char *wb = (!TW_LDS && wave == WAVES - 1) ? (unsigned char *)tile : wbuf + (size_t)wave * wbuf_bytes<R>();
+  unsigned char *wb = wave == WAVES - 1 ? (unsigned char *)tile : wbuf + (size_t)wave * wbuf_bytes<R>();
   R *tr = (R *)wb;          // [4][16][TR_LD]
   float *mg = (float *)wb;  // overlay: [4][MAG_LD]
   const int fb = wave * 4;
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(logmel_args a) {
       }
     }
   }
-  if (!TW_LDS) __syncthreads();  // fp64: the sample tile is dead now - wave 3's transposes and magnitudes move in
+  __syncthreads();  // the sample tile is dead now - wave 3's transposes and magnitudes move in
   // From here on the four waves never meet again: each one carries its own 4 frames to the output.
   if (!active) return;
   {
@@ -493,9 +493,14 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(logmel_args a) {
     int meta[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) meta[g] = a.melVmeta[g * 16 + j];
+    // fp64 (128-register budget): all 16 weight chunks in flight at once; fp32 (96 registers at 5 workgroups
+    // per CU): each group's chunks are fetched when its turn comes
+    constexpr bool WQ_LATE = sizeof(R) == 4;
     float4 wq[WW_MELV_CHUNKS];
+    if (!WQ_LATE) {
 #pragma unroll
-    for (int c = 0; c < WW_MELV_CHUNKS; ++c) wq[c] = wv[c * 16];
+      for (int c = 0; c < WW_MELV_CHUNKS; ++c) wq[c] = wv[c * 16];
+    }
     int band[3];
     float bias[3];
 #pragma unroll
@@ -508,6 +513,10 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(logmel_args a) {
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
         __builtin_amdgcn_sched_barrier(0);  // one group's magnitudes in flight at a time
+        if (WQ_LATE) {
+#pragma unroll
+          for (int c = 0; c < CAPQ[g]; ++c) wq[C0[g] + c] = wv[(C0[g] + c) * 16];
+        }
         lds_cfloat4 *mb = (lds_cfloat4 *)lds_opaque(mrow + (meta[g] & 0xffff));
         float acc = 0.f, acc1 = 0.f;  // two chains: a dependent fp32 FMA does not issue back to back
 #pragma unroll
@@ -526,6 +535,10 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(logmel_args a) {
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
         __builtin_amdgcn_sched_barrier(0);
+        if (WQ_LATE) {
+#pragma unroll
+          for (int c = 0; c < CAPQ[g]; ++c) wq[C0[g] + c] = wv[(C0[g] + c) * 16];
+        }
         lds_cfloat *mb = lds_opaque(mrow + (meta[g] & 0xffff));
         float acc = 0.f;
 #pragma unroll
@@ -580,9 +593,9 @@ static size_t logmel_smem(int hop) {
   size_t off = 0;
   off += 128 * sizeof(double2);
   off += sizeof(R) == 4 ? 2 * 256 * sizeof(cplx<R>) : 0;
-  off += (sizeof(R) == 4 ? WAVES : WAVES - 1) * wbuf_bytes<R>();
+  off += (WAVES - 1) * wbuf_bytes<R>();
   size_t tile_b = (size_t)(WIN + (FPB - 1) * hop + 16) * 4;
-  if (sizeof(R) == 8 && tile_b < (size_t)wbuf_bytes<R>()) tile_b = wbuf_bytes<R>();  // wave 3's buffer moves into the tile
+  if (tile_b < (size_t)wbuf_bytes<R>()) tile_b = wbuf_bytes<R>();  // wave 3's buffer moves into the tile
   off += tile_b;
   return (off + 15) & ~size_t(15);
 }
