@@ -357,7 +357,7 @@ def main():
                 "max_abs_posterior_diff_vs_bf16x3": alt_fp32_maxdiff,
                 "note": "same job with ww_model_set_precision(WW_PRECISION_FP32); per-rank time, not max-reduced"}
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(eng, pcm0)
+            line["cpu_baseline"] = cpu_baseline(eng, pcm0, float(os.environ.get("WW_BENCH_CPU_SECONDS", "10")))
         elif not args.no_cpu_baseline:
             line["cpu_baseline"] = None
         print(json.dumps(line))
