@@ -269,15 +269,21 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? 4 : 5) void logmel_kernel(log
         float o[VEC];
         if (gq[h] <= last) {
           const unsigned int w32[4] = {raw[h].x, raw[h].y, raw[h].z, raw[h].w};
+          if (F32IN) {
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) {
-            if (F32IN) {
-              o[e] = __uint_as_float(w32[e]);
-            } else {
-              const float x = (float)(int)(short)(w32[e >> 1] >> ((e & 1) * 16));
-              const float q0 = __fmul_rn(x, a.rdiv);
-              const float er = __fmaf_rn(-a.divisor, q0, x);
-              o[e] = __builtin_amdgcn_fmed3f(__fmaf_rn(er, a.rdiv, q0), -lim, lim);
+            for (int e = 0; e < VEC; ++e) o[e] = __uint_as_float(w32[e]);
+          } else {
+            // the exact quotient (see pcm_quot) on sample pairs: v_pk_mul_f32 / v_pk_fma_f32, two samples per issue
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 r2 = {a.rdiv, a.rdiv}, nb2 = {-a.divisor, -a.divisor};
+#pragma unroll
+            for (int e = 0; e < VEC; e += 2) {
+              const f32x2 x = {(float)(int)(short)(w32[e >> 1] & 0xffffu), (float)((int)w32[e >> 1] >> 16)};
+              const f32x2 q0 = x * r2;
+              const f32x2 er = __builtin_elementwise_fma(nb2, q0, x);
+              const f32x2 q = __builtin_elementwise_fma(er, r2, q0);
+              o[e] = __builtin_amdgcn_fmed3f(q.x, -lim, lim);
+              o[e + 1] = __builtin_amdgcn_fmed3f(q.y, -lim, lim);
             }
           }
         } else {  // ragged end of the whole buffer: element-wise, zero beyond it
