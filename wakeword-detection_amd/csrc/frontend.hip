@@ -175,11 +175,17 @@ __device__ __forceinline__ lds_cfloat *lds_opaque(const float *p) {
 }
 
 // (h[2n], h[2n+1]) for n = 16 n1 + j from the half table of 128 pairs (h[m] = h[511 - m])
-__device__ __forceinline__ double2 hann_pair(const double2 *tb, int n1, int j) {
+template <typename H2>
+__device__ __forceinline__ H2 hann_pair(const H2 *tb, int n1, int j) {
   if (n1 < 8) return tb[16 * n1 + j];
-  const double2 m = tb[16 * (15 - n1) + 15 - j];
-  return make_double2(m.y, m.x);
+  const H2 m = tb[16 * (15 - n1) + 15 - j];
+  H2 r;
+  r.x = m.y;
+  r.y = m.x;
+  return r;
 }
+template <typename R> struct hann_t { typedef double2 type; };
+template <> struct hann_t<float> { typedef float2 type; };  // fast mode: the window product in fp32 as well
 
 #define MAG_LD 272  // floats per frame of magnitudes: 257 + zero pad to 17*16; 16 mod 32, so the two frames a
                     // 32-lane write group touches use disjoint banks
@@ -213,7 +219,8 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? 4 : 5) void logmel_kernel(log
   // ---- LDS carve-up
   size_t off = 0;
   // Hann table: np.hanning is symmetric (h[n] = h[511 - n]), so the first 256 values serve as 128 pairs
-  double2 *tb_hann = (double2 *)(smem + off); off += 128 * sizeof(double2);
+  typedef typename hann_t<R>::type H2;
+  H2 *tb_hann = (H2 *)(smem + off); off += 128 * sizeof(double2);
   // fp32: twiddle tables in LDS.  fp64: LDS is the occupancy limiter (4 workgroups per CU need <= 40 KB each),
   // so the twiddles are rebuilt from two per-lane constants instead (W256^j and W512^j) - see below - and only
   // three of the four per-wave buffers are allocated: wave 3 uses the sample tile, which is dead once every wave
@@ -233,7 +240,12 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? 4 : 5) void logmel_kernel(log
   const int n_need = WIN + (nfb - 1) * a.hop;             // samples used by this block
   const int shift = (int)(g_first % VEC);
   auto fill_tables = [&](const double2 hv, const double2 twv) {
-    if (tid < 128) tb_hann[tid] = hv;
+    if (tid < 128) {
+      H2 hq;
+      hq.x = hv.x;
+      hq.y = hv.y;
+      tb_hann[tid] = hq;
+    }
     if (TW_LDS) {
       tb_tw[tid] = {(R)twv.x, (R)twv.y};
       tb_un[tid] = {(R)a.tw512[2 * tid], (R)a.tw512[2 * tid + 1]};
@@ -354,28 +366,28 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? 4 : 5) void logmel_kernel(log
     int f = fb + sub;
     f = f < nfb ? f : nfb - 1;  // surplus rows recompute the last frame (results unused)
     const float *src = tile + shift + f * a.hop;
-    // pass 1: lane j holds z[16 n1 + j], n1 = 0..15; Hann product in fp64 (tflite.py:175)
+    // pass 1: lane j holds z[16 n1 + j], n1 = 0..15; Hann product in fp64 (tflite.py:175; fp32 in the fast mode)
     if (((shift | a.hop) & 1) == 0) {  // block-uniform
       // 8-byte aligned pairs: ds_read_b64 (a quarter of the LDS time of the two-dword form, and with hop = 160
       // the four frames of a wave sit 32 banks apart: conflict-free)
       double xs[16];
       lds_read16_b64_s128(src + 2 * j, xs);
-      double2 h[16];
+      H2 h[16];
 #pragma unroll
       for (int n1 = 0; n1 < 16; ++n1) h[n1] = hann_pair(tb_hann, n1, j);
       lds_wait_all(xs);
 #pragma unroll
       for (int n1 = 0; n1 < 16; ++n1) {
-        v[n1].re = (R)((double)__int_as_float(__double2loint(xs[n1])) * h[n1].x);
-        v[n1].im = (R)((double)__int_as_float(__double2hiint(xs[n1])) * h[n1].y);
+        v[n1].re = (R)((R)__int_as_float(__double2loint(xs[n1])) * h[n1].x);
+        v[n1].im = (R)((R)__int_as_float(__double2hiint(xs[n1])) * h[n1].y);
       }
     } else {
 #pragma unroll
       for (int n1 = 0; n1 < 16; ++n1) {
         const int n = 16 * n1 + j;
-        const double2 h = hann_pair(tb_hann, n1, j);
-        v[n1].re = (R)((double)src[2 * n] * h.x);
-        v[n1].im = (R)((double)src[2 * n + 1] * h.y);
+        const H2 h = hann_pair(tb_hann, n1, j);
+        v[n1].re = (R)((R)src[2 * n] * h.x);
+        v[n1].im = (R)((R)src[2 * n + 1] * h.y);
       }
     }
   }
