@@ -315,6 +315,16 @@ def main():
                                         "MI355X_MICROARCH.md), rocprofv3 --pmc in separate passes, bytes per launch "
                                         "(profiles/r01/pmc_traffic.json)")
                 roof["algorithmic_bytes"] = nbytes
+            sq = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json"))).get("sq_counters_logmel_f64_v6_final")
+            if sq and dom == "logmel_kernel<f64>" and args.clips == 256:
+                # what bounds the kernel in practice, from the committed SQ counter passes (per CU: 4 vector ALUs, 1 LDS pipe;
+                # SQ_ACTIVE_INST_* count quad-cycles, SQ_BUSY_CYCLES is summed over the 32 shader engines)
+                cyc = sq["SQ_BUSY_CYCLES"] / 32.0
+                roof["pipes_busy"] = {"valu": round(sq["SQ_ACTIVE_INST_VALU"] * 4 / 1024.0 / cyc, 3),
+                                      "lds": round(sq["SQ_LDS_IDX_ACTIVE"] / 256.0 / cyc, 3),
+                                      "lds_bank_conflict_share": round(sq["SQ_LDS_BANK_CONFLICT"] / sq["SQ_LDS_IDX_ACTIVE"], 3),
+                                      "wave_cycles_in_waitcnt": round(sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"], 3),
+                                      "source": "profiles/r01/pmc_traffic.json: sq_counters_logmel_f64_v6_final (rocprofv3 --pmc, tools/pmc_fe.sh)"}
         except (OSError, KeyError, ValueError):
             pass
         roof["kernel"] = dom
