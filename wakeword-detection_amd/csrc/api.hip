@@ -563,7 +563,8 @@ int ww_model_load(ww_ctx *ctx, const void *blob, size_t len, ww_model **out) {
   if (!ctx || !blob || !out) return ww_fail(ctx, WW_EINVAL, "NULL argument");
   *out = nullptr;
   if (len < 16) return ww_fail(ctx, WW_EBLOB, "blob too short");
-  const uint32_t *h = (const uint32_t *)blob;
+  uint32_t h[4];
+  memcpy(h, blob, sizeof h);  // the caller's buffer need not be 4-byte aligned
   if (h[0] != 0x42485757u || h[1] != 1u) return ww_fail(ctx, WW_EBLOB, "bad blob magic/version");
   blob_view bv = {(const uint8_t *)blob, len, h[3], h[2]};
   if (16 + 32 * (size_t)bv.n > len) return ww_fail(ctx, WW_EBLOB, "section table exceeds blob");
@@ -660,14 +661,9 @@ static int logmel_host(ww_ctx *ctx, const ww_model *m, const void *samples, size
   WW_HIP(ctx, hipMemcpyAsync(d_s, (const char *)samples + (size_t)base * elt, (size_t)total_s * elt, hipMemcpyHostToDevice, ctx->stream));
   WW_HIP(ctx, hipMemcpyAsync(d_so, so.data(), sizeof(int64_t) * (n_utt + 1), hipMemcpyHostToDevice, ctx->stream));
   WW_HIP(ctx, hipMemcpyAsync(d_fo, frame_offs, sizeof(int64_t) * (n_utt + 1), hipMemcpyHostToDevice, ctx->stream));
-  // utterances go to blockIdx.y (<= 65535): split the batch if needed
-  for (int u0 = 0; u0 < n_utt; u0 += 65535) {
-    const int nu = (n_utt - u0) < 65535 ? (n_utt - u0) : 65535;
-    if (u0 != 0) return ww_fail(ctx, WW_EINVAL, "more than 65535 utterances in one call");
-    rc = ww_k_logmel(ctx, m, elt == 2 ? (const int16_t *)d_s : nullptr, elt == 4 ? (const float *)d_s : nullptr, d_so, d_fo,
-                     nu, total_f, max_f, fp, d_mel);
-    if (rc) return rc;
-  }
+  rc = ww_k_logmel(ctx, m, elt == 2 ? (const int16_t *)d_s : nullptr, elt == 4 ? (const float *)d_s : nullptr, d_so, d_fo,
+                   n_utt, total_f, max_f, fp, d_mel);
+  if (rc) return rc;
   WW_HIP(ctx, hipMemcpyAsync(mel, d_mel, (size_t)total_f * m->filt.n_mel * 4, hipMemcpyDeviceToHost, ctx->stream));
   WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return WW_OK;

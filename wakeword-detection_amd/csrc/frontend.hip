@@ -632,7 +632,6 @@ int ww_k_logmel(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, const floa
                 const ww_frontend_params *fp, float *d_mel) {
   if (n_utt <= 0 || total_frames <= 0 || max_frames_per_utt <= 0) return WW_OK;
   if (fp->hop <= 0 || fp->hop > 512) return ww_fail(ctx, WW_EINVAL, "hop %d out of range (1..512)", fp->hop);
-  if (n_utt > 65535) return ww_fail(ctx, WW_EINVAL, "at most 65535 utterances per call (got %d)", n_utt);
   logmel_args a = {};
   a.pcm = d_pcm; a.f32 = d_f32; a.sample_offs = d_sample_offs; a.frame_offs = d_frame_offs;
   a.n_utt = n_utt; a.hop = fp->hop; a.divisor = fp->pcm_divisor; a.clip = fp->clip; a.preemph = fp->pre_emphasis;
