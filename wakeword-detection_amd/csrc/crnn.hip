@@ -165,8 +165,10 @@ __global__ __launch_bounds__(CV_THREADS) void conv5x20_kernel(conv_args a) {
 // ------------------------------------------------------------------------------------------
 #define GB_M 64
 #define GB_N 64
+#ifndef GB_K
 #define GB_K 64
-#define GB_LD 72  // 288 B rows (32 mod 64): the operand ds_read_b128s are bank-conflict-free (68 was 2-way conflicted)
+#endif
+#define GB_LD (GB_K + 8)  // 288 B rows at K = 64 (32 mod 64): the operand ds_read_b128s are bank-conflict-free (68 was 2-way conflicted)
 
 struct gemm_args {
   const float *A;
@@ -191,14 +193,15 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(gemm_args g) {
   const int mt = (slot / g.n_tiles) * 8 + xcd, nt = slot % g.n_tiles;
   if (mt * GB_M >= g.M) return;
   const int m0 = mt * GB_M, n0 = nt * GB_N;
-  const int lrow = tid >> 4, lc4 = tid & 15;  // loader: rows lrow, lrow + 32; float4 column lc4
+  constexpr int C4 = GB_K / 4, LROWS = 512 / C4, LH = GB_M / LROWS;  // loader: LH rows per thread, float4 column lc4
+  const int lrow = tid / C4, lc4 = tid % C4;
   const int i16 = lane & 15, kk = lane >> 4;
 
-  float4 pa[2], pb[2];
+  float4 pa[LH], pb[LH];
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int r = lrow + 32 * h;
+    for (int h = 0; h < LH; ++h) {
+      const int r = lrow + LROWS * h;
       const int gm = m0 + r;
       pa[h] = gm < g.M ? *(const float4 *)(g.A + (size_t)gm * g.K + k0 + lc4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
       const int gn = n0 + r;
@@ -207,8 +210,8 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(gemm_args g) {
   };
   auto sstore = [&](int buf) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int r = lrow + 32 * h;
+    for (int h = 0; h < LH; ++h) {
+      const int r = lrow + LROWS * h;
       *(float4 *)(&As[buf][r * GB_LD + lc4 * 4]) = pa[h];
       *(float4 *)(&Bs[buf][r * GB_LD + lc4 * 4]) = pb[h];
     }
