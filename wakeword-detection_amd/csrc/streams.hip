@@ -45,6 +45,10 @@ struct ww_streams {
   int32_t *h_win_valid = nullptr;
   float *h_out = nullptr;
   int16_t *h_frames = nullptr;
+  // the four per-tick inputs live in ONE pinned block and ONE device block (frames | ctl | win_row | win_valid):
+  // a tick costs one host-to-device copy instead of four back-to-back DMA operations
+  char *h_pack = nullptr, *d_pack = nullptr;
+  size_t pack_bytes = 0;
   std::vector<int> fill, appended;
 };
 
@@ -168,10 +172,10 @@ int ww_stream_destroy(ww_streams *st) {
   if (!st) return WW_OK;
   hipSetDevice(st->ctx->device);
   hipStreamSynchronize(st->ctx->stream);
-  void *dev[] = {st->ring, st->hist[0], st->hist[1], st->prev, st->d_frames, st->d_ctl, st->d_win_row, st->d_win_valid, st->d_out, st->ws};
+  void *dev[] = {st->ring, st->hist[0], st->hist[1], st->prev, st->d_pack, st->d_out, st->ws};
   for (void *p : dev)
     if (p) hipFree(p);
-  void *host[] = {st->h_ctl, st->h_win_row, st->h_win_valid, st->h_out, st->h_frames};
+  void *host[] = {st->h_pack, st->h_out};
   for (void *p : host)
     if (p) hipHostFree(p);
   delete st;
@@ -194,17 +198,22 @@ int ww_stream_create(ww_ctx *ctx, const ww_model *model, int32_t S, const ww_fro
             hipMalloc((void **)&st->hist[0], hist_elems * 4) == hipSuccess &&
             hipMalloc((void **)&st->hist[1], hist_elems * 4) == hipSuccess &&
             hipMalloc((void **)&st->prev, (size_t)S * 4) == hipSuccess &&
-            hipMalloc((void **)&st->d_frames, (size_t)S * WW_CHUNK * 2) == hipSuccess &&
-            hipMalloc((void **)&st->d_ctl, (size_t)S * 16) == hipSuccess &&
-            hipMalloc((void **)&st->d_win_row, (size_t)2 * S * 8) == hipSuccess &&
-            hipMalloc((void **)&st->d_win_valid, (size_t)2 * S * 4) == hipSuccess &&
             hipMalloc((void **)&st->d_out, (size_t)2 * S * st->NO * 4) == hipSuccess &&
             hipMalloc(&st->ws, ws_bytes) == hipSuccess &&
-            hipHostMalloc((void **)&st->h_ctl, (size_t)S * 16) == hipSuccess &&
-            hipHostMalloc((void **)&st->h_win_row, (size_t)2 * S * 8) == hipSuccess &&
-            hipHostMalloc((void **)&st->h_win_valid, (size_t)2 * S * 4) == hipSuccess &&
-            hipHostMalloc((void **)&st->h_out, (size_t)2 * S * st->NO * 4) == hipSuccess &&
-            hipHostMalloc((void **)&st->h_frames, (size_t)S * WW_CHUNK * 2) == hipSuccess;
+            hipHostMalloc((void **)&st->h_out, (size_t)2 * S * st->NO * 4) == hipSuccess;
+  {
+    const size_t o_frames = 0, o_row = o_frames + (size_t)S * WW_CHUNK * 2, o_ctl = o_row + (size_t)2 * S * 8,
+                 o_valid = o_ctl + (size_t)S * 16;
+    st->pack_bytes = o_valid + (size_t)2 * S * 4;
+    ok = ok && hipMalloc((void **)&st->d_pack, st->pack_bytes) == hipSuccess &&
+         hipHostMalloc((void **)&st->h_pack, st->pack_bytes) == hipSuccess;
+    if (ok) {
+      st->h_frames = (int16_t *)(st->h_pack + o_frames); st->d_frames = (int16_t *)(st->d_pack + o_frames);
+      st->h_win_row = (int64_t *)(st->h_pack + o_row);   st->d_win_row = (int64_t *)(st->d_pack + o_row);
+      st->h_ctl = (int32_t *)(st->h_pack + o_ctl);       st->d_ctl = (int32_t *)(st->d_pack + o_ctl);
+      st->h_win_valid = (int32_t *)(st->h_pack + o_valid); st->d_win_valid = (int32_t *)(st->d_pack + o_valid);
+    }
+  }
   if (!ok) {
     ww_stream_destroy(st);
     return ww_fail(ctx, WW_ENOMEM, "cannot allocate state for %d streams", S);
@@ -280,12 +289,7 @@ int ww_stream_step(ww_streams *st, const int16_t *frames, const uint8_t *is_spee
     st->appended[s] = np;
   }
   memcpy(st->h_frames, frames, (size_t)S * WW_CHUNK * 2);
-  WW_HIP(ctx, hipMemcpyAsync(st->d_frames, st->h_frames, (size_t)S * WW_CHUNK * 2, hipMemcpyHostToDevice, ctx->stream));
-  WW_HIP(ctx, hipMemcpyAsync(st->d_ctl, st->h_ctl, (size_t)S * 16, hipMemcpyHostToDevice, ctx->stream));
-  if (nw) {
-    WW_HIP(ctx, hipMemcpyAsync(st->d_win_row, st->h_win_row, (size_t)nw * 8, hipMemcpyHostToDevice, ctx->stream));
-    WW_HIP(ctx, hipMemcpyAsync(st->d_win_valid, st->h_win_valid, (size_t)nw * 4, hipMemcpyHostToDevice, ctx->stream));
-  }
+  WW_HIP(ctx, hipMemcpyAsync(st->d_pack, st->h_pack, st->pack_bytes, hipMemcpyHostToDevice, ctx->stream));
   const ww_model *m = st->model;
   const ww_filter_dev &f = m->filt;
   stream_fe_args a = {};
