@@ -11,7 +11,8 @@
 // knows the number of posteriors a tick will produce and can size the launch exactly; all
 // sample and mel data stay in HBM.
 //
-//   stream_frontend_kernel  one workgroup (2 waves) per stream: shift the mel history by the
+//   stream_frontend_kernel  one workgroup (2 waves) per stream: read the tick's samples and control words from
+//                           pinned host memory, shift the mel history by the
 //                           rows appended last tick, normalise + pre-emphasise the 320 new
 //                           samples, FFT + mel for each new frame (one wave per frame) when
 //                           the stream's is_speech bit is set, keep the ring tail.
@@ -37,24 +38,30 @@ struct ww_streams {
   int32_t *d_ctl = nullptr;      // [S][4]: fill, n_frames, flags, appended_last_tick
   int64_t *d_win_row = nullptr;  // [2S]
   int32_t *d_win_valid = nullptr;
-  float *d_out = nullptr;        // [2S][NO]
   void *ws = nullptr;
   // host mirrors (pinned)
   int32_t *h_ctl = nullptr;
   int64_t *h_win_row = nullptr;
   int32_t *h_win_valid = nullptr;
   float *h_out = nullptr;
+  float *h_out_dev = nullptr;   // the device's address of h_out
   int16_t *h_frames = nullptr;
-  // the four per-tick inputs live in ONE pinned block and ONE device block (frames | ctl | win_row | win_valid):
-  // a tick costs one host-to-device copy instead of four back-to-back DMA operations
-  char *h_pack = nullptr, *d_pack = nullptr;
+  // the four per-tick inputs live in ONE pinned block (frames | win_row | ctl | win_valid) that the front-end kernel
+  // reads over the bus itself - no copy-engine operation on a tick's path (four back-to-back host-to-device copies
+  // cost 20 us of a 107 us tick); d_pack mirrors the layout and holds the window descriptors the kernel copies over
+  char *h_pack = nullptr, *d_pack = nullptr, *h_pack_dev = nullptr;  // h_pack_dev: the device's address of h_pack
   size_t pack_bytes = 0;
   std::vector<int> fill, appended;
 };
 
 struct stream_fe_args {
-  const int16_t *frames;
-  const int32_t *ctl;
+  const int16_t *frames;   // pinned host memory, read over the bus (640 B per stream and tick)
+  const int32_t *ctl;      // pinned host memory
+  const int64_t *h_row;    // pinned host: this tick's window rows / valid counts, copied to d_row / d_valid here
+  const int32_t *h_valid;  //   for the model kernels that follow on the stream
+  int64_t *d_row;
+  int32_t *d_valid;
+  int nw, S;
   float *ring;
   const float *hist_in;
   float *hist_out;
@@ -85,6 +92,11 @@ __global__ __launch_bounds__(128) void stream_frontend_kernel(stream_fe_args a) 
   float *wl = (float *)(smem + off); off += WW_MEL_TAPS * 64 * sizeof(float);
   float *x = (float *)(smem + off);  // [ST_RING]
 
+  // ---- this tick's window descriptors: host-pinned -> device arrays (read by the model kernels that follow)
+  for (int i = s * 128 + tid; i < a.nw; i += a.S * 128) {
+    a.d_row[i] = a.h_row[i];
+    a.d_valid[i] = a.h_valid[i];
+  }
   // ---- mel history: drop the rows that were appended last tick (hist_out[0..T) = hist_in[shift..shift+T))
   {
     const float *src = a.hist_in + ((size_t)s * a.HR + shift_rows) * a.F;
@@ -172,7 +184,7 @@ int ww_stream_destroy(ww_streams *st) {
   if (!st) return WW_OK;
   hipSetDevice(st->ctx->device);
   hipStreamSynchronize(st->ctx->stream);
-  void *dev[] = {st->ring, st->hist[0], st->hist[1], st->prev, st->d_pack, st->d_out, st->ws};
+  void *dev[] = {st->ring, st->hist[0], st->hist[1], st->prev, st->d_pack, st->ws};
   for (void *p : dev)
     if (p) hipFree(p);
   void *host[] = {st->h_pack, st->h_out};
@@ -198,7 +210,6 @@ int ww_stream_create(ww_ctx *ctx, const ww_model *model, int32_t S, const ww_fro
             hipMalloc((void **)&st->hist[0], hist_elems * 4) == hipSuccess &&
             hipMalloc((void **)&st->hist[1], hist_elems * 4) == hipSuccess &&
             hipMalloc((void **)&st->prev, (size_t)S * 4) == hipSuccess &&
-            hipMalloc((void **)&st->d_out, (size_t)2 * S * st->NO * 4) == hipSuccess &&
             hipMalloc(&st->ws, ws_bytes) == hipSuccess &&
             hipHostMalloc((void **)&st->h_out, (size_t)2 * S * st->NO * 4) == hipSuccess;
   {
@@ -217,6 +228,11 @@ int ww_stream_create(ww_ctx *ctx, const ww_model *model, int32_t S, const ww_fro
   if (!ok) {
     ww_stream_destroy(st);
     return ww_fail(ctx, WW_ENOMEM, "cannot allocate state for %d streams", S);
+  }
+  if (hipHostGetDevicePointer((void **)&st->h_out_dev, st->h_out, 0) != hipSuccess ||
+      hipHostGetDevicePointer((void **)&st->h_pack_dev, st->h_pack, 0) != hipSuccess) {
+    ww_stream_destroy(st);
+    return ww_fail(ctx, WW_EHIP, "pinned staging buffers are not visible to the device");
   }
   hipMemsetAsync(st->ring, 0, (size_t)S * ST_RING * 4, ctx->stream);
   hipMemsetAsync(st->hist[0], 0, hist_elems * 4, ctx->stream);
@@ -289,11 +305,16 @@ int ww_stream_step(ww_streams *st, const int16_t *frames, const uint8_t *is_spee
     st->appended[s] = np;
   }
   memcpy(st->h_frames, frames, (size_t)S * WW_CHUNK * 2);
-  WW_HIP(ctx, hipMemcpyAsync(st->d_pack, st->h_pack, st->pack_bytes, hipMemcpyHostToDevice, ctx->stream));
   const ww_model *m = st->model;
   const ww_filter_dev &f = m->filt;
   stream_fe_args a = {};
-  a.frames = st->d_frames; a.ctl = st->d_ctl; a.ring = st->ring;
+  // no copy engine on the tick's path: the kernel reads the pinned staging block itself
+  a.frames = (const int16_t *)(st->h_pack_dev + ((char *)st->h_frames - st->h_pack));
+  a.ctl = (const int32_t *)(st->h_pack_dev + ((char *)st->h_ctl - st->h_pack));
+  a.h_row = (const int64_t *)(st->h_pack_dev + ((char *)st->h_win_row - st->h_pack));
+  a.h_valid = (const int32_t *)(st->h_pack_dev + ((char *)st->h_win_valid - st->h_pack));
+  a.d_row = st->d_win_row; a.d_valid = st->d_win_valid; a.nw = nw; a.S = S;
+  a.ring = st->ring;
   a.hist_in = st->hist[st->cur]; a.hist_out = st->hist[st->cur ^ 1]; a.prev = st->prev;
   a.T = st->T; a.F = st->F; a.HR = st->HR;
   a.divisor = st->fp.pcm_divisor; a.clip = st->fp.clip; a.preemph = st->fp.pre_emphasis; a.hop = hop;
@@ -315,10 +336,11 @@ int ww_stream_step(ww_streams *st, const int16_t *frames, const uint8_t *is_spee
   if (nw) {
     const float *d_hist = st->hist[st->cur];
     int rc = m->kind == WW_KIND_CRNN
-                 ? ww_k_crnn_forward(ctx, m, d_hist, (int64_t)S * st->HR, st->d_win_row, st->d_win_valid, 0, 0, 0, nw, st->ws, st->d_out, nullptr)
-                 : ww_k_wave_forward(ctx, m, d_hist, (int64_t)S * st->HR, st->d_win_row, st->d_win_valid, 0, 0, 0, nw, st->ws, st->d_out, nullptr);
+                 ? ww_k_crnn_forward(ctx, m, d_hist, (int64_t)S * st->HR, st->d_win_row, st->d_win_valid, 0, 0, 0, nw, st->ws, st->h_out_dev, nullptr)
+                 : ww_k_wave_forward(ctx, m, d_hist, (int64_t)S * st->HR, st->d_win_row, st->d_win_valid, 0, 0, 0, nw, st->ws, st->h_out_dev, nullptr);
     if (rc) return rc;
-    WW_HIP(ctx, hipMemcpyAsync(st->h_out, st->d_out, (size_t)nw * st->NO * 4, hipMemcpyDeviceToHost, ctx->stream));
+    // the head kernels store the few posteriors of a tick straight into pinned host memory: no device-to-host copy
+    // (a DMA operation of its own) between the last kernel and the host's wake-up
   }
   WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
   // posterior element: width-1 head -> [0]; width-2 head -> [1]  
