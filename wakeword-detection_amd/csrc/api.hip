@@ -778,6 +778,32 @@ static int forward_host(ww_ctx *ctx, const ww_model *m, const float *mel, int64_
   const int T = m->info.window, F = m->info.n_mel, NO = m->info.n_out;
   const size_t enc_per = (size_t)m->info.enc_rows * m->info.enc_width;
   WW_HIP(ctx, hipSetDevice(ctx->device));
+  // Small calls (the reference's per-frame use: one window in, one posterior out, utils/time_tf_models.py) are
+  // latency-bound, and a copy-engine operation costs more than the few KB are worth: the window is staged in pinned
+  // host memory and the kernels read it over the bus themselves; the posteriors (and the encoder output) are stored
+  // into pinned host memory by the kernels.  No host-to-device or device-to-host copy on the path.
+  if ((size_t)rows * F * 4 <= (256u << 10) && nw <= 64) {
+    const size_t p_mel = ww_bump::need((size_t)rows * F, 4), p_out = ww_bump::need((size_t)nw * NO, 4);
+    const size_t p_enc = enc ? ww_bump::need((size_t)nw * enc_per, 4) : 0;
+    int rc = ww_ensure(ctx, ctx->pinned, p_mel + p_out + p_enc + 256, true);
+    if (rc) return rc;
+    if ((rc = ww_ensure(ctx, ctx->dev, model_ws(m, (int)nw) + 1024, false))) return rc;
+    char *dev_view = nullptr;
+    WW_HIP(ctx, hipHostGetDevicePointer((void **)&dev_view, ctx->pinned.ptr, 0));
+    ww_bump hb(ctx->pinned.ptr, ctx->pinned.cap);
+    float *h_mel = hb.take<float>((size_t)rows * F), *h_out = hb.take<float>((size_t)nw * NO);
+    float *h_enc = enc ? hb.take<float>((size_t)nw * enc_per) : nullptr;
+    auto dv = [&](void *h) { return (float *)(dev_view + ((char *)h - (char *)ctx->pinned.ptr)); };
+    memcpy(h_mel, mel, (size_t)rows * F * 4);
+    ww_bump db(ctx->dev.ptr, ctx->dev.cap);
+    void *ws = db.take<char>(model_ws(m, (int)nw));
+    rc = model_forward(ctx, m, dv(h_mel), rows, nullptr, nullptr, 0, hop, T, (int)nw, ws, dv(h_out), enc ? dv(h_enc) : nullptr);
+    if (rc) return rc;
+    WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(out, h_out, (size_t)nw * NO * 4);
+    if (enc) memcpy(enc, h_enc, (size_t)nw * enc_per * 4);
+    return WW_OK;
+  }
   const int chunk = nw < WW_MAX_CHUNK ? (int)nw : WW_MAX_CHUNK;
   const size_t b_mel = ww_bump::need((size_t)rows * F, 4), b_out = ww_bump::need((size_t)nw * NO, 4);
   const size_t b_enc = enc ? ww_bump::need((size_t)chunk * enc_per, 4) : 0;
