@@ -40,6 +40,34 @@ int ww_ensure(ww_ctx *ctx, ww_arena &a, size_t bytes, bool pinned) {
   return WW_OK;
 }
 
+
+// Small host-pointer calls are latency-bound, and a copy-engine operation (hipMemcpyAsync) costs more than a few KB
+// are worth: their inputs are staged in the context's pinned arena, which the kernels read over the bus themselves,
+// and their outputs are stored into it by the kernels.  ww_small_io carves that arena and translates addresses.
+#define WW_SMALL_IO_BYTES (256u << 10)
+struct ww_small_io {
+  ww_ctx *ctx;
+  char *host = nullptr, *dev = nullptr;
+  size_t off = 0;
+  explicit ww_small_io(ww_ctx *c) : ctx(c) {}
+  int init(size_t bytes) {
+    int rc = ww_ensure(ctx, ctx->pinned, bytes + 1024, true);
+    if (rc) return rc;
+    host = (char *)ctx->pinned.ptr;
+    if (hipHostGetDevicePointer((void **)&dev, host, 0) != hipSuccess)
+      return ww_fail(ctx, WW_EHIP, "pinned arena is not visible to the device");
+    return WW_OK;
+  }
+  template <typename T>
+  T *take(size_t n) {
+    T *r = (T *)(host + off);
+    off += ww_bump::need(n, sizeof(T));
+    return r;
+  }
+  template <typename T>
+  T *dv(T *h) const { return (T *)(dev + ((char *)h - host)); }
+};
+
 extern "C" {
 
 const char *ww_version(void) { return "wwhip 0.2 (gfx950)"; }
@@ -651,6 +679,23 @@ static int logmel_host(ww_ctx *ctx, const ww_model *m, const void *samples, size
   const int64_t base = sample_offs[0], total_s = sample_offs[n_utt] - base;
   const size_t b_s = ww_bump::need((size_t)total_s + 16, elt), b_o = ww_bump::need((size_t)n_utt + 1, 8);
   const size_t b_m = ww_bump::need((size_t)total_f * m->filt.n_mel, 4);
+  if (b_s + 2 * b_o + b_m <= WW_SMALL_IO_BYTES) {
+    ww_small_io io(ctx);
+    if ((rc = io.init(b_s + 2 * b_o + b_m))) return rc;
+    char *h_s = io.take<char>(b_s);
+    int64_t *h_so = io.take<int64_t>(n_utt + 1), *h_fo = io.take<int64_t>(n_utt + 1);
+    float *h_mel = io.take<float>((size_t)total_f * m->filt.n_mel);
+    memcpy(h_s, (const char *)samples + (size_t)base * elt, (size_t)total_s * elt);
+    memset(h_s + (size_t)total_s * elt, 0, 16 * elt);
+    for (int u = 0; u <= n_utt; ++u) h_so[u] = sample_offs[u] - base;
+    memcpy(h_fo, frame_offs, sizeof(int64_t) * (n_utt + 1));
+    rc = ww_k_logmel(ctx, m, elt == 2 ? (const int16_t *)io.dv(h_s) : nullptr, elt == 4 ? (const float *)io.dv(h_s) : nullptr,
+                     io.dv(h_so), io.dv(h_fo), n_utt, total_f, max_f, fp, io.dv(h_mel));
+    if (rc) return rc;
+    WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(mel, h_mel, (size_t)total_f * m->filt.n_mel * 4);
+    return WW_OK;
+  }
   if ((rc = ww_ensure(ctx, ctx->dev, b_s + 2 * b_o + b_m, false))) return rc;
   ww_bump bump(ctx->dev.ptr, ctx->dev.cap);
   char *d_s = bump.take<char>(b_s);
@@ -699,7 +744,18 @@ int ww_stft_mag(ww_ctx *ctx, const ww_model *m, const float *frames, int64_t n, 
   if (!frames || !mag) return ww_fail(ctx, WW_EINVAL, "NULL buffer");
   WW_HIP(ctx, hipSetDevice(ctx->device));
   const size_t b_f = ww_bump::need((size_t)n * WW_FFT_WINDOW, 4), b_m = ww_bump::need((size_t)n * WW_FFT_BINS, 4);
-  int rc = ww_ensure(ctx, ctx->dev, b_f + b_m, false);
+  int rc;
+  if (b_f + b_m <= WW_SMALL_IO_BYTES) {
+    ww_small_io io(ctx);
+    if ((rc = io.init(b_f + b_m))) return rc;
+    float *h_f = io.take<float>((size_t)n * WW_FFT_WINDOW), *h_m = io.take<float>((size_t)n * WW_FFT_BINS);
+    memcpy(h_f, frames, (size_t)n * WW_FFT_WINDOW * 4);
+    if ((rc = ww_k_stft_mag(ctx, m, io.dv(h_f), n, precise, io.dv(h_m)))) return rc;
+    WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(mag, h_m, (size_t)n * WW_FFT_BINS * 4);
+    return WW_OK;
+  }
+  rc = ww_ensure(ctx, ctx->dev, b_f + b_m, false);
   if (rc) return rc;
   ww_bump bump(ctx->dev.ptr, ctx->dev.cap);
   float *d_f = bump.take<float>((size_t)n * WW_FFT_WINDOW), *d_m = bump.take<float>((size_t)n * WW_FFT_BINS);
@@ -722,7 +778,18 @@ int ww_filter_apply(ww_ctx *ctx, const ww_model *m, const float *mag, int64_t n,
   WW_HIP(ctx, hipSetDevice(ctx->device));
   const int NBN = m->filt.n_bins, F = m->filt.n_mel;
   const size_t b_a = ww_bump::need((size_t)n * NBN, 4), b_b = ww_bump::need((size_t)n * F, 4);
-  int rc = ww_ensure(ctx, ctx->dev, b_a + b_b, false);
+  int rc;
+  if (b_a + b_b <= WW_SMALL_IO_BYTES) {
+    ww_small_io io(ctx);
+    if ((rc = io.init(b_a + b_b))) return rc;
+    float *h_a = io.take<float>((size_t)n * NBN), *h_b = io.take<float>((size_t)n * F);
+    memcpy(h_a, mag, (size_t)n * NBN * 4);
+    if ((rc = ww_k_mel_only(ctx, m, io.dv(h_a), n, io.dv(h_b)))) return rc;
+    WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(mel, h_b, (size_t)n * F * 4);
+    return WW_OK;
+  }
+  rc = ww_ensure(ctx, ctx->dev, b_a + b_b, false);
   if (rc) return rc;
   ww_bump bump(ctx->dev.ptr, ctx->dev.cap);
   float *d_a = bump.take<float>((size_t)n * NBN), *d_b = bump.take<float>((size_t)n * F);
@@ -741,7 +808,19 @@ int ww_detect(ww_ctx *ctx, const ww_model *m, const float *enc, int32_t n, float
   WW_HIP(ctx, hipSetDevice(ctx->device));
   const size_t per = (size_t)m->info.enc_rows * m->info.enc_width;
   const size_t b_a = ww_bump::need((size_t)n * per, 4), b_b = ww_bump::need((size_t)n * m->info.n_out, 4);
-  int rc = ww_ensure(ctx, ctx->dev, b_a + b_b, false);
+  int rc;
+  if (b_a + b_b <= WW_SMALL_IO_BYTES) {
+    ww_small_io io(ctx);
+    if ((rc = io.init(b_a + b_b))) return rc;
+    float *h_a = io.take<float>((size_t)n * per), *h_b = io.take<float>((size_t)n * m->info.n_out);
+    memcpy(h_a, enc, (size_t)n * per * 4);
+    rc = m->kind == WW_KIND_CRNN ? ww_k_crnn_detect(ctx, m, io.dv(h_a), n, io.dv(h_b)) : ww_k_wave_detect(ctx, m, io.dv(h_a), n, io.dv(h_b));
+    if (rc) return rc;
+    WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(out, h_b, (size_t)n * m->info.n_out * 4);
+    return WW_OK;
+  }
+  rc = ww_ensure(ctx, ctx->dev, b_a + b_b, false);
   if (rc) return rc;
   ww_bump bump(ctx->dev.ptr, ctx->dev.cap);
   float *d_a = bump.take<float>((size_t)n * per), *d_b = bump.take<float>((size_t)n * m->info.n_out);
@@ -782,27 +861,26 @@ static int forward_host(ww_ctx *ctx, const ww_model *m, const float *mel, int64_
   // latency-bound, and a copy-engine operation costs more than the few KB are worth: the window is staged in pinned
   // host memory and the kernels read it over the bus themselves; the posteriors (and the encoder output) are stored
   // into pinned host memory by the kernels.  No host-to-device or device-to-host copy on the path.
-  if ((size_t)rows * F * 4 <= (256u << 10) && nw <= 64) {
+  {
     const size_t p_mel = ww_bump::need((size_t)rows * F, 4), p_out = ww_bump::need((size_t)nw * NO, 4);
     const size_t p_enc = enc ? ww_bump::need((size_t)nw * enc_per, 4) : 0;
-    int rc = ww_ensure(ctx, ctx->pinned, p_mel + p_out + p_enc + 256, true);
-    if (rc) return rc;
-    if ((rc = ww_ensure(ctx, ctx->dev, model_ws(m, (int)nw) + 1024, false))) return rc;
-    char *dev_view = nullptr;
-    WW_HIP(ctx, hipHostGetDevicePointer((void **)&dev_view, ctx->pinned.ptr, 0));
-    ww_bump hb(ctx->pinned.ptr, ctx->pinned.cap);
-    float *h_mel = hb.take<float>((size_t)rows * F), *h_out = hb.take<float>((size_t)nw * NO);
-    float *h_enc = enc ? hb.take<float>((size_t)nw * enc_per) : nullptr;
-    auto dv = [&](void *h) { return (float *)(dev_view + ((char *)h - (char *)ctx->pinned.ptr)); };
-    memcpy(h_mel, mel, (size_t)rows * F * 4);
-    ww_bump db(ctx->dev.ptr, ctx->dev.cap);
-    void *ws = db.take<char>(model_ws(m, (int)nw));
-    rc = model_forward(ctx, m, dv(h_mel), rows, nullptr, nullptr, 0, hop, T, (int)nw, ws, dv(h_out), enc ? dv(h_enc) : nullptr);
-    if (rc) return rc;
-    WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    memcpy(out, h_out, (size_t)nw * NO * 4);
-    if (enc) memcpy(enc, h_enc, (size_t)nw * enc_per * 4);
-    return WW_OK;
+    if (p_mel + p_out + p_enc <= WW_SMALL_IO_BYTES && nw <= 64) {
+      ww_small_io io(ctx);
+      int rc = io.init(p_mel + p_out + p_enc);
+      if (rc) return rc;
+      if ((rc = ww_ensure(ctx, ctx->dev, model_ws(m, (int)nw) + 1024, false))) return rc;
+      float *h_mel = io.take<float>((size_t)rows * F), *h_out = io.take<float>((size_t)nw * NO);
+      float *h_enc = enc ? io.take<float>((size_t)nw * enc_per) : nullptr;
+      memcpy(h_mel, mel, (size_t)rows * F * 4);
+      ww_bump db(ctx->dev.ptr, ctx->dev.cap);
+      void *ws = db.take<char>(model_ws(m, (int)nw));
+      rc = model_forward(ctx, m, io.dv(h_mel), rows, nullptr, nullptr, 0, hop, T, (int)nw, ws, io.dv(h_out), enc ? io.dv(h_enc) : nullptr);
+      if (rc) return rc;
+      WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      memcpy(out, h_out, (size_t)nw * NO * 4);
+      if (enc) memcpy(enc, h_enc, (size_t)nw * enc_per * 4);
+      return WW_OK;
+    }
   }
   const int chunk = nw < WW_MAX_CHUNK ? (int)nw : WW_MAX_CHUNK;
   const size_t b_mel = ww_bump::need((size_t)rows * F, 4), b_out = ww_bump::need((size_t)nw * NO, 4);
