@@ -29,9 +29,13 @@ def test_library_exports_every_declared_symbol():
     assert lib.ww_num_frames(24000, 160) == 147 and lib.ww_num_frames(511, 160) == 0
 
 
-def test_library_carries_gfx950_code():
+def test_library_carries_gfx950_code(tmp_path):
+    import shutil
     from wwhip import _lib
-    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", _lib.LIB_PATH], capture_output=True, text=True)
+    # llvm-objdump --offloading unbundles the code objects NEXT TO its input: work on a copy in a scratch directory
+    lib = shutil.copy(_lib.LIB_PATH, tmp_path / "libwwhip.so")
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", str(lib)], capture_output=True, text=True,
+                         cwd=tmp_path)
     if out.returncode == 0 and out.stdout:
         assert "gfx950" in out.stdout
 
