@@ -106,6 +106,22 @@ def _close_all() -> None:
 atexit.register(_close_all)
 
 
+def _torch_first() -> None:
+    """PyTorch-ROCm wheels carry their own HIP runtime.  It works beside the system one that ``libwwhip.so`` links
+    (``/opt/rocm``) only when it is loaded FIRST; loaded second it reports "No HIP GPUs are available" (measured on
+    this image: torch 2.10+rocm7.0 beside ROCm 7.2).  The library does not need torch - but the evaluators hold their
+    device buffers in torch tensors and callers mix the two freely, so when torch is installed it goes first."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
+    except Exception:  # a broken torch install must not take the library down with it
+        pass
+
+
 def load() -> C.CDLL:
     """Load ``libwwhip.so``; raises ``RuntimeError`` if it has not been built."""
     global _lib
@@ -116,6 +132,7 @@ def load() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
                 "There is no CPU fallback for the wake-word hot path.")
+        _torch_first()
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported

@@ -108,26 +108,42 @@ def get_posterior(models_dir, model_type, eval_type, test_files, frame_width, sa
     else:
         stream = signals
     mels = eng.logmel(stream, frontend_params(1.0, False, 0.0, 160, True))
-    all_posterior: list = []
+    # every window of every file in ONE model launch: start rows within the concatenated mel rows
+    rows = np.concatenate(mels) if len(mels) > 1 else mels[0]
+    win_rows, counts = [], []
     frame_cursor = 0
     for i, fpc in enumerate(per_file):
         n_frames = int(fpc.sum())
-        if carry_over:
-            mel = mels[0][frame_cursor:frame_cursor + n_frames]
-            frame_cursor += n_frames
-        else:
-            mel = mels[i]
         ws = window_schedule(fpc, encoder_len, hop)
-        if len(ws):
-            # windows start every `hop` rows from row 0 -> one sliding launch
-            post = eng.slide_forward(mel[: ws[-1] + encoder_len], hop)[:, pidx]
-        else:
-            post = np.zeros(0, np.float32)
+        win_rows.append(frame_cursor + ws)
+        counts.append(len(ws))
+        frame_cursor += n_frames if carry_over else len(mels[i])
+    win_row = np.concatenate(win_rows) if win_rows else np.zeros(0, np.int64)
+    post = _forward_rows(eng, rows, win_row)[:, pidx] if len(win_row) else np.zeros(0, np.float32)
+    all_posterior: list = []
+    o = 0
+    for nw in counts:
+        p = post[o:o + nw]
+        o += nw
         if eval_type == "false_negatives":
-            all_posterior.append(np.max(post))  # raises on an empty clip, like the reference
+            all_posterior.append(np.max(p))  # raises on an empty clip, like the reference
         else:
-            all_posterior.extend(post.tolist())
+            all_posterior.extend(p.tolist())
     return all_posterior
+
+
+def _forward_rows(eng: Engine, rows: np.ndarray, win_row: np.ndarray) -> np.ndarray:
+    """encode+detect on the windows ``rows[r : r + T]`` for every r in ``win_row``: one upload, one launch."""
+    import torch  # only to hold the device buffers of the batched launch
+
+    d_mel = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32)).cuda()
+    d_row = torch.from_numpy(np.ascontiguousarray(win_row, dtype=np.int64)).cuda()
+    d_valid = torch.full((len(win_row),), eng.window, dtype=torch.int32, device="cuda")
+    d_out = torch.empty((len(win_row), eng.n_out), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    eng.forward_windows_dev(d_mel.data_ptr(), len(rows), d_row.data_ptr(), d_valid.data_ptr(), len(win_row), d_out.data_ptr())
+    eng.ctx.synchronize()
+    return d_out.cpu().numpy()
 
 
 def default_thresholds() -> np.ndarray:
