@@ -1,3 +1,4 @@
+"""Development tool: per-kernel times inside a streaming tick (128 streams) and the host-side tick time."""
 import os, sys, time, json
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path[:0] = [ROOT, os.path.join(ROOT, "wakeword-detection_amd")]
