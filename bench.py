@@ -8,17 +8,32 @@ already resident in HBM: int16 PCM [clips, 24000] -> log-mel -> one zero-padded 
 clip -> encode + detect -> posteriors [clips, n_out]   (BASELINE.json configs[1] for CRNN,
 configs[2] for Wavenet; 1 audio frame = one 10 ms hop = 160 samples, 150 per 1.5 s clip).
 
-N > 1: launched by torch.distributed.run, one rank per GPU; every rank owns its own shard of
-clips (weak scaling, no data-path collective).  The only exchange is the posterior gather
-(RCCL all_gather of the K*clips*n_out floats each rank produced), done once at the end of the
-timed region, as the offline evaluator would do after its shard is finished.
+N > 1.  Either something else started the ranks (torch.distributed.run sets WORLD_SIZE), or this
+process does it itself: with --gpus N and no WORLD_SIZE in the environment the parent - which
+never imports torch and never touches a GPU - starts N child ranks of this same file
+(subprocess, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_ADDR/MASTER_PORT in their environment), relays
+rank 0's single JSON line and exits non-zero if any child failed.  Every rank owns its own
+shard of clips (weak scaling, no data-path collective); the only exchange is the posterior
+gather (all_gather of the K*clips*n_out floats each rank produced, RCCL over xGMI), done once
+at the end of every timed region, as the offline evaluator does after its shard is finished.
 
-Rank 0 prints ONE JSON line (schema in the task contract) including
-  roofline     - dominant kernel, measured with HIP events around every launch in a separate
-                 pass of the same K steps (ww_profile_enable), priced against the fp32 MFMA
-                 peak (157.3 TFLOP/s) or HBM (8 TB/s) - figures in DESIGN.md section 4
-  cpu_baseline - the C restatement in oracle/ (NOT TFLite) timed on this box's host cores on
-                 a bounded sample of the same workload.
+Timing.  W untimed warm-up steps (at least one per pipelined context), then the region of
+EXACTLY K steps - barrier + synchronize on both sides, MAX over ranks - is repeated --repeats
+times; `value` / `ms_per_step` are those of the MEDIAN region and `timed_regions` holds
+min / median / max, so that a short K is not a single sample.  The input rotates over
+--rotate (24) distinct resident batches whatever K is: 24 x 12.3 MB = 295 MB > the 256 MiB
+Infinity Cache, so a step's PCM comes from HBM.
+
+Rank 0 prints ONE JSON line (schema in the task contract) that also carries
+  roofline      - dominant kernel, HIP events around every launch (ww_profile_enable) in a
+                  separate pass of the same steps, priced per DESIGN.md section 4
+  cpu_baseline  - the C restatement in oracle/ (NOT TFLite) on this box's host cores, bounded
+  single_stream - the same job on ONE context (strict batch-256 latency chain, --pipeline 1)
+  wavenet       - BASELINE configs[2]: split-bf16 MFMA and the fp32-MFMA parity mode
+  streaming     - BASELINE configs[4]: 128 streams per GPU in lock step, tick latency p50/p99
+  eval_testset  - BASELINE configs[0]/[3]: the 2,048-clip stand-in of the hey-snips test split,
+                  utterance-sharded over the N ranks, FRR @ 0.5 FA/h (the second half of the
+                  metric) next to the C-oracle value of the same flow (N = 1 only).
 """
 import argparse
 import json
@@ -32,8 +47,6 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np  # noqa: E402
-
 SAMPLES = 24000          # 1.5 s @ 16 kHz
 FRAMES_PER_CLIP = 150    # audio frames (10 ms hops) per clip
 PEAK_F32_MFMA = 157.3e12  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, 256 CUs
@@ -42,16 +55,44 @@ PEAK_BF16_MFMA = 2.5e15   # dense bf16, MI355X_MICROARCH.md
 PEAK_F64_VALU = 78.6e12   # fp64 vector FMA peak
 
 
+# ------------------------------------------------------------------------------------------------
+# parent: start the ranks (no torch, no GPU call in this process)
+# ------------------------------------------------------------------------------------------------
+def launch_ranks(n: int) -> int:
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    if any(codes) or not lines:
+        sys.stderr.write(f"bench.py: rank exit codes {codes}\n")
+        return next((c for c in codes if c), 1)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------
 def synth_pcm(rng, n_clips):
     """Gaussian noise sigma=2000 LSB + linear chirp 200->4000 Hz at 8000 LSB."""
+    import numpy as np
     t = np.arange(SAMPLES) / 16000.0
     phase = 2 * np.pi * (200.0 * t + 0.5 * (4000.0 - 200.0) / 1.5 * t * t)
     x = rng.normal(0.0, 2000.0, (n_clips, SAMPLES)) + 8000.0 * np.sin(phase)[None, :]
     return np.clip(np.rint(x), -32768, 32767).astype(np.int16)
 
 
-def kernel_flops(eng, n_clips):
-    """Algorithmic FLOPs (2*MAC) and HBM bytes per launch of each kernel for one step."""
+def kernel_work(eng, n_clips):
+    """name -> (bound, algorithmic HBM bytes, algorithmic FLOPs (2*MAC)) per launch; DESIGN.md section 4."""
     nf = (SAMPLES - 512) // 160 + 1
     out = {}
     fe_bytes = n_clips * (SAMPLES * 2 + nf * 40 * 4)
@@ -63,13 +104,14 @@ def kernel_flops(eng, n_clips):
         M = c.out_t * c.out_f
         K = c.conv_w.shape[1] * c.conv_w.shape[2]
         H = c.units
-        out["conv5x20_kernel"] = ("mfma", n_clips * (eng.window * 40 * 4 + M * 32 * 4), n_clips * 2.0 * M * K * 32)
-        out["gemm_nt_kernel<gru1>"] = ("mfma", n_clips * c.out_t * (M // c.out_t * 32 + 6 * H) * 4 + 6 * H * c.out_f * 32 * 4,
-                                       n_clips * 2.0 * c.out_t * (c.out_f * 32) * 6 * H)
-        out["gemm_nt_kernel<gru2>"] = ("mfma", n_clips * c.out_t * (2 * H + 6 * H) * 4, n_clips * 2.0 * c.out_t * 2 * H * 6 * H)
-        out["gru_kernel<seq>"] = ("latency", n_clips * c.out_t * (6 * H + 2 * H) * 4, n_clips * 2.0 * c.out_t * 2 * 3 * H * H)
-        out["gru_kernel<last+head>"] = ("latency", n_clips * c.out_t * 6 * H * 4,
-                                        n_clips * (2.0 * c.out_t * 2 * 3 * H * H + 2 * (64 * 64 + 64 * c.n_out)))
+        conv = (n_clips * (eng.window * 40 * 4 + M * 32 * 4), n_clips * 2.0 * M * K * 32)
+        proj = (n_clips * c.out_t * (M // c.out_t * 32 + 6 * H) * 4 + 6 * H * c.out_f * 32 * 4,
+                n_clips * 2.0 * c.out_t * (c.out_f * 32) * 6 * H)
+        out["conv5x20_kernel"] = ("mfma",) + conv
+        out["gemm_nt_kernel<gru1>"] = ("mfma",) + proj
+        # fused conv + projection: mel window in, gx1 out, feat never leaves the CU
+        out["convproj_kernel"] = ("mfma", n_clips * (eng.window * 40 * 4 + c.out_t * 6 * H * 4) + 6 * H * c.out_f * 32 * 4,
+                                  conv[1] + proj[1])
     else:
         w = eng.bundle.wavenet
         macs = w.n_frames * (w.n_mel * w.channels) + sum(
@@ -82,6 +124,7 @@ def kernel_flops(eng, n_clips):
 
 def cpu_baseline(eng, pcm_sample, budget_s=10.0):
     """Time the C restatement (oracle/ww_oracle.c, all host threads) on a bounded sample."""
+    import numpy as np
     from oracle import cpu as ocpu
     ora = ocpu.CpuOracle(eng.blob)
     # a 1-GPU box grants this job 16 CPUs (of many more logical ones): use exactly that share
@@ -115,11 +158,211 @@ def cpu_baseline(eng, pcm_sample, budget_s=10.0):
     }
 
 
+class Job:
+    """K steps of the clip path dealt round-robin to P contexts; inputs rotate over R resident batches;
+    step k writes its posteriors to row k of one [K, clips, n_out] buffer (what the gather sends)."""
+
+    def __init__(self, torch, engs, ctxs, d_pcm, clips, K, dist, comm_dev, world):
+        self.torch, self.engs, self.ctxs, self.d_pcm, self.clips, self.K = torch, engs, ctxs, d_pcm, clips, K
+        self.dist, self.comm_dev, self.world = dist, comm_dev, world
+        self.n_out = engs[0].n_out
+        self.d_all = torch.zeros((K, clips, self.n_out), dtype=torch.float32, device="cuda")
+        self.row_ptr = [self.d_all[k].data_ptr() for k in range(K)]
+        self.pcm_ptr = [t.data_ptr() for t in d_pcm]
+        self.gathered = None
+
+    def step(self, k, fp, only0=False):
+        e = self.engs[0] if only0 else self.engs[k % len(self.engs)]
+        e.clips_forward_dev(self.pcm_ptr[k % len(self.pcm_ptr)], self.clips, SAMPLES, self.row_ptr[k % self.K], fp)
+
+    def sync(self):
+        for c in self.ctxs:
+            c.synchronize()
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def warm(self, n, fp):
+        for k in range(n):
+            self.step(k, fp)
+        self.sync()
+        if self.dist is not None:  # the communicator too, outside the timed regions
+            self._gather()
+
+    def _gather(self):
+        src = self.d_all if self.comm_dev == "cuda" else self.d_all.cpu()
+        if self.gathered is None:
+            self.gathered = [self.torch.empty_like(src) for _ in range(self.world)]
+        self.dist.all_gather(self.gathered, src)
+
+    def region(self, fp, only0=False):
+        """EXACTLY K steps between barrier + synchronize; returns seconds (MAX over ranks)."""
+        self.barrier()
+        t0 = time.perf_counter()
+        for k in range(self.K):
+            self.step(k, fp, only0)
+        self.sync()
+        if self.dist is not None:
+            self._gather()  # posterior gather, once per job
+        self.barrier()
+        el = time.perf_counter() - t0
+        if self.dist is not None:
+            t = self.torch.tensor([el], dtype=self.torch.float64, device=self.comm_dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    def regions(self, n, fp, only0=False):
+        import numpy as np
+        ts = np.array([self.region(fp, only0) for _ in range(n)])
+        return {"n": int(n), "min_ms": float(ts.min() * 1e3), "median_ms": float(np.median(ts) * 1e3),
+                "max_ms": float(ts.max() * 1e3)}, float(np.median(ts))
+
+
+def throughput(world, K, clips, seconds):
+    return world * K * clips * FRAMES_PER_CLIP / seconds
+
+
+def roofline_of(eng, prof, clips, fast_frontend):
+    kw = kernel_work(eng, clips)
+    per_kernel = {}
+    dom, dom_ms = None, -1.0
+    for name, rec in prof.items():
+        avg = rec["total_ms"] / max(rec["calls"], 1)
+        per_kernel[name] = round(avg * 1e3, 3)  # microseconds
+        if name in kw and avg > dom_ms:
+            dom, dom_ms = name, avg
+    bound, nbytes, flops = kw[dom]
+    if bound == "hbm":
+        roof = {"bound": "hbm", "achieved": nbytes / (dom_ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s"}
+    elif dom.endswith("<bf16x3>"):
+        # three bf16 MFMAs per product: priced against the dense bf16 peak with 3x the algorithmic FLOPs
+        roof = {"bound": "mfma", "achieved": 3.0 * flops / (dom_ms * 1e-3) / 1e12, "peak": PEAK_BF16_MFMA / 1e12,
+                "unit": "TFLOP/s", "note": "split-bf16: 3 bf16 MFMA products per algorithmic product; "
+                f"algorithmic rate {flops / (dom_ms * 1e-3) / 1e12:.1f} TFLOP/s"}
+    else:
+        roof = {"bound": "mfma", "achieved": flops / (dom_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s"}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    if bound == "hbm" and not fast_frontend:
+        # the front end is priced against HBM as SURVEY 8(d) defines it; what actually bounds it is the fp64
+        # vector ALU (Hann product, two radix-16 DFTs and the untangling are all float64 like the reference)
+        tf64 = flops / (dom_ms * 1e-3) / 1e12
+        roof["fp64_valu"] = {"achieved_TFLOPs": tf64, "peak_TFLOPs": PEAK_F64_VALU / 1e12, "frac": tf64 * 1e12 / PEAK_F64_VALU,
+                             "note": "13.9 kFLOP per frame (SURVEY 8d); mostly adds, so half of the FMA peak is the ceiling"}
+    roof["traffic"] = None
+    for rnd in ("r02", "r01"):  # HBM-side bytes per launch from the committed PMC passes of the same workload
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")))["kernels"].get(dom)
+        except (OSError, KeyError, ValueError):
+            continue
+        if pmc and clips == 256:
+            roof["traffic"] = (2 * pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024
+            roof["traffic_note"] = ("2 x FETCH_SIZE + WRITE_SIZE (gfx950 reports half of 16-byte-per-lane streaming reads: "
+                                    "MI355X_MICROARCH.md), rocprofv3 --pmc in separate passes, bytes per launch "
+                                    f"(profiles/{rnd}/pmc_traffic.json)")
+            roof["algorithmic_bytes"] = nbytes
+            break
+    roof["kernel"] = dom
+    roof["kernel_avg_us"] = round(dom_ms * 1e3, 3)
+    roof["all_kernels_avg_us"] = per_kernel
+    roof["method"] = "HIP events around each launch (ww_profile_enable) on the launching stream, K steps right after the timed regions"
+    return roof
+
+
+def stream_leg(torch, np, dist, comm_dev, local_rank, S, ticks, warm=100):
+    """BASELINE configs[4] per GPU: S streams x int16[320] per 20 ms tick, is_speech = 1 (2 posteriors per
+    stream and tick); latency = tick submitted on the host -> posteriors visible on the host."""
+    from wwhip.engine import Engine, StreamBank
+    out = {"streams_per_gpu": S, "ticks": ticks, "warmup_ticks": warm,
+           "note": "per-tick latency, host frames in -> host posteriors out; MAX over ranks of each rank's percentile"}
+    rng = np.random.default_rng(5)
+    frames = np.clip(rng.normal(0, 2500, (64, S, 320)), -32768, 32767).astype(np.int16)
+    speech = np.ones(S, np.uint8)
+    for name, prec in (("CRNN", "fp32"), ("Wavenet", "bf16x3"), ("Wavenet", "fp32")):
+        eng = Engine(os.path.join(PKG, "assets", "tf_lite_models", name), device=local_rank, precision=prec)
+        bank = StreamBank(eng, S)
+        for t in range(warm):
+            bank.step(frames[t % 64], speech)
+        lat = np.empty(ticks)
+        n_post = 0
+        for t in range(ticks):
+            t0 = time.perf_counter()
+            _, n = bank.step(frames[t % 64], speech)
+            lat[t] = time.perf_counter() - t0
+            n_post += int(n.sum())
+        stats = [float(np.percentile(lat, 50) * 1e3), float(np.percentile(lat, 99) * 1e3), float(lat.mean() * 1e3)]
+        if dist is not None:
+            t = torch.tensor(stats, dtype=torch.float64, device=comm_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            stats = [float(v) for v in t.tolist()]
+        out[name.lower() if prec == "fp32" else f"{name.lower()}_{prec}"] = {
+            "p50_ms": stats[0], "p99_ms": stats[1], "mean_ms": stats[2], "posteriors_per_tick": n_post / ticks,
+            "realtime_factor": 0.020 / (stats[2] * 1e-3)}
+        bank.close()
+        eng.close()
+    return out
+
+
+def eval_leg(torch, np, dist, comm_dev, rank, world, local_rank, n_clips, with_oracle):
+    """BASELINE configs[0] stand-in / configs[3]: 2,048 ragged clips, utterances dealt longest-first round-robin to the
+    ranks, sliding posteriors (hop 2) + one window per clip, gather, rank 0 smooths + sweeps: FRR @ 0.5 FA/h."""
+    from wwhip.evaluate import synth_testset, evaluate_testset_sharded, frr_at_fa
+    from wwhip.models import engine_for
+    eng = engine_for(os.path.join(PKG, "assets", "tf_lite_models", "CRNN_softmax"), local_rank)
+    clips, labels = synth_testset(n_clips)
+    res = None
+    for attempt in range(2):  # the second pass is the timed one (page-locked staging exists, workspaces sized)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = evaluate_testset_sharded(eng, clips, labels, rank, world, comm_dev)
+        el = time.perf_counter() - t0
+    if rank != 0:
+        return None
+    audio_frames = sum((len(c) + 16000) // 160 for c in clips)
+    res = {"workload": f"{len(clips)} synthetic clips 0.8-2.5 s (SURVEY 8d cfg 1 stand-in, seed 1234), CRNN_softmax, "
+                       "0.5 s zero padding, sliding hop 2 + one window per clip, 30-tap smoothing, 100 thresholds",
+           "world_size": world, "seconds_host_pcm_in_to_curves_out": el, "audio_frames_per_s": audio_frames / el,
+           "windows": r["windows"], "negative_hours": r["hours"],
+           "frr_at_0.5_fa_per_hour": r["frr_at_0.5_fa_per_hour"], "fa_count_at_threshold_0.5": int(r["fa_count"][0]),
+           "one_window_accuracy": r["one_window_accuracy"], "posterior_checksum": r["posterior_checksum"]}
+    if with_oracle:
+        # the same flow on the C oracle (the checker), all clips: posteriors -> the same sweep in NumPy
+        from oracle import cpu as ocpu
+        from oracle import numpy_ref as NR
+        ora = ocpu.CpuOracle(eng.blob)
+        ocpu.set_threads(max(1, min(16, os.cpu_count() or 1)))
+        t0 = time.perf_counter()
+        lab, offs, pidx = labels.astype(bool), r["sliding_offsets"], eng.posterior_index
+        z = np.zeros(8000, np.int16)
+        o_pos, o_neg, maxdiff = [], [], 0.0
+        for i, c in enumerate(clips):
+            p = ora.slide_forward(ora.logmel(np.concatenate((z, c, z))), 2)[:, pidx]
+            if len(p):
+                maxdiff = max(maxdiff, float(np.abs(p - r["sliding"][offs[i]:offs[i + 1]]).max()))
+            if lab[i]:
+                o_pos.append(p.max() if len(p) else 0.0)
+            else:
+                o_neg.append(p)
+        of, oa, oc, _ = NR.far_frr(np.array(o_pos, np.float32), np.concatenate(o_neg), int(lab.sum()), r["hours"])
+        res["oracle"] = {"frr_at_0.5_fa_per_hour": frr_at_fa(of, oa, 0.5), "fa_count_at_threshold_0.5": int(oc[0]),
+                         "fa_counts_identical": bool(np.array_equal(oc, r["fa_count"])),
+                         "frr_identical": bool(np.array_equal(of, r["frr"])),
+                         "max_abs_posterior_diff": maxdiff, "seconds": time.perf_counter() - t0,
+                         "kind": "oracle/ww_oracle.c + oracle/numpy_ref.py (C restatement, NOT TFLite)"}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=0, help="timed regions of K steps each (median reported); 0 = auto: "
+                    "enough regions for >= 0.25 s of timed work, between 5 and 41")
     ap.add_argument("--model", choices=["crnn", "wavenet"], default="crnn")
     ap.add_argument("--clips", type=int, default=256)
     ap.add_argument("--rotate", type=int, default=24, help="distinct resident input batches to rotate over")
@@ -131,21 +374,31 @@ def main():
                     help="model contractions: fp32 MFMA, or (Wavenet only) three bf16 MFMAs on split operands with "
                          "fp32 accumulate; auto = fp32 for CRNN (BASELINE cfg 2), bf16x3 for Wavenet (cfg 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="headline job only: skip the wavenet / streaming / eval legs")
+    ap.add_argument("--stream-ticks", type=int, default=2000)
+    ap.add_argument("--eval-clips", type=int, default=2048)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
+
+    import numpy as np
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; no CPU fallback exists for the hot path")
     # WW_BENCH_BACKEND=gloo is a rehearsal mode for a one-GPU box (ranks share GPU 0, the gather
     # goes through host memory); the driver's multi-GPU runs use RCCL ("nccl"), one GPU per rank.
     backend = os.environ.get("WW_BENCH_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and world > n_dev:
+        raise SystemExit(f"--gpus {world} but only {n_dev} GPU(s) visible (WW_BENCH_BACKEND=gloo rehearses on fewer)")
     if backend != "nccl":
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)
+        local_rank = local_rank % max(n_dev, 1)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -160,185 +413,105 @@ def main():
     from wwhip.engine import Engine, frontend_params
     from wwhip import _lib
     P = max(1, args.pipeline)
+    K = args.steps
+    R = max(1, args.rotate)
+    W = max(args.warmup, P)  # every context once: workspaces sized before the first timed region
     ctxs = [_lib.Context(local_rank) for _ in range(P)]
-    model_dir = os.path.join(PKG, "assets", "tf_lite_models", "CRNN" if args.model == "crnn" else "Wavenet")
+    assets = os.path.join(PKG, "assets", "tf_lite_models")
+    fp = frontend_params(32767.0, True, 0.0, 160, not args.fast_frontend)
+
+    rng = np.random.default_rng(1000 + rank)
+    pcm0 = synth_pcm(rng, args.clips)
+    d_pcm = [torch.from_numpy(pcm0).cuda()]
+    for r in range(1, R):  # cheap decorrelated variants: roll + sign flip, generated on the device
+        d_pcm.append(torch.roll(d_pcm[0], shifts=37 * r, dims=1) * (1 if r % 2 == 0 else -1))
+    torch.cuda.synchronize()
+
+    def run_model(model, precision, want_profile):
+        engs = [Engine(os.path.join(assets, "CRNN" if model == "crnn" else "Wavenet"), device=local_rank, ctx=c,
+                       precision=precision) for c in ctxs]
+        job = Job(torch, engs, ctxs, d_pcm, args.clips, K, dist, comm_dev, world)
+        job.warm(W, fp)
+        n_rep = args.repeats
+        if n_rep <= 0:
+            probe = job.region(fp)
+            n_rep = int(min(41, max(5, 0.25 / max(probe, 1e-6)))) | 1
+        stats, med = job.regions(n_rep, fp)
+        res = {"engs": engs, "job": job, "stats": stats, "median_s": med}
+        res["posts"] = job.d_all[:min(K, R)].cpu().numpy()
+        if want_profile:
+            job.warm(1, fp)
+            s1, m1 = job.regions(max(3, n_rep // 2) | 1, fp, only0=True)
+            res["single"] = {"value": throughput(world, K, args.clips, m1), "unit": "audio frames/s",
+                             "ms_per_step": m1 / K * 1e3, "timed_regions": s1,
+                             "note": "same job, every step on ONE context / HIP stream (--pipeline 1): front end -> "
+                                     "model kernels of a batch strictly in sequence"}
+            ctxs[0].profile(True)
+            for k in range(K):
+                job.step(k, fp, only0=True)
+            res["prof"] = ctxs[0].profile_read()
+            ctxs[0].profile(False)
+        return res
+
     precision = args.precision if args.precision != "auto" else ("fp32" if args.model == "crnn" else "bf16x3")
     if args.model == "crnn" and precision != "bf16x6":
         precision = "fp32"
-    engs = [Engine(model_dir, device=local_rank, ctx=c, precision=precision) for c in ctxs]
-    ctx, eng = ctxs[0], engs[0]
-    fp = frontend_params(32767.0, True, 0.0, 160, not args.fast_frontend)
+    head = run_model(args.model, precision, True)
+    eng = head["engs"][0]
 
-    # R distinct resident input batches, rotated step by step: R * 12.3 MB exceeds the 256 MiB
-    # Infinity Cache, so every step's PCM comes from HBM rather than from a cache-warm copy.
-    rng = np.random.default_rng(1000 + rank)
-    R = max(1, min(args.rotate, args.steps))
-    pcm0 = synth_pcm(rng, args.clips)
-    d_pcm = []
-    for r in range(R):
-        if r == 0:
-            d_pcm.append(torch.from_numpy(pcm0).cuda())
-        else:  # cheap decorrelated variants: roll + sign flip, generated on the device
-            d_pcm.append(torch.roll(d_pcm[0], shifts=37 * r, dims=1) * (1 if r % 2 == 0 else -1))
-    K = args.steps
-    d_outs = [torch.zeros((args.clips, eng.n_out), dtype=torch.float32, device="cuda") for _ in range(R)]
-    d_all = torch.zeros((K, args.clips, eng.n_out), dtype=torch.float32, device="cuda")
-    slot_of_step = torch.arange(K, device="cuda") % R
-    torch.cuda.synchronize()
-
-    def step(k, only0=False):
-        r = k % R
-        e = eng if only0 else engs[k % P]
-        e.clips_forward_dev(d_pcm[r].data_ptr(), args.clips, SAMPLES, d_outs[r].data_ptr(), fp)
-
-    def sync_all():
-        for c in ctxs:
-            c.synchronize()
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for k in range(max(args.warmup, R * P)):  # every (context, batch) pair seen once: graphs captured
-        step(k)
-    sync_all()
-    if dist is not None:  # warm up the communicator outside the timed region
-        src = d_all.to(comm_dev)
-        tmp = [torch.empty_like(src) for _ in range(world)]
-        dist.all_gather(tmp, src)
-        del tmp, src
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(K):
-        step(k)
-    sync_all()
-    if dist is not None:
-        # posterior gather, once per job: every rank contributes the K*clips*n_out floats it produced
-        d_all = torch.stack(d_outs)[slot_of_step]  # two device kernels, not K copies
-        src = d_all.to(comm_dev)
-        gathered = [torch.empty_like(src) for _ in range(world)]
-        dist.all_gather(gathered, src)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    # ---- same region once more with the fp32-FFT front end (precise=0), reported as a side figure:
+    # ---- same regions with the fp32-FFT front end (precise=0), reported as a side figure:
     # posteriors stay within 5e-6 of the fp64-FFT path (tools/f32_error.py), log-mel within 1.4e-4
     alt = None
     if not args.fast_frontend:
         fp_fast = frontend_params(32767.0, True, 0.0, 160, False)
+        head["job"].warm(P, fp_fast)
+        s, m = head["job"].regions(max(3, head["stats"]["n"] // 2) | 1, fp_fast)
+        alt = {"value": throughput(world, K, args.clips, m), "unit": "audio frames/s", "ms_per_step": m / K * 1e3,
+               "timed_regions": s, "note": "same job with ww_frontend_params.precise=0 (fp32 butterflies)"}
 
-        def step_fast(k):
-            engs[k % P].clips_forward_dev(d_pcm[k % R].data_ptr(), args.clips, SAMPLES, d_outs[k % R].data_ptr(), fp_fast)
-        for k in range(R * P):
-            step_fast(k)
-        sync_all()
-        barrier()
-        t1 = time.perf_counter()
-        for k in range(K):
-            step_fast(k)
-        sync_all()
-        barrier()
-        alt = time.perf_counter() - t1
-        for k in range(R * P):  # restore the fp64-front-end outputs
-            step(k)
-        sync_all()
+    def close(res):
+        for e in res["engs"]:
+            e.close()
 
-    # ---- Wavenet: the same region with fp32 MFMA contractions (parity mode), reported alongside (cfg 3)
-    alt_fp32 = None
-    if precision == "bf16x3":
-        for e in engs:
-            e.set_precision("fp32")
-        for k in range(R * P):
-            step(k)
-        sync_all()
-        barrier()
-        t2 = time.perf_counter()
-        for k in range(K):
-            step(k)
-        sync_all()
-        barrier()
-        alt_fp32 = time.perf_counter() - t2
-        posts_fp32 = torch.stack(d_outs).cpu().numpy()
-        for e in engs:
-            e.set_precision("bf16x3")
-        for k in range(R * P):
-            step(k)
-        sync_all()
-        alt_fp32_maxdiff = float(np.abs(torch.stack(d_outs).cpu().numpy() - posts_fp32).max())
-
-    # ---- per-kernel pass (HIP events around every launch), same K steps
-    ctx.profile(True)
-    for k in range(K):
-        step(k, only0=True)
-    prof = ctx.profile_read()
-    ctx.profile(False)
-    posts = d_outs[0].cpu().numpy()
+    extra = {}
+    if not args.no_extra:
+        # ---- BASELINE configs[2] (or configs[1] when the headline is the Wavenet): the other model, same regions
+        if args.model == "crnn":
+            wv = run_model("wavenet", "bf16x3", True)
+            for e in wv["engs"]:
+                e.set_precision("fp32")
+            wv["job"].warm(P, fp)
+            s32, m32 = wv["job"].regions(max(3, wv["stats"]["n"] // 2) | 1, fp)
+            posts32 = wv["job"].d_all[:min(K, R)].cpu().numpy()
+            weng = wv["engs"][0]
+            extra["wavenet"] = {
+                "workload": f"Wavenet dilated-conv encode+detect, batch={args.clips}x1.5 s clips per GPU, same PCM, "
+                            f"{weng.window}x40 window (BASELINE configs[2])",
+                "bf16x3": {"value": throughput(world, K, args.clips, wv["median_s"]), "unit": "audio frames/s",
+                           "ms_per_step": wv["median_s"] / K * 1e3, "timed_regions": wv["stats"],
+                           "dtype": "bf16x3 (split-bf16 MFMA products, f32 accumulate)",
+                           "single_stream": wv["single"], "roofline": roofline_of(weng, wv["prof"], args.clips, args.fast_frontend)},
+                "fp32_mfma_parity_mode": {"value": throughput(world, K, args.clips, m32), "unit": "audio frames/s",
+                                          "ms_per_step": m32 / K * 1e3, "timed_regions": s32,
+                                          "max_abs_posterior_diff_vs_bf16x3": float(np.abs(posts32 - wv["posts"]).max())}}
+            close(wv)
+        # ---- BASELINE configs[4]: streaming
+        extra["streaming"] = stream_leg(torch, np, dist, comm_dev, local_rank, 128, args.stream_ticks)
+        # ---- BASELINE configs[0] stand-in / configs[3]: sharded evaluation, FRR @ 0.5 FA/h
+        extra["eval_testset"] = eval_leg(torch, np, dist, comm_dev, rank, world, local_rank, args.eval_clips,
+                                         with_oracle=(world == 1 and not args.no_cpu_baseline))
 
     if rank == 0:
-        total_frames = world * K * args.clips * FRAMES_PER_CLIP
-        kf = kernel_flops(eng, args.clips)
-        per_kernel = {}
-        dom, dom_ms = None, -1.0
-        for name, rec in prof.items():
-            avg = rec["total_ms"] / max(rec["calls"], 1)
-            per_kernel[name] = round(avg * 1e3, 3)  # microseconds
-            if name in kf and avg > dom_ms:
-                dom, dom_ms = name, avg
-        bound, nbytes, flops = kf[dom]
-        if bound == "hbm":
-            roof = {"bound": "hbm", "achieved": nbytes / (dom_ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s"}
-        elif dom.endswith("<bf16x3>"):
-            # three bf16 MFMAs per product: priced against the dense bf16 peak with 3x the algorithmic FLOPs
-            roof = {"bound": "mfma", "achieved": 3.0 * flops / (dom_ms * 1e-3) / 1e12, "peak": PEAK_BF16_MFMA / 1e12,
-                    "unit": "TFLOP/s", "note": "split-bf16: 3 bf16 MFMA products per algorithmic product; "
-                    f"algorithmic rate {flops / (dom_ms * 1e-3) / 1e12:.1f} TFLOP/s"}
-        else:
-            roof = {"bound": "mfma", "achieved": flops / (dom_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s"}
-        roof["frac"] = roof["achieved"] / roof["peak"]
-        if bound == "hbm" and not args.fast_frontend:
-            # the front end is priced against HBM as SURVEY 8(d) defines it; what actually bounds it is the fp64
-            # vector ALU (Hann product, two radix-16 DFTs and the untangling are all float64 like the reference)
-            tf64 = flops / (dom_ms * 1e-3) / 1e12
-            roof["fp64_valu"] = {"achieved_TFLOPs": tf64, "peak_TFLOPs": PEAK_F64_VALU / 1e12, "frac": tf64 * 1e12 / PEAK_F64_VALU,
-                                 "note": "13.9 kFLOP per frame (SURVEY 8d); mostly adds, so half of the FMA peak is the ceiling"}
-        roof["traffic"] = None
-        try:  # HBM-side bytes per launch from the committed PMC passes of the same workload
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))["kernels"].get(dom)
-            if pmc and args.clips == 256:
-                roof["traffic"] = (2 * pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024
-                roof["traffic_note"] = ("2 x FETCH_SIZE + WRITE_SIZE (gfx950 reports half of 16-byte-per-lane streaming reads: "
-                                        "MI355X_MICROARCH.md), rocprofv3 --pmc in separate passes, bytes per launch "
-                                        "(profiles/r01/pmc_traffic.json)")
-                roof["algorithmic_bytes"] = nbytes
-            sq = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json"))).get("sq_counters_logmel_f64_v6_final")
-            if sq and dom == "logmel_kernel<f64>" and args.clips == 256:
-                # what bounds the kernel in practice, from the committed SQ counter passes (per CU: 4 vector ALUs, 1 LDS pipe;
-                # SQ_ACTIVE_INST_* count quad-cycles, SQ_BUSY_CYCLES is summed over the 32 shader engines)
-                cyc = sq["SQ_BUSY_CYCLES"] / 32.0
-                roof["pipes_busy"] = {"valu": round(sq["SQ_ACTIVE_INST_VALU"] * 4 / 1024.0 / cyc, 3),
-                                      "lds": round(sq["SQ_LDS_IDX_ACTIVE"] / 256.0 / cyc, 3),
-                                      "lds_bank_conflict_share": round(sq["SQ_LDS_BANK_CONFLICT"] / sq["SQ_LDS_IDX_ACTIVE"], 3),
-                                      "wave_cycles_in_waitcnt": round(sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"], 3),
-                                      "source": "profiles/r01/pmc_traffic.json: sq_counters_logmel_f64_v6_final (rocprofv3 --pmc, tools/pmc_fe.sh)"}
-        except (OSError, KeyError, ValueError):
-            pass
-        roof["kernel"] = dom
-        roof["kernel_avg_us"] = round(dom_ms * 1e3, 3)
-        roof["all_kernels_avg_us"] = per_kernel
-        roof["method"] = "HIP events around each launch (ww_profile_enable), K steps right after the timed region"
+        roof = roofline_of(eng, head["prof"], args.clips, args.fast_frontend)
+        med = head["median_s"]
         line = {
-            "metric": "audio frames/sec (16 kHz, 40-mel, 10 ms hop)",
-            "value": total_frames / elapsed,
+            "metric": "audio frames/sec (16 kHz, 40-mel, 10 ms hop) + FRR@0.5 FA/h",
+            "value": throughput(world, K, args.clips, med),
             "unit": "audio frames/s",
             "n_gpus": world,
             "steps": K,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / K * 1e3,
+            "warmup": W,
+            "ms_per_step": med / K * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -351,26 +524,29 @@ def main():
                 "clips_per_gpu": args.clips,
                 "samples_per_clip": SAMPLES,
                 "resident_input_batches_rotated": R,
+                "resident_input_bytes": R * args.clips * SAMPLES * 2,
                 "pipelined_contexts": P,
                 "weights": "reference tf_lite_models (shipped fp32 weights)",
-                "parallelism": f"utterance-sharded x{world}, posterior all_gather once per job" if world > 1 else "single GPU",
+                "parallelism": f"utterance-sharded x{world}, posterior all_gather once per timed region" if world > 1 else "single GPU",
             },
+            "timed_regions": dict(head["stats"], note="each region = exactly `steps` steps between barrier+synchronize; "
+                                  "value and ms_per_step are the median region's"),
             "roofline": roof,
-            "posterior_checksum": float(np.sum(posts, dtype=np.float64)),
-            "alt_fp32_fft_frontend": None if alt is None else {
-                "value": total_frames / alt, "unit": "audio frames/s", "ms_per_step": alt / K * 1e3,
-                "note": "same job with ww_frontend_params.precise=0 (fp32 butterflies); per-rank time, not max-reduced"},
+            "posterior_checksum": float(np.sum(head["posts"][0], dtype=np.float64)),
+            "single_stream": head["single"],
+            "alt_fp32_fft_frontend": alt,
         }
-        if alt_fp32 is not None:
-            line["alt_fp32_mfma_parity_mode"] = {
-                "value": total_frames / alt_fp32, "unit": "audio frames/s", "ms_per_step": alt_fp32 / K * 1e3,
-                "max_abs_posterior_diff_vs_bf16x3": alt_fp32_maxdiff,
-                "note": "same job with ww_model_set_precision(WW_PRECISION_FP32); per-rank time, not max-reduced"}
+        if world > 1 and backend != "nccl":
+            line["config"]["rehearsal"] = f"{backend} backend, ranks share {n_dev} physical GPU(s): not a scaling measurement"
+        line.update(extra)
+        if extra.get("eval_testset"):
+            line["frr_at_0.5_fa_per_hour"] = extra["eval_testset"]["frr_at_0.5_fa_per_hour"]
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(eng, pcm0, float(os.environ.get("WW_BENCH_CPU_SECONDS", "10")))
         elif not args.no_cpu_baseline:
             line["cpu_baseline"] = None
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
+    close(head)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -97,3 +97,16 @@ def test_posterior_gather_gloo_world2(tmp_path):
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
+
+
+def test_bench_parent_starts_ranks_without_touching_a_gpu():
+    """`bench.py --gpus 2` with no WORLD_SIZE spawns its ranks itself.  Without a GPU the children refuse to run
+    ("no CPU fallback"), and the parent must report that as a failure instead of printing a line."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_gpu_bench_eval.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "rank exit codes" in r.stderr and "needs an MI355X" in r.stderr

@@ -1,0 +1,139 @@
+"""bench.py's contract (one JSON line, all BASELINE configs, self-launched ranks) and the sharded
+test-set evaluation (SURVEY 8d cfg 1 at full size, cfg 4 as 1 rank == 2 ranks) - on the MI355X.
+
+Every bench / multi-rank run is a CHILD process: nothing of this test process's GPU state is shared,
+and the 2-rank runs are gloo rehearsals in which both ranks use GPU 0 (one-GPU box)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 1e-4  # north_star: posteriors within 1e-4 of the reference arithmetic (here: of the oracle)
+
+
+def _bench(args, env=None, timeout=900):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                       timeout=timeout, env=dict(os.environ, WW_BENCH_CPU_SECONDS="1", **(env or {})))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+def test_bench_line_honours_the_contract():
+    """`python bench.py --steps K --warmup W` prints ONE JSON line with the driver's fields, the roofline of the
+    dominant kernel, the CPU baseline, and the legs for BASELINE configs[0], [2], [3]-as-1-rank and [4]."""
+    d = _bench(["--steps", "40", "--warmup", "4", "--stream-ticks", "300", "--eval-clips", "256"])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "timed_regions", "single_stream",
+                "wavenet", "streaming", "eval_testset", "frr_at_0.5_fa_per_hour"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 40 and d["warmup"] == 4 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    # the input rotation does not shrink with K: more resident PCM than the 256 MiB Infinity Cache
+    assert d["config"]["resident_input_batches_rotated"] >= 24 and d["config"]["resident_input_bytes"] > 256 << 20
+    frames = 40 * 256 * 150  # K steps x 256 clips x 10 ms hops of a 1.5 s clip
+    assert abs(d["value"] - frames / (d["ms_per_step"] * 40 * 1e-3)) / d["value"] < 1e-6
+    tr = d["timed_regions"]
+    assert tr["n"] >= 5 and tr["min_ms"] <= tr["median_ms"] <= tr["max_ms"]
+    assert abs(tr["median_ms"] - d["ms_per_step"] * 40) < 1e-6 * tr["median_ms"] + 1e-9
+    roof = d["roofline"]
+    assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and 0 < roof["frac"] < 1
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert d["value"] > 10 * cb["value"]  # north_star: >= 10x the CPU path at 1 GPU
+    assert 0 < d["single_stream"]["value"] <= d["value"] * 1.05
+    wv = d["wavenet"]
+    assert wv["bf16x3"]["value"] > 0 and wv["fp32_mfma_parity_mode"]["value"] > 0
+    assert wv["fp32_mfma_parity_mode"]["max_abs_posterior_diff_vs_bf16x3"] < TOL
+    st = d["streaming"]
+    assert st["streams_per_gpu"] == 128 and st["ticks"] == 300
+    for k in ("crnn", "wavenet_bf16x3", "wavenet"):
+        assert 0 < st[k]["p50_ms"] <= st[k]["p99_ms"] < 20.0  # a tick is 20 ms of audio
+        assert st[k]["posteriors_per_tick"] == 256.0
+    ev = d["eval_testset"]
+    assert ev["world_size"] == 1 and 0.0 <= ev["frr_at_0.5_fa_per_hour"] <= 1.0
+    assert ev["oracle"]["fa_counts_identical"] and ev["oracle"]["frr_identical"] and ev["oracle"]["max_abs_posterior_diff"] < TOL
+    assert d["frr_at_0.5_fa_per_hour"] == ev["frr_at_0.5_fa_per_hour"] == ev["oracle"]["frr_at_0.5_fa_per_hour"]
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE: the parent (no torch, no GPU) starts two child ranks and relays
+    rank 0's line.  One-GPU box: gloo rehearsal, both ranks on GPU 0 - the line says so."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "4",
+                        "--stream-ticks", "100", "--eval-clips", "128"], capture_output=True, text=True, timeout=900,
+                       env=dict(env, WW_BENCH_BACKEND="gloo", WW_BENCH_CPU_SECONDS="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 12 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert abs(d["value"] - 2 * 12 * 256 * 150 / (d["ms_per_step"] * 12 * 1e-3)) / d["value"] < 1e-6
+    assert "rehearsal" in d["config"] and "x2" in d["config"]["parallelism"]
+    assert d["eval_testset"]["world_size"] == 2 and d["streaming"]["crnn"]["p50_ms"] > 0
+
+
+@pytest.fixture(scope="module")
+def testset_one_rank(assets):
+    from wwhip.evaluate import synth_testset, evaluate_testset_sharded
+    from wwhip.models import engine_for
+    eng = engine_for(os.path.join(assets, "CRNN_softmax"))
+    clips, labels = synth_testset(2048)
+    return eng, clips, labels, evaluate_testset_sharded(eng, clips, labels)
+
+
+def test_cfg4_sharded_evaluation_identical_to_one_rank(testset_one_rank, tmp_path):
+    """BASELINE configs[3] / SURVEY 8(d) cfg 4 at full size (2,048 clips, 118,643 windows): utterances dealt over
+    2 ranks + posterior gather gives the FRR array, the FA counts and every posterior bit-identical to 1 rank."""
+    _, _, _, one = testset_one_rank
+    dump = tmp_path / "two_ranks.npz"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29653", os.path.join(ROOT, "tools", "eval_testset.py"),
+                        "--backend", "gloo", "--dump", str(dump)], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["world_size"] == 2 and line["clips"] == 2048
+    two = np.load(dump)
+    np.testing.assert_array_equal(two["frr"], one["frr"])
+    np.testing.assert_array_equal(two["fa_count"], one["fa_count"])
+    np.testing.assert_array_equal(two["sliding"], one["sliding"])
+    np.testing.assert_array_equal(two["one"], one["one_window_posteriors"])
+    assert float(two["checksum"]) == one["posterior_checksum"] == line["posterior_checksum"]
+    assert line["frr_at_0.5_fa_per_hour"] == one["frr_at_0.5_fa_per_hour"]
+
+
+def test_cfg1_full_size_vs_oracle(testset_one_rank):
+    """BASELINE configs[0] stand-in at full size: the GPU's FRR @ 0.5 FA/h, FRR array and FA counts equal the CPU
+    oracle's flow (C restatement for the posteriors, the NumPy restatement of plot_FRR_FAR for the sweep)."""
+    from oracle import cpu as ocpu
+    from oracle import numpy_ref as NR
+    from wwhip.evaluate import frr_at_fa
+    eng, clips, labels, one = testset_one_rank
+    ora = ocpu.CpuOracle(eng.blob)
+    ocpu.set_threads(max(1, min(16, os.cpu_count() or 1)))
+    lab, offs, pidx = labels.astype(bool), one["sliding_offsets"], eng.posterior_index
+    z = np.zeros(8000, np.int16)
+    o_pos, o_neg, o_one = [], [], []
+    for i, c in enumerate(clips):
+        p = ora.slide_forward(ora.logmel(np.concatenate((z, c, z))), 2)[:, pidx]
+        assert len(p) == offs[i + 1] - offs[i]
+        assert np.abs(p - one["sliding"][offs[i]:offs[i + 1]]).max() < TOL
+        (o_pos if lab[i] else o_neg).append(p.max() if lab[i] else p)
+        if i % 16 == 0:  # the a17 flow (one end-padded window per clip) on a sample
+            mel = ora.logmel(c)
+            w = np.zeros((eng.window, 40), np.float32)
+            w[:min(len(mel), eng.window)] = mel[:eng.window]
+            assert abs(ora.forward(w)[0, pidx] - one["one_window_posteriors"][i]) < TOL
+    wf, wa, wc, _ = NR.far_frr(np.array(o_pos, np.float32), np.concatenate(o_neg), int(lab.sum()), one["hours"])
+    np.testing.assert_array_equal(one["fa_count"], wc)
+    np.testing.assert_array_equal(one["frr"], wf)
+    assert one["frr_at_0.5_fa_per_hour"] == frr_at_fa(wf, wa, 0.5)

@@ -441,33 +441,3 @@ def test_demo_pipeline_on_a_wav(assets, tmp_path):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "demo.py"), "--models_dir", os.path.join(assets, "Wavenet"),
                         "--model_type", "Wavenet", "--wav", str(tmp_path / "in.wav")], capture_output=True, text=True, check=True)
     assert "wake events at (s):" in r.stdout and "Script completed" in r.stdout
-
-
-def test_bench_line_honours_the_contract():
-    """`python bench.py --steps K --warmup W` prints ONE JSON line with the driver's fields, the roofline of the
-    dominant kernel and the CPU baseline (run as a child process: nothing of this test's GPU state is shared)."""
-    import json
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, WW_BENCH_CPU_SECONDS="1")
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "40", "--warmup", "4"],
-                       capture_output=True, text=True, timeout=600, env=env)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, lines
-    d = json.loads(lines[0])
-    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
-        assert key in d, key
-    assert d["n_gpus"] == 1 and d["steps"] == 40 and d["warmup"] == 4 and d["higher_is_better"] is True
-    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
-    assert "workload" in d["config"] and "model" not in d["config"]
-    frames = 40 * 256 * 150  # K steps x 256 clips x 10 ms hops of a 1.5 s clip
-    assert abs(d["value"] - frames / (d["ms_per_step"] * 40 * 1e-3)) / d["value"] < 1e-6
-    roof = d["roofline"]
-    assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s")
-    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and 0 < roof["frac"] < 1
-    cb = d["cpu_baseline"]
-    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
-    assert d["value"] > 10 * cb["value"]  # north_star: >= 10x the CPU path at 1 GPU

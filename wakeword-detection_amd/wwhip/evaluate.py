@@ -136,11 +136,12 @@ def _forward_rows(eng: Engine, rows: np.ndarray, win_row: np.ndarray) -> np.ndar
     """encode+detect on the windows ``rows[r : r + T]`` for every r in ``win_row``: one upload, one launch."""
     import torch  # only to hold the device buffers of the batched launch
 
-    d_mel = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32)).cuda()
-    d_row = torch.from_numpy(np.ascontiguousarray(win_row, dtype=np.int64)).cuda()
-    d_valid = torch.full((len(win_row),), eng.window, dtype=torch.int32, device="cuda")
-    d_out = torch.empty((len(win_row), eng.n_out), dtype=torch.float32, device="cuda")
-    torch.cuda.synchronize()
+    dev = torch.device("cuda", eng.ctx.device)  # the engine's GPU, whatever torch's current device is
+    d_mel = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32)).to(dev)
+    d_row = torch.from_numpy(np.ascontiguousarray(win_row, dtype=np.int64)).to(dev)
+    d_valid = torch.full((len(win_row),), eng.window, dtype=torch.int32, device=dev)
+    d_out = torch.empty((len(win_row), eng.n_out), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize(dev)
     eng.forward_windows_dev(d_mel.data_ptr(), len(rows), d_row.data_ptr(), d_valid.data_ptr(), len(win_row), d_out.data_ptr())
     eng.ctx.synchronize()
     return d_out.cpu().numpy()
@@ -274,12 +275,13 @@ def clip_posteriors(engine: Engine, clips: Sequence[np.ndarray], hop: int = 2, f
     slide_row = np.repeat(foffs[:-1] - hop * woffs[:-1], nw) + hop * np.arange(int(woffs[-1]), dtype=np.int64)
     win_row = np.concatenate((foffs[:-1] + PAD // hop_s, slide_row)).astype(np.int64)
     win_valid = np.concatenate((np.minimum(nf_bare, T), np.full(int(woffs[-1]), T))).astype(np.int32)
-    d_pcm = pin.cuda(non_blocking=True)
-    d_so, d_fo = torch.from_numpy(soffs).cuda(), torch.from_numpy(foffs).cuda()
-    d_mel = torch.empty((max(total_f, 1), engine.n_mel), dtype=torch.float32, device="cuda")
-    d_row, d_valid = torch.from_numpy(win_row).cuda(), torch.from_numpy(win_valid).cuda()
-    d_out = torch.empty((len(win_row), engine.n_out), dtype=torch.float32, device="cuda")
-    torch.cuda.synchronize()
+    dev = torch.device("cuda", engine.ctx.device)  # the engine's GPU, whatever torch's current device is
+    d_pcm = pin.to(dev, non_blocking=True)
+    d_so, d_fo = torch.from_numpy(soffs).to(dev), torch.from_numpy(foffs).to(dev)
+    d_mel = torch.empty((max(total_f, 1), engine.n_mel), dtype=torch.float32, device=dev)
+    d_row, d_valid = torch.from_numpy(win_row).to(dev), torch.from_numpy(win_valid).to(dev)
+    d_out = torch.empty((len(win_row), engine.n_out), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize(dev)
     engine.logmel_dev(d_pcm.data_ptr(), d_so.data_ptr(), d_fo.data_ptr(), n, total_f, int(nf_pad.max()), d_mel.data_ptr(), fp)
     engine.forward_windows_dev(d_mel.data_ptr(), total_f, d_row.data_ptr(), d_valid.data_ptr(), len(win_row), d_out.data_ptr())
     engine.ctx.synchronize()
@@ -301,6 +303,47 @@ def evaluate_testset(engine: Engine, clips: Sequence[np.ndarray], labels: Sequen
     return {"thresholds": thr, "frr": frr, "fa_per_hour": fa, "fa_count": cnt, "frr_at_0.5_fa_per_hour": frr_at_fa(frr, fa, 0.5),
             "one_window_posteriors": p_one, "one_window_accuracy": float((preds == labels).mean()),
             "positives": pos, "negatives": neg, "hours": hours}
+
+
+def evaluate_testset_sharded(engine: Engine, clips: Sequence[np.ndarray], labels: Sequence[int], rank: int = 0,
+                             world: int = 1, comm_device: Optional[str] = None, thresholds=None, windowsize: int = 30):
+    """SURVEY 8(d) cfg 4: :func:`evaluate_testset` with the utterances dealt longest-first round-robin to ``world``
+    ranks (one process per GPU, ``torch.distributed`` already initialised by the caller when ``world > 1``).  Each rank
+    runs its own clips; the one exchange is the posterior gather; rank 0 smooths and sweeps.  Every posterior is a full
+    recompute of its window (``utils/evaluate_models.py:70-88``), so the result is identical for every ``world``.
+    Returns the result dict on rank 0 and ``None`` elsewhere."""
+    from . import dist as D
+    labels = np.asarray(labels).astype(bool)
+    T, n = engine.window, len(clips)
+    # global layout of the sliding posteriors: pure arithmetic, identical on every rank
+    n_frames = np.array([((len(c) + 16000) - WINDOW) // 160 + 1 for c in clips], np.int64)
+    n_win = np.where(n_frames >= T, (n_frames - T) // 2 + 1, 0)
+    offs = np.concatenate(([0], np.cumsum(n_win)))
+    mine = D.shard_by_length([len(c) for c in clips], world)[rank]
+    p_one, sliding = clip_posteriors(engine, [clips[i] for i in mine])
+    slots = np.concatenate([np.arange(offs[i], offs[i + 1]) for i in mine]) if mine else np.zeros(0, np.int64)
+    vals = np.concatenate(sliding) if sliding else np.zeros(0, np.float32)
+    if world > 1:
+        all_slide = D.gather_posteriors(vals, slots, int(offs[-1]), device=comm_device)
+        all_one = D.gather_posteriors(p_one, mine, n, device=comm_device)
+    else:
+        all_slide = np.zeros(int(offs[-1]), np.float32)
+        all_slide[slots] = vals
+        all_one = np.zeros(n, np.float32)
+        all_one[mine] = p_one
+    if rank != 0:
+        return None
+    # a clip shorter than the window yields no posterior (the reference's np.max would raise): 0
+    pos = np.array([all_slide[offs[i]:offs[i + 1]].max() if offs[i + 1] > offs[i] else 0.0
+                    for i in range(n) if labels[i]], np.float32)
+    neg = (np.concatenate([all_slide[offs[i]:offs[i + 1]] for i in range(n) if not labels[i]])
+           if (~labels).any() else np.zeros(0, np.float32))
+    hours = sum(len(clips[i]) + 16000 for i in range(n) if not labels[i]) / 16000.0 / 3600.0
+    thr, frr, fa, cnt = far_frr(pos, neg, max(int(labels.sum()), 1), hours, thresholds, windowsize, engine=engine)
+    return {"thresholds": thr, "frr": frr, "fa_per_hour": fa, "fa_count": cnt, "frr_at_0.5_fa_per_hour": frr_at_fa(frr, fa, 0.5),
+            "one_window_posteriors": all_one, "one_window_accuracy": float(((all_one >= 0.5) == labels).mean()),
+            "positives": pos, "negatives": neg, "hours": hours, "sliding": all_slide, "sliding_offsets": offs,
+            "windows": int(offs[-1]) + n, "posterior_checksum": float(all_slide.sum(dtype=np.float64))}
 
 
 # ----------------------------------------------------------------------------------------------
