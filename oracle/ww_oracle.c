@@ -337,7 +337,7 @@ int wwo_crnn_forward(const void *blob, size_t blob_len, const float *mel, int B,
   if (!m) return WWO_EBLOB;
   const int n_mel = m[0], T = m[1], C = m[2], KF = m[3], KT = m[4], SF = m[5], ST = m[6], PF = m[7], PT = m[8],
             OF = m[9], OT = m[10], H = m[11], NOUT = m[12], HEAD = m[13];
-  if (H > 64 || OT > 64 || KF * KT > 256 || C > 64) return WWO_EARG;
+  if (H > 64 || OT > 256 || KF * KT > 256 || C > 64) return WWO_EARG;
   const float *cw = bf(&b, "crnn.conv_w"), *cb = bf(&b, "crnn.conv_b");
   gru_t g1f = {bf(&b, "crnn.g1f.wx"), bf(&b, "crnn.g1f.bx"), bf(&b, "crnn.g1f.wh"), bf(&b, "crnn.g1f.bh"), 0, 0};
   gru_t g1b = {bf(&b, "crnn.g1b.wx"), bf(&b, "crnn.g1b.bx"), bf(&b, "crnn.g1b.wh"), bf(&b, "crnn.g1b.bh"), 0, 0};

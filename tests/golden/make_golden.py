@@ -18,6 +18,9 @@ What each fixture pins
                          model dir, from oracle/tflite_interp in fp32 and fp64 ("parity
                          unpinned": there is no TFLite runtime to produce these)
   evaluator.npz          seeded posterior streams -> np.convolve smoothing, FRR, FA/h
+  activation_timeout_trace.json  scripted (is_speech, activation) sequences through the reference
+                         ActivationTimeout + SpeechContext -> is_active after every frame and the
+                         events fired (spokestack/activation_timeout.py:25-38)
 """
 import json
 import os
@@ -260,7 +263,8 @@ def frontend():
 def models():
     rng = np.random.default_rng(99)
     out = {}
-    for d in ("CRNN", "CRNN_softmax", "Wavenet", "Wavenet_alt"):
+    # new directories go to the END: the seeded stream then leaves the earlier models' windows unchanged
+    for d in ("CRNN", "CRNN_softmax", "Wavenet", "Wavenet_alt", "CRNN_nosilence", "CRNN_nosilence_enhanced", "CRNN_old"):
         m32 = ModelDir(os.path.join(ASSETS, d), np.float32)
         m64 = ModelDir(os.path.join(ASSETS, d), np.float64)
         T = 151 if m32.is_crnn else 182
@@ -302,12 +306,58 @@ def evaluator():
     np.savez_compressed(os.path.join(HERE, "evaluator.npz"), **out)
 
 
+def activation_timeout_trace():
+    """The reference's ActivationTimeout (pure Python, importable here) driven frame by frame: the script sets
+    context.is_speech, optionally activates the context (what a wake-word trigger does), calls the stage and records
+    context.is_active plus the events the context fired."""
+    from spokestack.activation_timeout import ActivationTimeout  # noqa: E402  (the reference's)
+    rng = np.random.default_rng(21)
+    cases = []
+    for kw in ({}, {"frame_width": 10, "min_active": 100, "max_active": 300}, {"frame_width": 20, "min_active": 0, "max_active": 60},
+               {"frame_width": 30, "min_active": 500, "max_active": 5000}, {"frame_width": 20, "min_active": 200, "max_active": 200}):
+        for variant in range(3):
+            ctx = SpeechContext()
+            events = []
+            for name in ("activate", "deactivate"):
+                ctx.add_handler(name, (lambda n: (lambda c: events.append(n)))(name))
+            stage = ActivationTimeout(**kw)
+            n = 400 if variant < 2 else 120
+            # speech in runs (VAD-like), activations sprinkled while speech is on; variant 1 keeps speech on for long
+            # stretches (max_active path), variant 2 resets the stage in the middle
+            speech, frames = False, []
+            for t in range(n):
+                if rng.random() < (0.02 if variant == 1 else 0.08):
+                    speech = not speech
+                act = bool(speech and rng.random() < 0.05)
+                rec = {"is_speech": speech, "activate": act, "reset": bool(variant == 2 and t == 60)}
+                ctx.is_speech = speech
+                if act:
+                    ctx.is_active = True
+                if rec["reset"]:
+                    stage.reset()
+                n_ev = len(events)
+                stage(ctx, None)
+                rec["is_active"] = bool(ctx.is_active)
+                rec["events"] = events[n_ev:]
+                frames.append(rec)
+            bits = lambda k: "".join("1" if f[k] else "0" for f in frames)  # noqa: E731
+            cases.append({"kwargs": kw, "is_speech": bits("is_speech"), "activate": bits("activate"), "reset": bits("reset"),
+                          "is_active": bits("is_active"),
+                          "events": [[t, e] for t, f in enumerate(frames) for e in f["events"]]})
+    json.dump(cases, open(os.path.join(HERE, "activation_timeout_trace.json"), "w"))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:  # regenerate only the named fixtures: python make_golden.py models activation_timeout_trace
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     ringbuffer_trace()
     framing()
     pipeline_trace()
     frontend()
     models()
     evaluator()
+    activation_timeout_trace()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -8,7 +8,10 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-MODELS = ["CRNN", "CRNN_softmax", "Wavenet", "Wavenet_alt"]
+# every model artefact the reference ships (SURVEY Appendix D file inventory): tf_lite_models/{CRNN,Wavenet},
+# utils/Wavenet_files (Wavenet_alt), wwdetect/CRNN/models/Arik_CRNN_data_{original,nosilence,nosilence_enhanced}
+# (CRNN_softmax, CRNN_nosilence, CRNN_nosilence_enhanced) and utils/CRNN_files/*_old.tflite (CRNN_old: other conv geometry)
+MODELS = ["CRNN", "CRNN_softmax", "Wavenet", "Wavenet_alt", "CRNN_nosilence", "CRNN_nosilence_enhanced", "CRNN_old"]
 TOL_POST = 1e-4   # north_star: per-frame posteriors within 1e-4 fp32
 TOL_MEL = 1e-4    # log-mel (SURVEY 7 minimum slice)
 
@@ -106,7 +109,7 @@ def test_forward_vs_oracle_batch(engines, oracles, name):
     assert np.abs(got - want).max() < TOL_POST
 
 
-@pytest.mark.parametrize("name", ["CRNN", "Wavenet"])
+@pytest.mark.parametrize("name", ["CRNN", "Wavenet", "CRNN_old"])
 def test_slide_forward_vs_oracle(engines, oracles, name):
     rng = np.random.default_rng(22)
     e = engines[name]
@@ -118,17 +121,19 @@ def test_slide_forward_vs_oracle(engines, oracles, name):
     assert e.slide_forward(mel[: e.window - 1], hop=2).shape == (0, e.n_out)
 
 
-def test_forward_vs_keras_checkpoint(engines, golden):
-    """The HIP path against the Keras checkpoint the CRNN_softmax .tflite was converted from,
+@pytest.mark.parametrize("sub,name", [("", "CRNN_softmax"), ("nosilence", "CRNN_nosilence"),
+                                      ("nosilence_enhanced", "CRNN_nosilence_enhanced")])
+def test_forward_vs_keras_checkpoint(engines, golden, sub, name):
+    """The HIP path against the Keras checkpoints the three Arik_CRNN_data_* .tflite pairs were converted from,
     evaluated with Keras-documented layer semantics in float64 (oracle/keras_ref.py)."""
     from oracle import keras_ref
     rng = np.random.default_rng(23)
     wins = rng.uniform(0, 6.5, (9, 151, 40)).astype(np.float32)
     wins[0] = 0
     wins[1, 60:] = 0
-    kd = os.path.join(golden, "keras_h5")
+    kd = os.path.join(golden, "keras_h5", sub)
     want, want_enc = keras_ref.crnn_forward(os.path.join(kd, "encode.h5"), os.path.join(kd, "detect.h5"), wins)
-    got, enc = engines["CRNN_softmax"].forward(wins, want_enc=True)
+    got, enc = engines[name].forward(wins, want_enc=True)
     assert np.abs(got - want).max() < TOL_POST
     assert np.abs(enc.reshape(want_enc.shape) - want_enc).max() < 1e-4
 

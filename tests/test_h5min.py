@@ -1,8 +1,9 @@
 """Minimal HDF5 reader/writer and the Keras-checkpoint cross-checks.
 
 The fixtures under tests/golden/keras_h5 are the reference's own h5py-written Keras checkpoints
-(wwdetect/CRNN/models/Arik_CRNN_data_original/{encode,detect}.h5); the .tflite files converted
-from them ship as assets/tf_lite_models/CRNN_softmax."""
+(wwdetect/CRNN/models/Arik_CRNN_data_{original,nosilence,nosilence_enhanced}/{encode,detect}.h5); the
+.tflite files converted from them ship as assets/tf_lite_models/CRNN_softmax, CRNN_nosilence and
+CRNN_nosilence_enhanced."""
 import json
 import os
 
@@ -10,6 +11,10 @@ import numpy as np
 import pytest
 
 from wwhip import h5min, weights
+
+
+# (Keras checkpoint directory under tests/golden/keras_h5, asset directory converted from it)
+KERAS_PAIRS = [("", "CRNN_softmax"), ("nosilence", "CRNN_nosilence"), ("nosilence_enhanced", "CRNN_nosilence_enhanced")]
 
 
 @pytest.fixture(scope="module")
@@ -36,10 +41,12 @@ def test_reads_h5py_written_checkpoint(keras_dir):
             mw["conv2d/nope"]
 
 
-def test_keras_weights_equal_tflite_weights(keras_dir, assets):
+@pytest.mark.parametrize("sub,asset", KERAS_PAIRS)
+def test_keras_weights_equal_tflite_weights(keras_dir, assets, sub, asset):
     """Every tensor the TFLite reader assigns a role to (by graph wiring) is bit-identical to the
     tensor Keras stored under that role's name."""
-    c = weights.load_model_dir(os.path.join(assets, "CRNN_softmax")).crnn
+    keras_dir = os.path.join(keras_dir, sub)
+    c = weights.load_model_dir(os.path.join(assets, asset)).crnn
     with h5min.File(os.path.join(keras_dir, "encode.h5")) as f, h5min.File(os.path.join(keras_dir, "detect.h5")) as g:
         mw, dw = f["model_weights"], g["model_weights"]
         np.testing.assert_array_equal(np.transpose(mw["conv2d/conv2d/kernel:0"][()][:, :, 0, :], (2, 0, 1)), c.conv_w)
@@ -64,11 +71,13 @@ def test_keras_weights_equal_tflite_weights(keras_dir, assets):
     assert gru["units"] == c.units and cfg[4]["config"]["merge_mode"] == "concat"
 
 
-def test_keras_semantics_agree_with_flatbuffer_oracle(keras_dir, assets):
+@pytest.mark.parametrize("sub,asset", KERAS_PAIRS)
+def test_keras_semantics_agree_with_flatbuffer_oracle(keras_dir, assets, sub, asset):
     """Keras-documented layer semantics on the checkpoint vs the C restatement of the flatbuffer."""
+    keras_dir = os.path.join(keras_dir, sub)
     from oracle import keras_ref
     from oracle.cpu import CpuOracle
-    ora = CpuOracle(weights.pack_blob(weights.load_model_dir(os.path.join(assets, "CRNN_softmax"))))
+    ora = CpuOracle(weights.pack_blob(weights.load_model_dir(os.path.join(assets, asset))))
     rng = np.random.default_rng(5)
     w = rng.uniform(0, 6.5, (5, 151, 40)).astype(np.float32)
     w[1] = 0
@@ -133,14 +142,16 @@ def test_not_hdf5(tmp_path):
         h5min.File(str(p))
 
 
-def test_crnn_against_pytorch_layers(keras_dir, assets):
+@pytest.mark.parametrize("sub,asset", KERAS_PAIRS)
+def test_crnn_against_pytorch_layers(keras_dir, assets, sub, asset):
     """A fifth, library-grade reading: the Keras checkpoint's weights loaded into torch.nn.Conv2d /
     torch.nn.GRU(bidirectional) / torch.nn.Linear (PyTorch's GRU is the same reset-after formulation; gates are
     ordered r, z, n instead of z, r, h) and run on the CPU, against the C restatement of the flatbuffer."""
+    keras_dir = os.path.join(keras_dir, sub)
     import torch
     import torch.nn.functional as F
     from oracle.cpu import CpuOracle
-    ora = CpuOracle(weights.pack_blob(weights.load_model_dir(os.path.join(assets, "CRNN_softmax"))))
+    ora = CpuOracle(weights.pack_blob(weights.load_model_dir(os.path.join(assets, asset))))
     with h5min.File(os.path.join(keras_dir, "encode.h5")) as f, h5min.File(os.path.join(keras_dir, "detect.h5")) as g:
         mw, dw = f["model_weights"], g["model_weights"]
         k = torch.tensor(mw["conv2d/conv2d/kernel:0"][()]).permute(3, 2, 0, 1).contiguous()   # [out, in, kh, kw]

@@ -147,6 +147,32 @@ def test_activation_timeout_semantics():
     assert not ctx.is_active        # max_active exceeded
 
 
+def test_activation_timeout_replays_reference_trace(golden):
+    """tests/golden/activation_timeout_trace.json was recorded from the reference's own ActivationTimeout and
+    SpeechContext (spokestack/activation_timeout.py:25-38; tests/golden/make_golden.py): same script in, same
+    is_active after every frame and the same activate / deactivate events out."""
+    cases = json.load(open(os.path.join(golden, "activation_timeout_trace.json")))
+    assert len(cases) == 15
+    for case in cases:
+        ctx = SpeechContext()
+        events = []
+        for name in ("activate", "deactivate"):
+            ctx.add_handler(name, (lambda n: (lambda c: events.append(n)))(name))
+        stage = ActivationTimeout(**case["kwargs"])
+        got_events = []
+        for t, (sp, act, rst, want) in enumerate(zip(case["is_speech"], case["activate"], case["reset"], case["is_active"])):
+            ctx.is_speech = sp == "1"
+            if act == "1":
+                ctx.is_active = True
+            if rst == "1":
+                stage.reset()
+            n_ev = len(events)
+            stage(ctx, None)
+            assert ctx.is_active == (want == "1"), (case["kwargs"], t)
+            got_events += [[t, e] for e in events[n_ev:]]
+        assert got_events == case["events"]
+
+
 def test_frame_schedule_matches_reference_ring(golden):
     z = np.load(os.path.join(golden, "framing.npz"))
     for name in ["single_24000", "single_short", "single_tiny", "two_files_3200", "ragged"]:

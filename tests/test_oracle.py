@@ -8,7 +8,7 @@ from oracle import cpu, numpy_ref as NR
 from oracle.tflite_interp import ModelDir
 from wwhip import weights as W
 
-MODELS = ["CRNN", "CRNN_softmax", "Wavenet", "Wavenet_alt"]
+MODELS = ["CRNN", "CRNN_softmax", "Wavenet", "Wavenet_alt", "CRNN_nosilence", "CRNN_nosilence_enhanced", "CRNN_old"]
 
 
 @pytest.fixture(scope="module")

@@ -7,7 +7,7 @@ import pytest
 from wwhip import tflite_reader as R
 from wwhip import weights as W
 
-MODELS = ["CRNN", "CRNN_softmax", "Wavenet", "Wavenet_alt"]
+MODELS = ["CRNN", "CRNN_softmax", "Wavenet", "Wavenet_alt", "CRNN_nosilence", "CRNN_nosilence_enhanced", "CRNN_old"]
 
 
 def test_filter_graph_constants(assets):
@@ -58,7 +58,7 @@ def test_blob_roundtrip(assets, name):
     assert int(u["__kind__"][0]) == b.kind
     assert np.array_equal(u["filter.w"].reshape(40, 257), b.filt.weight)
     if b.kind == W.KIND_CRNN:
-        assert np.array_equal(u["crnn.g1b.wx"].reshape(96, 640), b.crnn.gru1[1].w_x)
+        assert np.array_equal(u["crnn.g1b.wx"].reshape(96, -1), b.crnn.gru1[1].w_x)
     else:
         assert np.array_equal(u["wave.w_tanh"].reshape(24, 3, 16, 16)[5], b.wavenet.blocks[5].w_tanh)
     assert len(blob) % 16 == 0
@@ -109,3 +109,22 @@ def test_filter_weights_are_the_slaney_mel_filterbank(assets):
         assert not f.bias.any()
         # y = 0.5 * (ln(max(x, 1e-5)) - ln(1e-5))
         assert abs(f.floor - 1e-5) < 1e-12 and abs(f.log_offset + np.log(1e-5)) < 1e-6 and f.scale == 0.5
+
+
+def test_old_crnn_export_geometry(assets):
+    """utils/CRNN_files/{encode,detect}_old.tflite: same op set, different conv (20x5 kernel over freq x time,
+    stride 8x2, VALID) -> [74 steps][3*32 features]; sigmoid head."""
+    b = W.load_model_dir(os.path.join(assets, "CRNN_old"))
+    c = b.crnn
+    assert c.conv_w.shape == (32, 20, 5) and (c.stride_f, c.stride_t) == (8, 2)
+    assert c.pad_f == (0, 0) and c.pad_t == (0, 0) and (c.out_f, c.out_t) == (3, 74)
+    assert c.gru1[0].w_x.shape == (96, 96) and c.gru2[0].w_x.shape == (96, 64)
+    assert c.head_kind == W.HEAD_SIGMOID and b.posterior_index == 0
+
+
+@pytest.mark.parametrize("name,probs", [("CRNN_softmax", [0.8681737, 0.13182628]),
+                                        ("CRNN_nosilence_enhanced", [0.5368042, 0.46319583])])
+def test_softmax_variants_on_zeros_match_survey_appendix_b(assets, name, probs):
+    from oracle.tflite_interp import ModelDir
+    got = ModelDir(os.path.join(assets, name)).window(np.zeros((151, 40), np.float32))
+    np.testing.assert_allclose(got, probs, atol=2e-7)

@@ -383,20 +383,27 @@ static int load_crnn(ww_ctx *ctx, ww_model *m, const blob_view &bv) {
   c.n_mel = meta[0]; c.T = meta[1]; c.C = meta[2]; c.KF = meta[3]; c.KT = meta[4]; c.SF = meta[5]; c.ST = meta[6];
   c.PF = meta[7]; c.PT = meta[8]; c.OF = meta[9]; c.OT = meta[10]; c.H = meta[11]; c.NOUT = meta[12]; c.HEAD = meta[13];
   const int K = c.KF * c.KT, KP = 112;
-  if (c.C != 32 || c.H != 32 || c.KT % 4 != 0 || K > KP || c.ST % 4 != 0 || c.NOUT < 1 || c.NOUT > 8 ||
-      (c.OF * c.C) % 64 != 0 || c.OT > 20 || c.T * c.n_mel > 6 * 256 * 4 || c.n_mel != m->filt.n_mel)
+  if (c.H != 32 || c.C < 1 || c.C > 64 || c.NOUT < 1 || c.NOUT > 8 || c.OT < 1 || c.OF < 1 || K < 1 || c.n_mel != m->filt.n_mel ||
+      c.T * c.n_mel > 16384)
     return ww_fail(ctx, WW_EBLOB, "unsupported CRNN geometry (C=%d H=%d K=%dx%d stride %dx%d)", c.C, c.H, c.KF, c.KT, c.SF, c.ST);
-  if (c.n_mel != 40 || c.KF != 5 || c.KT != 20 || c.SF != 2 || c.ST != 8 || c.PF != 1 || c.PT != 6 || c.OF != 20 || c.OT != 19)
-    return ww_fail(ctx, WW_EBLOB, "CRNN conv geometry differs from the 40x151 / 5x20 / stride 2x8 the kernels are built for");
-  const int max_kf = (KP - 1) / c.KT;  // padded k rows touch kf up to this
-  if ((c.OF - 1) * c.SF + max_kf >= 44 || c.n_mel + c.PF > 44 || (c.OT - 1) * c.ST + c.KT > 164 || c.T + c.PT > 164)
-    return ww_fail(ctx, WW_EBLOB, "CRNN window %dx%d does not fit the conv LDS image", c.n_mel, c.T);
+  // the geometry of wwdetect/CRNN/train.py:27-49 (every current export) runs on the kernels built for it
+  c.generic = !(c.C == 32 && c.n_mel == 40 && c.T == 151 && c.KF == 5 && c.KT == 20 && c.SF == 2 && c.ST == 8 && c.PF == 1 &&
+                c.PT == 6 && c.OF == 20 && c.OT == 19);
+  c.FEATP = (c.OF * c.C + 63) / 64 * 64;
   NEED_F(cw, "crnn.conv_w", (size_t)c.C * K);
   NEED_F(cb, "crnn.conv_b", c.C);
-  std::vector<float> w4((size_t)KP / 4 * 32 * 4, 0.f);
-  for (int ch = 0; ch < c.C; ++ch)
-    for (int k = 0; k < K; ++k) w4[((size_t)(k / 4) * 32 + ch) * 4 + (k % 4)] = cw[(size_t)ch * K + k];
-  c.conv_w = upload(m, w4);
+  if (!c.generic) {
+    std::vector<float> w4((size_t)KP / 4 * 32 * 4, 0.f);
+    for (int ch = 0; ch < c.C; ++ch)
+      for (int k = 0; k < K; ++k) w4[((size_t)(k / 4) * 32 + ch) * 4 + (k % 4)] = cw[(size_t)ch * K + k];
+    c.conv_w = upload(m, w4);
+  } else {
+    std::vector<float> wt((size_t)K * c.C);
+    for (int ch = 0; ch < c.C; ++ch)
+      for (int k = 0; k < K; ++k) wt[(size_t)k * c.C + ch] = cw[(size_t)ch * K + k];
+    c.conv_wt = upload(m, wt);
+    c.conv_w = c.conv_wt;
+  }
   c.conv_b = upload(m, std::vector<float>(cb, cb + c.C));
   const int G = 3 * c.H;
   auto cat2 = [&](const char *a, const char *b, size_t each, std::vector<float> &out) -> int {
@@ -411,6 +418,12 @@ static int load_crnn(ww_ctx *ctx, ww_model *m, const blob_view &bv) {
   int rc;
   const size_t in1 = (size_t)c.OF * c.C, in2 = 2 * (size_t)c.H;
   if ((rc = cat2("crnn.g1f.wx", "crnn.g1b.wx", G * in1, v))) return rc; c.wx1 = upload(m, v);
+  if (c.generic) {
+    std::vector<float> wp((size_t)2 * G * c.FEATP, 0.f);
+    for (int r = 0; r < 2 * G; ++r) memcpy(&wp[(size_t)r * c.FEATP], &v[(size_t)r * in1], in1 * sizeof(float));
+    c.wx1p = upload(m, wp);
+    if (!c.wx1p) return ww_fail(ctx, WW_ENOMEM, "CRNN upload failed");
+  }
   {  // three-way bf16 split of the same matrix for the bf16x6 GEMM (crnn.hip)
     auto rne = [](float f) -> uint16_t {
       uint32_t u;

@@ -103,6 +103,12 @@ struct ww_crnn_dev {
   float *wh2 = nullptr;
   float *bh2 = nullptr;
   float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
+  // Any other conv geometry (utils/CRNN_files/*_old.tflite: 20x5 kernel, stride 8x2, VALID, 74 steps of 96 features)
+  // takes the generic kernels of crnn.hip: direct conv, the same MFMA GEMM on K padded to FEATP, step-wise GRUs.
+  bool generic = false;
+  int FEATP = 0;               // OF*C rounded up to the GEMM's K tile (64)
+  float *conv_wt = nullptr;    // [KF*KT][C]
+  float *wx1p = nullptr;       // [2*3H][FEATP], zero padded
 };
 
 struct ww_wave_dev {

@@ -668,6 +668,139 @@ int ww_k_crnn_detect(ww_ctx *ctx, const ww_model *m, const float *d_enc, int nw,
 }
 
 // ------------------------------------------------------------------------------------------
+// Generic geometry (ww_crnn_dev::generic): the older export the reference still ships
+// (utils/CRNN_files/{encode,detect}_old.tflite - Conv2D 20x5 over freq x time, stride 8x2, VALID ->
+// 74 steps of 3*32 features) and any other conv shape a retrained checkpoint may use.  Correctness path,
+// not a tuned one: direct convolution on the vector ALU, the MFMA GEMM above on K padded to 64, one
+// workgroup per window walking the recurrence with the step inputs read from global memory.
+// ------------------------------------------------------------------------------------------
+struct convg_args {
+  const float *mel;
+  win_addr wa;
+  const float *wt;    // [KF*KT][C]
+  const float *bias;  // [C]
+  float *feat;        // [Nw][OT][FEATP]
+  int n_mel, T, C, KF, KT, SF, ST, PF, PT, OF, OT, FEATP;
+};
+
+__global__ __launch_bounds__(256) void conv_generic_kernel(convg_args a) {
+  extern __shared__ __align__(16) float cg_win[];  // [T][n_mel], rows >= valid zero
+  const int tid = threadIdx.x, w = blockIdx.x;
+  int64_t row;
+  int valid;
+  window_span(a.wa, w, a.T, row, valid);
+  const float *src = a.mel + row * a.n_mel;
+  for (int i = tid; i < a.T * a.n_mel; i += 256) cg_win[i] = i < valid * a.n_mel ? src[i] : 0.f;
+  __syncthreads();
+  float *dst = a.feat + (size_t)w * a.OT * a.FEATP;
+  const int feat_w = a.OF * a.C;
+  for (int o = tid; o < a.OT * a.FEATP; o += 256) {
+    const int t = o / a.FEATP, col = o - t * a.FEATP;
+    float v = 0.f;
+    if (col < feat_w) {
+      const int f = col / a.C, c = col - f * a.C;
+      float acc = 0.f;
+      for (int kf = 0; kf < a.KF; ++kf) {
+        const int im = f * a.SF - a.PF + kf;
+        if (im < 0 || im >= a.n_mel) continue;
+        for (int kt = 0; kt < a.KT; ++kt) {
+          const int it = t * a.ST - a.PT + kt;
+          if (it < 0 || it >= a.T) continue;
+          acc = fmaf(cg_win[it * a.n_mel + im], a.wt[(size_t)(kf * a.KT + kt) * a.C + c], acc);
+        }
+      }
+      v = fmaxf(acc + a.bias[c], 0.f);
+    }
+    dst[o] = v;
+  }
+}
+
+struct grug_args {
+  const float *gx;   // [Nw][OT][2*3H] input projections incl. b_x
+  const float *wh, *bh;
+  float *seq;        // [Nw][OT][2H] (fwd | bwd) or nullptr
+  float *last;       // [Nw][2H] (fwd_last | bwd_last) or nullptr
+  int OT;
+};
+
+// wave 0 = forward, wave 1 = backward; the next step's three gate inputs are in flight while this step computes
+__global__ __launch_bounds__(128) void gru_generic_kernel(grug_args a) {
+  constexpr int H = GR_H;
+  __shared__ __align__(16) float hbuf[2][2][H];
+  const int tid = threadIdx.x, lane = tid & 63, dir = tid >> 6;
+  const int unit = lane >> 1, half = lane & 1;
+  const int w = blockIdx.x, OT = a.OT;
+  gru_w g;
+  gru_load_w(g, a.wh, a.bh, dir, unit, half);
+  if (tid < 2 * H) hbuf[tid >> 5][0][tid & 31] = 0.f;
+  __syncthreads();
+  const float *gxl = a.gx + (size_t)w * OT * 6 * H + dir * 3 * H + unit;
+  float h_own = 0.f;
+  int t = dir ? OT - 1 : 0;
+  float gz = gxl[(size_t)t * 6 * H], gr = gxl[(size_t)t * 6 * H + H], gc = gxl[(size_t)t * 6 * H + 2 * H];
+  for (int s = 0; s < OT; ++s) {
+    const int cur = s & 1;
+    const int tn = dir ? t - 1 : t + 1;
+    float nz = 0.f, nr = 0.f, nc = 0.f;
+    if (s + 1 < OT) {
+      nz = gxl[(size_t)tn * 6 * H]; nr = gxl[(size_t)tn * 6 * H + H]; nc = gxl[(size_t)tn * 6 * H + 2 * H];
+    }
+    h_own = gru_step(g, &hbuf[dir][cur][0], half, gz, gr, gc, h_own);
+    if (half == 0) {
+      hbuf[dir][cur ^ 1][unit] = h_own;
+      if (a.seq) a.seq[((size_t)w * OT + t) * 2 * H + dir * H + unit] = h_own;
+    }
+    wsync_h();
+    gz = nz; gr = nr; gc = nc;
+    t = tn;
+  }
+  if (a.last && half == 0) a.last[(size_t)w * 2 * H + dir * H + unit] = h_own;
+}
+
+static size_t crnn_generic_workspace(const ww_crnn_dev &c, int nw) {
+  const size_t rows = (size_t)nw * c.OT;
+  return ww_bump::need(rows * c.FEATP, 4) + ww_bump::need(rows * 6 * c.H, 4) + ww_bump::need(rows * 2 * c.H, 4) +
+         ww_bump::need((size_t)nw * 2 * c.H, 4) + 1024;
+}
+
+static void launch_gemm(ww_ctx *ctx, const char *name, const float *A, const float *W, const float *bias, float *C, int M, int N, int K) {
+  const int n_tiles = (N + GB_N - 1) / GB_N, m_tiles = (M + GB_M - 1) / GB_M;
+  gemm_args g = {A, W, bias, C, M, N, K, n_tiles};
+  ww_launch_scope scope(ctx, name);
+  // ids: 8 XCDs x (m-tiles of that residue, rounded up) x n-tiles; ids whose m-tile is past the end exit at once
+  hipLaunchKernelGGL(gemm_nt_kernel, dim3(8 * ((m_tiles + 7) / 8) * n_tiles), dim3(512), 0, ctx->stream, g);
+}
+
+static int crnn_forward_generic(ww_ctx *ctx, const ww_model *m, const win_addr &wa, const float *d_mel, int nw, void *ws,
+                                float *d_out, float *d_enc) {
+  const ww_crnn_dev &c = m->crnn;
+  const size_t rows = (size_t)nw * c.OT;
+  ww_bump b(ws, ~size_t(0));
+  float *feat = b.take<float>(rows * c.FEATP), *gx = b.take<float>(rows * 6 * c.H), *seq = b.take<float>(rows * 2 * c.H);
+  float *enc = b.take<float>((size_t)nw * 2 * c.H);
+  if (d_enc) enc = d_enc;
+  {
+    convg_args a = {d_mel, wa, c.conv_wt, c.conv_b, feat, c.n_mel, c.T, c.C, c.KF, c.KT, c.SF, c.ST, c.PF, c.PT, c.OF, c.OT, c.FEATP};
+    ww_launch_scope scope(ctx, "conv_generic_kernel");
+    hipLaunchKernelGGL(conv_generic_kernel, dim3(nw), dim3(256), (size_t)c.T * c.n_mel * sizeof(float), ctx->stream, a);
+  }
+  launch_gemm(ctx, "gemm_nt_kernel<gru1,generic>", feat, c.wx1p, c.bx1, gx, (int)rows, 6 * c.H, c.FEATP);
+  {
+    grug_args a = {gx, c.wh1, c.bh1, seq, nullptr, c.OT};
+    ww_launch_scope scope(ctx, "gru_generic_kernel<seq>");
+    hipLaunchKernelGGL(gru_generic_kernel, dim3(nw), dim3(128), 0, ctx->stream, a);
+  }
+  launch_gemm(ctx, "gemm_nt_kernel<gru2,generic>", seq, c.wx2, c.bx2, gx, (int)rows, 6 * c.H, 2 * c.H);
+  {
+    grug_args a = {gx, c.wh2, c.bh2, nullptr, enc, c.OT};
+    ww_launch_scope scope(ctx, "gru_generic_kernel<last>");
+    hipLaunchKernelGGL(gru_generic_kernel, dim3(nw), dim3(128), 0, ctx->stream, a);
+  }
+  WW_HIP(ctx, hipGetLastError());
+  return ww_k_crnn_detect(ctx, m, enc, nw, d_out);
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 struct crnn_ws {
@@ -685,6 +818,7 @@ static crnn_ws carve(const ww_model *m, int nw, void *ws) {
 
 size_t ww_crnn_workspace(const ww_model *m, int nw) {
   const ww_crnn_dev &c = m->crnn;
+  if (c.generic) return crnn_generic_workspace(c, nw);
   return ww_bump::need((size_t)nw * c.OT * c.OF * c.C, 4) + ww_bump::need((size_t)nw * c.OT * 6 * c.H, 4) + 1024;
 }
 
@@ -693,8 +827,9 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
                       float *d_out, float *d_enc) {
   if (nw <= 0) return WW_OK;
   const ww_crnn_dev &c = m->crnn;
-  crnn_ws s = carve(m, nw, ws);
   win_addr wa = {d_win_row, d_win_valid, row0, hop, valid_const, mel_rows};
+  if (c.generic) return crnn_forward_generic(ctx, m, wa, d_mel, nw, ws, d_out, d_enc);
+  crnn_ws s = carve(m, nw, ws);
   {
     conv_args a = {d_mel, wa, c.conv_w, c.conv_b, s.feat, c.n_mel, c.T, c.KF, c.KT, c.SF, c.ST, c.PF, c.PT, c.OF, c.OT};
     ww_launch_scope scope(ctx, "conv5x20_kernel");

@@ -229,16 +229,22 @@ def extract_crnn(encode: R.Model, detect: R.Model) -> CrnnParams:
     if len(convs) != 1 or convs[0].inputs[0] != sg.inputs[0]:
         raise GraphPatternError("CRNN encoder must start with one CONV_2D on the input")
     conv = convs[0]
-    if conv.options["padding"] != "SAME" or conv.options["activation"] != 1:
-        raise GraphPatternError("CRNN conv must be SAME + fused ReLU")
+    if conv.options["padding"] not in ("SAME", "VALID") or conv.options["activation"] != 1:
+        raise GraphPatternError("CRNN conv must be SAME or VALID with fused ReLU")
     in_shape = sg.tensors[sg.inputs[0]].shape  # [1, mel, frames, 1]
     n_mel, n_frames = int(in_shape[1]), int(in_shape[2])
     w = _const(sg, conv.inputs[1]).astype(np.float32)  # [C, kf, kt, 1]
     if w.shape[3] != 1:
         raise GraphPatternError("CRNN conv expects one input channel")
     sf, st = int(conv.options["stride_h"]), int(conv.options["stride_w"])
-    out_f, pad_f = _same_pad(n_mel, w.shape[1], sf)
-    out_t, pad_t = _same_pad(n_frames, w.shape[2], st)
+    if conv.options["padding"] == "SAME":
+        out_f, pad_f = _same_pad(n_mel, w.shape[1], sf)
+        out_t, pad_t = _same_pad(n_frames, w.shape[2], st)
+    else:  # the older export under utils/CRNN_files/*_old.tflite: 20x5 kernel, stride 8x2, no padding
+        out_f, pad_f = (n_mel - w.shape[1]) // sf + 1, (0, 0)
+        out_t, pad_t = (n_frames - w.shape[2]) // st + 1, (0, 0)
+    if tuple(sg.tensors[conv.outputs[0]].shape[1:3]) != (out_f, out_t):
+        raise GraphPatternError("conv output shape differs from the padding arithmetic")
 
     # feature order check: TRANSPOSE [0,2,1,3] then RESHAPE -> feature = f*C + c
     tr = sg.consumers(conv.outputs[0])
