@@ -418,6 +418,13 @@ static int load_crnn(ww_ctx *ctx, ww_model *m, const blob_view &bv) {
   int rc;
   const size_t in1 = (size_t)c.OF * c.C, in2 = 2 * (size_t)c.H;
   if ((rc = cat2("crnn.g1f.wx", "crnn.g1b.wx", G * in1, v))) return rc; c.wx1 = upload(m, v);
+  if (!c.generic) {
+    std::vector<float> ws(v.size());
+    for (size_t n = 0; n < (size_t)2 * G; ++n)
+      for (size_t k = 0; k < in1; ++k) ws[((k / 4) * 2 * G + n) * 4 + (k % 4)] = v[n * in1 + k];
+    c.wx1s = upload(m, ws);
+    if (!c.wx1s) return ww_fail(ctx, WW_ENOMEM, "CRNN upload failed");
+  }
   if (c.generic) {
     std::vector<float> wp((size_t)2 * G * c.FEATP, 0.f);
     for (int r = 0; r < 2 * G; ++r) memcpy(&wp[(size_t)r * c.FEATP], &v[(size_t)r * in1], in1 * sizeof(float));
@@ -452,6 +459,13 @@ static int load_crnn(ww_ctx *ctx, ww_model *m, const blob_view &bv) {
   if ((rc = cat2("crnn.g1f.wh", "crnn.g1b.wh", (size_t)G * c.H, v))) return rc; c.wh1 = upload(m, v);
   if ((rc = cat2("crnn.g1f.bh", "crnn.g1b.bh", G, v))) return rc; c.bh1 = upload(m, v);
   if ((rc = cat2("crnn.g2f.wx", "crnn.g2b.wx", G * in2, v))) return rc; c.wx2 = upload(m, v);
+  {
+    std::vector<float> ws(v.size());
+    for (size_t n = 0; n < (size_t)2 * G; ++n)
+      for (size_t k = 0; k < in2; ++k) ws[((k / 4) * 2 * G + n) * 4 + (k % 4)] = v[n * in2 + k];
+    c.wx2s = upload(m, ws);
+    if (!c.wx2s) return ww_fail(ctx, WW_ENOMEM, "CRNN upload failed");
+  }
   if ((rc = cat2("crnn.g2f.bx", "crnn.g2b.bx", G, v))) return rc; c.bx2 = upload(m, v);
   if ((rc = cat2("crnn.g2f.wh", "crnn.g2b.wh", (size_t)G * c.H, v))) return rc; c.wh2 = upload(m, v);
   if ((rc = cat2("crnn.g2f.bh", "crnn.g2b.bh", G, v))) return rc; c.bh2 = upload(m, v);

@@ -22,6 +22,8 @@
 //                     detect head.  Waves 2/3 stage the head weights into LDS meanwhile.
 #include "common.h"
 
+#include <cstdlib>
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct win_addr {
@@ -630,6 +632,377 @@ __global__ __launch_bounds__(256) void gru_head_kernel(gru_head_args a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// crnn_fused_kernel: the whole CRNN for one window in one workgroup - the conv output (feat, 48.6 KB per
+// window) and the layer-1 input projections (gx1, 14.6 KB) never leave the CU.
+//
+//   A  stage the 151x40 window transposed into LDS (as conv5x20_kernel)
+//   B  conv as implicit GEMM on v_mfma_f32_16x16x4_f32, 3 of the 24 m-tiles per wave -> feat[19][640] in LDS
+//   C  layer-1 input projection gx1[19][192] = feat x Wx1^T: the 19 rows are ONE 16-row MFMA tile plus a 3-row
+//      remainder on v_mfma_f32_4x4x1_16b_f32 (16 blocks of 4x4x1 at the same 32 MAC/cycle): with the blocks dealt
+//      as (k sub-step kk, column quad cg) the B operand is the SAME register as the 16x16x4's
+//      (lane = kk*16 + col), the A operand is feat[16 + lane%4][k + 4 kk ..], and the four kk partial sums of a
+//      column meet in two cross-lane adds at the very end - 20 rows of matrix time for 19 instead of 32.
+//      Waves: 4 column groups of 3 n-tiles x 2 halves of K; the upper half leaves its sums in the gx buffer, the
+//      lower half adds its own and the bias.  W_x1 (491 KB) streams from L2 straight into registers in
+//      B-operand order ([k/4][192][4], one contiguous KB per wave load), two k-steps ahead of its use.
+//   D  layer-1 recurrence (wave 0 forward, wave 1 backward) | waves 2, 3 fetch the layer-2 recurrent weights |
+//      waves 4-7 copy W_x2 (B-operand order, 48 KB) into the dead feat space
+//   E  layer-2 input projection on MFMA, both operands out of LDS, all 8 waves
+//   F  layer-2 recurrence (waves 2, 3) | waves 4-7 stage the detect head over W_x2
+//   G  detect head (wave 0)
+//
+// LDS: the window image (28.9 KB; after B it holds gx, seq1, h, the head's small vectors) + feat (49.2 KB; after C
+// W_x2, then the head's first layer) = 78.1 KB, two workgroups per CU: one's recurrences and staging run beside
+// the other's MFMA phases.
+// ------------------------------------------------------------------------------------------
+#define CF_THREADS 512
+#define CF_FLD 648  // feat row: 640 + 8; FLD/4 = 162 = 2 (mod 16): the 16-lane groups of the A-operand ds_read_b128 hit 16 distinct slots
+#define CF_IMG_FLOATS (CV_ROWS * CV_LDT)
+#define CF_FEAT_FLOATS (CV_OT * CF_FLD)
+#define CF_SMEM_BYTES ((CF_IMG_FLOATS + CF_FEAT_FLOATS) * 4)
+// offsets (floats) inside the image region once the conv is done
+#define CF_GX 0
+#define CF_SEQ (20 * GR_GX_LD)
+#define CF_HB (CF_SEQ + 32 * GR_SEQ_LD)   // h[layer 2][dir 2][ping-pong 2][32]
+#define CF_ENC (CF_HB + 2 * 2 * 2 * GR_H)
+#define CF_HID (CF_ENC + 2 * GR_H)
+#define CF_W2S (CF_HID + 2 * GR_H)
+static_assert(CF_W2S + 8 * 64 <= CF_IMG_FLOATS, "post-conv LDS layout exceeds the image region");
+static_assert(64 * GR_W1_LD <= CF_FEAT_FLOATS && 16 * 192 * 4 <= CF_FEAT_FLOATS, "feat region too small for its later tenants");
+
+struct fused_args {
+  const float *mel;
+  win_addr wa;
+  const float *w4;    // conv weights [112/4][32][4]
+  const float *cbias; // [32]
+  const float *wx1s;  // W_x1 in B-operand order [640/4][192][4]
+  const float *bx1;   // [192]
+  const float *wh1, *bh1;
+  const float *wx2s;  // W_x2 in B-operand order [64/4][192][4]
+  const float *bx2, *wh2, *bh2, *w1, *b1, *w2, *b2;
+  float *enc;         // optional [Nw][64]
+  float *out;         // [Nw][NOUT]
+  int T, NOUT, HEAD;
+  int stop_after;     // development: leave after phase n (1 = A ... 5 = E); >= 100: W_x1 re-read from one k-step (L1-hot); 0 = normal
+  long long *stamps;  // development: [blocks][8 waves][10] s_memtime at the phase boundaries (nullptr = off)
+  int gru_prio;       // development: s_setprio level of the recurrence waves (default 0)
+};
+
+// one direction of one GRU layer over the OT steps held in LDS (gx rows incl. b_x), h ping-pong in hd
+template <bool SEQ>
+__device__ __forceinline__ float cf_recurrence(const gru_w &g, const float *gxs, float *hd, float *seq1, int dir, int unit, int half) {
+  constexpr int H = GR_H, OT = CV_OT;
+  const float *gxl = gxs + dir * 3 * H + unit;
+  float h_own = 0.f;
+  int t = dir ? OT - 1 : 0;
+  for (int s = 0; s < OT; ++s) {
+    const int cur = s & 1;
+    const float gz = gxl[t * GR_GX_LD], gr = gxl[t * GR_GX_LD + H], gc = gxl[t * GR_GX_LD + 2 * H];
+    h_own = gru_step(g, hd + cur * H, half, gz, gr, gc, h_own);
+    if (half == 0) {
+      hd[(cur ^ 1) * H + unit] = h_own;
+      if (SEQ) seq1[t * GR_SEQ_LD + dir * H + unit] = h_own;
+    }
+    wsync_h();
+    t = dir ? t - 1 : t + 1;
+  }
+  return h_own;
+}
+
+__global__ __launch_bounds__(CF_THREADS, 4) void crnn_fused_kernel(fused_args a) {
+  extern __shared__ __align__(16) float cf_smem[];
+  float *img = cf_smem, *feat = cf_smem + CF_IMG_FLOATS;
+  constexpr int H = GR_H, OT = CV_OT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kk = lane >> 4;
+  const int w = blockIdx.x;
+#define CF_STAMP(i_)                                                                                          \
+  if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 8 + wave) * 10 + (i_)] = __builtin_amdgcn_s_memtime();
+  CF_STAMP(0)
+  int64_t row;
+  int valid;
+  window_span(a.wa, w, a.T, row, valid);
+
+  // conv weights for this lane (B operand of mfma 16x16x4: lane (j, kk)); issued first, used after the staging
+  float4 wreg[CV_KB][2];
+#pragma unroll
+  for (int kb = 0; kb < CV_KB; ++kb)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) wreg[kb][n] = *(const float4 *)(a.w4 + ((size_t)(kb * 4 + kk) * 32 + n * 16 + j) * 4);
+  const float cb0 = a.cbias[j], cb1 = a.cbias[16 + j];
+
+  // ---- A: stage the window (loads first, then zero the image, then the transposed scatter)
+  {
+    constexpr int MAXV = 3;  // 3 * 512 float4 >= 151 * 40 / 4
+    const float *src = a.mel + row * CV_NMEL;
+    const int n = valid * CV_NMEL;
+    const bool al16 = ((((uintptr_t)src) & 15) == 0);
+    float4 stage[MAXV];
+#pragma unroll
+    for (int q = 0; q < MAXV; ++q) {
+      const int i = (q * CF_THREADS + tid) * 4;
+      if (al16 && i + 3 < n) {
+        stage[q] = *(const float4 *)(src + i);
+      } else {
+        stage[q].x = i < n ? src[i] : 0.f;
+        stage[q].y = i + 1 < n ? src[i + 1] : 0.f;
+        stage[q].z = i + 2 < n ? src[i + 2] : 0.f;
+        stage[q].w = i + 3 < n ? src[i + 3] : 0.f;
+      }
+    }
+    for (int i = tid; i < CF_IMG_FLOATS / 4; i += CF_THREADS) ((float4 *)img)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < MAXV; ++q) {
+      const int i = (q * CF_THREADS + tid) * 4;
+      const float e[4] = {stage[q].x, stage[q].y, stage[q].z, stage[q].w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int ii = i + c;
+        if (ii < n) {
+          const int it = ii / CV_NMEL, im = ii - it * CV_NMEL;
+          img[(im + CV_PF) * CV_LDT + it + CV_PT] = e[c];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  CF_STAMP(1)
+  if (a.stop_after == 1) return;
+  // ---- B: conv -> feat (LDS)
+  {
+    constexpr int M = CV_OT * CV_OF;
+#pragma unroll 1
+    for (int mt = wave; mt < (M + 15) / 16; mt += CF_THREADS / 64) {
+      int m = mt * 16 + j;
+      if (m >= M) m = M - 1;
+      const int t = m / CV_OF, f = m - t * CV_OF;
+      const float *abase = img + (f * CV_SF) * CV_LDT + t * CV_ST;
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < CV_KB; ++kb) {
+        const int k4 = kb * 16 + kk * 4;
+        const int kf = k4 / CV_KT, kt = k4 - kf * CV_KT;
+        const float4 av = *(const float4 *)(abase + kf * CV_LDT + kt);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wreg[kb][0].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wreg[kb][1].x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wreg[kb][0].y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wreg[kb][1].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wreg[kb][0].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wreg[kb][1].z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wreg[kb][0].w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wreg[kb][1].w, acc1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mo = mt * 16 + kk * 4 + r;
+        if (mo < M) {
+          const int to = mo / CV_OF, fo = mo - to * CV_OF;
+          feat[to * CF_FLD + fo * 32 + j] = fmaxf(acc0[r] + cb0, 0.f);
+          feat[to * CF_FLD + fo * 32 + 16 + j] = fmaxf(acc1[r] + cb1, 0.f);
+        }
+      }
+    }
+  }
+  // the first two k-steps of W_x1 are requested before the barrier: their L2 latency passes while the slower waves finish
+  const int ng = wave & 3, kh = wave >> 2;
+  const float *wb = a.wx1s + ((size_t)(kh * 80 + kk) * 192 + ng * 48 + j) * 4;  // + ks * KS_STRIDE; + n * 64
+  const size_t KS_STRIDE = a.stop_after >= 100 ? 0 : (size_t)4 * 192 * 4;
+  float4 bq[3][3];
+#pragma unroll
+  for (int n = 0; n < 3; ++n) {
+    bq[0][n] = *(const float4 *)(wb + n * 64);
+    bq[1][n] = *(const float4 *)(wb + KS_STRIDE + n * 64);
+  }
+  CF_STAMP(2)
+  __syncthreads();  // feat complete; the image is dead from here on
+  CF_STAMP(3)
+  if (a.stop_after == 2) return;
+  float *gxs = img + CF_GX, *seq1 = img + CF_SEQ, *hb = img + CF_HB, *encs = img + CF_ENC, *hid = img + CF_HID, *w2s = img + CF_W2S;
+  for (int i = tid; i < 32 * GR_SEQ_LD; i += CF_THREADS) seq1[i] = 0.f;
+  if (tid < 2 * 2 * 2 * H) hb[tid] = 0.f;
+
+  // ---- C: layer-1 input projection
+  const int unit = lane >> 1, half = lane & 1, dir = wave & 1;
+  gru_w g;  // waves 0, 1: layer 1; waves 2, 3: layer 2
+  {
+    const float *a0p = feat + j * CF_FLD + kh * 320 + kk * 4;
+    const int r1 = 16 + (lane & 3);
+    const float *a1p = feat + (r1 < OT ? r1 : OT - 1) * CF_FLD + kh * 320 + kk * 4;  // lane%4 == 3: row 19 does not exist, its sums are never stored
+    f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 rem[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    // operand ring, fully unrolled so that the slots are plain registers (a rotating copy would have to wait for the
+    // load it copies): W two k-steps ahead (L2), feat one step ahead (LDS)
+    float4 avq[2], rvq[2];
+    avq[0] = *(const float4 *)(a0p);
+    rvq[0] = *(const float4 *)(a1p);
+#pragma unroll
+    for (int ks = 0; ks < 20; ++ks) {
+      if (ks + 2 < 20) {
+#pragma unroll
+        for (int n = 0; n < 3; ++n) bq[(ks + 2) % 3][n] = *(const float4 *)(wb + (ks + 2) * KS_STRIDE + n * 64);
+      }
+      if (ks + 1 < 20) {
+        avq[(ks + 1) & 1] = *(const float4 *)(a0p + (ks + 1) * 16);
+        rvq[(ks + 1) & 1] = *(const float4 *)(a1p + (ks + 1) * 16);
+      }
+      const float4 av = avq[ks & 1], rv = rvq[ks & 1];
+      const float4 *b = bq[ks % 3];
+      // consecutive MFMAs go to different accumulators (dependent-accumulator latency 40 > issue 32)
+#define CF_ROUND(e_)                                                                                   \
+  acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.e_, b[0].e_, acc[0], 0, 0, 0);                       \
+  acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.e_, b[1].e_, acc[1], 0, 0, 0);                       \
+  acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.e_, b[2].e_, acc[2], 0, 0, 0);                       \
+  rem[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(rv.e_, b[0].e_, rem[0], 0, 0, 0);                         \
+  rem[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(rv.e_, b[1].e_, rem[1], 0, 0, 0);                         \
+  rem[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(rv.e_, b[2].e_, rem[2], 0, 0, 0);
+      CF_ROUND(x) CF_ROUND(y) CF_ROUND(z) CF_ROUND(w)
+#undef CF_ROUND
+    }
+    // recurrent weights of the waves that will run the recurrences: requested here, needed two barriers later
+    if (wave < 4) gru_load_w(g, wave < 2 ? a.wh1 : a.wh2, wave < 2 ? a.bh1 : a.bh2, dir, unit, half);
+    // the four k sub-steps of a column sit in lanes col, col+16, col+32, col+48
+#pragma unroll
+    for (int n = 0; n < 3; ++n)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        float v = rem[n][i];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        rem[n][i] = v;
+      }
+    CF_STAMP(4)
+    if (kh == 1) {  // upper half of K: leave the sums in gx
+#pragma unroll
+      for (int n = 0; n < 3; ++n) {
+        const int col = ng * 48 + n * 16 + j;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gxs[(kk * 4 + r) * GR_GX_LD + col] = acc[n][r];
+        if (kk == 0) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) gxs[(16 + i) * GR_GX_LD + col] = rem[n][i];
+        }
+      }
+    }
+    __syncthreads();  // upper-half sums in place; nobody reads feat any more
+    if (kh == 0) {
+#pragma unroll
+      for (int n = 0; n < 3; ++n) {
+        const int col = ng * 48 + n * 16 + j;
+        const float bv = a.bx1[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float *p = &gxs[(kk * 4 + r) * GR_GX_LD + col];
+          *p = (acc[n][r] + *p) + bv;
+        }
+        if (kk == 0) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            float *p = &gxs[(16 + i) * GR_GX_LD + col];
+            *p = (rem[n][i] + *p) + bv;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  CF_STAMP(5)
+  if (a.stop_after == 3) return;
+
+  // ---- D: layer-1 recurrence (waves 0, 1) | waves 4..7: W_x2 (B-operand order) -> the feat space
+  float *wx2l = feat;  // [16 k-quads][192][4]
+  if (wave < 2) {
+    if (a.gru_prio) __builtin_amdgcn_s_setprio(3);
+    cf_recurrence<true>(g, gxs, hb + dir * 2 * H, seq1, dir, unit, half);
+    __builtin_amdgcn_s_setprio(0);
+  } else if (wave >= 4) {
+    const float4 *src = (const float4 *)a.wx2s;
+    for (int i = tid - 256; i < 16 * 192; i += 256) ((float4 *)wx2l)[i] = src[i];
+  }
+  __syncthreads();
+  CF_STAMP(6)
+  if (a.stop_after == 4) return;
+
+  // ---- E: layer-2 input projection gx2[t][n] = seq1[t][:] . Wx2[n][:] + bx2[n]  (M = 32 with 19 valid rows, K = 64, N = 192)
+  {
+    const int pmt = wave >> 2, pn0 = (wave & 3) * 3;
+    f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const float4 av = *(const float4 *)(&seq1[(pmt * 16 + j) * GR_SEQ_LD + kb * 16 + kk * 4]);
+      float4 bv[3];
+#pragma unroll
+      for (int n = 0; n < 3; ++n) bv[n] = *(const float4 *)(&wx2l[((kb * 4 + kk) * 192 + (pn0 + n) * 16 + j) * 4]);
+#pragma unroll
+      for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv[n].x, acc[n], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv[n].y, acc[n], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv[n].z, acc[n], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv[n].w, acc[n], 0, 0, 0);
+    }
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+      const int col = (pn0 + n) * 16 + j;
+      const float bb = a.bx2[col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = pmt * 16 + kk * 4 + r;
+        if (t < OT) gxs[t * GR_GX_LD + col] = acc[n][r] + bb;
+      }
+    }
+  }
+  __syncthreads();
+  CF_STAMP(7)
+  if (a.stop_after == 5) return;
+
+  // ---- F: layer-2 recurrence (waves 2, 3): only the last state of each direction is kept | waves 4..7: head -> LDS
+  float *w1s = feat;  // [64][GR_W1_LD], over W_x2
+  if (wave == 2 || wave == 3) {
+    if (a.gru_prio) __builtin_amdgcn_s_setprio(3);
+    const float h_last = cf_recurrence<false>(g, gxs, hb + (2 + dir) * 2 * H, nullptr, dir, unit, half);
+    __builtin_amdgcn_s_setprio(0);
+    if (half == 0) {
+      encs[dir * H + unit] = h_last;
+      if (a.enc) a.enc[(size_t)w * 2 * H + dir * H + unit] = h_last;
+    }
+  } else if (wave >= 4) {
+    const int t2 = tid - 256;
+    for (int i = t2; i < 64 * 64; i += 256) w1s[(i >> 6) * GR_W1_LD + (i & 63)] = a.w1[i];
+    for (int i = t2; i < a.NOUT * 64; i += 256) w2s[i] = a.w2[i];
+  }
+  __syncthreads();
+  CF_STAMP(8)
+
+  // ---- G: detect head: Dense(64, relu) -> Dense(NOUT) -> sigmoid | softmax   (wave 0)
+  if (wave == 0) {
+    float acc = 0.f;
+#pragma unroll 16
+    for (int k = 0; k < 2 * H; ++k) acc = fmaf(w1s[lane * GR_W1_LD + k], encs[k], acc);
+    hid[lane] = fmaxf(acc + a.b1[lane], 0.f);
+    wsync_g();
+    float y = 0.f;
+    if (lane < a.NOUT) {
+      for (int k = 0; k < 2 * H; ++k) y = fmaf(w2s[lane * 64 + k], hid[k], y);
+      y += a.b2[lane];
+    }
+    if (a.HEAD == 0) {
+      if (lane < a.NOUT) a.out[(size_t)w * a.NOUT + lane] = sigmoid_f(y);
+    } else {
+      float mx = (lane < a.NOUT) ? y : -INFINITY;
+      for (int o = 1; o < 8; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      float e = (lane < a.NOUT) ? expf(y - mx) : 0.f;
+      float sum = e;
+      for (int o = 1; o < 8; o <<= 1) sum += __shfl_xor(sum, o);
+      if (lane < a.NOUT) a.out[(size_t)w * a.NOUT + lane] = e / sum;
+    }
+  }
+  CF_STAMP(9)
+#undef CF_STAMP
+}
+
 // detect.tflite alone (reference detect_model(x), wakeword/tflite.py:228-229): one wave per row
 __global__ __launch_bounds__(64) void crnn_detect_kernel(const float *enc, const float *w1, const float *b1, const float *w2,
                                                          const float *b2, float *out, int NOUT, int HEAD) {
@@ -829,6 +1202,48 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
   const ww_crnn_dev &c = m->crnn;
   win_addr wa = {d_win_row, d_win_valid, row0, hop, valid_const, mel_rows};
   if (c.generic) return crnn_forward_generic(ctx, m, wa, d_mel, nw, ws, d_out, d_enc);
+  static const bool split_chain = getenv("WWHIP_CRNN_SPLIT") != nullptr;  // development: the three-kernel chain
+  if (!split_chain && m->precision != WW_PRECISION_BF16X6) {
+    fused_args a = {d_mel, wa, c.conv_w, c.conv_b, c.wx1s, c.bx1, c.wh1, c.bh1, c.wx2s, c.bx2, c.wh2, c.bh2,
+                    c.w1, c.b1, c.w2, c.b2, d_enc, d_out, c.T, c.NOUT, c.HEAD, 0, nullptr, 0};
+    {
+      static const char *pr = getenv("WWHIP_CF_PRIO");
+      if (pr) a.gru_prio = atoi(pr);
+    }
+    static const char *stop_env = getenv("WWHIP_CF_STOP");
+    if (stop_env) a.stop_after = atoi(stop_env);
+    static bool attr_set = false;
+    if (!attr_set) {
+      WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
+      attr_set = true;
+    }
+    static const bool want_stamps = getenv("WWHIP_CF_STAMPS") != nullptr;  // development: phase timeline to stderr
+    if (want_stamps) {
+      WW_HIP(ctx, hipMalloc((void **)&a.stamps, (size_t)nw * 80 * sizeof(long long)));
+      WW_HIP(ctx, hipMemsetAsync(a.stamps, 0, (size_t)nw * 80 * sizeof(long long), ctx->stream));
+    }
+    {
+      ww_launch_scope scope(ctx, "crnn_fused_kernel");
+      hipLaunchKernelGGL(crnn_fused_kernel, dim3(nw), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, a);
+    }
+    WW_HIP(ctx, hipGetLastError());
+    if (want_stamps) {
+      std::vector<long long> h((size_t)nw * 80);
+      WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      WW_HIP(ctx, hipMemcpy(h.data(), a.stamps, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+      WW_HIP(ctx, hipFree(a.stamps));
+      long long t0 = h[0];
+      for (size_t i = 0; i < h.size(); ++i) if (h[i] && h[i] < t0) t0 = h[i];
+      for (int b : {0, nw / 2, nw - 1}) {
+        for (int wv : {0, 1, 2, 7}) {
+          fprintf(stderr, "block %d wave %d:", b, wv);
+          for (int i = 0; i < 10; ++i) fprintf(stderr, " %lld", h[((size_t)b * 8 + wv) * 10 + i] - t0);
+          fprintf(stderr, "\n");
+        }
+      }
+    }
+    return WW_OK;
+  }
   crnn_ws s = carve(m, nw, ws);
   {
     conv_args a = {d_mel, wa, c.conv_w, c.conv_b, s.feat, c.n_mel, c.T, c.KF, c.KT, c.SF, c.ST, c.PF, c.PT, c.OF, c.OT};
