@@ -633,30 +633,32 @@ __global__ __launch_bounds__(256) void gru_head_kernel(gru_head_args a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// crnn_fused_kernel: the whole CRNN for one window in one workgroup - the conv output (feat, 48.6 KB per
+// crnn_fused_kernel: the whole CRNN for one window in one 4-wave workgroup - the conv output (feat, 48.6 KB per
 // window) and the layer-1 input projections (gx1, 14.6 KB) never leave the CU.
 //
 //   A  stage the 151x40 window transposed into LDS (as conv5x20_kernel)
-//   B  conv as implicit GEMM on v_mfma_f32_16x16x4_f32, 3 of the 24 m-tiles per wave -> feat[19][640] in LDS
+//   B  conv as implicit GEMM on v_mfma_f32_16x16x4_f32, 6 of the 24 m-tiles per wave -> feat[19][640] in LDS
 //   C  layer-1 input projection gx1[19][192] = feat x Wx1^T: the 19 rows are ONE 16-row MFMA tile plus a 3-row
 //      remainder on v_mfma_f32_4x4x1_16b_f32 (16 blocks of 4x4x1 at the same 32 MAC/cycle): with the blocks dealt
 //      as (k sub-step kk, column quad cg) the B operand is the SAME register as the 16x16x4's
 //      (lane = kk*16 + col), the A operand is feat[16 + lane%4][k + 4 kk ..], and the four kk partial sums of a
 //      column meet in two cross-lane adds at the very end - 20 rows of matrix time for 19 instead of 32.
-//      Waves: 4 column groups of 3 n-tiles x 2 halves of K; the upper half leaves its sums in the gx buffer, the
-//      lower half adds its own and the bias.  W_x1 (491 KB) streams from L2 straight into registers in
-//      B-operand order ([k/4][192][4], one contiguous KB per wave load), two k-steps ahead of its use.
-//   D  layer-1 recurrence (wave 0 forward, wave 1 backward) | waves 2, 3 fetch the layer-2 recurrent weights |
-//      waves 4-7 copy W_x2 (B-operand order, 48 KB) into the dead feat space
-//   E  layer-2 input projection on MFMA, both operands out of LDS, all 8 waves
-//   F  layer-2 recurrence (waves 2, 3) | waves 4-7 stage the detect head over W_x2
+//      Each wave owns 3 of the 12 n-tiles over the whole K.  W_x1 (491 KB) streams from L2 straight into registers
+//      in B-operand order ([k/4][192][4], one contiguous KB per wave load), three k-steps ahead of its use.
+//   D  layer-1 recurrence (wave 0 forward, wave 1 backward) | waves 2, 3 copy W_x2 (B-operand order, 48 KB) into the
+//      dead feat space
+//   E  layer-2 input projection, the same 16 + 3 row split, both operands out of LDS
+//   F  layer-2 recurrence (waves 2, 3) | waves 0, 1 stage the detect head over W_x2
 //   G  detect head (wave 0)
 //
+// One wave per SIMD: v_mfma_f32_16x16x4_f32 reaches its issue rate from a single wave with independent accumulators,
+// while two such waves on a SIMD got in each other's way (8-wave form of this kernel: the older wave of a SIMD took
+// 14.8k cycles over 9.6k cycles of MFMAs and its partner advanced only once it was alone).
 // LDS: the window image (28.9 KB; after B it holds gx, seq1, h, the head's small vectors) + feat (49.2 KB; after C
 // W_x2, then the head's first layer) = 78.1 KB, two workgroups per CU: one's recurrences and staging run beside
 // the other's MFMA phases.
 // ------------------------------------------------------------------------------------------
-#define CF_THREADS 512
+#define CF_THREADS 256
 #define CF_FLD 648  // feat row: 640 + 8; FLD/4 = 162 = 2 (mod 16): the 16-lane groups of the A-operand ds_read_b128 hit 16 distinct slots
 #define CF_IMG_FLOATS (CV_ROWS * CV_LDT)
 #define CF_FEAT_FLOATS (CV_OT * CF_FLD)
@@ -684,9 +686,9 @@ struct fused_args {
   float *enc;         // optional [Nw][64]
   float *out;         // [Nw][NOUT]
   int T, NOUT, HEAD;
-  int stop_after;     // development: leave after phase n (1 = A ... 5 = E); >= 100: W_x1 re-read from one k-step (L1-hot); 0 = normal
-  long long *stamps;  // development: [blocks][8 waves][10] s_memtime at the phase boundaries (nullptr = off)
-  int gru_prio;       // development: s_setprio level of the recurrence waves (default 0)
+  int stop_after;     // development: leave after phase n (1 = A ... 5 = E); 0 = normal
+  long long *stamps;  // development: [blocks][4 waves][10] s_memtime at the phase boundaries (nullptr = off)
+  int gru_prio;       // development: s_setprio level of the recurrence waves
 };
 
 // one direction of one GRU layer over the OT steps held in LDS (gx rows incl. b_x), h ping-pong in hd
@@ -710,7 +712,17 @@ __device__ __forceinline__ float cf_recurrence(const gru_w &g, const float *gxs,
   return h_own;
 }
 
-__global__ __launch_bounds__(CF_THREADS, 4) void crnn_fused_kernel(fused_args a) {
+// one operand quad of the 16 + 3 row product: 3 n-tiles x (16x16x4 on rows 0..15, 4x4x1 on rows 16..18); consecutive
+// MFMAs go to different accumulators (dependent-accumulator latency 40 > issue 32)
+#define CF_ROUND(av_, rv_, b_, e_)                                                                     \
+  acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_.e_, b_[0].e_, acc[0], 0, 0, 0);                     \
+  acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_.e_, b_[1].e_, acc[1], 0, 0, 0);                     \
+  acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_.e_, b_[2].e_, acc[2], 0, 0, 0);                     \
+  rem[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(rv_.e_, b_[0].e_, rem[0], 0, 0, 0);                       \
+  rem[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(rv_.e_, b_[1].e_, rem[1], 0, 0, 0);                       \
+  rem[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(rv_.e_, b_[2].e_, rem[2], 0, 0, 0);
+
+__global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a) {
   extern __shared__ __align__(16) float cf_smem[];
   float *img = cf_smem, *feat = cf_smem + CF_IMG_FLOATS;
   constexpr int H = GR_H, OT = CV_OT;
@@ -718,7 +730,7 @@ __global__ __launch_bounds__(CF_THREADS, 4) void crnn_fused_kernel(fused_args a)
   const int j = lane & 15, kk = lane >> 4;
   const int w = blockIdx.x;
 #define CF_STAMP(i_)                                                                                          \
-  if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 8 + wave) * 10 + (i_)] = __builtin_amdgcn_s_memtime();
+  if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wave) * 10 + (i_)] = __builtin_amdgcn_s_memtime();
   CF_STAMP(0)
   int64_t row;
   int valid;
@@ -733,8 +745,9 @@ __global__ __launch_bounds__(CF_THREADS, 4) void crnn_fused_kernel(fused_args a)
   const float cb0 = a.cbias[j], cb1 = a.cbias[16 + j];
 
   // ---- A: stage the window (loads first, then zero the image, then the transposed scatter)
+  int a_off[6], o_off[6][4];
   {
-    constexpr int MAXV = 3;  // 3 * 512 float4 >= 151 * 40 / 4
+    constexpr int MAXV = 6;  // 6 * 256 float4 >= 151 * 40 / 4
     const float *src = a.mel + row * CV_NMEL;
     const int n = valid * CV_NMEL;
     const bool al16 = ((((uintptr_t)src) & 15) == 0);
@@ -752,6 +765,22 @@ __global__ __launch_bounds__(CF_THREADS, 4) void crnn_fused_kernel(fused_args a)
       }
     }
     for (int i = tid; i < CF_IMG_FLOATS / 4; i += CF_THREADS) ((float4 *)img)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // while the window is on its way: LDS offsets of this lane's conv operands and results for its six m-tiles
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      constexpr int M = CV_OT * CV_OF;
+      const int mt = wave + 4 * i;
+      int m = mt * 16 + j;
+      if (m >= M) m = M - 1;
+      const int t = m / CV_OF, f = m - t * CV_OF;
+      a_off[i] = (f * CV_SF) * CV_LDT + t * CV_ST;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mo = mt * 16 + kk * 4 + r;
+        const int to = mo / CV_OF, fo = mo - to * CV_OF;
+        o_off[i][r] = mo < M ? to * CF_FLD + fo * 32 + j : -1;
+      }
+    }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < MAXV; ++q) {
@@ -770,51 +799,67 @@ __global__ __launch_bounds__(CF_THREADS, 4) void crnn_fused_kernel(fused_args a)
   __syncthreads();
   CF_STAMP(1)
   if (a.stop_after == 1) return;
-  // ---- B: conv -> feat (LDS)
+  // ---- B: conv -> feat (LDS).  Six m-tiles per wave, software-pipelined by hand: the next tile's A operands are read while
+  //      this tile's MFMAs run, and the previous tile's ReLU + store sit in the middle of them.  Vector instructions between
+  //      fp32 MFMAs cost matrix time, so the loop holds none it can avoid: operand and store offsets were computed during the
+  //      staging (a_off, o_off), the bias is the accumulators' initial value.
   {
-    constexpr int M = CV_OT * CV_OF;
-#pragma unroll 1
-    for (int mt = wave; mt < (M + 15) / 16; mt += CF_THREADS / 64) {
-      int m = mt * 16 + j;
-      if (m >= M) m = M - 1;
-      const int t = m / CV_OF, f = m - t * CV_OF;
-      const float *abase = img + (f * CV_SF) * CV_LDT + t * CV_ST;
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    auto load_a = [&](float4(&av)[CV_KB], int i) {
+      const float *abase = img + a_off[i];
 #pragma unroll
       for (int kb = 0; kb < CV_KB; ++kb) {
         const int k4 = kb * 16 + kk * 4;
         const int kf = k4 / CV_KT, kt = k4 - kf * CV_KT;
-        const float4 av = *(const float4 *)(abase + kf * CV_LDT + kt);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wreg[kb][0].x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wreg[kb][1].x, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wreg[kb][0].y, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wreg[kb][1].y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wreg[kb][0].z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wreg[kb][1].z, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wreg[kb][0].w, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wreg[kb][1].w, acc1, 0, 0, 0);
+        av[kb] = *(const float4 *)(abase + kf * CV_LDT + kt);
       }
+    };
+    auto store_tile = [&](int i, const f32x4 &r0, const f32x4 &r1) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int mo = mt * 16 + kk * 4 + r;
-        if (mo < M) {
-          const int to = mo / CV_OF, fo = mo - to * CV_OF;
-          feat[to * CF_FLD + fo * 32 + j] = fmaxf(acc0[r] + cb0, 0.f);
-          feat[to * CF_FLD + fo * 32 + 16 + j] = fmaxf(acc1[r] + cb1, 0.f);
+        if (i < 5 || o_off[i][r] >= 0) {  // only the last tile of wave 3 has rows past M
+          feat[o_off[i][r]] = fmaxf(r0[r], 0.f);
+          feat[o_off[i][r] + 16] = fmaxf(r1[r], 0.f);
         }
       }
-    }
-  }
-  // the first two k-steps of W_x1 are requested before the barrier: their L2 latency passes while the slower waves finish
-  const int ng = wave & 3, kh = wave >> 2;
-  const float *wb = a.wx1s + ((size_t)(kh * 80 + kk) * 192 + ng * 48 + j) * 4;  // + ks * KS_STRIDE; + n * 64
-  const size_t KS_STRIDE = a.stop_after >= 100 ? 0 : (size_t)4 * 192 * 4;
-  float4 bq[3][3];
+    };
+#define CF_CONV_KB(kb_)                                                                              \
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i & 1][kb_].x, wreg[kb_][0].x, acc0, 0, 0, 0);       \
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i & 1][kb_].x, wreg[kb_][1].x, acc1, 0, 0, 0);       \
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i & 1][kb_].y, wreg[kb_][0].y, acc0, 0, 0, 0);       \
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i & 1][kb_].y, wreg[kb_][1].y, acc1, 0, 0, 0);       \
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i & 1][kb_].z, wreg[kb_][0].z, acc0, 0, 0, 0);       \
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i & 1][kb_].z, wreg[kb_][1].z, acc1, 0, 0, 0);       \
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i & 1][kb_].w, wreg[kb_][0].w, acc0, 0, 0, 0);       \
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i & 1][kb_].w, wreg[kb_][1].w, acc1, 0, 0, 0);
+    float4 av[2][CV_KB];
+    f32x4 prev0 = {0.f, 0.f, 0.f, 0.f}, prev1 = {0.f, 0.f, 0.f, 0.f};
+    load_a(av[0], 0);
 #pragma unroll
-  for (int n = 0; n < 3; ++n) {
-    bq[0][n] = *(const float4 *)(wb + n * 64);
-    bq[1][n] = *(const float4 *)(wb + KS_STRIDE + n * 64);
+    for (int i = 0; i < 6; ++i) {
+      if (i + 1 < 6) load_a(av[(i + 1) & 1], i + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 acc0 = {cb0, cb0, cb0, cb0}, acc1 = {cb1, cb1, cb1, cb1};
+      CF_CONV_KB(0) CF_CONV_KB(1) CF_CONV_KB(2)
+      __builtin_amdgcn_sched_barrier(0);
+      if (i > 0) store_tile(i - 1, prev0, prev1);
+      __builtin_amdgcn_sched_barrier(0);
+      CF_CONV_KB(3) CF_CONV_KB(4) CF_CONV_KB(5) CF_CONV_KB(6)
+      prev0 = acc0;
+      prev1 = acc1;
+    }
+    store_tile(5, prev0, prev1);
+#undef CF_CONV_KB
   }
+  // (raw buffer loads with a scalar k-step offset would take the 64-bit pointer adds off the vector ALU, but this compiler
+  //  lowers __builtin_amdgcn_raw_buffer_load_b128 to a one-dword load on gfx950: not used)
+  const float *wb = a.wx1s + ((size_t)kk * 192 + wave * 48 + j) * 4;
+  constexpr size_t KS_STRIDE = (size_t)4 * 192 * 4;
+  auto w_ld = [&](int ks, int n) { return *(const float4 *)(wb + ks * KS_STRIDE + n * 64); };
+  float4 bq[4][3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int n = 0; n < 3; ++n) bq[s][n] = w_ld(s, n);
   CF_STAMP(2)
   __syncthreads();  // feat complete; the image is dead from here on
   CF_STAMP(3)
@@ -827,130 +872,96 @@ __global__ __launch_bounds__(CF_THREADS, 4) void crnn_fused_kernel(fused_args a)
   const int unit = lane >> 1, half = lane & 1, dir = wave & 1;
   gru_w g;  // waves 0, 1: layer 1; waves 2, 3: layer 2
   {
-    const float *a0p = feat + j * CF_FLD + kh * 320 + kk * 4;
+    const float *a0p = feat + j * CF_FLD + kk * 4;
     const int r1 = 16 + (lane & 3);
-    const float *a1p = feat + (r1 < OT ? r1 : OT - 1) * CF_FLD + kh * 320 + kk * 4;  // lane%4 == 3: row 19 does not exist, its sums are never stored
+    const float *a1p = feat + (r1 < OT ? r1 : OT - 1) * CF_FLD + kk * 4;  // lane%4 == 3: row 19 does not exist, its sums are never stored
     f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     f32x4 rem[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     // operand ring, fully unrolled so that the slots are plain registers (a rotating copy would have to wait for the
-    // load it copies): W two k-steps ahead (L2), feat one step ahead (LDS)
+    // load it copies): W three k-steps ahead (L2), feat one step ahead (LDS)
     float4 avq[2], rvq[2];
     avq[0] = *(const float4 *)(a0p);
     rvq[0] = *(const float4 *)(a1p);
 #pragma unroll
-    for (int ks = 0; ks < 20; ++ks) {
-      if (ks + 2 < 20) {
+    for (int ks = 0; ks < 40; ++ks) {
+      if (ks + 3 < 40) {
 #pragma unroll
-        for (int n = 0; n < 3; ++n) bq[(ks + 2) % 3][n] = *(const float4 *)(wb + (ks + 2) * KS_STRIDE + n * 64);
+        for (int n = 0; n < 3; ++n) bq[(ks + 3) & 3][n] = w_ld(ks + 3, n);
       }
-      if (ks + 1 < 20) {
+      if (ks + 1 < 40) {
         avq[(ks + 1) & 1] = *(const float4 *)(a0p + (ks + 1) * 16);
         rvq[(ks + 1) & 1] = *(const float4 *)(a1p + (ks + 1) * 16);
       }
+      __builtin_amdgcn_sched_barrier(0);  // the prefetches stay HERE: sunk to just before their use, the LDS reads cost ~130 cycles per k-step
       const float4 av = avq[ks & 1], rv = rvq[ks & 1];
-      const float4 *b = bq[ks % 3];
-      // consecutive MFMAs go to different accumulators (dependent-accumulator latency 40 > issue 32)
-#define CF_ROUND(e_)                                                                                   \
-  acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.e_, b[0].e_, acc[0], 0, 0, 0);                       \
-  acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.e_, b[1].e_, acc[1], 0, 0, 0);                       \
-  acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.e_, b[2].e_, acc[2], 0, 0, 0);                       \
-  rem[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(rv.e_, b[0].e_, rem[0], 0, 0, 0);                         \
-  rem[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(rv.e_, b[1].e_, rem[1], 0, 0, 0);                         \
-  rem[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(rv.e_, b[2].e_, rem[2], 0, 0, 0);
-      CF_ROUND(x) CF_ROUND(y) CF_ROUND(z) CF_ROUND(w)
-#undef CF_ROUND
+      const float4 *b = bq[ks & 3];
+      CF_ROUND(av, rv, b, x) CF_ROUND(av, rv, b, y) CF_ROUND(av, rv, b, z) CF_ROUND(av, rv, b, w)
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // recurrent weights of the waves that will run the recurrences: requested here, needed two barriers later
-    if (wave < 4) gru_load_w(g, wave < 2 ? a.wh1 : a.wh2, wave < 2 ? a.bh1 : a.bh2, dir, unit, half);
+    // recurrent weights: requested here, needed a barrier (waves 0, 1) or a whole recurrence (waves 2, 3) later
+    gru_load_w(g, wave < 2 ? a.wh1 : a.wh2, wave < 2 ? a.bh1 : a.bh2, dir, unit, half);
     // the four k sub-steps of a column sit in lanes col, col+16, col+32, col+48
 #pragma unroll
-    for (int n = 0; n < 3; ++n)
+    for (int n = 0; n < 3; ++n) {
+      const int col = wave * 48 + n * 16 + j;
+      const float bv = a.bx1[col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gxs[(kk * 4 + r) * GR_GX_LD + col] = acc[n][r] + bv;
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         float v = rem[n][i];
         v += __shfl_xor(v, 16);
         v += __shfl_xor(v, 32);
-        rem[n][i] = v;
-      }
-    CF_STAMP(4)
-    if (kh == 1) {  // upper half of K: leave the sums in gx
-#pragma unroll
-      for (int n = 0; n < 3; ++n) {
-        const int col = ng * 48 + n * 16 + j;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) gxs[(kk * 4 + r) * GR_GX_LD + col] = acc[n][r];
-        if (kk == 0) {
-#pragma unroll
-          for (int i = 0; i < 3; ++i) gxs[(16 + i) * GR_GX_LD + col] = rem[n][i];
-        }
-      }
-    }
-    __syncthreads();  // upper-half sums in place; nobody reads feat any more
-    if (kh == 0) {
-#pragma unroll
-      for (int n = 0; n < 3; ++n) {
-        const int col = ng * 48 + n * 16 + j;
-        const float bv = a.bx1[col];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float *p = &gxs[(kk * 4 + r) * GR_GX_LD + col];
-          *p = (acc[n][r] + *p) + bv;
-        }
-        if (kk == 0) {
-#pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            float *p = &gxs[(16 + i) * GR_GX_LD + col];
-            *p = (rem[n][i] + *p) + bv;
-          }
-        }
+        if (kk == 0) gxs[(16 + i) * GR_GX_LD + col] = v + bv;
       }
     }
   }
-  __syncthreads();
+  CF_STAMP(4)
+  __syncthreads();  // gx complete; nobody reads feat any more
   CF_STAMP(5)
   if (a.stop_after == 3) return;
 
-  // ---- D: layer-1 recurrence (waves 0, 1) | waves 4..7: W_x2 (B-operand order) -> the feat space
+  // ---- D: layer-1 recurrence (waves 0, 1) | waves 2, 3: W_x2 (B-operand order) -> the feat space
   float *wx2l = feat;  // [16 k-quads][192][4]
   if (wave < 2) {
     if (a.gru_prio) __builtin_amdgcn_s_setprio(3);
     cf_recurrence<true>(g, gxs, hb + dir * 2 * H, seq1, dir, unit, half);
     __builtin_amdgcn_s_setprio(0);
-  } else if (wave >= 4) {
+  } else {
     const float4 *src = (const float4 *)a.wx2s;
-    for (int i = tid - 256; i < 16 * 192; i += 256) ((float4 *)wx2l)[i] = src[i];
+#pragma unroll 4
+    for (int i = tid - 128; i < 16 * 192; i += 128) ((float4 *)wx2l)[i] = src[i];
   }
   __syncthreads();
   CF_STAMP(6)
   if (a.stop_after == 4) return;
 
-  // ---- E: layer-2 input projection gx2[t][n] = seq1[t][:] . Wx2[n][:] + bx2[n]  (M = 32 with 19 valid rows, K = 64, N = 192)
+  // ---- E: layer-2 input projection gx2[t][n] = seq1[t][:] . Wx2[n][:] + bx2[n]  (19 rows, K = 64, N = 192): rows 0..15 as one
+  //      MFMA tile, rows 16..18 on the 4x4x1 form, 3 n-tiles per wave
   {
-    const int pmt = wave >> 2, pn0 = (wave & 3) * 3;
     f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 rem[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-      const float4 av = *(const float4 *)(&seq1[(pmt * 16 + j) * GR_SEQ_LD + kb * 16 + kk * 4]);
-      float4 bv[3];
+      const float4 av = *(const float4 *)(&seq1[j * GR_SEQ_LD + kb * 16 + kk * 4]);
+      const float4 rv = *(const float4 *)(&seq1[(16 + (lane & 3)) * GR_SEQ_LD + kb * 16 + kk * 4]);  // row 19 is zero
+      float4 b[3];
 #pragma unroll
-      for (int n = 0; n < 3; ++n) bv[n] = *(const float4 *)(&wx2l[((kb * 4 + kk) * 192 + (pn0 + n) * 16 + j) * 4]);
-#pragma unroll
-      for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv[n].x, acc[n], 0, 0, 0);
-#pragma unroll
-      for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv[n].y, acc[n], 0, 0, 0);
-#pragma unroll
-      for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv[n].z, acc[n], 0, 0, 0);
-#pragma unroll
-      for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv[n].w, acc[n], 0, 0, 0);
+      for (int n = 0; n < 3; ++n) b[n] = *(const float4 *)(&wx2l[((kb * 4 + kk) * 192 + (wave * 3 + n) * 16 + j) * 4]);
+      CF_ROUND(av, rv, b, x) CF_ROUND(av, rv, b, y) CF_ROUND(av, rv, b, z) CF_ROUND(av, rv, b, w)
     }
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
-      const int col = (pn0 + n) * 16 + j;
+      const int col = (wave * 3 + n) * 16 + j;
       const float bb = a.bx2[col];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int t = pmt * 16 + kk * 4 + r;
-        if (t < OT) gxs[t * GR_GX_LD + col] = acc[n][r] + bb;
+      for (int r = 0; r < 4; ++r) gxs[(kk * 4 + r) * GR_GX_LD + col] = acc[n][r] + bb;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        float v = rem[n][i];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (kk == 0) gxs[(16 + i) * GR_GX_LD + col] = v + bb;
       }
     }
   }
@@ -958,9 +969,9 @@ __global__ __launch_bounds__(CF_THREADS, 4) void crnn_fused_kernel(fused_args a)
   CF_STAMP(7)
   if (a.stop_after == 5) return;
 
-  // ---- F: layer-2 recurrence (waves 2, 3): only the last state of each direction is kept | waves 4..7: head -> LDS
+  // ---- F: layer-2 recurrence (waves 2, 3): only the last state of each direction is kept | waves 0, 1: head -> LDS
   float *w1s = feat;  // [64][GR_W1_LD], over W_x2
-  if (wave == 2 || wave == 3) {
+  if (wave >= 2) {
     if (a.gru_prio) __builtin_amdgcn_s_setprio(3);
     const float h_last = cf_recurrence<false>(g, gxs, hb + (2 + dir) * 2 * H, nullptr, dir, unit, half);
     __builtin_amdgcn_s_setprio(0);
@@ -968,10 +979,9 @@ __global__ __launch_bounds__(CF_THREADS, 4) void crnn_fused_kernel(fused_args a)
       encs[dir * H + unit] = h_last;
       if (a.enc) a.enc[(size_t)w * 2 * H + dir * H + unit] = h_last;
     }
-  } else if (wave >= 4) {
-    const int t2 = tid - 256;
-    for (int i = t2; i < 64 * 64; i += 256) w1s[(i >> 6) * GR_W1_LD + (i & 63)] = a.w1[i];
-    for (int i = t2; i < a.NOUT * 64; i += 256) w2s[i] = a.w2[i];
+  } else {
+    for (int i = tid; i < 64 * 64; i += 128) w1s[(i >> 6) * GR_W1_LD + (i & 63)] = a.w1[i];
+    for (int i = tid; i < a.NOUT * 64; i += 128) w2s[i] = a.w2[i];
   }
   __syncthreads();
   CF_STAMP(8)
@@ -1002,6 +1012,7 @@ __global__ __launch_bounds__(CF_THREADS, 4) void crnn_fused_kernel(fused_args a)
   CF_STAMP(9)
 #undef CF_STAMP
 }
+#undef CF_ROUND
 
 // detect.tflite alone (reference detect_model(x), wakeword/tflite.py:228-229): one wave per row
 __global__ __launch_bounds__(64) void crnn_detect_kernel(const float *enc, const float *w1, const float *b1, const float *w2,
@@ -1207,8 +1218,8 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
     fused_args a = {d_mel, wa, c.conv_w, c.conv_b, c.wx1s, c.bx1, c.wh1, c.bh1, c.wx2s, c.bx2, c.wh2, c.bh2,
                     c.w1, c.b1, c.w2, c.b2, d_enc, d_out, c.T, c.NOUT, c.HEAD, 0, nullptr, 0};
     {
-      static const char *pr = getenv("WWHIP_CF_PRIO");
-      if (pr) a.gru_prio = atoi(pr);
+      static const char *pr = getenv("WWHIP_CF_PRIO");  // development; default on: +1.5 % at scale, nothing at 256 windows
+      a.gru_prio = pr ? atoi(pr) : 1;
     }
     static const char *stop_env = getenv("WWHIP_CF_STOP");
     if (stop_env) a.stop_after = atoi(stop_env);
@@ -1219,8 +1230,8 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
     }
     static const bool want_stamps = getenv("WWHIP_CF_STAMPS") != nullptr;  // development: phase timeline to stderr
     if (want_stamps) {
-      WW_HIP(ctx, hipMalloc((void **)&a.stamps, (size_t)nw * 80 * sizeof(long long)));
-      WW_HIP(ctx, hipMemsetAsync(a.stamps, 0, (size_t)nw * 80 * sizeof(long long), ctx->stream));
+      WW_HIP(ctx, hipMalloc((void **)&a.stamps, (size_t)nw * 40 * sizeof(long long)));
+      WW_HIP(ctx, hipMemsetAsync(a.stamps, 0, (size_t)nw * 40 * sizeof(long long), ctx->stream));
     }
     {
       ww_launch_scope scope(ctx, "crnn_fused_kernel");
@@ -1228,16 +1239,16 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
     }
     WW_HIP(ctx, hipGetLastError());
     if (want_stamps) {
-      std::vector<long long> h((size_t)nw * 80);
+      std::vector<long long> h((size_t)nw * 40);
       WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
       WW_HIP(ctx, hipMemcpy(h.data(), a.stamps, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
       WW_HIP(ctx, hipFree(a.stamps));
       long long t0 = h[0];
       for (size_t i = 0; i < h.size(); ++i) if (h[i] && h[i] < t0) t0 = h[i];
       for (int b : {0, nw / 2, nw - 1}) {
-        for (int wv : {0, 1, 2, 7}) {
+        for (int wv : {0, 1, 2, 3}) {
           fprintf(stderr, "block %d wave %d:", b, wv);
-          for (int i = 0; i < 10; ++i) fprintf(stderr, " %lld", h[((size_t)b * 8 + wv) * 10 + i] - t0);
+          for (int i = 0; i < 10; ++i) fprintf(stderr, " %lld", h[((size_t)b * 4 + wv) * 10 + i] - t0);
           fprintf(stderr, "\n");
         }
       }
