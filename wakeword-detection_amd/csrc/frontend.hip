@@ -19,8 +19,12 @@
 // LDS ~38 %; the rest is dependency latency inside a wave's transform, which is why occupancy pays: 4 workgroups
 // per CU need <= 128 VGPRs and <= 40 KB of LDS each.  In fp64 that is met by giving wave 3 the sample tile as its
 // transpose buffer (the tile is dead once every wave has formed its Hann products: one extra barrier) and by
-// rebuilding the W256 twiddles on the ALU instead of keeping a 4 KB table.  (Halving the transposes' footprint by
-// running them two frames at a time costs more LDS instructions than the occupancy returns: DESIGN.md 7.1.)
+// keeping no twiddle table in LDS: the fp64 twiddles (W256^(j k1), W512^k: two 4 KB tables every wave of the chip
+// shares) are read through the vector L1 - 23 sixteen-byte loads per lane for the 88 fp64 instructions that rebuilt
+// them from two per-lane constants (round 2: VALU instructions per wave 935 -> 855, kernel -1.5 %: the kernel is
+// bound by the latency chains of its LDS round trips and by its 2.5 launch rounds, not by issue slots; -DWW_TW_GLOBAL=0
+// restores the ALU form).  (Halving the transposes' footprint by running them two frames at a time costs more LDS
+// instructions than the occupancy returns: DESIGN.md 7.1.)
 // (stft_mag_kernel and the streaming kernel keep the earlier one-wave-per-frame radix-4 Stockham
 // FFT of fft_device.h: they are not on the batched path.)
 //
@@ -226,6 +230,10 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? 4 : 5) void logmel_kernel(log
   // three of the four per-wave buffers are allocated: wave 3 uses the sample tile, which is dead once every wave
   // has formed its Hann products (one extra barrier).
   constexpr bool TW_LDS = sizeof(R) == 4;
+#ifndef WW_TW_GLOBAL
+#define WW_TW_GLOBAL 1
+#endif
+  constexpr bool TW_GLOBAL = WW_TW_GLOBAL != 0;  // fp64: twiddles from the L1-resident tables instead of the vector ALU
   cplx<R> *tb_tw = (cplx<R> *)(smem + off); off += TW_LDS ? 256 * sizeof(cplx<R>) : 0;   // [k1][j] = W256^(j k1)
   cplx<R> *tb_un = (cplx<R> *)(smem + off); off += TW_LDS ? 256 * sizeof(cplx<R>) : 0;   // W512^k
   const cplx<R> base_tw = {(R)a.tw16[2 * (16 + j)], (R)a.tw16[2 * (16 + j) + 1]};          // W256^j
@@ -399,6 +407,14 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? 4 : 5) void logmel_kernel(log
     if (TW_LDS) {
 #pragma unroll
       for (int pos = 1; pos < 16; ++pos) v[pos] = cmul(v[pos], tb_tw[k_of(pos) * 16 + j]);
+    } else if (TW_GLOBAL) {
+      // fp64: the 4 KB table [k1][j] stays in the vector L1 (every wave of the chip reads the same 4 KB): fifteen 16-byte
+      // loads per lane in place of the 84 fp64 instructions of the product tree below
+#pragma unroll
+      for (int pos = 1; pos < 16; ++pos) {
+        const double2 t = *(const double2 *)(a.tw16 + 2 * (k_of(pos) * 16 + j));
+        v[pos] = cmul(v[pos], cplx<R>{(R)t.x, (R)t.y});
+      }
     } else {
       // W256^(j k1) for k1 = 1..15 as powers of W256^j (product tree, depth <= 4: a few fp64 ulp)
       cplx<R> p[16];
@@ -476,7 +492,15 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? 4 : 5) void logmel_kernel(log
     for (int k2 = 0; k2 < 8; ++k2) {
       const cplx<R> own = w[pos_of(k2)];
       // W512^(j + 16 k2) = W512^j * W32^k2
-      const cplx<R> un = TW_LDS ? tb_un[j + 16 * k2] : cmul(base_un, cplx<R>{(R)W32_RE[k2], (R)W32_IM[k2]});
+      cplx<R> un;
+      if (TW_LDS) {
+        un = tb_un[j + 16 * k2];
+      } else if (TW_GLOBAL) {
+        const double2 t = *(const double2 *)(a.tw512 + 2 * (j + 16 * k2));
+        un = cplx<R>{(R)t.x, (R)t.y};
+      } else {
+        un = cmul(base_un, cplx<R>{(R)W32_RE[k2], (R)W32_IM[k2]});
+      }
       const R er = own.re + pz[k2].re, ei = own.im - pz[k2].im;
       const R orr = own.im + pz[k2].im, oi = pz[k2].re - own.re;
       const R tr_ = orr * un.re - oi * un.im, ti_ = orr * un.im + oi * un.re;

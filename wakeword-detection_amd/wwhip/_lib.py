@@ -16,7 +16,8 @@ from typing import Dict, Optional
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libwwhip.so")
+# WWHIP_LIB: development only - an alternative build of the same library (kernel A/B comparisons)
+LIB_PATH = os.environ.get("WWHIP_LIB") or os.path.join(_PKG, "libwwhip.so")
 
 WW_OK, WW_EINVAL, WW_EBLOB, WW_EHIP, WW_ENOMEM, WW_ESTATE, WW_ENODEVICE = 0, -1, -2, -3, -4, -5, -6
 KIND_CRNN, KIND_WAVENET = 1, 2
