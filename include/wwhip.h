@@ -79,6 +79,12 @@ int ww_ctx_synchronize(ww_ctx *ctx);
 void *ww_ctx_stream(ww_ctx *ctx);
 const char *ww_last_error(const ww_ctx *ctx); /* ctx may be NULL: error of a failed create */
 const char *ww_version(void);
+/* Which HIP runtime the library actually runs on.  libwwhip.so links libamdhip64 by soname; a host program that has
+ * already loaded another copy (PyTorch-ROCm wheels bundle their own) decides which one that is.  built_hip_version =
+ * HIP_VERSION of the headers at compile time, runtime_version / driver_version = hipRuntimeGetVersion /
+ * hipDriverGetVersion of the loaded runtime (0 if unavailable), all as major * 10,000,000 + minor * 100,000 + patch.
+ * The Python binding warns when the major versions differ (wwhip/_lib.py). */
+int ww_runtime_info(int32_t *built_hip_version, int32_t *runtime_version, int32_t *driver_version);
 
 /* Per-kernel timing with HIP events on the ctx stream (bench.py roofline leg).  While
  * enabled every kernel launch is bracketed by two events; ww_profile_read synchronises and

@@ -441,3 +441,76 @@ def test_demo_pipeline_on_a_wav(assets, tmp_path):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "demo.py"), "--models_dir", os.path.join(assets, "Wavenet"),
                         "--model_type", "Wavenet", "--wav", str(tmp_path / "in.wav")], capture_output=True, text=True, check=True)
     assert "wake events at (s):" in r.stdout and "Script completed" in r.stdout
+
+
+def test_many_stream_pipeline_matches_single_stream_stages(assets):
+    """SURVEY 8(f) rank 3 / BASELINE configs[4] as a PIPELINE: VadBank -> WakewordBank -> one ActivationTimeout per stream
+    over 128 streams in lock step, against 128 independent single-stream chains
+    VoiceActivityDetector -> WakewordTrigger -> ActivationTimeout driven the way SpeechPipeline._dispatch drives them
+    (demo.py:29-36, spokestack/pipeline.py:25-28): same is_speech / is_active after every tick, same activate /
+    deactivate events, same posteriors."""
+    from wwhip.activation_timeout import ActivationTimeout
+    from wwhip.context import SpeechContext
+    from wwhip.vad import VadBank, VoiceActivityDetector
+    from wwhip.wakeword import WakewordBank, WakewordTrigger
+    S, TICKS, THR = 128, 90, 0.02
+    mdir = os.path.join(assets, "CRNN")
+    rng = np.random.default_rng(77)
+    frames = np.clip(rng.normal(0, 2500, (TICKS, S, 320)), -32768, 32767).astype(np.int16)
+    # scripted raw VAD decisions: runs of speech / non-speech of random length per stream
+    raw = np.zeros((TICKS, S), bool)
+    for s in range(S):
+        t, v = 0, bool(rng.random() < 0.5)
+        while t < TICKS:
+            n = int(rng.integers(1, 25))
+            raw[t:t + n, s] = v
+            t, v = t + n, not v
+    kw_vad = dict(frame_width=20, vad_rise_delay=40, vad_fall_delay=60)
+    kw_to = dict(frame_width=20, min_active=60, max_active=200)
+
+    def make_ctx(log):
+        ctx = SpeechContext()
+        for name in ("activate", "deactivate"):
+            ctx.add_handler(name, (lambda n: (lambda c: log.append(n)))(name))
+        return ctx
+
+    # ---- the banked pipeline
+    b_logs = [[] for _ in range(S)]
+    b_ctx = [make_ctx(b_logs[s]) for s in range(S)]
+    vad_bank = VadBank(S, **kw_vad)
+    wake_bank = WakewordBank(S, mdir, posterior_threshold=THR)
+    b_to = [ActivationTimeout(**kw_to) for _ in range(S)]
+    b_state = np.zeros((TICKS, S, 2), bool)
+    b_post = []
+    for t in range(TICKS):
+        speech = vad_bank.step(raw[t])
+        for s in range(S):
+            b_ctx[s].is_speech = bool(speech[s])
+        post = wake_bank.step(b_ctx, frames[t])
+        b_post.append(post.copy())
+        for s in range(S):
+            b_to[s](b_ctx[s], frames[t, s])
+            b_state[t, s] = (b_ctx[s].is_speech, b_ctx[s].is_active)
+    wake_bank.close()
+
+    # ---- 128 single-stream chains, stage order of demo.py: vad, wake word, timeout
+    n_active = 0
+    for s in range(S):
+        log = []
+        ctx = make_ctx(log)
+        tick = {"t": 0}
+        vad = VoiceActivityDetector(classifier=lambda fb, sr: bool(raw[tick["t"], s]), **kw_vad)
+        wake = WakewordTrigger(model_dir=mdir, model_type="CRNN", posterior_threshold=THR)
+        timeout = ActivationTimeout(**kw_to)
+        for t in range(TICKS):
+            tick["t"] = t
+            for stage in (vad, wake, timeout):
+                stage(ctx, frames[t, s])
+            assert (ctx.is_speech, ctx.is_active) == tuple(b_state[t, s]), (s, t)
+        wake.close()
+        assert log == b_logs[s], s
+        n_active += "activate" in log
+    # the script exercises both outcomes
+    assert 4 <= n_active <= S - 4, n_active
+    assert any("deactivate" in lg for lg in b_logs)
+    assert np.isfinite(np.array(b_post)).all()

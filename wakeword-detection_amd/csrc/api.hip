@@ -70,7 +70,17 @@ struct ww_small_io {
 
 extern "C" {
 
-const char *ww_version(void) { return "wwhip 0.2 (gfx950)"; }
+const char *ww_version(void) { return "wwhip 0.3 (gfx950)"; }
+
+int ww_runtime_info(int32_t *built_hip_version, int32_t *runtime_version, int32_t *driver_version) {
+  if (built_hip_version) *built_hip_version = HIP_VERSION;  // headers the library was compiled against
+  int rt = 0, drv = 0;
+  const hipError_t e1 = hipRuntimeGetVersion(&rt);
+  const hipError_t e2 = hipDriverGetVersion(&drv);  // may fail where no GPU is visible: reported as 0
+  if (runtime_version) *runtime_version = e1 == hipSuccess ? rt : 0;
+  if (driver_version) *driver_version = e2 == hipSuccess ? drv : 0;
+  return e1 == hipSuccess ? WW_OK : WW_EHIP;
+}
 
 const char *ww_last_error(const ww_ctx *ctx) { return ctx ? ctx->err : g_err; }
 
@@ -84,7 +94,7 @@ int ww_ctx_create(int device, void *external_stream, ww_ctx **out) {
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) return ww_fail(nullptr, WW_EHIP, "hipGetDeviceProperties failed");
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return ww_fail(nullptr, WW_ENODEVICE, "device %d is %s; libwwhip.so carries gfx950 code only", device, prop.gcnArchName);
-  if (hipSetDevice(device) != hipSuccess) return ww_fail(nullptr, WW_EHIP, "hipSetDevice(%d) failed", device);
+  ww_device_scope dev_scope(device);  // the stream and events below are created on `device`; the caller's current device is restored
   ww_ctx *c = new ww_ctx();
   c->device = device;
   if (external_stream) {
@@ -104,7 +114,7 @@ int ww_ctx_create(int device, void *external_stream, ww_ctx **out) {
 
 int ww_ctx_destroy(ww_ctx *ctx) {
   if (!ctx) return WW_OK;
-  hipSetDevice(ctx->device);
+  ww_device_scope dev_scope(ctx->device);
   hipStreamSynchronize(ctx->stream);
   ctx->drop_graphs(nullptr);
   for (auto &co : ctx->clip_offs) {
@@ -624,7 +634,7 @@ int ww_model_load(ww_ctx *ctx, const void *blob, size_t len, ww_model **out) {
   blob_view bv = {(const uint8_t *)blob, len, h[3], h[2]};
   if (16 + 32 * (size_t)bv.n > len) return ww_fail(ctx, WW_EBLOB, "section table exceeds blob");
   if (bv.kind != WW_KIND_CRNN && bv.kind != WW_KIND_WAVENET) return ww_fail(ctx, WW_EBLOB, "unknown model kind %u", bv.kind);
-  WW_HIP(ctx, hipSetDevice(ctx->device));
+  ww_device_scope dev_scope(ctx->device);  // the caller's current device is left as it was
   ww_model *m = new ww_model();
   m->ctx = ctx;
   m->kind = (int)bv.kind;
@@ -644,7 +654,7 @@ int ww_model_load(ww_ctx *ctx, const void *blob, size_t len, ww_model **out) {
 int ww_model_free(ww_model *m) {
   if (!m) return WW_OK;
   if (m->ctx) {
-    hipSetDevice(m->ctx->device);
+    ww_device_scope dev_scope(m->ctx->device);
     hipStreamSynchronize(m->ctx->stream);
     m->ctx->drop_graphs(m);
   }
@@ -690,7 +700,7 @@ static int logmel_host(ww_ctx *ctx, const ww_model *m, const void *samples, size
   if (n_utt < 0) return ww_fail(ctx, WW_EINVAL, "negative utterance count");
   int rc = check_fp(ctx, fp, elt == 2);
   if (rc) return rc;
-  WW_HIP(ctx, hipSetDevice(ctx->device));
+  ww_device_scope dev_scope(ctx->device);  // the caller's current device is left as it was
   frame_offs[0] = 0;
   int64_t max_f = 0;
   for (int u = 0; u < n_utt; ++u) {
@@ -769,7 +779,7 @@ int ww_stft_mag(ww_ctx *ctx, const ww_model *m, const float *frames, int64_t n, 
   if (n < 0) return ww_fail(ctx, WW_EINVAL, "negative frame count");
   if (n == 0) return WW_OK;
   if (!frames || !mag) return ww_fail(ctx, WW_EINVAL, "NULL buffer");
-  WW_HIP(ctx, hipSetDevice(ctx->device));
+  ww_device_scope dev_scope(ctx->device);  // the caller's current device is left as it was
   const size_t b_f = ww_bump::need((size_t)n * WW_FFT_WINDOW, 4), b_m = ww_bump::need((size_t)n * WW_FFT_BINS, 4);
   int rc;
   if (b_f + b_m <= WW_SMALL_IO_BYTES) {
@@ -802,7 +812,7 @@ int ww_filter_apply(ww_ctx *ctx, const ww_model *m, const float *mag, int64_t n,
   if (n < 0) return ww_fail(ctx, WW_EINVAL, "negative row count");
   if (n == 0) return WW_OK;
   if (!mag || !mel) return ww_fail(ctx, WW_EINVAL, "NULL buffer");
-  WW_HIP(ctx, hipSetDevice(ctx->device));
+  ww_device_scope dev_scope(ctx->device);  // the caller's current device is left as it was
   const int NBN = m->filt.n_bins, F = m->filt.n_mel;
   const size_t b_a = ww_bump::need((size_t)n * NBN, 4), b_b = ww_bump::need((size_t)n * F, 4);
   int rc;
@@ -832,7 +842,7 @@ int ww_detect(ww_ctx *ctx, const ww_model *m, const float *enc, int32_t n, float
   if (n < 0) return ww_fail(ctx, WW_EINVAL, "negative row count");
   if (n == 0) return WW_OK;
   if (!enc || !out) return ww_fail(ctx, WW_EINVAL, "NULL buffer");
-  WW_HIP(ctx, hipSetDevice(ctx->device));
+  ww_device_scope dev_scope(ctx->device);  // the caller's current device is left as it was
   const size_t per = (size_t)m->info.enc_rows * m->info.enc_width;
   const size_t b_a = ww_bump::need((size_t)n * per, 4), b_b = ww_bump::need((size_t)n * m->info.n_out, 4);
   int rc;
@@ -883,7 +893,7 @@ static int forward_host(ww_ctx *ctx, const ww_model *m, const float *mel, int64_
                         float *enc) {
   const int T = m->info.window, F = m->info.n_mel, NO = m->info.n_out;
   const size_t enc_per = (size_t)m->info.enc_rows * m->info.enc_width;
-  WW_HIP(ctx, hipSetDevice(ctx->device));
+  ww_device_scope dev_scope(ctx->device);  // the caller's current device is left as it was
   // Small calls (the reference's per-frame use: one window in, one posterior out, utils/time_tf_models.py) are
   // latency-bound, and a copy-engine operation costs more than the few KB are worth: the window is staged in pinned
   // host memory and the kernels read it over the bus themselves; the posteriors (and the encoder output) are stored
@@ -1086,7 +1096,7 @@ int ww_far_frr(ww_ctx *ctx, const float *pos, int64_t n_pos, const float *neg, i
   if ((n_pos && !pos) || (n_neg && !neg)) return ww_fail(ctx, WW_EINVAL, "NULL posterior buffer");
   if (win > 0 && n_neg > 0 && n_neg < win)
     return ww_fail(ctx, WW_EINVAL, "negative stream shorter than the smoothing window (np.convolve 'same' would change its length)");
-  WW_HIP(ctx, hipSetDevice(ctx->device));
+  ww_device_scope dev_scope(ctx->device);  // the caller's current device is left as it was
   const size_t b_p = ww_bump::need((size_t)n_pos + 1, 4), b_n = ww_bump::need((size_t)n_neg + 1, 4);
   const size_t b_s = ww_bump::need((size_t)n_neg + 1, 8), b_t = ww_bump::need((size_t)n_thr, 8);
   int rc = ww_ensure(ctx, ctx->dev, b_p + b_n + b_s + 3 * b_t + 1024, false);
@@ -1117,7 +1127,7 @@ int ww_superframe_smooth(ww_ctx *ctx, const float *in, int64_t n, int32_t T, flo
   if (!ctx || (n > 0 && (!in || !wake))) return ww_fail(ctx, WW_EINVAL, "NULL argument");
   if (n < 0) return ww_fail(ctx, WW_EINVAL, "bad sizes");
   if (n == 0) return WW_OK;
-  WW_HIP(ctx, hipSetDevice(ctx->device));
+  ww_device_scope dev_scope(ctx->device);  // the caller's current device is left as it was
   const size_t b_in = ww_bump::need((size_t)n * T * 2, 4), b_p = ww_bump::need((size_t)n * T, 1), b_w = ww_bump::need((size_t)n, 1);
   int rc = ww_ensure(ctx, ctx->dev, b_in + b_p + b_w + 1024, false);
   if (rc) return rc;

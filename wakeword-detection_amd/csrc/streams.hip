@@ -182,7 +182,7 @@ extern "C" {
 
 int ww_stream_destroy(ww_streams *st) {
   if (!st) return WW_OK;
-  hipSetDevice(st->ctx->device);
+  ww_device_scope dev_scope(st->ctx->device);
   hipStreamSynchronize(st->ctx->stream);
   void *dev[] = {st->ring, st->hist[0], st->hist[1], st->prev, st->d_pack, st->ws};
   for (void *p : dev)
@@ -200,7 +200,7 @@ int ww_stream_create(ww_ctx *ctx, const ww_model *model, int32_t S, const ww_fro
   if (S <= 0 || S > 65535) return ww_fail(ctx, WW_EINVAL, "stream count %d out of range (1..65535)", S);
   if (fp->hop != 160) return ww_fail(ctx, WW_EINVAL, "streaming mode supports hop 160 (10 ms @ 16 kHz) only, got %d", fp->hop);
   if (!(fp->pcm_divisor > 0.f)) return ww_fail(ctx, WW_EINVAL, "pcm_divisor must be positive");
-  WW_HIP(ctx, hipSetDevice(ctx->device));
+  ww_device_scope dev_scope(ctx->device);  // the caller's current device is left as it was
   ww_streams *st = new ww_streams();
   st->ctx = ctx; st->model = model; st->S = S; st->fp = *fp;
   st->T = model->info.window; st->F = model->info.n_mel; st->NO = model->info.n_out; st->HR = st->T + 2;
@@ -251,7 +251,7 @@ int ww_stream_reset(ww_streams *st, const int32_t *ids, int32_t n) {
   if (ids && n < 0) return ww_fail(ctx, WW_EINVAL, "negative id count");
   const int count = ids ? n : st->S;
   if (count == 0) return WW_OK;
-  WW_HIP(ctx, hipSetDevice(ctx->device));
+  ww_device_scope dev_scope(ctx->device);  // the caller's current device is left as it was
   int32_t *d_ids = nullptr;
   if (ids) {
     for (int i = 0; i < n; ++i)
@@ -280,7 +280,7 @@ int ww_stream_step(ww_streams *st, const int16_t *frames, const uint8_t *is_spee
   if (!st) return WW_EINVAL;
   ww_ctx *ctx = st->ctx;
   if (!frames || !is_speech || !post || !n_post) return ww_fail(ctx, WW_EINVAL, "NULL argument");
-  WW_HIP(ctx, hipSetDevice(ctx->device));
+  ww_device_scope dev_scope(ctx->device);  // the caller's current device is left as it was
   const int S = st->S, hop = st->fp.hop;
   int nw = 0;
   for (int s = 0; s < S; ++s) {

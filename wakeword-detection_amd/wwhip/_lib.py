@@ -44,6 +44,7 @@ SYMBOLS: Dict[str, tuple] = {
     "ww_ctx_stream": (_vp, [_vp]),
     "ww_last_error": (C.c_char_p, [_vp]),
     "ww_version": (C.c_char_p, []),
+    "ww_runtime_info": (C.c_int, [_P(_i32), _P(_i32), _P(_i32)]),
     "ww_profile_enable": (C.c_int, [_vp, C.c_int]),
     "ww_profile_read": (C.c_int, [_vp, C.c_char_p, _sz]),
     "ww_timer_start": (C.c_int, [_vp]),
@@ -140,7 +141,29 @@ def load() -> C.CDLL:
             fn.restype = res
             fn.argtypes = args
         _lib = lib
+        _check_runtime(lib)
         return lib
+
+
+def runtime_info() -> Dict[str, int]:
+    """HIP version the library was built against and the one it is running on (``ww_runtime_info``)."""
+    b, r, d = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    load().ww_runtime_info(C.byref(b), C.byref(r), C.byref(d))
+    return {"built": int(b.value), "runtime": int(r.value), "driver": int(d.value)}
+
+
+def _check_runtime(lib: C.CDLL) -> None:
+    """The library's libamdhip64 binds to whichever copy the process loaded first (torch's bundled runtime when torch
+    is imported, see :func:`_torch_first`).  A different MAJOR version than the build headers means different struct
+    layouts behind the same symbols: say so loudly instead of failing somewhere inside a launch."""
+    import warnings
+    b, r, d = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    rc = lib.ww_runtime_info(C.byref(b), C.byref(r), C.byref(d))
+    if rc != WW_OK or r.value == 0:
+        return  # no runtime answer (e.g. no GPU in a build container): Context() will fail loudly if it matters
+    if b.value // 10_000_000 != r.value // 10_000_000:
+        warnings.warn(f"libwwhip.so was built against HIP {b.value} but runs on HIP runtime {r.value} "
+                      f"(driver {d.value}): major versions differ", RuntimeWarning, stacklevel=3)
 
 
 def ptr(a: Optional[np.ndarray]):

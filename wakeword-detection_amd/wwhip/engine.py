@@ -226,7 +226,7 @@ class StreamBank:
             raise ValueError("is_speech must have one entry per stream")
         _lib.raise_for(self._lib.ww_stream_step(self._h, _lib.ptr(f), _lib.ptr(flags), _lib.ptr(self._post), _lib.ptr(self._n)),
                        self.engine.ctx.handle)
-        return self._post, self._n
+        return self._post.copy(), self._n.copy()  # the caller owns what it gets (like TFLiteModel's get_tensor copies)
 
     def reset(self, ids: Optional[Sequence[int]] = None) -> None:
         if ids is None:
