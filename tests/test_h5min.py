@@ -195,3 +195,38 @@ def test_crnn_against_pytorch_layers(keras_dir, assets, sub, asset):
     p_o, e_o = ora.forward(wins, want_enc=True)
     assert np.abs(post - p_o).max() < 2e-6
     assert np.abs(enc.numpy() - e_o.reshape(len(wins), 64)).max() < 5e-6
+
+
+def test_unsupported_hdf5_features_are_named(tmp_path):
+    """Outside the 'earliest'-format subset the reader refuses by name instead of half-reading."""
+    raw = bytearray(2048)
+    raw[:8] = b"\x89HDF\r\n\x1a\n"
+    raw[8] = 2  # superblock version 2 (libver='latest')
+    raw[9] = raw[10] = 8
+    p = tmp_path / "v2.h5"
+    p.write_bytes(bytes(raw))
+    with pytest.raises(NotImplementedError, match="superblock version 2"):
+        h5min.File(str(p))
+    with pytest.raises(NotImplementedError, match="compound"):
+        h5min._parse_dtype(bytes([0x16, 1, 0, 0, 8, 0, 0, 0]) + bytes(24), 0)   # class 6, version 1
+    with pytest.raises(NotImplementedError, match="dataspace message version 2"):
+        h5min._parse_dataspace(bytes([2, 1, 0, 1]) + bytes(16), 0)
+
+
+def test_h5min_files_open_with_libhdf5(tmp_path):
+    """Where h5py is installed (not in the build image): a 1,000-clip feature file written by h5min - a multi-level
+    group B-tree - read back by libhdf5, data and attributes compared."""
+    h5py = pytest.importorskip("h5py")
+    rng = np.random.default_rng(3)
+    clips = {f"utt_{i:04d}_{rng.integers(1 << 20):05x}": (rng.normal(0, 1, (int(rng.integers(0, 120)), 40)).astype(np.float32),
+                                                          {"is_hotword": int(i % 9 == 0), "speaker": i % 31,
+                                                           "speech_start_ts": -1 if i % 4 else 7, "speech_end_ts": i % 90})
+             for i in range(1000)}
+    path = str(tmp_path / "feat.h5")
+    h5min.write_datasets(path, clips)
+    with h5py.File(path, "r") as f:
+        assert sorted(f.keys()) == sorted(clips)
+        for name, (arr, attrs) in clips.items():
+            np.testing.assert_array_equal(f[name][()], arr)
+            for k, v in attrs.items():
+                assert f[name].attrs[k] == v

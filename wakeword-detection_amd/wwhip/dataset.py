@@ -18,11 +18,15 @@ import json
 import os
 from typing import Any, Callable, Dict, List, Optional, Sequence
 
+import logging
+
 import numpy as np
 
 from .engine import Engine, frontend_params
 from .evaluate import frame_schedule, read_wav
 from .models import engine_for
+
+_LOG = logging.getLogger(__name__)
 
 
 def speech_bounds(samples: np.ndarray, frame_len: int, hop_len: int, sample_rate: int,
@@ -133,12 +137,16 @@ def write_h5(path: str, audio_clips: Sequence[dict]) -> None:
         import h5py  # type: ignore
     except ImportError:
         from . import h5min
+        # the built-in writer emits the same "earliest"-format structures h5py does; its output has only been read back
+        # by h5min itself in this image (tests/test_h5min.py cross-checks against h5py wherever h5py is installed)
+        _LOG.info("h5py is not installed: writing %s with the built-in HDF5 writer (wwhip.h5min)", path)
         h5min.write_datasets(path, {
             c["file_name"]: (np.asarray(c["features"], np.float32),
                              {"is_hotword": c["is_hotword"], "speaker": c["speaker"],
                               "speech_start_ts": c["speech_start_ts"], "speech_end_ts": c["speech_end_ts"]})
             for c in audio_clips})
         return
+    _LOG.info("writing %s with h5py", path)
     with h5py.File(path, "w") as h5f:  # pragma: no cover - h5py is not installed in this image
         for c in audio_clips:
             dset = h5f.create_dataset(c["file_name"], data=np.asarray(c["features"], np.float32))

@@ -7,9 +7,12 @@ The reference stores its pre-computed log-mel features as one HDF5 dataset per c
 default "earliest" format: superblock version 0, version-1 object headers, old-style groups
 (symbol-table B-tree + local heap), contiguous dataset storage, variable-length strings in a
 global heap.  This module implements that subset of the published HDF5 file format
-(https://docs.hdfgroup.org/hdf5/develop/_f_m_t3.html), plus chunked storage with the
-deflate / shuffle filters and compact link messages so that files produced with other common
-h5py options still load:
+(https://docs.hdfgroup.org/hdf5/develop/_f_m_t3.html) and nothing else: anything outside it - superblock
+version 2/3 and version-2 object headers (``libver='latest'``), link-message groups, chunked or filtered
+(deflate / shuffle) dataset storage, compound / array / bitfield / reference datatypes - raises
+``NotImplementedError`` naming the feature, so that a file written with other h5py options fails loudly
+instead of being half-read (install h5py for those: ``wwhip.evaluate.open_h5`` prefers it when present).
+Every line of the reader is exercised by tests/test_h5min.py on h5py-written files.
 
     with h5min.File(path) as f:                 # read-only
         for key in f.keys():
@@ -27,7 +30,6 @@ files and is checked by reading its output back.
 from __future__ import annotations
 
 import struct
-import zlib
 from typing import Any, Dict, Iterator, List, Optional, Tuple
 
 import numpy as np
@@ -78,36 +80,8 @@ def _parse_dtype(buf: bytes, off: int) -> Tuple[_DType, int]:
         return _DType(np.dtype(f"{order}f{size}"), size=size), 8 + 12
     if cls == 3:  # fixed-length string
         return _DType(np.dtype(f"S{size}"), size=size, strpad=b0 & 0x0F), 8
-    if cls == 4:  # bitfield
-        return _DType(np.dtype(f"<u{size}"), size=size), 8 + 4
-    if cls == 6:  # compound
-        n = b0 | (b1 << 8)
-        fields = []
-        q = p
-        for _ in range(n):
-            end = buf.index(b"\0", q)
-            name = buf[q:end].decode("utf-8")
-            q = q + _pad8(end - q + 1) if ver < 3 else end + 1
-            if ver == 1:
-                boff, = struct.unpack_from("<I", buf, q)
-                q += 4 + 1 + 3 + 4 + 4 + 16  # offset, dimensionality, reserved, perm, reserved, 4 dims
-            elif ver == 2:
-                boff, = struct.unpack_from("<I", buf, q)
-                q += 4
-            else:
-                nb = max(1, (size.bit_length() + 7) // 8)
-                boff = int.from_bytes(buf[q:q + nb], "little")
-                q += nb
-            sub, used = _parse_dtype(buf, q)
-            if sub.kind != "plain":
-                raise H5FormatError("compound members with variable-length parts are not supported")
-            q += used
-            fields.append((name, sub.np, boff))
-        dt = np.dtype({"names": [f[0] for f in fields], "formats": [f[1] for f in fields],
-                       "offsets": [f[2] for f in fields], "itemsize": size})
-        return _DType(dt, size=size), q - off
-    if cls == 7:  # reference
-        return _DType(np.dtype(f"<u{size}"), size=size), 8
+    if cls in (4, 6, 7):  # bitfield, compound, reference: the feature files and Keras checkpoints hold none
+        raise NotImplementedError(f"HDF5 datatype class {cls} ({ {4: 'bitfield', 6: 'compound', 7: 'reference'}[cls] })")
     if cls == 8:  # enumeration
         n = b0 | (b1 << 8)
         base, used = _parse_dtype(buf, p)
@@ -127,15 +101,8 @@ def _parse_dtype(buf: bytes, off: int) -> Tuple[_DType, int]:
         base, used = _parse_dtype(buf, p)
         kind = "vlen_str" if vtype == 1 else "vlen_seq"
         return _DType(np.dtype("V%d" % size), kind=kind, size=size, base=base), 8 + used
-    if cls == 10:  # array
-        if ver < 2:
-            raise H5FormatError("array datatype version 1 not supported")
-        rank = buf[p]
-        q = p + 1 + (3 if ver == 2 else 0)
-        dims = struct.unpack_from("<%dI" % rank, buf, q)
-        q += 4 * rank + (4 * rank if ver == 2 else 0)
-        base, used = _parse_dtype(buf, q)
-        return _DType(np.dtype((base.np, tuple(dims))), size=size), q + used - off
+    if cls == 10:
+        raise NotImplementedError("HDF5 array datatype")
     raise H5FormatError(f"unsupported datatype class {cls}")
 
 
@@ -143,10 +110,8 @@ def _parse_dataspace(buf: bytes, off: int) -> Tuple[Optional[Tuple[int, ...]], i
     ver, rank, flags = buf[off], buf[off + 1], buf[off + 2]
     if ver == 1:
         p = off + 8
-    elif ver == 2:
-        if buf[off + 3] == 2:  # null dataspace
-            return None, 4
-        p = off + 4
+    elif ver == 2:  # written with libver='latest'; h5py's default ('earliest') and this module's writer use version 1
+        raise NotImplementedError("HDF5 dataspace message version 2")
     else:
         raise H5FormatError(f"dataspace version {ver}")
     dims = struct.unpack_from("<%dQ" % rank, buf, p)
@@ -205,7 +170,8 @@ class Dataset(_Object):
         self._shape, _ = _parse_dataspace(ds.data, 0)
         self._dt, _ = _parse_dtype(dt.data, 0)
         self._layout = lay.data
-        self._filters = self._parse_filters()
+        if self._find(0x000B) is not None:
+            raise NotImplementedError(f"{name}: filtered (deflate / shuffle / fletcher32) dataset storage")
 
     @property
     def shape(self) -> Tuple[int, ...]:
@@ -222,47 +188,6 @@ class Dataset(_Object):
     def __len__(self) -> int:
         return self.shape[0]
 
-    def _parse_filters(self) -> List[Tuple[int, Tuple[int, ...]]]:
-        m = self._find(0x000B)
-        if m is None:
-            return []
-        b = m.data
-        ver, n = b[0], b[1]
-        p = 8 if ver == 1 else 2
-        out = []
-        for _ in range(n):
-            fid, = struct.unpack_from("<H", b, p)
-            if ver == 1 or fid >= 256:
-                nlen, flags, ncd = struct.unpack_from("<HHH", b, p + 2)
-                p += 8
-                p += _pad8(nlen) if ver == 1 else nlen
-            else:
-                flags, ncd = struct.unpack_from("<HH", b, p + 2)
-                p += 6
-            cd = struct.unpack_from("<%dI" % ncd, b, p)
-            p += 4 * ncd
-            if ver == 1 and ncd % 2:
-                p += 4
-            out.append((fid, cd))
-        return out
-
-    def _unfilter(self, raw: bytes, mask: int) -> bytes:
-        for i, (fid, cd) in reversed(list(enumerate(self._filters))):
-            if mask & (1 << i):
-                continue
-            if fid == 1:
-                raw = zlib.decompress(raw)
-            elif fid == 2:
-                es = cd[0] if cd else self._dt.size
-                a = np.frombuffer(raw, np.uint8)
-                n = len(a) // es
-                raw = a[: n * es].reshape(es, n).T.tobytes() + a[n * es:].tobytes()
-            elif fid == 3:  # fletcher32: checksum trails the data
-                raw = raw[:-4]
-            else:
-                raise H5FormatError(f"{self.name}: unsupported filter id {fid}")
-        return raw
-
     def _raw(self) -> bytes:
         f, b = self._f, self._layout
         shape = self.shape
@@ -272,51 +197,16 @@ class Dataset(_Object):
         if ver == 3:
             cls = b[1]
             if cls == 0:
-                size, = struct.unpack_from("<H", b, 2)
-                return b[4:4 + size]
+                raise NotImplementedError(f"{self.name}: compact dataset storage")
             if cls == 1:
                 addr, size = struct.unpack_from("<QQ", b, 2)
                 return b"\0" * nbytes if addr == UNDEF else f._buf[addr:addr + nbytes]
             if cls == 2:
-                ndim = b[2]
-                addr, = struct.unpack_from("<Q", b, 3)
-                cdims = struct.unpack_from("<%dI" % ndim, b, 11)
-                return self._read_chunks(addr, cdims[:-1], nbytes)
+                raise NotImplementedError(f"{self.name}: chunked dataset storage")
             raise H5FormatError(f"layout class {cls}")
-        if ver in (1, 2):
-            ndim, cls = b[1], b[2]
-            p = 8
-            addr = UNDEF
-            if cls != 0:
-                addr, = struct.unpack_from("<Q", b, p)
-                p += 8
-            dims = struct.unpack_from("<%dI" % ndim, b, p)
-            p += 4 * ndim
-            if cls == 0:
-                size, = struct.unpack_from("<I", b, p)
-                return b[p + 4:p + 4 + size]
-            if cls == 1:
-                return b"\0" * nbytes if addr == UNDEF else f._buf[addr:addr + nbytes]
-            return self._read_chunks(addr, dims[:-1], nbytes)
+        if ver in (1, 2):  # libhdf5 older than 1.6
+            raise NotImplementedError(f"{self.name}: data layout message version {ver}")
         raise H5FormatError(f"layout version {ver}")
-
-    def _read_chunks(self, btree: int, cdims: Tuple[int, ...], nbytes: int) -> bytes:
-        shape = self.shape
-        es = self._dt.size
-        out = np.zeros(shape, dtype=np.dtype("V%d" % es))
-        if btree == UNDEF:
-            return out.tobytes()
-        rank = len(shape)
-        for size, mask, offs, addr in self._f._iter_chunks(btree, rank):
-            raw = self._unfilter(self._f._buf[addr:addr + size], mask)
-            chunk = np.frombuffer(raw, dtype=out.dtype, count=int(np.prod(cdims))).reshape(cdims)
-            sl_out, sl_in = [], []
-            for d in range(rank):
-                n = min(cdims[d], shape[d] - offs[d])
-                sl_out.append(slice(offs[d], offs[d] + n))
-                sl_in.append(slice(0, n))
-            out[tuple(sl_out)] = chunk[tuple(sl_in)]
-        return out.tobytes()
 
     def __getitem__(self, key) -> Any:
         arr = self._f._decode(self._raw(), self._dt, self._shape)
@@ -342,18 +232,9 @@ class Group(_Object):
                 btree, heap = struct.unpack_from("<QQ", st.data, 0)
                 for name, addr in self._f._iter_symbols(btree, heap):
                     links[name] = addr
-            for m in self._msgs:  # compact new-style groups
-                if m.type == 0x0006:
-                    name, addr = self._f._parse_link(m.data)
-                    if addr is not None:
-                        links[name] = addr
-            if st is None and self._find(0x0002) is not None:
-                li = self._find(0x0002).data
-                flags = li[1]
-                p = 2 + (8 if flags & 1 else 0)
-                fheap, = struct.unpack_from("<Q", li, p)
-                if fheap != UNDEF:
-                    raise H5FormatError(f"{self.name}: dense (fractal-heap) group storage is not supported")
+            if st is None and (self._find(0x0002) is not None or any(m.type == 0x0006 for m in self._msgs)):
+                # link-info / link messages: groups written with libver='latest'
+                raise NotImplementedError(f"{self.name}: new-style HDF5 groups (link messages / fractal-heap storage)")
             self._links = links
         return self._links
 
@@ -416,10 +297,8 @@ class File(Group):
             self._base, = struct.unpack_from("<Q", b, p)
             root = p + 32  # root group symbol table entry
             _, addr, cache = struct.unpack_from("<QQI", b, root)
-        elif ver in (2, 3):
-            if b[base + 9] != 8 or b[base + 10] != 8:
-                raise H5FormatError("only 8-byte offsets and lengths are supported")
-            self._base, _, _, addr = struct.unpack_from("<QQQQ", b, base + 12)
+        elif ver in (2, 3):  # written with libver='latest' (v2 object headers, link messages): not what the reference writes
+            raise NotImplementedError(f"{path}: HDF5 superblock version {ver}")
         else:
             raise H5FormatError(f"superblock version {ver}")
         self._cache: Dict[int, _Object] = {}
@@ -446,34 +325,8 @@ class File(Group):
         b = self._buf
         addr += self._base if addr != UNDEF else 0
         msgs: List[_Message] = []
-        if b[addr:addr + 4] == b"OHDR":  # version 2
-            flags = b[addr + 5]
-            p = addr + 6
-            if flags & 0x20:
-                p += 16
-            if flags & 0x10:
-                p += 4
-            nb = 1 << (flags & 3)
-            size = int.from_bytes(b[p:p + nb], "little")
-            p += nb
-            blocks = [(p, size)]
-            track = bool(flags & 4)
-            while blocks:
-                q, sz = blocks.pop(0)
-                end = q + sz
-                while q + 4 <= end:
-                    mtype = b[q]
-                    msize, = struct.unpack_from("<H", b, q + 1)
-                    mflags = b[q + 3]
-                    q += 4 + (2 if track else 0)
-                    data = bytes(b[q:q + msize])
-                    q += msize
-                    if mtype == 0x10:
-                        coff, clen = struct.unpack_from("<QQ", data, 0)
-                        blocks.append((coff + self._base + 4, clen - 8))  # skip "OCHK", drop checksum
-                    elif mtype != 0:
-                        msgs.append(_Message(mtype, mflags, data))
-            return msgs
+        if b[addr:addr + 4] == b"OHDR":
+            raise NotImplementedError("HDF5 version-2 object headers")
         ver, _, nmsg, _, hsize = struct.unpack_from("<BBHII", b, addr)
         if ver != 1:
             raise H5FormatError(f"object header version {ver} at {addr}")
@@ -536,48 +389,6 @@ class File(Group):
                 children.append(struct.unpack_from("<Q", b, p)[0] + self._base)
                 p += 8
             stack.extend(reversed(children))
-
-    def _iter_chunks(self, btree: int, rank: int):
-        b = self._buf
-        stack = [btree + self._base]
-        while stack:
-            node = stack.pop()
-            if b[node:node + 4] != b"TREE":
-                raise H5FormatError("bad chunk B-tree signature")
-            ntype, level, used = struct.unpack_from("<BBH", b, node + 4)
-            if ntype != 1:
-                raise H5FormatError("expected a chunk B-tree node")
-            p = node + 24
-            ksz = 8 + 8 * (rank + 1)
-            for i in range(used):
-                size, mask = struct.unpack_from("<II", b, p)
-                offs = struct.unpack_from("<%dQ" % rank, b, p + 8)
-                child, = struct.unpack_from("<Q", b, p + ksz)
-                p += ksz + 8
-                if level == 0:
-                    yield size, mask, offs, child + self._base
-                else:
-                    stack.append(child + self._base)
-
-    def _parse_link(self, d: bytes) -> Tuple[str, Optional[int]]:
-        flags = d[1]
-        p = 2
-        ltype = 0
-        if flags & 8:
-            ltype = d[p]
-            p += 1
-        if flags & 4:
-            p += 8
-        if flags & 0x10:
-            p += 1
-        nb = 1 << (flags & 3)
-        nlen = int.from_bytes(d[p:p + nb], "little")
-        p += nb
-        name = d[p:p + nlen].decode("utf-8")
-        p += nlen
-        if ltype != 0:
-            return name, None  # soft / external links are not followed
-        return name, struct.unpack_from("<Q", d, p)[0]
 
     # -- values --------------------------------------------------------------------------------
     def _global_heap(self, addr: int) -> Dict[int, bytes]:
