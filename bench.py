@@ -104,14 +104,10 @@ def kernel_work(eng, n_clips):
         M = c.out_t * c.out_f
         K = c.conv_w.shape[1] * c.conv_w.shape[2]
         H = c.units
-        conv = (n_clips * (eng.window * 40 * 4 + M * 32 * 4), n_clips * 2.0 * M * K * 32)
-        proj = (n_clips * c.out_t * (M // c.out_t * 32 + 6 * H) * 4 + 6 * H * c.out_f * 32 * 4,
-                n_clips * 2.0 * c.out_t * (c.out_f * 32) * 6 * H)
-        out["conv5x20_kernel"] = ("mfma",) + conv
-        out["gemm_nt_kernel<gru1>"] = ("mfma",) + proj
-        # fused conv + projection: mel window in, gx1 out, feat never leaves the CU
-        out["convproj_kernel"] = ("mfma", n_clips * (eng.window * 40 * 4 + c.out_t * 6 * H * 4) + 6 * H * c.out_f * 32 * 4,
-                                  conv[1] + proj[1])
+        # the whole model in one kernel: mel window in, posterior out; the 622 KB of weights are read once per XCD
+        flops = 2.0 * (M * K * 32 + c.out_t * (c.out_f * 32) * 6 * H + c.out_t * 2 * H * 6 * H + 2 * c.out_t * 2 * 3 * H * H
+                       + 64 * 64 + 64 * c.n_out)
+        out["crnn_fused_kernel"] = ("mfma", n_clips * (eng.window * 40 * 4 + c.n_out * 4) + 8 * 622724, n_clips * flops)
     else:
         w = eng.bundle.wavenet
         macs = w.n_frames * (w.n_mel * w.channels) + sum(
@@ -370,7 +366,7 @@ def main():
                     help="independent contexts (HIP streams) the steps are dealt to round-robin; batches are "
                          "independent, so consecutive steps may overlap on the GPU")
     ap.add_argument("--fast-frontend", action="store_true", help="fp32 FFT instead of the reference's fp64")
-    ap.add_argument("--precision", choices=["auto", "fp32", "bf16x3", "bf16x6"], default="auto",
+    ap.add_argument("--precision", choices=["auto", "fp32", "bf16x3"], default="auto",
                     help="model contractions: fp32 MFMA, or (Wavenet only) three bf16 MFMAs on split operands with "
                          "fp32 accumulate; auto = fp32 for CRNN (BASELINE cfg 2), bf16x3 for Wavenet (cfg 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -454,7 +450,7 @@ def main():
         return res
 
     precision = args.precision if args.precision != "auto" else ("fp32" if args.model == "crnn" else "bf16x3")
-    if args.model == "crnn" and precision != "bf16x6":
+    if args.model == "crnn":
         precision = "fp32"
     head = run_model(args.model, precision, True)
     eng = head["engs"][0]

@@ -114,14 +114,9 @@ int ww_model_get_info(const ww_model *model, ww_model_info *out);
  *                       bits per operand - posteriors within 4e-6 of fp32 (tolerance 1e-4).  Plain
  *                       single-pass bf16 misses the tolerance (6e-4 .. 1e-3) and is not offered.
  *                       CRNN models accept the call and keep fp32.
- *   WW_PRECISION_BF16X6 CRNN's layer-1 input projection (the K = 640 GEMM) with operands split three ways
- *                       (24 mantissa bits) and six bf16 MFMA products per product, fp32 accumulate: results at
- *                       the rounding level of the fp32 kernel (measured in tests/test_gpu_parity.py), but no longer
- *                       IEEE fp32 multiply-add - opt-in and experimental: correct, but not faster than the fp32 kernel
- *                       yet (LDS-bound).  Wavenet models accept the call and keep fp32. */
+ * (Value 2 was round 1's experimental BF16X6 projection mode; it was not faster than fp32 and is retired: WW_EINVAL.) */
 #define WW_PRECISION_FP32 0
 #define WW_PRECISION_BF16X3 1
-#define WW_PRECISION_BF16X6 2
 int ww_model_set_precision(ww_model *model, int precision);
 
 /* ---- front end: PCM -> log-mel ---------------------------------------------------------

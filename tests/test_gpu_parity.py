@@ -176,27 +176,21 @@ def test_wavenet_split_bf16_mode(assets, oracles, golden, name):
         e.close()
 
 
-@pytest.mark.parametrize("name", ["CRNN", "CRNN_softmax"])
-def test_crnn_bf16x6_projection_mode(assets, oracles, name):
-    """ww_model_set_precision(BF16X6): the K = 640 projection GEMM as six bf16 MFMA products on three-way split
-    operands - posteriors must stay at the rounding level of the fp32 kernel."""
-    from wwhip.engine import Engine
-    e = Engine(os.path.join(assets, name), precision="bf16x6")
-    try:
-        rng = np.random.default_rng(71)
-        wins = rng.uniform(0, 6.5, (300, e.window, 40)).astype(np.float32)
-        wins[3] = 0
-        wins[4, 100:] = 0
-        got, enc = e.forward(wins, want_enc=True)
-        want, want_enc = oracles[name].forward(wins, want_enc=True)
-        assert np.abs(got - want).max() < 2e-6
-        assert np.abs(enc.reshape(want_enc.shape) - want_enc).max() < 2e-5
-        e.set_precision("fp32")
-        ref = e.forward(wins)
+def test_retired_precision_mode_is_refused(engines):
+    """Round 1's experimental bf16x6 projection mode (WW_PRECISION value 2) is gone: asking for it is an error, and
+    bf16x3 on a CRNN is accepted and leaves the fp32 arithmetic in place (include/wwhip.h)."""
+    import ctypes as C
+    from wwhip import _lib
+    e = engines["CRNN"]
+    assert _lib.load().ww_model_set_precision(e.handle, 2) == _lib.WW_EINVAL
+    with pytest.raises(ValueError):
         e.set_precision("bf16x6")
-        assert np.abs(e.forward(wins) - ref).max() < 2e-6
-    finally:
-        e.close()
+    rng = np.random.default_rng(71)
+    wins = rng.uniform(0, 6.5, (9, e.window, 40)).astype(np.float32)
+    ref = e.forward(wins)
+    e.set_precision("bf16x3")
+    np.testing.assert_array_equal(e.forward(wins), ref)
+    e.set_precision("fp32")
 
 
 def test_forward_rejects_bad_shape(engines):

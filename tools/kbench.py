@@ -12,7 +12,7 @@ model = sys.argv[1] if len(sys.argv) > 1 else "crnn"
 clips = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 fast = "fast" in sys.argv[4:]
-precision = "bf16x3" if "bf16x3" in sys.argv[4:] else ("bf16x6" if "bf16x6" in sys.argv[4:] else "fp32")
+precision = "bf16x3" if "bf16x3" in sys.argv[4:] else "fp32"
 ctx = _lib.Context(0)
 eng = Engine(os.path.join(ROOT, "wakeword-detection_amd/assets/tf_lite_models", "CRNN" if model == "crnn" else "Wavenet"), ctx=ctx, precision=precision)
 rng = np.random.default_rng(0)

@@ -10,7 +10,7 @@ import bench
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 pcm = bench.synth_pcm(np.random.default_rng(5), 256)
 d = torch.from_numpy(pcm).cuda()
-for name, prec in (("CRNN", "fp32"), ("CRNN", "bf16x6"), ("Wavenet", "fp32"), ("Wavenet", "bf16x3")):
+for name, prec in (("CRNN", "fp32"), ("Wavenet", "fp32"), ("Wavenet", "bf16x3")):
     eng = Engine(os.path.join(ROOT, "wakeword-detection_amd/assets/tf_lite_models", name), precision=prec)
     out = torch.zeros((256, eng.n_out), device="cuda")
     fp = frontend_params()

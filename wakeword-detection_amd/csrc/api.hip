@@ -441,30 +441,6 @@ static int load_crnn(ww_ctx *ctx, ww_model *m, const blob_view &bv) {
     c.wx1p = upload(m, wp);
     if (!c.wx1p) return ww_fail(ctx, WW_ENOMEM, "CRNN upload failed");
   }
-  {  // three-way bf16 split of the same matrix for the bf16x6 GEMM (crnn.hip)
-    auto rne = [](float f) -> uint16_t {
-      uint32_t u;
-      memcpy(&u, &f, 4);
-      u += 0x7FFFu + ((u >> 16) & 1u);
-      return (uint16_t)(u >> 16);
-    };
-    auto tof = [](uint16_t h) -> float {
-      uint32_t u = (uint32_t)h << 16;
-      float f;
-      memcpy(&f, &u, 4);
-      return f;
-    };
-    std::vector<unsigned short> w3(3 * v.size());
-    for (size_t i = 0; i < v.size(); ++i) {
-      const uint16_t h = rne(v[i]);
-      const float r1 = v[i] - tof(h);
-      const uint16_t mm = rne(r1);
-      const uint16_t l = rne(r1 - tof(mm));
-      w3[i] = h; w3[v.size() + i] = mm; w3[2 * v.size() + i] = l;
-    }
-    c.wx1_3 = upload(m, w3);
-    if (!c.wx1_3) return ww_fail(ctx, WW_ENOMEM, "CRNN upload failed");
-  }
   if ((rc = cat2("crnn.g1f.bx", "crnn.g1b.bx", G, v))) return rc; c.bx1 = upload(m, v);
   if ((rc = cat2("crnn.g1f.wh", "crnn.g1b.wh", (size_t)G * c.H, v))) return rc; c.wh1 = upload(m, v);
   if ((rc = cat2("crnn.g1f.bh", "crnn.g1b.bh", G, v))) return rc; c.bh1 = upload(m, v);
@@ -671,7 +647,7 @@ int ww_model_get_info(const ww_model *m, ww_model_info *out) {
 
 int ww_model_set_precision(ww_model *m, int precision) {
   if (!m) return WW_EINVAL;
-  if (precision != WW_PRECISION_FP32 && precision != WW_PRECISION_BF16X3 && precision != WW_PRECISION_BF16X6)
+  if (precision != WW_PRECISION_FP32 && precision != WW_PRECISION_BF16X3)
     return ww_fail(m->ctx, WW_EINVAL, "unknown precision %d", precision);
   m->precision = precision;
   return WW_OK;

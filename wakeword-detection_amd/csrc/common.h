@@ -95,7 +95,6 @@ struct ww_crnn_dev {
   float *conv_b = nullptr;   // [C]
   float *wx1 = nullptr;      // [2*3H][OF*C]  rows: fwd z,r,h then bwd z,r,h
   float *wx1s = nullptr;     // the same matrix in MFMA B-operand order [OF*C/4][2*3H][4] (crnn_fused_kernel)
-  unsigned short *wx1_3 = nullptr;  // the same matrix as three bf16 planes [3][2*3H][OF*C] (bf16x6 mode)
   float *bx1 = nullptr;      // [2*3H]
   float *wh1 = nullptr;      // [2][3H][H]
   float *bh1 = nullptr;      // [2][3H]

@@ -4,22 +4,15 @@
 // (tf_lite_models/CRNN; architecture wwdetect/CRNN/model.py:21-56; call sites
 // spokestack/wakeword/tflite.py:193-231, utils/evaluate_models.py:76-80).
 //
-//   conv5x20_kernel   Conv2D(1->32, 5x20, stride 2x8, SAME, ReLU) as an implicit GEMM on
-//                     v_mfma_f32_16x16x4_f32: one workgroup per window, the 151x40 window is
-//                     staged once (transposed, zero-bordered) in LDS, conv weights live in
-//                     registers, output is written in the [t][f*32+c] order of the
-//                     Permute+Reshape (model.py:37-39).
-//   gemm_nt_kernel    C[M][N] = A[M][K] * W[N][K]^T + b, 64x64x64 tiles, fp32 MFMA, register
-//                     prefetch + double-buffered LDS, XCD-aware tile order.  Used for the GRU input
-//                     projections of both directions at once (N = 2*3H = 192).  At M = 4864 it is bound by
-//                     moving operands (L2 -> LDS -> registers), not by the matrix pipe: see
-//                     gemm_nt_bf16x6_kernel, whose 3.5x shorter matrix time changes the total by 5 %.
-//   gru_head_kernel   one workgroup per window runs everything behind the layer-1 projections:
-//                     layer-1 recurrence (wave 0 forward, wave 1 backward; W_h in registers, K
-//                     split over adjacent lane pairs, partial dots joined by one DPP swap, h
-//                     exchanged through LDS), the layer-2 input projection for both directions
-//                     as an MFMA GEMM out of LDS (all 4 waves), the layer-2 recurrence and the
-//                     detect head.  Waves 2/3 stage the head weights into LDS meanwhile.
+//   crnn_fused_kernel  the whole model for one window in one 4-wave workgroup: Conv2D(1->32, 5x20, stride 2x8, SAME,
+//                      ReLU) as an implicit GEMM, the layer-1 input projections of both GRU directions (K = 640,
+//                      N = 192), both bidirectional GRU layers and the detect head - nothing between the mel window
+//                      and the posterior leaves the CU (header of the kernel below).
+//   generic path       any other conv geometry (utils/CRNN_files/*_old.tflite): conv_generic_kernel, gemm_nt_kernel
+//                      (C = A W^T + b, 64x64x64 tiles, fp32 MFMA, XCD-aware tile order), gru_generic_kernel,
+//                      crnn_detect_kernel.
+// Round 1's three-kernel chain (conv5x20_kernel -> gemm_nt_kernel -> gru_head_kernel, 52 us per 256 windows against
+// 34 us fused) and its bf16x6 projection GEMM are gone; their measurements are in DESIGN.md 7.1.
 #include "common.h"
 
 #include <cstdlib>
@@ -63,104 +56,6 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf
 #define CV_PT 6
 #define CV_OF 20
 #define CV_OT 19
-
-struct conv_args {
-  const float *mel;
-  win_addr wa;
-  const float *w4;    // [K/4][32][4]  (k-quad major), K padded to 112 with zeros
-  const float *bias;  // [32]
-  float *feat;        // [Nw][OT][OF*32]
-  int n_mel, T, KF, KT, SF, ST, PF, PT, OF, OT;
-};
-
-__global__ __launch_bounds__(CV_THREADS) void conv5x20_kernel(conv_args a) {
-  __shared__ __align__(16) float img[CV_ROWS * CV_LDT];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int w = blockIdx.x;
-  int64_t row;
-  int valid;
-  window_span(a.wa, w, a.T, row, valid);
-
-  // conv weights for this lane (B operand of mfma 16x16x4: lane (j = lane&15, kk = lane>>4)); issued
-  // first so that their latency hides behind the window staging
-  const int j = lane & 15, kk = lane >> 4;
-  float4 wreg[CV_KB][2];
-#pragma unroll
-  for (int kb = 0; kb < CV_KB; ++kb)
-#pragma unroll
-    for (int n = 0; n < 2; ++n) wreg[kb][n] = *(const float4 *)(a.w4 + ((size_t)(kb * 4 + kk) * 32 + n * 16 + j) * 4);
-  const float b0 = a.bias[j], b1 = a.bias[16 + j];
-
-  // the window is one contiguous [valid][n_mel] block: issue all 16-byte loads first, then
-  // zero the image, then scatter the registers into the transposed (mel-major) image
-  constexpr int CV_MAXV = 3;  // 3 * 512 float4 >= 151 * 40 / 4
-  const float *src = a.mel + row * CV_NMEL;
-  const int n = valid * CV_NMEL;
-  const bool al16 = ((((uintptr_t)src) & 15) == 0);
-  float4 stage[CV_MAXV];
-#pragma unroll
-  for (int q = 0; q < CV_MAXV; ++q) {
-    const int i = (q * CV_THREADS + tid) * 4;
-    if (al16 && i + 3 < n) {
-      stage[q] = *(const float4 *)(src + i);
-    } else {
-      stage[q].x = i < n ? src[i] : 0.f;
-      stage[q].y = i + 1 < n ? src[i + 1] : 0.f;
-      stage[q].z = i + 2 < n ? src[i + 2] : 0.f;
-      stage[q].w = i + 3 < n ? src[i + 3] : 0.f;
-    }
-  }
-  for (int i = tid; i < CV_ROWS * CV_LDT / 4; i += CV_THREADS) ((float4 *)img)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < CV_MAXV; ++q) {
-    const int i = (q * CV_THREADS + tid) * 4;
-    const float e[4] = {stage[q].x, stage[q].y, stage[q].z, stage[q].w};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int ii = i + c;
-      if (ii < n) {
-        const int it = ii / CV_NMEL, im = ii - it * CV_NMEL;
-        img[(im + CV_PF) * CV_LDT + it + CV_PT] = e[c];
-      }
-    }
-  }
-  __syncthreads();
-
-  constexpr int M = CV_OT * CV_OF;
-  constexpr int n_mt = (M + 15) / 16;
-  float *dst = a.feat + (size_t)w * M * 32;
-  for (int mt = wave; mt < n_mt; mt += CV_THREADS / 64) {
-    int m = mt * 16 + j;  // A operand row for this lane (i = lane & 15)
-    if (m >= M) m = M - 1;
-    const int t = m / CV_OF, f = m - t * CV_OF;
-    const float *abase = img + (f * CV_SF) * CV_LDT + t * CV_ST;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kb = 0; kb < CV_KB; ++kb) {
-      const int k4 = kb * 16 + kk * 4;
-      const int kf = k4 / CV_KT, kt = k4 - kf * CV_KT;
-      const float4 av = *(const float4 *)(abase + kf * CV_LDT + kt);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wreg[kb][0].x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wreg[kb][1].x, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wreg[kb][0].y, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wreg[kb][1].y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wreg[kb][0].z, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wreg[kb][1].z, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wreg[kb][0].w, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wreg[kb][1].w, acc1, 0, 0, 0);
-    }
-    // D layout: col = lane & 15, row = (lane >> 4) * 4 + r
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int mo = mt * 16 + kk * 4 + r;
-      if (mo < M) {
-        dst[(size_t)mo * 32 + j] = fmaxf(acc0[r] + b0, 0.f);
-        dst[(size_t)mo * 32 + 16 + j] = fmaxf(acc1[r] + b1, 0.f);
-      }
-    }
-  }
-}
 
 // ------------------------------------------------------------------------------------------
 // GEMM  C[M][N] = A[M][K] * W[N][K]^T + bias[N]
@@ -257,159 +152,8 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(gemm_args g) {
 }
 
 // ------------------------------------------------------------------------------------------
-// gemm_nt_bf16x6_kernel (WW_PRECISION_BF16X6): the same C = A W^T + b on the bf16 matrix pipe.
-// Every operand is split three ways, x = h + m + l with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)
-// (24 mantissa bits), and a*b is taken as ah*bh + ah*bm + am*bh + am*bm + ah*bl + al*bh - six
-// v_mfma_f32_16x16x32_bf16 with fp32 accumulate, 96 matrix cycles per K = 32 against 256 for eight
-// v_mfma_f32_16x16x4_f32, and on the pipe that runs beside the vector ALU.  The dropped terms are below
-// 2^-32 of the product: the result differs from the fp32 kernel's at the rounding level (tools/bf16x3_error.py
-// has the error model; tests/test_gpu_parity.py the measurement).
-// 64x64 tile, 4 waves (one per SIMD), each a 32x32 sub-tile = 2x2 MFMA tiles: with three planes per operand the
-// LDS operand traffic per MFMA is what bounds the wave-tile size from below.  A is split while it is staged
-// (VALU work that overlaps the MFMAs), W arrives pre-split from the host.
+// GRU building blocks (one lane pair per unit: K split over adjacent lanes, joined by one DPP swap)
 // ------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-#define G6_LD 80  // bf16 per LDS row: 64 k-values + 16 pad = 160 B; row strides of 32 (mod 64) bytes give every lane group of a
-                  // ds_read_b128 sixteen distinct 16-byte slots (144 B would be 2-way conflicted)
-
-struct gemm6_args {
-  const float *A;
-  const unsigned short *W3;  // [3 planes][N][K] bf16 (h, m, l)
-  const float *bias;
-  float *C;
-  int M, N, K;
-};
-
-// two fp32 values -> the three packed bf16 pairs (h, m, l)
-__device__ __forceinline__ void split3_pair(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
-  const bf16x2_t hh = __builtin_convertvector((f32x2_t){a, b}, bf16x2_t);
-  h = __builtin_bit_cast(unsigned, hh);
-  const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
-  const bf16x2_t mm = __builtin_convertvector((f32x2_t){ra, rb}, bf16x2_t);
-  m = __builtin_bit_cast(unsigned, mm);
-  const bf16x2_t ll = __builtin_convertvector((f32x2_t){ra - __uint_as_float(m << 16), rb - __uint_as_float(m & 0xffff0000u)}, bf16x2_t);
-  l = __builtin_bit_cast(unsigned, ll);
-}
-
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_nt_bf16x6_kernel(gemm6_args g) {
-  extern __shared__ __align__(16) unsigned short g6_smem[];
-  // [buf 2][operand A|W][plane 3][64 rows][G6_LD]
-  auto plane = [&](int buf, int opnd, int p) { return g6_smem + (((size_t)buf * 2 + opnd) * 3 + p) * 64 * G6_LD; };
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
-  const int lrow = tid >> 2, lk = (tid & 3) * 16;  // loader: one row, 16 consecutive k
-  const int i16 = lane & 15, kg = lane >> 4;
-
-  float4 pa[4];
-  uint4 pw00, pw01, pw10, pw11, pw20, pw21;  // named scalars: as an array this prefetch set was kept in scratch
-  // rows past M / N are clamped, not masked: their products land in accumulator rows / columns that are never stored
-  const float *arow = g.A + (size_t)(m0 + lrow < g.M ? m0 + lrow : g.M - 1) * g.K + lk;
-  const unsigned short *wrow = g.W3 + (size_t)(n0 + lrow < g.N ? n0 + lrow : g.N - 1) * g.K + lk;
-  const size_t wplane = (size_t)g.N * g.K;
-  auto gload = [&](int k0) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) pa[q] = *(const float4 *)(arow + k0 + 4 * q);
-    pw00 = *(const uint4 *)(wrow + k0);
-    pw01 = *(const uint4 *)(wrow + k0 + 8);
-    pw10 = *(const uint4 *)(wrow + wplane + k0);
-    pw11 = *(const uint4 *)(wrow + wplane + k0 + 8);
-    pw20 = *(const uint4 *)(wrow + 2 * wplane + k0);
-    pw21 = *(const uint4 *)(wrow + 2 * wplane + k0 + 8);
-  };
-  auto sstore = [&](int buf) {
-    unsigned h[8], m[8], l[8];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      split3_pair(pa[q].x, pa[q].y, h[2 * q], m[2 * q], l[2 * q]);
-      split3_pair(pa[q].z, pa[q].w, h[2 * q + 1], m[2 * q + 1], l[2 * q + 1]);
-    }
-    const int o = lrow * G6_LD + lk;
-    *(uint4 *)(plane(buf, 0, 0) + o) = make_uint4(h[0], h[1], h[2], h[3]);
-    *(uint4 *)(plane(buf, 0, 0) + o + 8) = make_uint4(h[4], h[5], h[6], h[7]);
-    *(uint4 *)(plane(buf, 0, 1) + o) = make_uint4(m[0], m[1], m[2], m[3]);
-    *(uint4 *)(plane(buf, 0, 1) + o + 8) = make_uint4(m[4], m[5], m[6], m[7]);
-    *(uint4 *)(plane(buf, 0, 2) + o) = make_uint4(l[0], l[1], l[2], l[3]);
-    *(uint4 *)(plane(buf, 0, 2) + o + 8) = make_uint4(l[4], l[5], l[6], l[7]);
-    *(uint4 *)(plane(buf, 1, 0) + o) = pw00;
-    *(uint4 *)(plane(buf, 1, 0) + o + 8) = pw01;
-    *(uint4 *)(plane(buf, 1, 1) + o) = pw10;
-    *(uint4 *)(plane(buf, 1, 1) + o + 8) = pw11;
-    *(uint4 *)(plane(buf, 1, 2) + o) = pw20;
-    *(uint4 *)(plane(buf, 1, 2) + o + 8) = pw21;
-  };
-
-  f32x4 acc[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
-  const int nk = g.K / 64;
-  gload(0);
-  sstore(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    gload((kt + 1 < nk ? kt + 1 : kt) * 64);  // unconditional (clamped): no branch, no drain at a join
-    __builtin_amdgcn_sched_barrier(0);        // issued HERE, a whole MFMA section ahead of their use
-    // both k32-steps' operands are read up front (second set while the first set's MFMAs run): with three planes
-    // per operand the reads are as long as the MFMAs, so they must not sit between them
-    bf16x8_t a[2][2][3], w[2][2][3];
-    auto rd = [&](int s32) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          a[s32][t][p] = *(const bf16x8_t *)(plane(cur, 0, p) + (wr * 32 + t * 16 + i16) * G6_LD + s32 * 32 + kg * 8);
-          w[s32][t][p] = *(const bf16x8_t *)(plane(cur, 1, p) + (wc * 32 + t * 16 + i16) * G6_LD + s32 * 32 + kg * 8);
-        }
-    };
-    // small terms first; the four accumulators take turns so that no MFMA waits on its predecessor
-#define G6_TERM(s_, pa_, pw_)                                                                                    \
-  acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s_][0][pa_], w[s_][0][pw_], acc[0][0], 0, 0, 0);          \
-  acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s_][0][pa_], w[s_][1][pw_], acc[0][1], 0, 0, 0);          \
-  acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s_][1][pa_], w[s_][0][pw_], acc[1][0], 0, 0, 0);          \
-  acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s_][1][pa_], w[s_][1][pw_], acc[1][1], 0, 0, 0);
-#define G6_STEP(s_) G6_TERM(s_, 0, 2) G6_TERM(s_, 2, 0) G6_TERM(s_, 1, 1) G6_TERM(s_, 0, 1) G6_TERM(s_, 1, 0) G6_TERM(s_, 0, 0)
-    rd(0);
-    __builtin_amdgcn_sched_barrier(0);
-    rd(1);
-    G6_STEP(0)
-    __builtin_amdgcn_sched_barrier(0);
-    G6_STEP(1)
-#undef G6_STEP
-#undef G6_TERM
-    // (the split of the NEXT tile is free to mingle with the second step's MFMAs, but not to move in front of
-    // the first step's: there it would wait for the global loads it is meant to hide)
-    if (kt + 1 < nk) sstore(cur ^ 1);
-    __syncthreads();
-  }
-#pragma unroll
-  for (int tn = 0; tn < 2; ++tn) {
-    const int gn = n0 + wc * 32 + tn * 16 + i16;
-    const float bv = (gn < g.N) ? g.bias[gn] : 0.f;
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int gm = m0 + wr * 32 + tm * 16 + kg * 4 + r;
-        if (gm < g.M && gn < g.N) g.C[(size_t)gm * g.N + gn] = acc[tm][tn][r] + bv;
-      }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// GRU layer 1 -> layer-2 projection -> GRU layer 2 -> detect head, one workgroup per window
-// ------------------------------------------------------------------------------------------
-struct gru_head_args {
-  const float *gx1;  // [Nw][OT][2*3H]  layer-1 input projections incl. b_x, cols [dir][gate z,r,h][unit]
-  const float *wh1, *bh1;  // [2][3H][H], [2][3H]
-  const float *wx2, *bx2;  // [2*3H][2H], [2*3H]
-  const float *wh2, *bh2;
-  const float *w1, *b1, *w2, *b2;  // detect head
-  float *enc;        // optional [Nw][2H] encoder output (fwd_last | bwd_last)
-  float *out;        // [Nw][NOUT]
-  int OT, NOUT, HEAD;
-};
-
 #define GR_H 32
 #define GR_SEQ_LD 68   // seq1 row: 64 values + 4 pad
 #define GR_GX_LD 196   // gx2 row: 192 values + 4 pad
@@ -493,145 +237,6 @@ __device__ __forceinline__ void wsync_g() {
   __builtin_amdgcn_wave_barrier();
 }
 
-__global__ __launch_bounds__(256) void gru_head_kernel(gru_head_args a) {
-  constexpr int H = GR_H;
-  __shared__ __align__(16) float hbuf[2][2][H];          // [dir][ping-pong][unit]
-  __shared__ __align__(16) float seq1[32 * GR_SEQ_LD];   // layer-1 outputs [t][fwd | bwd], rows >= OT zero
-  __shared__ __align__(16) float gx2[20 * GR_GX_LD];     // layer-2 input projections [t][dir][gate][unit]
-  __shared__ float w1s[64 * GR_W1_LD];
-  __shared__ float w2s[8 * 64];
-  __shared__ float encs[2 * H];
-  __shared__ float hid[2 * H];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int w = blockIdx.x;
-  const int OT = a.OT;
-  const int unit = lane >> 1, half = lane & 1;
-  const int j = lane & 15, kk = lane >> 4;
-
-  // ---- prefetch: recurrent weights (waves 0,1), this wave's slice of W_x2 as MFMA B operands
-  gru_w g1, g2;
-  const int dir = wave & 1;
-  if (wave < 2) {
-    gru_load_w(g1, a.wh1, a.bh1, dir, unit, half);
-    gru_load_w(g2, a.wh2, a.bh2, dir, unit, half);
-  }
-  float4 bw[3][4];  // n-tiles wave*3 .. wave*3+2, k-blocks 0..3
-  float bb[3];
-#pragma unroll
-  for (int n = 0; n < 3; ++n) {
-    const int col = (wave * 3 + n) * 16 + j;
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) bw[n][kb] = *(const float4 *)(a.wx2 + (size_t)col * 2 * H + kb * 16 + kk * 4);
-    bb[n] = a.bx2[col];
-  }
-  // layer-1 input projections of this window -> LDS (the gx2 buffer is free until layer 1 is done):
-  // one coalesced 16-byte pass instead of three dependent global loads on every serial step
-  {
-    const float4 *src = (const float4 *)(a.gx1 + (size_t)w * OT * 6 * H);
-    for (int q = tid; q < OT * 6 * H / 4; q += 256) {
-      const int e = q * 4, t = e / (6 * H), c = e - t * 6 * H;
-      *(float4 *)(&gx2[t * GR_GX_LD + c]) = src[q];
-    }
-  }
-  for (int i = tid; i < 32 * GR_SEQ_LD; i += 256) seq1[i] = 0.f;
-  if (tid < 2 * H) hbuf[tid >> 5][0][tid & 31] = 0.f;
-  __syncthreads();
-
-  // ---- layer 1 recurrence (waves 0,1); waves 2,3 stage the detect head weights meanwhile
-  if (wave < 2) {
-    const float *gxl = gx2 + dir * 3 * H + unit;
-    float h_own = 0.f;
-    int t = dir ? OT - 1 : 0;
-    for (int s = 0; s < OT; ++s) {
-      const int cur = s & 1;
-      const float gz = gxl[t * GR_GX_LD], gr = gxl[t * GR_GX_LD + H], gc = gxl[t * GR_GX_LD + 2 * H];
-      h_own = gru_step(g1, &hbuf[dir][cur][0], half, gz, gr, gc, h_own);
-      if (half == 0) {
-        hbuf[dir][cur ^ 1][unit] = h_own;
-        seq1[t * GR_SEQ_LD + dir * H + unit] = h_own;
-      }
-      wsync_h();
-      t = dir ? t - 1 : t + 1;
-    }
-  } else {
-    const int t2 = tid - 128;
-    for (int i = t2; i < 64 * 64; i += 128) w1s[(i >> 6) * GR_W1_LD + (i & 63)] = a.w1[i];
-    for (int i = t2; i < a.NOUT * 64; i += 128) w2s[i] = a.w2[i];
-  }
-  __syncthreads();
-
-  // ---- layer-2 input projection, both directions: gx2[t][n] = seq1[t][:] . Wx2[n][:] + bx2[n]
-  //      M = 32 (19 valid rows), K = 64, N = 192: wave owns 3 n-tiles, 2 m-tiles each
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      const float4 av = *(const float4 *)(&seq1[(mt * 16 + j) * GR_SEQ_LD + kb * 16 + kk * 4]);
-#pragma unroll
-      for (int n = 0; n < 3; ++n) {
-        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bw[n][kb].x, acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bw[n][kb].y, acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bw[n][kb].z, acc[n], 0, 0, 0);
-        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bw[n][kb].w, acc[n], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int n = 0; n < 3; ++n)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int t = mt * 16 + kk * 4 + r;
-        if (t < OT) gx2[t * GR_GX_LD + (wave * 3 + n) * 16 + j] = acc[n][r] + bb[n];
-      }
-  }
-  if (tid < 2 * H) hbuf[tid >> 5][0][tid & 31] = 0.f;
-  __syncthreads();
-
-  // ---- layer 2 recurrence: only the last state of each direction is kept
-  if (wave < 2) {
-    const float *gxl = gx2 + dir * 3 * H + unit;
-    float h_own = 0.f;
-    int t = dir ? OT - 1 : 0;
-    for (int s = 0; s < OT; ++s) {
-      const int cur = s & 1;
-      const float gz = gxl[t * GR_GX_LD], gr = gxl[t * GR_GX_LD + H], gc = gxl[t * GR_GX_LD + 2 * H];
-      h_own = gru_step(g2, &hbuf[dir][cur][0], half, gz, gr, gc, h_own);
-      if (half == 0) hbuf[dir][cur ^ 1][unit] = h_own;
-      wsync_h();
-      t = dir ? t - 1 : t + 1;
-    }
-    if (half == 0) {
-      encs[dir * H + unit] = h_own;
-      if (a.enc) a.enc[(size_t)w * 2 * H + dir * H + unit] = h_own;
-    }
-  }
-  __syncthreads();
-
-  // ---- detect head: Dense(64, relu) -> Dense(NOUT) -> sigmoid | softmax   (wave 0)
-  if (wave == 0) {
-    float acc = 0.f;
-#pragma unroll 16
-    for (int k = 0; k < 2 * H; ++k) acc = fmaf(w1s[lane * GR_W1_LD + k], encs[k], acc);
-    hid[lane] = fmaxf(acc + a.b1[lane], 0.f);
-    wsync_g();
-    float y = 0.f;
-    if (lane < a.NOUT) {
-      for (int k = 0; k < 2 * H; ++k) y = fmaf(w2s[lane * 64 + k], hid[k], y);
-      y += a.b2[lane];
-    }
-    if (a.HEAD == 0) {
-      if (lane < a.NOUT) a.out[(size_t)w * a.NOUT + lane] = sigmoid_f(y);
-    } else {
-      float mx = (lane < a.NOUT) ? y : -INFINITY;
-      for (int o = 1; o < 8; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-      float e = (lane < a.NOUT) ? expf(y - mx) : 0.f;
-      float sum = e;
-      for (int o = 1; o < 8; o <<= 1) sum += __shfl_xor(sum, o);
-      if (lane < a.NOUT) a.out[(size_t)w * a.NOUT + lane] = e / sum;
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------
 // crnn_fused_kernel: the whole CRNN for one window in one 4-wave workgroup - the conv output (feat, 48.6 KB per
 // window) and the layer-1 input projections (gx1, 14.6 KB) never leave the CU.
@@ -686,9 +291,7 @@ struct fused_args {
   float *enc;         // optional [Nw][64]
   float *out;         // [Nw][NOUT]
   int T, NOUT, HEAD;
-  int stop_after;     // development: leave after phase n (1 = A ... 5 = E); 0 = normal
   long long *stamps;  // development: [blocks][4 waves][10] s_memtime at the phase boundaries (nullptr = off)
-  int gru_prio;       // development: s_setprio level of the recurrence waves
 };
 
 // one direction of one GRU layer over the OT steps held in LDS (gx rows incl. b_x), h ping-pong in hd
@@ -798,7 +401,6 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
   }
   __syncthreads();
   CF_STAMP(1)
-  if (a.stop_after == 1) return;
   // ---- B: conv -> feat (LDS).  Six m-tiles per wave, software-pipelined by hand: the next tile's A operands are read while
   //      this tile's MFMAs run, and the previous tile's ReLU + store sit in the middle of them.  Vector instructions between
   //      fp32 MFMAs cost matrix time, so the loop holds none it can avoid: operand and store offsets were computed during the
@@ -863,7 +465,6 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
   CF_STAMP(2)
   __syncthreads();  // feat complete; the image is dead from here on
   CF_STAMP(3)
-  if (a.stop_after == 2) return;
   float *gxs = img + CF_GX, *seq1 = img + CF_SEQ, *hb = img + CF_HB, *encs = img + CF_ENC, *hid = img + CF_HID, *w2s = img + CF_W2S;
   for (int i = tid; i < 32 * GR_SEQ_LD; i += CF_THREADS) seq1[i] = 0.f;
   if (tid < 2 * 2 * 2 * H) hb[tid] = 0.f;
@@ -919,12 +520,11 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
   CF_STAMP(4)
   __syncthreads();  // gx complete; nobody reads feat any more
   CF_STAMP(5)
-  if (a.stop_after == 3) return;
 
   // ---- D: layer-1 recurrence (waves 0, 1) | waves 2, 3: W_x2 (B-operand order) -> the feat space
   float *wx2l = feat;  // [16 k-quads][192][4]
   if (wave < 2) {
-    if (a.gru_prio) __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(3);  // the serial chain issues ahead of a co-resident workgroup's MFMA stream (+1.5 % at scale)
     cf_recurrence<true>(g, gxs, hb + dir * 2 * H, seq1, dir, unit, half);
     __builtin_amdgcn_s_setprio(0);
   } else {
@@ -934,7 +534,6 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
   }
   __syncthreads();
   CF_STAMP(6)
-  if (a.stop_after == 4) return;
 
   // ---- E: layer-2 input projection gx2[t][n] = seq1[t][:] . Wx2[n][:] + bx2[n]  (19 rows, K = 64, N = 192): rows 0..15 as one
   //      MFMA tile, rows 16..18 on the 4x4x1 form, 3 n-tiles per wave
@@ -967,12 +566,11 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
   }
   __syncthreads();
   CF_STAMP(7)
-  if (a.stop_after == 5) return;
 
   // ---- F: layer-2 recurrence (waves 2, 3): only the last state of each direction is kept | waves 0, 1: head -> LDS
   float *w1s = feat;  // [64][GR_W1_LD], over W_x2
   if (wave >= 2) {
-    if (a.gru_prio) __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(3);  // the serial chain issues ahead of a co-resident workgroup's MFMA stream (+1.5 % at scale)
     const float h_last = cf_recurrence<false>(g, gxs, hb + (2 + dir) * 2 * H, nullptr, dir, unit, half);
     __builtin_amdgcn_s_setprio(0);
     if (half == 0) {
@@ -1187,23 +785,10 @@ static int crnn_forward_generic(ww_ctx *ctx, const ww_model *m, const win_addr &
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-struct crnn_ws {
-  float *feat, *gx1;
-};
-
-static crnn_ws carve(const ww_model *m, int nw, void *ws) {
-  const ww_crnn_dev &c = m->crnn;
-  ww_bump b(ws, ~size_t(0));
-  crnn_ws r;
-  r.feat = b.take<float>((size_t)nw * c.OT * c.OF * c.C);
-  r.gx1 = b.take<float>((size_t)nw * c.OT * 6 * c.H);
-  return r;
-}
-
 size_t ww_crnn_workspace(const ww_model *m, int nw) {
   const ww_crnn_dev &c = m->crnn;
   if (c.generic) return crnn_generic_workspace(c, nw);
-  return ww_bump::need((size_t)nw * c.OT * c.OF * c.C, 4) + ww_bump::need((size_t)nw * c.OT * 6 * c.H, 4) + 1024;
+  return 1024;  // crnn_fused_kernel keeps every intermediate in LDS
 }
 
 int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *d_win_row,
@@ -1213,77 +798,37 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
   const ww_crnn_dev &c = m->crnn;
   win_addr wa = {d_win_row, d_win_valid, row0, hop, valid_const, mel_rows};
   if (c.generic) return crnn_forward_generic(ctx, m, wa, d_mel, nw, ws, d_out, d_enc);
-  static const bool split_chain = getenv("WWHIP_CRNN_SPLIT") != nullptr;  // development: the three-kernel chain
-  if (!split_chain && m->precision != WW_PRECISION_BF16X6) {
-    fused_args a = {d_mel, wa, c.conv_w, c.conv_b, c.wx1s, c.bx1, c.wh1, c.bh1, c.wx2s, c.bx2, c.wh2, c.bh2,
-                    c.w1, c.b1, c.w2, c.b2, d_enc, d_out, c.T, c.NOUT, c.HEAD, 0, nullptr, 0};
-    {
-      static const char *pr = getenv("WWHIP_CF_PRIO");  // development; default on: +1.5 % at scale, nothing at 256 windows
-      a.gru_prio = pr ? atoi(pr) : 1;
-    }
-    static const char *stop_env = getenv("WWHIP_CF_STOP");
-    if (stop_env) a.stop_after = atoi(stop_env);
-    static bool attr_set = false;
-    if (!attr_set) {
-      WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
-      attr_set = true;
-    }
-    static const bool want_stamps = getenv("WWHIP_CF_STAMPS") != nullptr;  // development: phase timeline to stderr
-    if (want_stamps) {
-      WW_HIP(ctx, hipMalloc((void **)&a.stamps, (size_t)nw * 40 * sizeof(long long)));
-      WW_HIP(ctx, hipMemsetAsync(a.stamps, 0, (size_t)nw * 40 * sizeof(long long), ctx->stream));
-    }
-    {
-      ww_launch_scope scope(ctx, "crnn_fused_kernel");
-      hipLaunchKernelGGL(crnn_fused_kernel, dim3(nw), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, a);
-    }
-    WW_HIP(ctx, hipGetLastError());
-    if (want_stamps) {
-      std::vector<long long> h((size_t)nw * 40);
-      WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      WW_HIP(ctx, hipMemcpy(h.data(), a.stamps, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
-      WW_HIP(ctx, hipFree(a.stamps));
-      long long t0 = h[0];
-      for (size_t i = 0; i < h.size(); ++i) if (h[i] && h[i] < t0) t0 = h[i];
-      for (int b : {0, nw / 2, nw - 1}) {
-        for (int wv : {0, 1, 2, 3}) {
-          fprintf(stderr, "block %d wave %d:", b, wv);
-          for (int i = 0; i < 10; ++i) fprintf(stderr, " %lld", h[((size_t)b * 4 + wv) * 10 + i] - t0);
-          fprintf(stderr, "\n");
-        }
-      }
-    }
-    return WW_OK;
+  fused_args a = {d_mel, wa, c.conv_w, c.conv_b, c.wx1s, c.bx1, c.wh1, c.bh1, c.wx2s, c.bx2, c.wh2, c.bh2,
+                  c.w1, c.b1, c.w2, c.b2, d_enc, d_out, c.T, c.NOUT, c.HEAD, nullptr};
+  static bool attr_set = false;
+  if (!attr_set) {
+    WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
+    attr_set = true;
   }
-  crnn_ws s = carve(m, nw, ws);
-  {
-    conv_args a = {d_mel, wa, c.conv_w, c.conv_b, s.feat, c.n_mel, c.T, c.KF, c.KT, c.SF, c.ST, c.PF, c.PT, c.OF, c.OT};
-    ww_launch_scope scope(ctx, "conv5x20_kernel");
-    hipLaunchKernelGGL(conv5x20_kernel, dim3(nw), dim3(CV_THREADS), 0, ctx->stream, a);
-  }
-  const int M = nw * c.OT;
-  if (m->precision == WW_PRECISION_BF16X6) {
-    gemm6_args g = {s.feat, c.wx1_3, c.bx1, s.gx1, M, 6 * c.H, c.OF * c.C};
-    constexpr int smem = 2 * 2 * 3 * 64 * G6_LD * 2;  // 122,880 B
-    static bool attr_set = false;
-    if (!attr_set) {
-      WW_HIP(ctx, hipFuncSetAttribute((const void *)gemm_nt_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-      attr_set = true;
-    }
-    ww_launch_scope scope(ctx, "gemm_nt_kernel<gru1,bf16x6>");
-    hipLaunchKernelGGL(gemm_nt_bf16x6_kernel, dim3((M + 63) / 64, (6 * c.H + 63) / 64), dim3(256), smem, ctx->stream, g);
-  } else {
-    const int n_tiles = (6 * c.H + GB_N - 1) / GB_N, m_tiles = (M + GB_M - 1) / GB_M;
-    gemm_args g = {s.feat, c.wx1, c.bx1, s.gx1, M, 6 * c.H, c.OF * c.C, n_tiles};
-    ww_launch_scope scope(ctx, "gemm_nt_kernel<gru1>");
-    // ids: 8 XCDs x (m-tiles of that residue, rounded up) x n-tiles; ids whose m-tile is past the end exit at once
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3(8 * ((m_tiles + 7) / 8) * n_tiles), dim3(512), 0, ctx->stream, g);
+  // development: WWHIP_CF_STAMPS=1 prints the s_memtime stamps of the phase boundaries (first, middle and last workgroup)
+  static const bool want_stamps = getenv("WWHIP_CF_STAMPS") != nullptr;
+  if (want_stamps) {
+    WW_HIP(ctx, hipMalloc((void **)&a.stamps, (size_t)nw * 40 * sizeof(long long)));
+    WW_HIP(ctx, hipMemsetAsync(a.stamps, 0, (size_t)nw * 40 * sizeof(long long), ctx->stream));
   }
   {
-    gru_head_args a = {s.gx1, c.wh1, c.bh1, c.wx2, c.bx2, c.wh2, c.bh2, c.w1, c.b1, c.w2, c.b2, d_enc, d_out, c.OT, c.NOUT, c.HEAD};
-    ww_launch_scope scope(ctx, "gru_head_kernel");
-    hipLaunchKernelGGL(gru_head_kernel, dim3(nw), dim3(256), 0, ctx->stream, a);
+    ww_launch_scope scope(ctx, "crnn_fused_kernel");
+    hipLaunchKernelGGL(crnn_fused_kernel, dim3(nw), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, a);
   }
   WW_HIP(ctx, hipGetLastError());
+  if (want_stamps) {
+    std::vector<long long> h((size_t)nw * 40);
+    WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    WW_HIP(ctx, hipMemcpy(h.data(), a.stamps, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    WW_HIP(ctx, hipFree(a.stamps));
+    for (int b : {0, nw / 2, nw - 1}) {
+      for (int wv = 0; wv < 4; ++wv) {
+        const long long *t = &h[((size_t)b * 4 + wv) * 10];
+        fprintf(stderr, "block %d wave %d:", b, wv);
+        for (int i = 0; i < 10; ++i) fprintf(stderr, " %lld", t[i] - t[0]);  // clocks of different XCDs are not comparable
+        fprintf(stderr, "\n");
+      }
+    }
+  }
   return WW_OK;
 }

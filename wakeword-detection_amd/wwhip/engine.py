@@ -52,7 +52,7 @@ class Engine:
     def set_precision(self, precision: str) -> None:
         """``"fp32"`` (default, fp32 MFMA) or ``"bf16x3"`` (Wavenet blocks as three bf16 MFMAs on
         split operands, fp32 accumulate; see ``ww_model_set_precision`` in include/wwhip.h)."""
-        modes = {"fp32": _lib.PRECISION_FP32, "bf16x3": _lib.PRECISION_BF16X3, "bf16x6": _lib.PRECISION_BF16X6}
+        modes = {"fp32": _lib.PRECISION_FP32, "bf16x3": _lib.PRECISION_BF16X3}
         if precision not in modes:
             raise ValueError(f"precision must be one of {sorted(modes)}")
         self._chk(self._lib.ww_model_set_precision(self._model, modes[precision]))
