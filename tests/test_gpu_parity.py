@@ -176,6 +176,25 @@ def test_wavenet_split_bf16_mode(assets, oracles, golden, name):
         e.close()
 
 
+@pytest.mark.parametrize("name", ["CRNN", "CRNN_softmax"])
+def test_crnn_large_batch_path(engines, oracles, name):
+    """Above 1,024 windows per launch the CRNN runs as crnn_fused_kernel<front> + gru_tail_kernel (the recurrences of six
+    windows share a CU): same results as the one-kernel path bit for bit, and the oracle's within tolerance - windows
+    with partial validity included, encoder output too."""
+    rng = np.random.default_rng(31)
+    e = engines[name]
+    wins = rng.uniform(0, 6.5, (1500, e.window, 40)).astype(np.float32)
+    wins[::13, 120:] = 0
+    wins[7] = 0
+    big, big_enc = e.forward(wins, want_enc=True)           # one launch of 1,500 windows: front + tail
+    small = np.concatenate([e.forward(wins[i:i + 500]) for i in range(0, 1500, 500)])  # three fused launches
+    np.testing.assert_array_equal(big, small)
+    idx = rng.choice(1500, 96, replace=False)
+    want, want_enc = oracles[name].forward(wins[idx], want_enc=True)
+    assert np.abs(big[idx] - want).max() < TOL_POST
+    assert np.abs(big_enc[idx].reshape(want_enc.shape) - want_enc).max() < 1e-4
+
+
 def test_retired_precision_mode_is_refused(engines):
     """Round 1's experimental bf16x6 projection mode (WW_PRECISION value 2) is gone: asking for it is an error, and
     bf16x3 on a CRNN is accepted and leaves the fp32 arithmetic in place (include/wwhip.h)."""

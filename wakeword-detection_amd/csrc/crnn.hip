@@ -292,6 +292,7 @@ struct fused_args {
   float *out;         // [Nw][NOUT]
   int T, NOUT, HEAD;
   long long *stamps;  // development: [blocks][4 waves][10] s_memtime at the phase boundaries (nullptr = off)
+  float *gx_out;      // FRONT_ONLY: [Nw][OT][192] layer-1 input projections incl. b_x
 };
 
 // one direction of one GRU layer over the OT steps held in LDS (gx rows incl. b_x), h ping-pong in hd
@@ -325,6 +326,7 @@ __device__ __forceinline__ float cf_recurrence(const gru_w &g, const float *gxs,
   rem[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(rv_.e_, b_[1].e_, rem[1], 0, 0, 0);                       \
   rem[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(rv_.e_, b_[2].e_, rem[2], 0, 0, 0);
 
+template <bool FRONT_ONLY>
 __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a) {
   extern __shared__ __align__(16) float cf_smem[];
   float *img = cf_smem, *feat = cf_smem + CF_IMG_FLOATS;
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
       __builtin_amdgcn_sched_barrier(0);
     }
     // recurrent weights: requested here, needed a barrier (waves 0, 1) or a whole recurrence (waves 2, 3) later
-    gru_load_w(g, wave < 2 ? a.wh1 : a.wh2, wave < 2 ? a.bh1 : a.bh2, dir, unit, half);
+    if (!FRONT_ONLY) gru_load_w(g, wave < 2 ? a.wh1 : a.wh2, wave < 2 ? a.bh1 : a.bh2, dir, unit, half);
     // the four k sub-steps of a column sit in lanes col, col+16, col+32, col+48
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
@@ -520,6 +522,16 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
   CF_STAMP(4)
   __syncthreads();  // gx complete; nobody reads feat any more
   CF_STAMP(5)
+  if (FRONT_ONLY) {
+    // large batches: the recurrences run in their own kernel (gru_tail_kernel), where six windows share a CU and no MFMA
+    // stream competes with their serial chains; gx1 (14.6 KB per window) crosses memory instead of feat (48.6 KB)
+    float4 *dst = (float4 *)(a.gx_out + (size_t)w * OT * 6 * H);
+    for (int q = tid; q < OT * 6 * H / 4; q += CF_THREADS) {
+      const int e = q * 4, t = e / (6 * H), c = e - t * 6 * H;
+      dst[q] = *(const float4 *)(&gxs[t * GR_GX_LD + c]);
+    }
+    return;
+  }
 
   // ---- D: layer-1 recurrence (waves 0, 1) | waves 2, 3: W_x2 (B-operand order) -> the feat space
   float *wx2l = feat;  // [16 k-quads][192][4]
@@ -610,6 +622,122 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
   CF_STAMP(9)
 #undef CF_STAMP
 }
+
+// ------------------------------------------------------------------------------------------
+// gru_tail_kernel: everything behind the layer-1 input projections for one window in a TWO-wave workgroup (wave 0
+// forward, wave 1 backward), for large batches: 25 KB of LDS and 2 waves per window put six windows on a CU, so the
+// strictly serial recurrences (38 steps of ~500 cycles) of twelve waves interleave on the vector ALUs instead of one
+// window's sitting beside another's fp32 MFMA stream (which runs on the same datapath: measured 2x slower steps).
+// Phases as D..G of crnn_fused_kernel; the layer-2 projection takes its B operands straight from L2.
+// ------------------------------------------------------------------------------------------
+struct tail_args {
+  const float *gx1;   // [Nw][OT][192]
+  const float *wh1, *bh1;
+  const float *wx2s;  // B-operand order [16][192][4]
+  const float *bx2, *wh2, *bh2, *w1, *b1, *w2, *b2;
+  float *enc, *out;
+  int NOUT, HEAD;
+};
+// LDS (floats): gx [20][196] | seq1 [20][68] (rows 19 zero) | h [2][2][2][32] | enc [64] | hid [64] = 22.7 KB: six per CU
+#define GT_SEQ (20 * GR_GX_LD)
+#define GT_HB (GT_SEQ + 20 * GR_SEQ_LD)
+#define GT_ENC (GT_HB + 2 * 2 * 2 * GR_H)
+#define GT_HID (GT_ENC + 2 * GR_H)
+#define GT_SMEM_FLOATS (GT_HID + 2 * GR_H)
+
+__global__ __launch_bounds__(128, 3) void gru_tail_kernel(tail_args a) {
+  constexpr int H = GR_H, OT = CV_OT;
+  __shared__ __align__(16) float sm[GT_SMEM_FLOATS];
+  float *gxs = sm, *seq1 = sm + GT_SEQ, *hb = sm + GT_HB, *encs = sm + GT_ENC, *hid = sm + GT_HID;
+  const int tid = threadIdx.x, lane = tid & 63, dir = tid >> 6;
+  const int j = lane & 15, kk = lane >> 4, unit = lane >> 1, half = lane & 1;
+  const int w = blockIdx.x;
+  gru_w g;
+  gru_load_w(g, a.wh1, a.bh1, dir, unit, half);
+  {
+    const float4 *src = (const float4 *)(a.gx1 + (size_t)w * OT * 6 * H);
+    for (int q = tid; q < OT * 6 * H / 4; q += 128) {
+      const int e = q * 4, t = e / (6 * H), c = e - t * 6 * H;
+      *(float4 *)(&gxs[t * GR_GX_LD + c]) = src[q];
+    }
+  }
+  for (int i = tid; i < 20 * GR_SEQ_LD; i += 128) seq1[i] = 0.f;
+  for (int i = tid; i < 2 * 2 * 2 * H; i += 128) hb[i] = 0.f;
+  __syncthreads();
+  cf_recurrence<true>(g, gxs, hb + dir * 2 * H, seq1, dir, unit, half);
+  gru_load_w(g, a.wh2, a.bh2, dir, unit, half);  // in flight during the projection
+  __syncthreads();
+  // layer-2 input projection: wave d owns n-tiles 6 d .. 6 d + 5, in two passes of three
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    const int nt0 = dir * 6 + pass * 3;
+    f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 rem[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float4 bq[4][3];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int n = 0; n < 3; ++n) bq[kb][n] = *(const float4 *)(a.wx2s + ((size_t)(kb * 4 + kk) * 192 + (nt0 + n) * 16 + j) * 4);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const float4 av = *(const float4 *)(&seq1[j * GR_SEQ_LD + kb * 16 + kk * 4]);
+      const float4 rv = *(const float4 *)(&seq1[(16 + (lane & 3)) * GR_SEQ_LD + kb * 16 + kk * 4]);  // row 19 is zero
+      const float4 *b = bq[kb];
+      CF_ROUND(av, rv, b, x) CF_ROUND(av, rv, b, y) CF_ROUND(av, rv, b, z) CF_ROUND(av, rv, b, w)
+    }
+    __syncthreads();  // pass 0: both waves are done reading gx1 before anybody overwrites it (gx2 takes its place)
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+      const int col = (nt0 + n) * 16 + j;
+      const float bb = a.bx2[col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gxs[(kk * 4 + r) * GR_GX_LD + col] = acc[n][r] + bb;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        float v = rem[n][i];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (kk == 0) gxs[(16 + i) * GR_GX_LD + col] = v + bb;
+      }
+    }
+  }
+  __syncthreads();
+  const float h_last = cf_recurrence<false>(g, gxs, hb + (2 + dir) * 2 * H, nullptr, dir, unit, half);
+  if (half == 0) {
+    encs[dir * H + unit] = h_last;
+    if (a.enc) a.enc[(size_t)w * 2 * H + dir * H + unit] = h_last;
+  }
+  __syncthreads();
+  if (dir == 0) {  // detect head, w1 row `lane` straight from L2 (16 KB, shared by every workgroup)
+    float acc = 0.f;  // one chain in k order: bit-identical to crnn_fused_kernel's head
+    const float4 *wr = (const float4 *)(a.w1 + (size_t)lane * 2 * H);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float4 wv = wr[q];
+      const float4 ev = *(const float4 *)(&encs[q * 4]);
+      acc = fmaf(wv.x, ev.x, acc); acc = fmaf(wv.y, ev.y, acc);
+      acc = fmaf(wv.z, ev.z, acc); acc = fmaf(wv.w, ev.w, acc);
+    }
+    hid[lane] = fmaxf(acc + a.b1[lane], 0.f);
+    wsync_g();
+    float y = 0.f;
+    if (lane < a.NOUT) {
+      for (int k = 0; k < 2 * H; ++k) y = fmaf(a.w2[lane * 64 + k], hid[k], y);
+      y += a.b2[lane];
+    }
+    if (a.HEAD == 0) {
+      if (lane < a.NOUT) a.out[(size_t)w * a.NOUT + lane] = sigmoid_f(y);
+    } else {
+      float mx = (lane < a.NOUT) ? y : -INFINITY;
+      for (int o = 1; o < 8; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      float e = (lane < a.NOUT) ? expf(y - mx) : 0.f;
+      float sum = e;
+      for (int o = 1; o < 8; o <<= 1) sum += __shfl_xor(sum, o);
+      if (lane < a.NOUT) a.out[(size_t)w * a.NOUT + lane] = e / sum;
+    }
+  }
+}
+
 #undef CF_ROUND
 
 // detect.tflite alone (reference detect_model(x), wakeword/tflite.py:228-229): one wave per row
@@ -785,9 +913,19 @@ static int crnn_forward_generic(ww_ctx *ctx, const ww_model *m, const win_addr &
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+// Above this many windows per launch the recurrences move to gru_tail_kernel (one more kernel boundary and 14.6 KB per
+// window through memory buy a CU-filling mix; below it one workgroup per window end to end is the shorter path).
+static int crnn_split_threshold() {
+  static const char *e = getenv("WWHIP_CRNN_SPLIT_AT");  // development: 0 = always fused
+  static const int v = e ? atoi(e) : 1024;
+  return v;
+}
+
 size_t ww_crnn_workspace(const ww_model *m, int nw) {
   const ww_crnn_dev &c = m->crnn;
   if (c.generic) return crnn_generic_workspace(c, nw);
+  const int thr = crnn_split_threshold();
+  if (thr > 0 && nw > thr) return ww_bump::need((size_t)nw * c.OT * 6 * c.H, 4) + 1024;
   return 1024;  // crnn_fused_kernel keeps every intermediate in LDS
 }
 
@@ -799,11 +937,28 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
   win_addr wa = {d_win_row, d_win_valid, row0, hop, valid_const, mel_rows};
   if (c.generic) return crnn_forward_generic(ctx, m, wa, d_mel, nw, ws, d_out, d_enc);
   fused_args a = {d_mel, wa, c.conv_w, c.conv_b, c.wx1s, c.bx1, c.wh1, c.bh1, c.wx2s, c.bx2, c.wh2, c.bh2,
-                  c.w1, c.b1, c.w2, c.b2, d_enc, d_out, c.T, c.NOUT, c.HEAD, nullptr};
+                  c.w1, c.b1, c.w2, c.b2, d_enc, d_out, c.T, c.NOUT, c.HEAD, nullptr, nullptr};
   static bool attr_set = false;
   if (!attr_set) {
-    WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
+    WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
+    WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
     attr_set = true;
+  }
+  const int thr = crnn_split_threshold();
+  if (thr > 0 && nw > thr) {
+    ww_bump b(ws, ~size_t(0));
+    a.gx_out = b.take<float>((size_t)nw * c.OT * 6 * c.H);
+    {
+      ww_launch_scope scope(ctx, "crnn_fused_kernel<front>");
+      hipLaunchKernelGGL(crnn_fused_kernel<true>, dim3(nw), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, a);
+    }
+    tail_args t = {a.gx_out, c.wh1, c.bh1, c.wx2s, c.bx2, c.wh2, c.bh2, c.w1, c.b1, c.w2, c.b2, d_enc, d_out, c.NOUT, c.HEAD};
+    {
+      ww_launch_scope scope(ctx, "gru_tail_kernel");
+      hipLaunchKernelGGL(gru_tail_kernel, dim3(nw), dim3(128), 0, ctx->stream, t);
+    }
+    WW_HIP(ctx, hipGetLastError());
+    return WW_OK;
   }
   // development: WWHIP_CF_STAMPS=1 prints the s_memtime stamps of the phase boundaries (first, middle and last workgroup)
   static const bool want_stamps = getenv("WWHIP_CF_STAMPS") != nullptr;
@@ -813,7 +968,7 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
   }
   {
     ww_launch_scope scope(ctx, "crnn_fused_kernel");
-    hipLaunchKernelGGL(crnn_fused_kernel, dim3(nw), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, a);
+    hipLaunchKernelGGL(crnn_fused_kernel<false>, dim3(nw), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, a);
   }
   WW_HIP(ctx, hipGetLastError());
   if (want_stamps) {
