@@ -465,6 +465,28 @@ def main():
         alt = {"value": throughput(world, K, args.clips, m), "unit": "audio frames/s", "ms_per_step": m / K * 1e3,
                "timed_regions": s, "note": "same job with ww_frontend_params.precise=0 (fp32 butterflies)"}
 
+    # ---- CRNN only: the same regions with conv + projection on split-bf16 MFMA (ww_model_set_precision(BF16X3)); fp32 stays
+    # the headline (BASELINE configs[1] is an fp32 configuration), this is what the bf16 matrix pipe buys at <= 3e-5 on posteriors
+    alt_bf16 = None
+    if args.model == "crnn" and precision == "fp32":
+        for e in head["engs"]:
+            e.set_precision("bf16x3")
+        head["job"].warm(P, fp)
+        s, m = head["job"].regions(max(3, head["stats"]["n"] // 2) | 1, fp)
+        posts_b = head["job"].d_all[:min(K, R)].cpu().numpy()
+        alt_bf16 = {"value": throughput(world, K, args.clips, m), "unit": "audio frames/s", "ms_per_step": m / K * 1e3,
+                    "timed_regions": s, "max_abs_posterior_diff_vs_fp32": float(np.abs(posts_b - head["posts"]).max()),
+                    "note": "same job, CRNN conv + layer-1 projection as split-bf16 MFMA products (3 per product, fp32 "
+                            "accumulate); recurrences, head and the fp64-FFT front end unchanged"}
+        ctxs[0].profile(True)
+        for k in range(min(K, 100)):
+            head["job"].step(k, fp, only0=True)
+        pb = ctxs[0].profile_read()
+        ctxs[0].profile(False)
+        alt_bf16["all_kernels_avg_us"] = {k: round(v["total_ms"] / max(v["calls"], 1) * 1e3, 3) for k, v in pb.items()}
+        for e in head["engs"]:
+            e.set_precision("fp32")
+
     def close(res):
         for e in res["engs"]:
             e.close()
@@ -531,6 +553,7 @@ def main():
             "posterior_checksum": float(np.sum(head["posts"][0], dtype=np.float64)),
             "single_stream": head["single"],
             "alt_fp32_fft_frontend": alt,
+            "alt_crnn_split_bf16": alt_bf16,
         }
         if world > 1 and backend != "nccl":
             line["config"]["rehearsal"] = f"{backend} backend, ranks share {n_dev} physical GPU(s): not a scaling measurement"

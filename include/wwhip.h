@@ -108,12 +108,14 @@ int ww_model_get_info(const ww_model *model, ww_model_info *out);
 
 /* Arithmetic of the model contractions.  The reference runs fp32 TFLite kernels; SURVEY 8(d) cfg 3 asks
  * for the Wavenet convs on bf16 MFMA with fp32 accumulate next to an fp32 parity mode.
- *   WW_PRECISION_FP32   (default) v_mfma_f32_16x16x4_f32 everywhere.
+ *   WW_PRECISION_FP32   (default) v_mfma_f32_16x16x4_f32 everywhere: bit for bit a k-ordered fp32 fmaf chain.
  *   WW_PRECISION_BF16X3 Wavenet's 24 gated blocks as split-bf16: x = hi + lo (two bf16), a*b =
  *                       ah*bh + ah*bl + al*bh on v_mfma_f32_16x16x32_bf16, fp32 accumulate; 16 mantissa
  *                       bits per operand - posteriors within 4e-6 of fp32 (tolerance 1e-4).  Plain
  *                       single-pass bf16 misses the tolerance (6e-4 .. 1e-3) and is not offered.
- *                       CRNN models accept the call and keep fp32.
+ *                       CRNN models: the conv and the layer-1 input projection (88 % of the FLOPs) take the same
+ *                       split form (crnn_fused_bf16_kernel); the recurrences and the head stay fp32; posteriors
+ *                       within 1e-5 of fp32.  (CRNNs of another conv geometry keep fp32.)
  * (Value 2 was round 1's experimental BF16X6 projection mode; it was not faster than fp32 and is retired: WW_EINVAL.) */
 #define WW_PRECISION_FP32 0
 #define WW_PRECISION_BF16X3 1

@@ -196,20 +196,45 @@ def test_crnn_large_batch_path(engines, oracles, name):
 
 
 def test_retired_precision_mode_is_refused(engines):
-    """Round 1's experimental bf16x6 projection mode (WW_PRECISION value 2) is gone: asking for it is an error, and
-    bf16x3 on a CRNN is accepted and leaves the fp32 arithmetic in place (include/wwhip.h)."""
-    import ctypes as C
+    """Round 1's experimental bf16x6 projection mode (WW_PRECISION value 2) is gone: asking for it is an error."""
     from wwhip import _lib
     e = engines["CRNN"]
     assert _lib.load().ww_model_set_precision(e.handle, 2) == _lib.WW_EINVAL
     with pytest.raises(ValueError):
         e.set_precision("bf16x6")
-    rng = np.random.default_rng(71)
-    wins = rng.uniform(0, 6.5, (9, e.window, 40)).astype(np.float32)
-    ref = e.forward(wins)
-    e.set_precision("bf16x3")
-    np.testing.assert_array_equal(e.forward(wins), ref)
-    e.set_precision("fp32")
+
+
+@pytest.mark.parametrize("name", ["CRNN", "CRNN_softmax", "CRNN_nosilence_enhanced"])
+def test_crnn_split_bf16_mode(assets, oracles, golden, name):
+    """ww_model_set_precision(BF16X3) on a CRNN: conv and layer-1 projection on bf16 MFMA with split operands
+    (crnn_fused_bf16_kernel) stay within the north-star tolerance of the fp32 oracle, in both the one-kernel form and the
+    front + tail form of large batches; fp32 remains the default and is restored exactly."""
+    from wwhip.engine import Engine
+    e = Engine(os.path.join(assets, name), precision="bf16x3")
+    try:
+        rng = np.random.default_rng(41)
+        wins = rng.uniform(0, 6.5, (300, e.window, 40)).astype(np.float32)
+        wins[3] = 0
+        wins[4, 100:] = 0
+        wins[5] = np.clip(rng.normal(3, 1.5, (e.window, 40)), 0, 8)
+        got, enc = e.forward(wins, want_enc=True)
+        want, want_enc = oracles[name].forward(wins, want_enc=True)
+        assert np.abs(got - want).max() < 2e-5          # north star 1e-4
+        assert np.abs(enc.reshape(want_enc.shape) - want_enc).max() < 2e-4
+        z = np.load(os.path.join(golden, "models.npz"))
+        assert np.abs(e.forward(z[name + ".windows"]) - z[name + ".det64"]).max() < 2e-5
+        mel = rng.uniform(0, 6.5, (e.window + 40, 40)).astype(np.float32)
+        assert np.abs(e.slide_forward(mel, 2) - oracles[name].slide_forward(mel, 2)).max() < 2e-5
+        big = rng.uniform(0, 6.5, (1300, e.window, 40)).astype(np.float32)   # > 1,024 windows: front + tail kernels
+        big[::7, 140:] = 0
+        got_big = e.forward(big)
+        np.testing.assert_array_equal(got_big[:300], e.forward(big[:300]))   # same arithmetic in both forms
+        e.set_precision("fp32")
+        ref = e.forward(big)
+        assert np.abs(got_big - ref).max() < 5e-5      # measured 2.5e-5 over 1,300 windows
+        assert np.abs(e.forward(wins) - want).max() < 2e-6
+    finally:
+        e.close()
 
 
 def test_forward_rejects_bad_shape(engines):

@@ -433,7 +433,58 @@ static int load_crnn(ww_ctx *ctx, ww_model *m, const blob_view &bv) {
     for (size_t n = 0; n < (size_t)2 * G; ++n)
       for (size_t k = 0; k < in1; ++k) ws[((k / 4) * 2 * G + n) * 4 + (k % 4)] = v[n * in1 + k];
     c.wx1s = upload(m, ws);
-    if (!c.wx1s) return ww_fail(ctx, WW_ENOMEM, "CRNN upload failed");
+    // split-bf16 mode (WW_PRECISION_BF16X3): x = hi + lo, both bf16 round-to-nearest-even
+    auto rne = [](float f) -> uint16_t {
+      uint32_t u;
+      memcpy(&u, &f, 4);
+      u += 0x7FFFu + ((u >> 16) & 1u);
+      return (uint16_t)(u >> 16);
+    };
+    auto tof = [](uint16_t h) -> float {
+      uint32_t u = (uint32_t)h << 16;
+      float f;
+      memcpy(&f, &u, 4);
+      return f;
+    };
+    auto split = [&](float x, uint16_t &h, uint16_t &l) {
+      h = rne(x);
+      l = rne(x - tof(h));
+    };
+    {  // W_x1 [192][640] -> [plane][k-step 20][n-tile 12][lane = g*16 + j][8]: element e is W[nt*16 + j][ks*32 + 8 g + e]
+      std::vector<unsigned short> wb((size_t)2 * 20 * 12 * 64 * 8);
+      for (int ks = 0; ks < 20; ++ks)
+        for (int nt = 0; nt < 12; ++nt)
+          for (int ln = 0; ln < 64; ++ln)
+            for (int e = 0; e < 8; ++e) {
+              const int gq = ln >> 4, jj = ln & 15;
+              uint16_t h, l;
+              split(v[(size_t)(nt * 16 + jj) * in1 + ks * 32 + 8 * gq + e], h, l);
+              const size_t o = (((size_t)ks * 12 + nt) * 64 + ln) * 8 + e;
+              wb[o] = h;
+              wb[(size_t)20 * 12 * 64 * 8 + o] = l;
+            }
+      c.wx1b = upload(m, wb);
+    }
+    {  // conv weights [32][5][20] -> [plane][k-step 4][m-tile 2][lane = g*16 + i][8]: group G = ks*4 + g = kf*3 + h holds
+       // kt'' = 8 h + e with kt = kt'' - 2 (zero outside 0..19); G = 15 is all zero
+      std::vector<unsigned short> wb((size_t)2 * 4 * 2 * 64 * 8, 0);
+      for (int ks = 0; ks < 4; ++ks)
+        for (int mt = 0; mt < 2; ++mt)
+          for (int ln = 0; ln < 64; ++ln)
+            for (int e = 0; e < 8; ++e) {
+              const int gq = ln >> 4, ii = ln & 15, Gq = ks * 4 + gq;
+              const int kf = Gq / 3, kt = (Gq % 3) * 8 + e - 2;
+              float x = 0.f;
+              if (Gq < 15 && kt >= 0 && kt < c.KT) x = cw[(size_t)(mt * 16 + ii) * K + kf * c.KT + kt];
+              uint16_t h, l;
+              split(x, h, l);
+              const size_t o = (((size_t)ks * 2 + mt) * 64 + ln) * 8 + e;
+              wb[o] = h;
+              wb[(size_t)4 * 2 * 64 * 8 + o] = l;
+            }
+      c.cwb = upload(m, wb);
+    }
+    if (!c.wx1s || !c.wx1b || !c.cwb) return ww_fail(ctx, WW_ENOMEM, "CRNN upload failed");
   }
   if (c.generic) {
     std::vector<float> wp((size_t)2 * G * c.FEATP, 0.f);

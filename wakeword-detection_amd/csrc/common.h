@@ -100,6 +100,8 @@ struct ww_crnn_dev {
   float *bh1 = nullptr;      // [2][3H]
   float *wx2 = nullptr;      // [2*3H][2H]
   float *wx2s = nullptr;     // the same in MFMA B-operand order [2H/4][2*3H][4]
+  unsigned short *cwb = nullptr;   // split-bf16 mode: conv weights hi/lo planes in A-operand order (crnn_fused_bf16_kernel)
+  unsigned short *wx1b = nullptr;  // split-bf16 mode: W_x1 hi/lo planes in B-operand order
   float *bx2 = nullptr;
   float *wh2 = nullptr;
   float *bh2 = nullptr;

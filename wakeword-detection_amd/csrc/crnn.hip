@@ -293,6 +293,8 @@ struct fused_args {
   int T, NOUT, HEAD;
   long long *stamps;  // development: [blocks][4 waves][10] s_memtime at the phase boundaries (nullptr = off)
   float *gx_out;      // FRONT_ONLY: [Nw][OT][192] layer-1 input projections incl. b_x
+  const unsigned short *cwb;   // bf16x3: conv weights, A-operand order [plane 2][k-step 4][m-tile 2][lane 64][8]
+  const unsigned short *wx1b;  // bf16x3: W_x1, B-operand order [plane 2][k-step 20][n-tile 12][lane 64][8]
 };
 
 // one direction of one GRU layer over the OT steps held in LDS (gx rows incl. b_x), h ping-pong in hd
@@ -326,6 +328,107 @@ __device__ __forceinline__ float cf_recurrence(const gru_w &g, const float *gxs,
   rem[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(rv_.e_, b_[1].e_, rem[1], 0, 0, 0);                       \
   rem[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(rv_.e_, b_[2].e_, rem[2], 0, 0, 0);
 
+// development: s_memtime at the phase boundaries (fused_args::stamps; nullptr = off)
+#define CF_STAMP(i_)                                                                                          \
+  if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wave) * 10 + (i_)] = __builtin_amdgcn_s_memtime();
+
+// Phases D..G of the fused kernels (fp32 and split-bf16 front halves share them): gx1 is in LDS, g holds this wave's
+// recurrent weights (waves 0, 1: layer 1; waves 2, 3: layer 2).
+__device__ __forceinline__ void cf_phases_d_to_g(const fused_args &a, float *img, float *feat, const gru_w &g, int w) {
+  constexpr int H = GR_H, OT = CV_OT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kk = lane >> 4;
+  const int unit = lane >> 1, half = lane & 1, dir = wave & 1;
+  float *gxs = img + CF_GX, *seq1 = img + CF_SEQ, *hb = img + CF_HB, *encs = img + CF_ENC, *hid = img + CF_HID, *w2s = img + CF_W2S;
+  // ---- D: layer-1 recurrence (waves 0, 1) | waves 2, 3: W_x2 (B-operand order) -> the feat space
+  float *wx2l = feat;  // [16 k-quads][192][4]
+  if (wave < 2) {
+    __builtin_amdgcn_s_setprio(3);  // the serial chain issues ahead of a co-resident workgroup's MFMA stream (+1.5 % at scale)
+    cf_recurrence<true>(g, gxs, hb + dir * 2 * H, seq1, dir, unit, half);
+    __builtin_amdgcn_s_setprio(0);
+  } else {
+    const float4 *src = (const float4 *)a.wx2s;
+#pragma unroll 4
+    for (int i = tid - 128; i < 16 * 192; i += 128) ((float4 *)wx2l)[i] = src[i];
+  }
+  __syncthreads();
+  CF_STAMP(6)
+
+  // ---- E: layer-2 input projection gx2[t][n] = seq1[t][:] . Wx2[n][:] + bx2[n]  (19 rows, K = 64, N = 192): rows 0..15 as one
+  //      MFMA tile, rows 16..18 on the 4x4x1 form, 3 n-tiles per wave
+  {
+    f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 rem[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const float4 av = *(const float4 *)(&seq1[j * GR_SEQ_LD + kb * 16 + kk * 4]);
+      const float4 rv = *(const float4 *)(&seq1[(16 + (lane & 3)) * GR_SEQ_LD + kb * 16 + kk * 4]);  // row 19 is zero
+      float4 b[3];
+#pragma unroll
+      for (int n = 0; n < 3; ++n) b[n] = *(const float4 *)(&wx2l[((kb * 4 + kk) * 192 + (wave * 3 + n) * 16 + j) * 4]);
+      CF_ROUND(av, rv, b, x) CF_ROUND(av, rv, b, y) CF_ROUND(av, rv, b, z) CF_ROUND(av, rv, b, w)
+    }
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+      const int col = (wave * 3 + n) * 16 + j;
+      const float bb = a.bx2[col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gxs[(kk * 4 + r) * GR_GX_LD + col] = acc[n][r] + bb;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        float v = rem[n][i];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (kk == 0) gxs[(16 + i) * GR_GX_LD + col] = v + bb;
+      }
+    }
+  }
+  __syncthreads();
+  CF_STAMP(7)
+
+  // ---- F: layer-2 recurrence (waves 2, 3): only the last state of each direction is kept | waves 0, 1: head -> LDS
+  float *w1s = feat;  // [64][GR_W1_LD], over W_x2
+  if (wave >= 2) {
+    __builtin_amdgcn_s_setprio(3);  // the serial chain issues ahead of a co-resident workgroup's MFMA stream (+1.5 % at scale)
+    const float h_last = cf_recurrence<false>(g, gxs, hb + (2 + dir) * 2 * H, nullptr, dir, unit, half);
+    __builtin_amdgcn_s_setprio(0);
+    if (half == 0) {
+      encs[dir * H + unit] = h_last;
+      if (a.enc) a.enc[(size_t)w * 2 * H + dir * H + unit] = h_last;
+    }
+  } else {
+    for (int i = tid; i < 64 * 64; i += 128) w1s[(i >> 6) * GR_W1_LD + (i & 63)] = a.w1[i];
+    for (int i = tid; i < a.NOUT * 64; i += 128) w2s[i] = a.w2[i];
+  }
+  __syncthreads();
+  CF_STAMP(8)
+
+  // ---- G: detect head: Dense(64, relu) -> Dense(NOUT) -> sigmoid | softmax   (wave 0)
+  if (wave == 0) {
+    float acc = 0.f;
+#pragma unroll 16
+    for (int k = 0; k < 2 * H; ++k) acc = fmaf(w1s[lane * GR_W1_LD + k], encs[k], acc);
+    hid[lane] = fmaxf(acc + a.b1[lane], 0.f);
+    wsync_g();
+    float y = 0.f;
+    if (lane < a.NOUT) {
+      for (int k = 0; k < 2 * H; ++k) y = fmaf(w2s[lane * 64 + k], hid[k], y);
+      y += a.b2[lane];
+    }
+    if (a.HEAD == 0) {
+      if (lane < a.NOUT) a.out[(size_t)w * a.NOUT + lane] = sigmoid_f(y);
+    } else {
+      float mx = (lane < a.NOUT) ? y : -INFINITY;
+      for (int o = 1; o < 8; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      float e = (lane < a.NOUT) ? expf(y - mx) : 0.f;
+      float sum = e;
+      for (int o = 1; o < 8; o <<= 1) sum += __shfl_xor(sum, o);
+      if (lane < a.NOUT) a.out[(size_t)w * a.NOUT + lane] = e / sum;
+    }
+  }
+  CF_STAMP(9)
+}
+
 template <bool FRONT_ONLY>
 __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a) {
   extern __shared__ __align__(16) float cf_smem[];
@@ -334,8 +437,6 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kk = lane >> 4;
   const int w = blockIdx.x;
-#define CF_STAMP(i_)                                                                                          \
-  if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wave) * 10 + (i_)] = __builtin_amdgcn_s_memtime();
   CF_STAMP(0)
   int64_t row;
   int valid;
@@ -533,94 +634,246 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
     return;
   }
 
-  // ---- D: layer-1 recurrence (waves 0, 1) | waves 2, 3: W_x2 (B-operand order) -> the feat space
-  float *wx2l = feat;  // [16 k-quads][192][4]
-  if (wave < 2) {
-    __builtin_amdgcn_s_setprio(3);  // the serial chain issues ahead of a co-resident workgroup's MFMA stream (+1.5 % at scale)
-    cf_recurrence<true>(g, gxs, hb + dir * 2 * H, seq1, dir, unit, half);
-    __builtin_amdgcn_s_setprio(0);
-  } else {
-    const float4 *src = (const float4 *)a.wx2s;
-#pragma unroll 4
-    for (int i = tid - 128; i < 16 * 192; i += 128) ((float4 *)wx2l)[i] = src[i];
-  }
-  __syncthreads();
-  CF_STAMP(6)
+  cf_phases_d_to_g(a, img, feat, g, w);
+}
 
-  // ---- E: layer-2 input projection gx2[t][n] = seq1[t][:] . Wx2[n][:] + bx2[n]  (19 rows, K = 64, N = 192): rows 0..15 as one
-  //      MFMA tile, rows 16..18 on the 4x4x1 form, 3 n-tiles per wave
+// ------------------------------------------------------------------------------------------
+// crnn_fused_bf16_kernel (WW_PRECISION_BF16X3): phases A..C of crnn_fused_kernel on the bf16 matrix pipe with split
+// operands, x = hi + lo (two bf16, 16 mantissa bits) and a*b = ah*bh + ah*bl + al*bh on v_mfma_f32_16x16x32_bf16 with
+// fp32 accumulate - the arithmetic of the split-bf16 Wavenet (wavenet.hip).  48 matrix cycles per 16x16x32 products
+// against 256 for eight v_mfma_f32_16x16x4_f32, and on a pipe that runs beside the vector ALU (the fp32 MFMA does not).
+// Posteriors move by <= 1e-5 against the fp32 kernel (tests/test_gpu_parity.py); fp32 stays the default.
+//   A  the window goes to LDS as two bf16 planes [mel + 1][frame + 8] (pairs of frames packed per 32-bit store)
+//   B  conv TRANSPOSED: channels are the MFMA rows (weights = A operand), the 380 output positions its columns, so a
+//      lane ends up with 4 consecutive channels of one position = one 8-byte store per plane into feat[t][f*32 + c].
+//      K = (kf, kt'') with kt padded 20 -> 24 and shifted by 2, so that every group of 8 k is 16 aligned bytes of one
+//      image row: 15 groups + 1 zero group = 4 k-steps of 32
+//   C  projection: rows 0..15 and 16..18 (+13 clamped) as two MFMA row tiles, 3 n-tiles per wave, W_x1 hi/lo planes
+//      streamed from L2 in B-operand order, two k-steps ahead
+//   D..G as the fp32 kernel (cf_phases_d_to_g).
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#define CB_LD 168   // image row, bf16 elements: frame + 8
+#define CB_ROWS 43  // mel + 1
+#define CB_FLD 648  // feat row, bf16 elements
+#define CFB_IMG_FLOATS 7232  // two bf16 image planes (28,896 B) rounded up; the fp32 kernel's image region is 7,216 floats
+#define CFB_SMEM_BYTES ((CFB_IMG_FLOATS + CF_FEAT_FLOATS) * 4)
+static_assert(2 * CB_ROWS * CB_LD * 2 <= CFB_IMG_FLOATS * 4 && 2 * CV_OT * CB_FLD * 2 <= CF_FEAT_FLOATS * 4 && CF_W2S + 8 * 64 <= CFB_IMG_FLOATS,
+              "bf16 planes / post-conv tenants exceed their LDS regions");
+
+// (a, b) -> packed bf16 pairs hi and lo with a ~ hi.x + lo.x, b ~ hi.y + lo.y
+__device__ __forceinline__ void split2_pair(float a, float b, unsigned &h, unsigned &l) {
+  const bf16x2_t hh = __builtin_convertvector((f32x2_t){a, b}, bf16x2_t);
+  h = __builtin_bit_cast(unsigned, hh);
+  const bf16x2_t ll = __builtin_convertvector((f32x2_t){a - __uint_as_float(h << 16), b - __uint_as_float(h & 0xffff0000u)}, bf16x2_t);
+  l = __builtin_bit_cast(unsigned, ll);
+}
+
+template <bool FRONT_ONLY>
+__global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_bf16_kernel(fused_args a) {
+  extern __shared__ __align__(16) float cf_smem[];
+  float *img = cf_smem, *feat = cf_smem + CFB_IMG_FLOATS;
+  unsigned short *imgh = (unsigned short *)img, *imgl = imgh + CB_ROWS * CB_LD;
+  unsigned short *fth = (unsigned short *)feat, *ftl = fth + CV_OT * CB_FLD;
+  constexpr int H = GR_H, OT = CV_OT, M = CV_OT * CV_OF;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kk = lane >> 4;
+  const int w = blockIdx.x;
+  CF_STAMP(0)
+  int64_t row;
+  int valid;
+  window_span(a.wa, w, a.T, row, valid);
+
+  // conv weights, A operand (rows = channels): [plane][k-step 4][m-tile 2][lane][8 bf16]
+  uint4 wq[2][4][2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) wq[p][ks][mt] = ((const uint4 *)a.cwb)[((p * 4 + ks) * 2 + mt) * 64 + lane];
+  float cb[2][4];  // bias of this lane's channels mt*16 + kk*4 + r
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cb[mt][r] = a.cbias[mt * 16 + kk * 4 + r];
+
+  // ---- A: stage the window as bf16 hi / lo planes; a thread owns (frame pair, mel quad) items
+  int b_off[6], f_off[6];  // per position tile of this wave: image offset of (t, f), feat offset of (t, f); -1 past M
   {
-    f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    f32x4 rem[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    constexpr int NIT = 3;  // 3 * 256 >= 76 frame pairs * 10 mel quads
+    const float *src = a.mel + row * CV_NMEL;
+    const bool al16 = ((((uintptr_t)src) & 15) == 0);
+    float4 lo4[NIT], hi4[NIT];
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      const float4 av = *(const float4 *)(&seq1[j * GR_SEQ_LD + kb * 16 + kk * 4]);
-      const float4 rv = *(const float4 *)(&seq1[(16 + (lane & 3)) * GR_SEQ_LD + kb * 16 + kk * 4]);  // row 19 is zero
-      float4 b[3];
-#pragma unroll
-      for (int n = 0; n < 3; ++n) b[n] = *(const float4 *)(&wx2l[((kb * 4 + kk) * 192 + (wave * 3 + n) * 16 + j) * 4]);
-      CF_ROUND(av, rv, b, x) CF_ROUND(av, rv, b, y) CF_ROUND(av, rv, b, z) CF_ROUND(av, rv, b, w)
+    for (int q = 0; q < NIT; ++q) {
+      const int item = q * CF_THREADS + tid, fp = item / 10, mq = item - fp * 10;
+      const int f0 = 2 * fp, f1 = 2 * fp + 1;
+      auto ld = [&](int fr) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (fr < valid) {
+          const float *p = src + fr * CV_NMEL + mq * 4;
+          if (al16) v = *(const float4 *)p;
+          else v = make_float4(p[0], p[1], p[2], p[3]);
+        }
+        return v;
+      };
+      lo4[q] = ld(f0);
+      hi4[q] = ld(f1);
     }
+    for (int i = tid; i < CFB_IMG_FLOATS / 4; i += CF_THREADS) ((float4 *)img)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int n = 0; n < 3; ++n) {
-      const int col = (wave * 3 + n) * 16 + j;
-      const float bb = a.bx2[col];
+    for (int i = 0; i < 6; ++i) {
+      const int m = (wave + 4 * i) * 16 + j, mc = m < M ? m : M - 1;
+      const int t = mc / CV_OF, f = mc - t * CV_OF;
+      b_off[i] = (2 * f) * CB_LD + 8 * t;
+      f_off[i] = m < M ? t * CB_FLD + f * 32 : -1;
+    }
+    __syncthreads();
 #pragma unroll
-      for (int r = 0; r < 4; ++r) gxs[(kk * 4 + r) * GR_GX_LD + col] = acc[n][r] + bb;
+    for (int q = 0; q < NIT; ++q) {
+      const int item = q * CF_THREADS + tid, fp = item / 10, mq = item - fp * 10;
+      if (2 * fp < a.T) {
+        const float x0[4] = {lo4[q].x, lo4[q].y, lo4[q].z, lo4[q].w}, x1[4] = {hi4[q].x, hi4[q].y, hi4[q].z, hi4[q].w};
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        float v = rem[n][i];
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        if (kk == 0) gxs[(16 + i) * GR_GX_LD + col] = v + bb;
+        for (int c = 0; c < 4; ++c) {
+          unsigned h, l;
+          split2_pair(x0[c], x1[c], h, l);
+          const int o = (mq * 4 + c + 1) * CB_LD + 2 * fp + 8;  // even: one aligned 32-bit store per plane
+          *(unsigned *)(imgh + o) = h;
+          *(unsigned *)(imgl + o) = l;
+        }
       }
     }
   }
   __syncthreads();
-  CF_STAMP(7)
+  CF_STAMP(1)
 
-  // ---- F: layer-2 recurrence (waves 2, 3): only the last state of each direction is kept | waves 0, 1: head -> LDS
-  float *w1s = feat;  // [64][GR_W1_LD], over W_x2
-  if (wave >= 2) {
-    __builtin_amdgcn_s_setprio(3);  // the serial chain issues ahead of a co-resident workgroup's MFMA stream (+1.5 % at scale)
-    const float h_last = cf_recurrence<false>(g, gxs, hb + (2 + dir) * 2 * H, nullptr, dir, unit, half);
-    __builtin_amdgcn_s_setprio(0);
-    if (half == 0) {
-      encs[dir * H + unit] = h_last;
-      if (a.enc) a.enc[(size_t)w * 2 * H + dir * H + unit] = h_last;
+  // ---- B: conv (transposed) -> feat planes
+  {
+    auto load_x = [&](bf16x8_t(&xh)[4], bf16x8_t(&xl)[4], int i) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        int G = ks * 4 + kk;
+        G = G < 15 ? G : 14;  // the 16th group has zero weights: any valid address
+        const int kf = G / 3, h8 = (G - kf * 3) * 8;
+        const int o = b_off[i] + kf * CB_LD + h8;
+        xh[ks] = *(const bf16x8_t *)(imgh + o);
+        xl[ks] = *(const bf16x8_t *)(imgl + o);
+      }
+    };
+    auto store_pos = [&](int i, const f32x4 (&r)[2]) {
+      if (f_off[i] >= 0) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          unsigned h0, l0, h1, l1;
+          split2_pair(fmaxf(r[mt][0], 0.f), fmaxf(r[mt][1], 0.f), h0, l0);
+          split2_pair(fmaxf(r[mt][2], 0.f), fmaxf(r[mt][3], 0.f), h1, l1);
+          const int o = f_off[i] + mt * 16 + kk * 4;
+          *(uint2 *)(fth + o) = make_uint2(h0, h1);
+          *(uint2 *)(ftl + o) = make_uint2(l0, l1);
+        }
+      }
+    };
+    bf16x8_t xh[2][4], xl[2][4];
+    f32x4 prev[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    load_x(xh[0], xl[0], 0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      if (i + 1 < 6) load_x(xh[(i + 1) & 1], xl[(i + 1) & 1], i + 1);
+      f32x4 acc[2] = {{cb[0][0], cb[0][1], cb[0][2], cb[0][3]}, {cb[1][0], cb[1][1], cb[1][2], cb[1][3]}};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const bf16x8_t wh = __builtin_bit_cast(bf16x8_t, wq[0][ks][mt]), wl = __builtin_bit_cast(bf16x8_t, wq[1][ks][mt]);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[i & 1][ks], acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[i & 1][ks], acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[i & 1][ks], acc[mt], 0, 0, 0);
+        }
+      if (i > 0) store_pos(i - 1, prev);
+      prev[0] = acc[0];
+      prev[1] = acc[1];
     }
-  } else {
-    for (int i = tid; i < 64 * 64; i += 128) w1s[(i >> 6) * GR_W1_LD + (i & 63)] = a.w1[i];
-    for (int i = tid; i < a.NOUT * 64; i += 128) w2s[i] = a.w2[i];
+    store_pos(5, prev);
   }
+  // W_x1 planes, B operand: [plane][k-step 20][n-tile 12][lane][8 bf16]; this wave's n-tiles are 3 wave .. 3 wave + 2
+  auto w_ld = [&](int p, int ks, int n) { return ((const uint4 *)a.wx1b)[((size_t)(p * 20 + ks) * 12 + wave * 3 + n) * 64 + lane]; };
+  uint4 bq[3][2][3];  // [ring slot][plane][n]
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int n = 0; n < 3; ++n) bq[s2][p][n] = w_ld(p, s2, n);
+  CF_STAMP(2)
+  __syncthreads();  // feat complete; the image is dead from here on
+  CF_STAMP(3)
+  float *gxs = img + CF_GX, *seq1 = img + CF_SEQ, *hb = img + CF_HB;
+  for (int i = tid; i < 32 * GR_SEQ_LD; i += CF_THREADS) seq1[i] = 0.f;
+  if (tid < 2 * 2 * 2 * H) hb[tid] = 0.f;
+
+  // ---- C: layer-1 input projection
+  const int unit = lane >> 1, half = lane & 1, dir = wave & 1;
+  gru_w g;
+  {
+    const int r1 = 16 + j < OT ? 16 + j : OT - 1;  // rows 19..31 of the second row tile do not exist: clamped, never stored
+    const unsigned short *a0h = fth + j * CB_FLD + kk * 8, *a0l = ftl + j * CB_FLD + kk * 8;
+    const unsigned short *a1h = fth + r1 * CB_FLD + kk * 8, *a1l = ftl + r1 * CB_FLD + kk * 8;
+    f32x4 acc[2][3];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int n = 0; n < 3; ++n) acc[mt][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 20; ++ks) {
+      if (ks + 2 < 20) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int n = 0; n < 3; ++n) bq[(ks + 2) % 3][p][n] = w_ld(p, ks + 2, n);
+      }
+      const bf16x8_t ah[2] = {*(const bf16x8_t *)(a0h + ks * 32), *(const bf16x8_t *)(a1h + ks * 32)};
+      const bf16x8_t al[2] = {*(const bf16x8_t *)(a0l + ks * 32), *(const bf16x8_t *)(a1l + ks * 32)};
+#pragma unroll
+      for (int n = 0; n < 3; ++n) {
+        const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, bq[ks % 3][0][n]), bl = __builtin_bit_cast(bf16x8_t, bq[ks % 3][1][n]);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          acc[mt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh, acc[mt][n], 0, 0, 0);
+          acc[mt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl, acc[mt][n], 0, 0, 0);
+          acc[mt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh, acc[mt][n], 0, 0, 0);
+        }
+      }
+    }
+    if (!FRONT_ONLY) gru_load_w(g, wave < 2 ? a.wh1 : a.wh2, wave < 2 ? a.bh1 : a.bh2, dir, unit, half);
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+      const int col = wave * 48 + n * 16 + j;
+      const float bv = a.bx1[col];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int t = mt * 16 + kk * 4 + r;
+          if (t < OT) gxs[t * GR_GX_LD + col] = acc[mt][n][r] + bv;
+        }
+    }
+  }
+  CF_STAMP(4)
   __syncthreads();
-  CF_STAMP(8)
-
-  // ---- G: detect head: Dense(64, relu) -> Dense(NOUT) -> sigmoid | softmax   (wave 0)
-  if (wave == 0) {
-    float acc = 0.f;
-#pragma unroll 16
-    for (int k = 0; k < 2 * H; ++k) acc = fmaf(w1s[lane * GR_W1_LD + k], encs[k], acc);
-    hid[lane] = fmaxf(acc + a.b1[lane], 0.f);
-    wsync_g();
-    float y = 0.f;
-    if (lane < a.NOUT) {
-      for (int k = 0; k < 2 * H; ++k) y = fmaf(w2s[lane * 64 + k], hid[k], y);
-      y += a.b2[lane];
+  CF_STAMP(5)
+  if (FRONT_ONLY) {
+    float4 *dst = (float4 *)(a.gx_out + (size_t)w * OT * 6 * H);
+    for (int q = tid; q < OT * 6 * H / 4; q += CF_THREADS) {
+      const int e = q * 4, t = e / (6 * H), c = e - t * 6 * H;
+      dst[q] = *(const float4 *)(&gxs[t * GR_GX_LD + c]);
     }
-    if (a.HEAD == 0) {
-      if (lane < a.NOUT) a.out[(size_t)w * a.NOUT + lane] = sigmoid_f(y);
-    } else {
-      float mx = (lane < a.NOUT) ? y : -INFINITY;
-      for (int o = 1; o < 8; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-      float e = (lane < a.NOUT) ? expf(y - mx) : 0.f;
-      float sum = e;
-      for (int o = 1; o < 8; o <<= 1) sum += __shfl_xor(sum, o);
-      if (lane < a.NOUT) a.out[(size_t)w * a.NOUT + lane] = e / sum;
-    }
+    return;
   }
-  CF_STAMP(9)
-#undef CF_STAMP
+  cf_phases_d_to_g(a, img, feat, g, w);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -937,11 +1190,14 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
   win_addr wa = {d_win_row, d_win_valid, row0, hop, valid_const, mel_rows};
   if (c.generic) return crnn_forward_generic(ctx, m, wa, d_mel, nw, ws, d_out, d_enc);
   fused_args a = {d_mel, wa, c.conv_w, c.conv_b, c.wx1s, c.bx1, c.wh1, c.bh1, c.wx2s, c.bx2, c.wh2, c.bh2,
-                  c.w1, c.b1, c.w2, c.b2, d_enc, d_out, c.T, c.NOUT, c.HEAD, nullptr, nullptr};
+                  c.w1, c.b1, c.w2, c.b2, d_enc, d_out, c.T, c.NOUT, c.HEAD, nullptr, nullptr, c.cwb, c.wx1b};
+  const bool bf16 = m->precision == WW_PRECISION_BF16X3;
   static bool attr_set = false;
   if (!attr_set) {
     WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
     WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
+    WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, CFB_SMEM_BYTES));
+    WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, CFB_SMEM_BYTES));
     attr_set = true;
   }
   const int thr = crnn_split_threshold();
@@ -949,8 +1205,9 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
     ww_bump b(ws, ~size_t(0));
     a.gx_out = b.take<float>((size_t)nw * c.OT * 6 * c.H);
     {
-      ww_launch_scope scope(ctx, "crnn_fused_kernel<front>");
-      hipLaunchKernelGGL(crnn_fused_kernel<true>, dim3(nw), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, a);
+      ww_launch_scope scope(ctx, bf16 ? "crnn_fused_kernel<front,bf16x3>" : "crnn_fused_kernel<front>");
+      if (bf16) hipLaunchKernelGGL(crnn_fused_bf16_kernel<true>, dim3(nw), dim3(CF_THREADS), CFB_SMEM_BYTES, ctx->stream, a);
+      else hipLaunchKernelGGL(crnn_fused_kernel<true>, dim3(nw), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, a);
     }
     tail_args t = {a.gx_out, c.wh1, c.bh1, c.wx2s, c.bx2, c.wh2, c.bh2, c.w1, c.b1, c.w2, c.b2, d_enc, d_out, c.NOUT, c.HEAD};
     {
@@ -967,8 +1224,9 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
     WW_HIP(ctx, hipMemsetAsync(a.stamps, 0, (size_t)nw * 40 * sizeof(long long), ctx->stream));
   }
   {
-    ww_launch_scope scope(ctx, "crnn_fused_kernel");
-    hipLaunchKernelGGL(crnn_fused_kernel<false>, dim3(nw), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, a);
+    ww_launch_scope scope(ctx, bf16 ? "crnn_fused_kernel<bf16x3>" : "crnn_fused_kernel");
+    if (bf16) hipLaunchKernelGGL(crnn_fused_bf16_kernel<false>, dim3(nw), dim3(CF_THREADS), CFB_SMEM_BYTES, ctx->stream, a);
+    else hipLaunchKernelGGL(crnn_fused_kernel<false>, dim3(nw), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, a);
   }
   WW_HIP(ctx, hipGetLastError());
   if (want_stamps) {
