@@ -263,6 +263,22 @@ def roofline_of(eng, prof, clips, fast_frontend):
     roof["kernel"] = dom
     roof["kernel_avg_us"] = round(dom_ms * 1e3, 3)
     roof["all_kernels_avg_us"] = per_kernel
+    # every priced kernel of the step against its own bound (the dominant one is the object itself)
+    every = {}
+    for name, rec in prof.items():
+        if name not in kw:
+            continue
+        b, nb, fl = kw[name]
+        t = rec["total_ms"] / max(rec["calls"], 1) * 1e-3
+        if b == "hbm":
+            every[name] = {"bound": "hbm", "achieved": nb / t / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": nb / t / PEAK_HBM}
+        elif name.endswith("<bf16x3>"):
+            every[name] = {"bound": "mfma", "achieved": 3.0 * fl / t / 1e12, "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s",
+                           "frac": 3.0 * fl / t / PEAK_BF16_MFMA}
+        else:
+            every[name] = {"bound": "mfma", "achieved": fl / t / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
+                           "frac": fl / t / PEAK_F32_MFMA}
+    roof["kernels"] = every
     roof["method"] = "HIP events around each launch (ww_profile_enable) on the launching stream, K steps right after the timed regions"
     return roof
 

@@ -19,3 +19,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 for c in FETCH_SIZE WRITE_SIZE; do for m in crnn wavenet; do python3 $R/tools/pmc_summary.py $O/pmct_${c}_$m; done; done
 ls $O $O/prof_single | head -40
+cd $R
+python tools/slide_throughput.py 10 > $O/slide_throughput_10min.json 2> /dev/null
+bash tools/pmc_crnn.sh 256 > $O/sq_crnn_256.txt 2>&1
+bash tools/pmc_crnn.sh 4096 > $O/sq_crnn_4096.txt 2>&1
+bash tools/pmc_fe.sh > $O/sq_logmel_256.txt 2>&1
+for f in sq_crnn_256 sq_crnn_4096 sq_logmel_256; do echo $f; tail -n 6 $O/$f.txt; done
