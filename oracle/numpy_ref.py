@@ -205,3 +205,76 @@ def wfst_smooth(posterior_probs) -> List[int]:
         path[t] = st
         st = int(back[t, st])
     return path
+
+
+class RefKeywordRecognizer:
+    """Reference ``spokestack/asr/keyword/tflite.py:15-195`` on ``RefRing``s, with the three models supplied as
+    callables (``filter_model``: ``[1,257] -> [1,40]``; ``encode_model(window, state) -> (frame, state)``;
+    ``detect_model(window) -> [[posteriors]]``).  ``context`` needs ``is_active``, ``transcript``, ``confidence``, ``event``."""
+
+    def __init__(self, classes, filter_model, encode_model, detect_model, mel_length: int, mel_width: int, state_shape,
+                 encode_length: int, encode_width: int, pre_emphasis: float = 0.97, sample_rate: int = 16000,
+                 fft_hop_length: int = 10, posterior_threshold: float = 0.5, window_size: int = 512) -> None:
+        self.classes = classes
+        self.pre_emphasis = pre_emphasis
+        self.hop_length = int(fft_hop_length * sample_rate / 1000)  # :41
+        self.filter_model, self.encode_model, self.detect_model = filter_model, encode_model, detect_model
+        self._window_size = window_size  # :62
+        self._fft_window = np.hanning(self._window_size)  # :63
+        self.state = np.zeros(state_shape, np.float32)  # :75
+        self.sample_window = RefRing(self._window_size)  # :79-81
+        self.frame_window = RefRing(mel_length, (mel_width,))  # :82-84
+        self.encode_window = RefRing(encode_length, (encode_width,))  # :85-87
+        self.frame_window.fill(0.0)  # :91
+        self.encode_window.fill(-1.0)  # :92
+        self._posterior_threshold = posterior_threshold
+        self._prev_sample = 0.0
+        self._is_active = False
+
+    def __call__(self, context, frame) -> None:  # :98-105
+        self._sample(context, frame)
+        if not context.is_active and self._is_active:
+            self._detect(context)
+        self._is_active = context.is_active
+
+    def _sample(self, context, frame) -> None:  # :107-129
+        frame = normalise_pcm(frame)
+        prev_sample = frame[-1]
+        frame -= self.pre_emphasis * np.append(self._prev_sample, frame[:-1])
+        self._prev_sample = prev_sample
+        for sample in frame:
+            self.sample_window.write(sample)
+            if self.sample_window.is_full:
+                if context.is_active:
+                    self._analyze()
+                self.sample_window.rewind().seek(self.hop_length)
+
+    def _analyze(self) -> None:  # :131-158
+        fr = self.sample_window.read_all()
+        fr = np.abs(np.fft.rfft(fr * self._fft_window, n=self._window_size)).astype(np.float32)
+        mel = self.filter_model(np.expand_dims(fr, 0))[0]
+        self.frame_window.rewind().seek(1)
+        self.frame_window.write(mel)
+        win = np.expand_dims(self.frame_window.read_all(), 0)
+        enc, self.state = self.encode_model(win, self.state)
+        self.encode_window.rewind().seek(1)
+        self.encode_window.write(enc)
+
+    def _detect(self, context) -> None:  # :165-184
+        win = np.expand_dims(self.encode_window.read_all(), 0)
+        posterior = self.detect_model(win)[0][0]
+        class_index = np.argmax(posterior)
+        confidence = posterior[class_index]
+        if confidence >= self._posterior_threshold:
+            context.transcript = self.classes[class_index]
+            context.confidence = confidence
+            context.event("recognize")
+        else:
+            context.event("timeout")
+        self.reset()
+
+    def reset(self) -> None:  # :186-191
+        self.sample_window.reset()
+        self.frame_window.reset().fill(0.0)
+        self.encode_window.reset().fill(-1.0)
+        self.state[:] = 0.0

@@ -514,3 +514,67 @@ def test_many_stream_pipeline_matches_single_stream_stages(assets):
     assert 4 <= n_active <= S - 4, n_active
     assert any("deactivate" in lg for lg in b_logs)
     assert np.isfinite(np.array(b_post)).all()
+
+
+def test_keyword_recognizer_matches_the_reference_loop(assets, oracle_dirs):
+    """``KeywordRecognizer`` (spokestack/asr/keyword/tflite.py:99-184) - HIP front end, frames analysed
+    only while the context is active, autoregressive encoder, detection on the falling edge of ``is_active`` - against the
+    literal restatement of the reference class (oracle/numpy_ref.RefKeywordRecognizer, op-by-op filter graph).  The
+    reference ships no keyword models: encoder and detector are deterministic stand-ins with TFLiteModel's protocol."""
+    from spokestack.asr.keyword.tflite import KeywordRecognizer  # the reference's import path
+    from wwhip.keyword import CallableModel
+    from wwhip.context import SpeechContext
+    from oracle import numpy_ref as NR
+    rng = np.random.default_rng(55)
+    MEL_LEN, ENC_LEN, ENC_W, CLASSES = 12, 9, 6, ["up", "down", "stop"]
+    w_enc = rng.normal(0, 0.3, (40, ENC_W)).astype(np.float32)
+    w_st = rng.normal(0, 0.3, (ENC_W, ENC_W)).astype(np.float32)
+    w_det = rng.normal(0, 1.0, (ENC_W, len(CLASSES))).astype(np.float32)
+
+    def encode(win, state):  # [1, MEL_LEN, 40], [1, ENC_W] -> ([1, ENC_W], [1, ENC_W])
+        e = np.tanh(win[0].mean(axis=0) @ w_enc * 0.2 + state[0] @ w_st).astype(np.float32)[None]
+        return e, (0.5 * state + 0.5 * e).astype(np.float32)
+
+    def detect(win):  # [1, ENC_LEN, ENC_W] -> [[p_class...]]
+        z = win[0].mean(axis=0) @ w_det
+        p = np.exp(z - z.max())
+        return [(p / p.sum()).astype(np.float32)[None]]
+
+    enc_m = CallableModel(encode, [(1, MEL_LEN, 40), (1, ENC_W)], [(1, ENC_W), (1, ENC_W)])
+    det_m = CallableModel(detect, [(1, ENC_LEN, ENC_W)], [(1, len(CLASSES))])
+    with pytest.raises(ValueError):
+        KeywordRecognizer(["a", "b"], encode_model=enc_m, detect_model=det_m, filter_model_dir=os.path.join(assets, "CRNN"))
+    with pytest.raises(ValueError):
+        KeywordRecognizer(CLASSES, fft_window_type="hamming", encode_model=enc_m, detect_model=det_m,
+                          filter_model_dir=os.path.join(assets, "CRNN"))
+
+    def run(stage, thr_note):
+        ctx = SpeechContext()
+        events = []
+        for name in ("recognize", "timeout"):
+            ctx.add_handler(name, (lambda n: (lambda c: events.append((n, c.transcript, float(c.confidence)))))(name))
+        trace = []
+        for t in range(len(frames)):
+            ctx.is_active = bool(active[t])
+            stage(ctx, frames[t])
+            trace.append(len(events))
+        return events, trace
+
+    frames = np.clip(rng.normal(0, 4000, (160, 320)), -32768, 32767).astype(np.int16)
+    active = np.zeros(160, bool)
+    for a, b in ((5, 40), (41, 43), (60, 61), (90, 150)):   # long, very short (no frame completes), one tick, long
+        active[a:b] = True
+    mdir = oracle_dirs["CRNN"]
+    seen = set()
+    for thr in (0.2, 0.995):
+        got = run(KeywordRecognizer(CLASSES, model_dir=os.path.join(assets, "CRNN"), posterior_threshold=thr,
+                                    encode_model=enc_m, detect_model=det_m), thr)
+        ref = NR.RefKeywordRecognizer(CLASSES, lambda a: mdir.filter(a)[0], encode, lambda w: detect(w), MEL_LEN, 40, (1, ENC_W),
+                                      ENC_LEN, ENC_W, posterior_threshold=thr)
+        want = run(ref, thr)
+        assert got[1] == want[1]                                   # the same tick fires each event
+        assert len(got[0]) == len(want[0]) == 4
+        for (gn, gt, gc), (wn, wt, wc) in zip(got[0], want[0]):
+            assert (gn, gt) == (wn, wt) and abs(gc - wc) < TOL
+        seen |= {e[0] for e in got[0]}
+    assert seen == {"recognize", "timeout"}
