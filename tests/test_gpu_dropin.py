@@ -578,3 +578,37 @@ def test_keyword_recognizer_matches_the_reference_loop(assets, oracle_dirs):
             assert (gn, gt) == (wn, wt) and abs(gc - wc) < TOL
         seen |= {e[0] for e in got[0]}
     assert seen == {"recognize", "timeout"}
+
+
+def test_entry_points_leave_the_callers_device_alone(assets):
+    """Every C entry point switches to its context's device only for the duration of the call (ww_device_scope): with
+    torch on ANOTHER current device the engine on device 0 still computes correctly and torch's current device is
+    unchanged.  Needs two GPUs (skipped on the one-GPU boxes); with one GPU the same calls at least must not move it."""
+    import torch
+    from wwhip import _lib
+    from wwhip.engine import Engine
+    from wwhip.evaluate import clip_posteriors, synth_testset
+    from oracle.cpu import CpuOracle
+    n_dev = torch.cuda.device_count()
+    other = 1 if n_dev >= 2 else 0
+    torch.cuda.set_device(other)
+    try:
+        ctx = _lib.Context(0)
+        eng = Engine(os.path.join(assets, "CRNN"), device=0, ctx=ctx)
+        assert torch.cuda.current_device() == other
+        rng = np.random.default_rng(2)
+        wins = rng.uniform(0, 6, (5, eng.window, 40)).astype(np.float32)
+        got = eng.forward(wins)
+        mel = eng.logmel([np.clip(rng.normal(0, 3000, 9000), -32768, 32767).astype(np.int16)])[0]
+        clips, _ = synth_testset(6, seed=9)
+        p_one, _ = clip_posteriors(eng, clips)          # torch buffers must land on the ENGINE's device
+        assert torch.cuda.current_device() == other
+        ora = CpuOracle(eng.blob)
+        assert np.abs(got - ora.forward(wins)).max() < TOL and mel.shape[1] == 40 and len(p_one) == 6
+        eng.close()
+        ctx.close()
+        assert torch.cuda.current_device() == other
+    finally:
+        torch.cuda.set_device(0)
+    if n_dev < 2:
+        pytest.skip("one GPU: only the no-op half of the check could run")
