@@ -229,7 +229,13 @@ def test_crnn_split_bf16_mode(assets, oracles, golden, name):
         big[::7, 140:] = 0
         got_big = e.forward(big)
         np.testing.assert_array_equal(got_big[:300], e.forward(big[:300]))   # same arithmetic in both forms
+        # ragged clips: windows with valid < T rows (zero padded in the kernel's staging) and sliding windows
+        from wwhip.evaluate import clip_posteriors, synth_testset
+        clips, _ = synth_testset(40, seed=5, min_s=0.6, max_s=2.4)
+        one_b, slide_b = clip_posteriors(e, clips)
         e.set_precision("fp32")
+        one_f, slide_f = clip_posteriors(e, clips)
+        assert np.abs(one_b - one_f).max() < 5e-5 and np.abs(np.concatenate(slide_b) - np.concatenate(slide_f)).max() < 5e-5
         ref = e.forward(big)
         assert np.abs(got_big - ref).max() < 5e-5      # measured 2.5e-5 over 1,300 windows
         assert np.abs(e.forward(wins) - want).max() < 2e-6
