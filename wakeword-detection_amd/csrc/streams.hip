@@ -12,10 +12,14 @@
 // sample and mel data stay in HBM.
 //
 //   stream_frontend_kernel  one workgroup (2 waves) per stream: read the tick's samples and control words from
-//                           pinned host memory, shift the mel history by the
-//                           rows appended last tick, normalise + pre-emphasise the 320 new
+//                           pinned host memory, normalise + pre-emphasise the 320 new
 //                           samples, FFT + mel for each new frame (one wave per frame) when
 //                           the stream's is_speech bit is set, keep the ring tail.
+//   The mel window of a stream is a MIRRORED ring of R = T + 1 slots (2R rows): row k of the stream's history is written at
+//   k % R and at k % R + R, so the latest T rows up to row k are always the contiguous block [(k + 2) % R, +T) that the
+//   model kernels' window descriptors want - two 160-byte stores per new frame instead of moving the whole 24-29 KB window
+//   every tick (round 1's ping-pong shift).  The one spare slot is what lets BOTH windows of a two-frame tick be evaluated
+//   after both rows are in place: the window that ends at row k leaves out exactly the slot of row k + 1.
 //   then the regular CRNN / Wavenet kernels run on the compacted list of new windows.
 #include "common.h"
 #include "fft_device.h"
@@ -27,15 +31,14 @@ struct ww_streams {
   const ww_model *model = nullptr;
   int S = 0;
   ww_frontend_params fp = {};
-  int T = 0, F = 0, NO = 0, HR = 0;  // HR = history rows per stream = T + 2
+  int T = 0, F = 0, NO = 0, HR = 0;  // HR = history rows per stream = 2 (T + 1) (mirrored ring)
   // device state
   float *ring = nullptr;      // [S][ST_RING]
-  float *hist[2] = {nullptr, nullptr};  // [S][T + 2][F], ping-pong
+  float *hist = nullptr;      // [S][2 (T + 1)][F], mirrored ring
   float *prev = nullptr;      // [S] pre-emphasis carry (raw previous sample)
-  int cur = 0;
   // per-tick device buffers
   int16_t *d_frames = nullptr;   // [S][320]
-  int32_t *d_ctl = nullptr;      // [S][4]: fill, n_frames, flags, appended_last_tick
+  int32_t *d_ctl = nullptr;      // [S][4]: fill, n_frames, flags, pos (history rows written so far, mod T + 1)
   int64_t *d_win_row = nullptr;  // [2S]
   int32_t *d_win_valid = nullptr;
   void *ws = nullptr;
@@ -51,7 +54,7 @@ struct ww_streams {
   // cost 20 us of a 107 us tick); d_pack mirrors the layout and holds the window descriptors the kernel copies over
   char *h_pack = nullptr, *d_pack = nullptr, *h_pack_dev = nullptr;  // h_pack_dev: the device's address of h_pack
   size_t pack_bytes = 0;
-  std::vector<int> fill, appended;
+  std::vector<int> fill, pos;
 };
 
 struct stream_fe_args {
@@ -63,8 +66,7 @@ struct stream_fe_args {
   int32_t *d_valid;
   int nw, S;
   float *ring;
-  const float *hist_in;
-  float *hist_out;
+  float *hist;
   float *prev;
   int T, F, HR;
   float divisor;
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(128) void stream_frontend_kernel(stream_fe_args a) 
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int s = blockIdx.x;
-  const int fill = a.ctl[s * 4 + 0], n_frames = a.ctl[s * 4 + 1], flags = a.ctl[s * 4 + 2], shift_rows = a.ctl[s * 4 + 3];
+  const int fill = a.ctl[s * 4 + 0], n_frames = a.ctl[s * 4 + 1], flags = a.ctl[s * 4 + 2], pos = a.ctl[s * 4 + 3];
   const bool speech = flags & 1, skip = flags & 2;
 
   size_t off = 0;
@@ -96,31 +98,6 @@ __global__ __launch_bounds__(128) void stream_frontend_kernel(stream_fe_args a) 
   for (int i = s * 128 + tid; i < a.nw; i += a.S * 128) {
     a.d_row[i] = a.h_row[i];
     a.d_valid[i] = a.h_valid[i];
-  }
-  // ---- mel history: drop the rows that were appended last tick (hist_out[0..T) = hist_in[shift..shift+T))
-  {
-    const float *src = a.hist_in + ((size_t)s * a.HR + shift_rows) * a.F;
-    float *dst = a.hist_out + (size_t)s * a.HR * a.F;
-    if ((a.F & 3) == 0) {  // rows are multiples of 16 bytes: every load of the copy in flight before the first store
-      const int n4 = a.T * a.F / 4;
-      const float4 *s4 = (const float4 *)src;
-      float4 *d4 = (float4 *)dst;
-      for (int i0 = 0; i0 < n4; i0 += 128 * 4) {
-        float4 v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int i = i0 + q * 128 + tid;
-          v[q] = i < n4 ? s4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int i = i0 + q * 128 + tid;
-          if (i < n4) d4[i] = v[q];
-        }
-      }
-    } else {
-      for (int i = tid; i < a.T * a.F; i += 128) dst[i] = src[i];
-    }
   }
   if (skip) return;  // context.is_active: the frame is not sampled at all (tflite.py:139-140)
 
@@ -158,7 +135,14 @@ __global__ __launch_bounds__(128) void stream_frontend_kernel(stream_fe_args a) 
     const int st = lane < a.n_mel ? a.start[lane] : 0;
     const float bias = lane < a.n_mel ? a.bias[lane] : 0.0f;
     const float mv = mel_band(mg, wl, st, bias, a.floor_v, a.log_off, a.scale, lane);
-    if (lane < a.n_mel) a.hist_out[((size_t)s * a.HR + a.T + wave) * a.F + lane] = mv;
+    if (lane < a.n_mel) {
+      const int slots = a.T + 1;
+      int p = pos + wave;  // mirrored ring: the row goes to p % slots and p % slots + slots
+      p = p >= slots ? p - slots : p;
+      float *h = a.hist + ((size_t)s * a.HR + p) * a.F + lane;
+      h[0] = mv;
+      h[(size_t)slots * a.F] = mv;
+    }
   }
   __syncthreads();
   // ---- keep the ring tail
@@ -166,16 +150,11 @@ __global__ __launch_bounds__(128) void stream_frontend_kernel(stream_fe_args a) 
   for (int i = tid; i < keep; i += 128) ring[i] = x[n_frames * a.hop + i];
 }
 
-__global__ void stream_reset_kernel(float *ring, float *hist0, float *hist1, const int32_t *ids, int n, int S, int HR, int F) {
+__global__ void stream_reset_kernel(float *hist, const int32_t *ids, int S, int HR, int F) {
   const int b = blockIdx.x;
   const int s = ids ? ids[b] : b;
   if (s < 0 || s >= S) return;
-  for (int i = threadIdx.x; i < HR * F; i += blockDim.x) {
-    hist0[(size_t)s * HR * F + i] = 0.f;
-    hist1[(size_t)s * HR * F + i] = 0.f;
-  }
-  (void)ring;
-  (void)n;
+  for (int i = threadIdx.x; i < HR * F; i += blockDim.x) hist[(size_t)s * HR * F + i] = 0.f;
 }
 
 extern "C" {
@@ -184,7 +163,7 @@ int ww_stream_destroy(ww_streams *st) {
   if (!st) return WW_OK;
   ww_device_scope dev_scope(st->ctx->device);
   hipStreamSynchronize(st->ctx->stream);
-  void *dev[] = {st->ring, st->hist[0], st->hist[1], st->prev, st->d_pack, st->ws};
+  void *dev[] = {st->ring, st->hist, st->prev, st->d_pack, st->ws};
   for (void *p : dev)
     if (p) hipFree(p);
   void *host[] = {st->h_pack, st->h_out};
@@ -203,12 +182,11 @@ int ww_stream_create(ww_ctx *ctx, const ww_model *model, int32_t S, const ww_fro
   ww_device_scope dev_scope(ctx->device);  // the caller's current device is left as it was
   ww_streams *st = new ww_streams();
   st->ctx = ctx; st->model = model; st->S = S; st->fp = *fp;
-  st->T = model->info.window; st->F = model->info.n_mel; st->NO = model->info.n_out; st->HR = st->T + 2;
+  st->T = model->info.window; st->F = model->info.n_mel; st->NO = model->info.n_out; st->HR = 2 * (st->T + 1);
   const size_t hist_elems = (size_t)S * st->HR * st->F;
   size_t ws_bytes = (model->kind == WW_KIND_CRNN ? ww_crnn_workspace(model, 2 * S) : ww_wave_workspace(model, 2 * S));
   bool ok = hipMalloc((void **)&st->ring, (size_t)S * ST_RING * 4) == hipSuccess &&
-            hipMalloc((void **)&st->hist[0], hist_elems * 4) == hipSuccess &&
-            hipMalloc((void **)&st->hist[1], hist_elems * 4) == hipSuccess &&
+            hipMalloc((void **)&st->hist, hist_elems * 4) == hipSuccess &&
             hipMalloc((void **)&st->prev, (size_t)S * 4) == hipSuccess &&
             hipMalloc(&st->ws, ws_bytes) == hipSuccess &&
             hipHostMalloc((void **)&st->h_out, (size_t)2 * S * st->NO * 4) == hipSuccess;
@@ -235,12 +213,11 @@ int ww_stream_create(ww_ctx *ctx, const ww_model *model, int32_t S, const ww_fro
     return ww_fail(ctx, WW_EHIP, "pinned staging buffers are not visible to the device");
   }
   hipMemsetAsync(st->ring, 0, (size_t)S * ST_RING * 4, ctx->stream);
-  hipMemsetAsync(st->hist[0], 0, hist_elems * 4, ctx->stream);
-  hipMemsetAsync(st->hist[1], 0, hist_elems * 4, ctx->stream);
+  hipMemsetAsync(st->hist, 0, hist_elems * 4, ctx->stream);
   hipMemsetAsync(st->prev, 0, (size_t)S * 4, ctx->stream);
   WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
   st->fill.assign(S, 0);
-  st->appended.assign(S, 0);
+  st->pos.assign(S, 0);
   *out = st;
   return WW_OK;
 }
@@ -262,8 +239,7 @@ int ww_stream_reset(ww_streams *st, const int32_t *ids, int32_t n) {
     WW_HIP(ctx, hipMemcpyAsync(st->d_win_valid, st->h_win_valid, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     d_ids = st->d_win_valid;
   }
-  hipLaunchKernelGGL(stream_reset_kernel, dim3(count), dim3(256), 0, ctx->stream, st->ring, st->hist[0], st->hist[1], d_ids,
-                     count, st->S, st->HR, st->F);
+  hipLaunchKernelGGL(stream_reset_kernel, dim3(count), dim3(256), 0, ctx->stream, st->hist, d_ids, st->S, st->HR, st->F);
   WW_HIP(ctx, hipGetLastError());
   WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
   // WakewordTrigger.reset (tflite.py:241-246): sample window emptied, frame window zeroed;
@@ -271,7 +247,7 @@ int ww_stream_reset(ww_streams *st, const int32_t *ids, int32_t n) {
   for (int i = 0; i < count; ++i) {
     const int s = ids ? ids[i] : i;
     st->fill[s] = 0;
-    st->appended[s] = 0;
+    st->pos[s] = 0;
   }
   return WW_OK;
 }
@@ -293,16 +269,17 @@ int ww_stream_step(ww_streams *st, const int16_t *frames, const uint8_t *is_spee
     st->h_ctl[s * 4 + 0] = st->fill[s];
     st->h_ctl[s * 4 + 1] = nf;
     st->h_ctl[s * 4 + 2] = flags;
-    st->h_ctl[s * 4 + 3] = st->appended[s];
+    st->h_ctl[s * 4 + 3] = st->pos[s];
     const int np = (flags & 1) && !(flags & 2) ? nf : 0;
     n_post[s] = np;
     for (int k = 0; k < np; ++k) {
-      st->h_win_row[nw] = (int64_t)s * st->HR + k + 1;
+      // the T rows that end at this tick's new row k are the contiguous block that starts at (pos + k + 2) % R
+      st->h_win_row[nw] = (int64_t)s * st->HR + (st->pos[s] + k + 2) % (st->T + 1);
       st->h_win_valid[nw] = st->T;
       ++nw;
     }
     if (!(flags & 2)) st->fill[s] = st->fill[s] + WW_CHUNK - nf * hop;
-    st->appended[s] = np;
+    st->pos[s] = (st->pos[s] + np) % (st->T + 1);
   }
   memcpy(st->h_frames, frames, (size_t)S * WW_CHUNK * 2);
   const ww_model *m = st->model;
@@ -315,7 +292,7 @@ int ww_stream_step(ww_streams *st, const int16_t *frames, const uint8_t *is_spee
   a.h_valid = (const int32_t *)(st->h_pack_dev + ((char *)st->h_win_valid - st->h_pack));
   a.d_row = st->d_win_row; a.d_valid = st->d_win_valid; a.nw = nw; a.S = S;
   a.ring = st->ring;
-  a.hist_in = st->hist[st->cur]; a.hist_out = st->hist[st->cur ^ 1]; a.prev = st->prev;
+  a.hist = st->hist; a.prev = st->prev;
   a.T = st->T; a.F = st->F; a.HR = st->HR;
   a.divisor = st->fp.pcm_divisor; a.clip = st->fp.clip; a.preemph = st->fp.pre_emphasis; a.hop = hop;
   a.start = f.start; a.wpad = f.wpad; a.bias = f.bias;
@@ -332,9 +309,8 @@ int ww_stream_step(ww_streams *st, const int16_t *frames, const uint8_t *is_spee
     }
   }
   WW_HIP(ctx, hipGetLastError());
-  st->cur ^= 1;
   if (nw) {
-    const float *d_hist = st->hist[st->cur];
+    const float *d_hist = st->hist;
     int rc = m->kind == WW_KIND_CRNN
                  ? ww_k_crnn_forward(ctx, m, d_hist, (int64_t)S * st->HR, st->d_win_row, st->d_win_valid, 0, 0, 0, nw, st->ws, st->h_out_dev, nullptr)
                  : ww_k_wave_forward(ctx, m, d_hist, (int64_t)S * st->HR, st->d_win_row, st->d_win_valid, 0, 0, 0, nw, st->ws, st->h_out_dev, nullptr);
