@@ -413,9 +413,12 @@ def main():
         local_rank = local_rank % max(n_dev, 1)
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # WW_BENCH_FORCE_DIST=1: go through the process-group code (barriers, the posterior all_gather, MAX-reduced times) even
+    # at world size 1 - lets a one-GPU box exercise the RCCL path the multi-GPU runs take
+    if world > 1 or os.environ.get("WW_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29671")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:

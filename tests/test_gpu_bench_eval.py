@@ -137,3 +137,36 @@ def test_cfg1_full_size_vs_oracle(testset_one_rank):
     np.testing.assert_array_equal(one["fa_count"], wc)
     np.testing.assert_array_equal(one["frr"], wf)
     assert one["frr_at_0.5_fa_per_hour"] == frr_at_fa(wf, wa, 0.5)
+
+
+def test_bench_rccl_path_at_world_size_one():
+    """The multi-GPU runs use the `nccl` (= RCCL) backend with device tensors in the posterior gather and the timing
+    reductions; a one-GPU box can at least run that code at world size 1 (WW_BENCH_FORCE_DIST=1)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "4", "--no-extra",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
+                       env=dict(env, WW_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["timed_regions"]["n"] >= 5
+
+
+def test_posterior_gather_over_rccl(tmp_path):
+    """wwhip.dist.gather_posteriors with the nccl backend and CUDA payloads (one rank: the collective still runs)."""
+    script = tmp_path / "g.py"
+    script.write_text(f"""
+import os, sys
+sys.path[:0] = [{ROOT!r}, os.path.join({ROOT!r}, "wakeword-detection_amd")]
+import numpy as np, torch, torch.distributed as dist
+from wwhip import dist as D
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+idx = [4, 0, 2]
+full = D.gather_posteriors(np.array([0.4, 0.0, 0.2], np.float32), idx, 6, device="cuda")
+assert full.tolist() == [0.0, 0.0, np.float32(0.2), 0.0, np.float32(0.4), 0.0], full
+dist.barrier(); dist.destroy_process_group(); print("ok")
+""")
+    env = dict({k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")},
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29672", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
