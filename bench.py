@@ -387,7 +387,7 @@ def main():
                          "fp32 accumulate; auto = fp32 for CRNN (BASELINE cfg 2), bf16x3 for Wavenet (cfg 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="headline job only: skip the wavenet / streaming / eval legs")
-    ap.add_argument("--stream-ticks", type=int, default=2000)
+    ap.add_argument("--stream-ticks", type=int, default=10000)
     ap.add_argument("--eval-clips", type=int, default=2048)
     args = ap.parse_args()
 
