@@ -624,7 +624,7 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
   __syncthreads();  // gx complete; nobody reads feat any more
   CF_STAMP(5)
   if (FRONT_ONLY) {
-    // large batches: the recurrences run in their own kernel (gru_tail_kernel), where six windows share a CU and no MFMA
+    // large batches: the recurrences run in their own kernel (gru_tail_kernel), where seven windows share a CU and no MFMA
     // stream competes with their serial chains; gx1 (14.6 KB per window) crosses memory instead of feat (48.6 KB)
     float4 *dst = (float4 *)(a.gx_out + (size_t)w * OT * 6 * H);
     for (int q = tid; q < OT * 6 * H / 4; q += CF_THREADS) {
@@ -878,8 +878,8 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_bf16_kernel(fused_ar
 
 // ------------------------------------------------------------------------------------------
 // gru_tail_kernel: everything behind the layer-1 input projections for one window in a TWO-wave workgroup (wave 0
-// forward, wave 1 backward), for large batches: 25 KB of LDS and 2 waves per window put six windows on a CU, so the
-// strictly serial recurrences (38 steps of ~500 cycles) of twelve waves interleave on the vector ALUs instead of one
+// forward, wave 1 backward), for large batches: 22.7 KB of LDS, 128 registers and 2 waves per window put seven windows on a CU, so the
+// strictly serial recurrences (38 steps of ~500 cycles) of fourteen waves interleave on the vector ALUs instead of one
 // window's sitting beside another's fp32 MFMA stream (which runs on the same datapath: measured 2x slower steps).
 // Phases as D..G of crnn_fused_kernel; the layer-2 projection takes its B operands straight from L2.
 // ------------------------------------------------------------------------------------------
@@ -891,14 +891,14 @@ struct tail_args {
   float *enc, *out;
   int NOUT, HEAD;
 };
-// LDS (floats): gx [20][196] | seq1 [20][68] (rows 19 zero) | h [2][2][2][32] | enc [64] | hid [64] = 22.7 KB: six per CU
+// LDS (floats): gx [20][196] | seq1 [20][68] (rows 19 zero) | h [2][2][2][32] | enc [64] | hid [64] = 22.7 KB: seven per CU
 #define GT_SEQ (20 * GR_GX_LD)
 #define GT_HB (GT_SEQ + 20 * GR_SEQ_LD)
 #define GT_ENC (GT_HB + 2 * 2 * 2 * GR_H)
 #define GT_HID (GT_ENC + 2 * GR_H)
 #define GT_SMEM_FLOATS (GT_HID + 2 * GR_H)
 
-__global__ __launch_bounds__(128, 3) void gru_tail_kernel(tail_args a) {
+__global__ __launch_bounds__(128, 4) void gru_tail_kernel(tail_args a) {
   constexpr int H = GR_H, OT = CV_OT;
   __shared__ __align__(16) float sm[GT_SMEM_FLOATS];
   float *gxs = sm, *seq1 = sm + GT_SEQ, *hb = sm + GT_HB, *encs = sm + GT_ENC, *hid = sm + GT_HID;
@@ -918,7 +918,6 @@ __global__ __launch_bounds__(128, 3) void gru_tail_kernel(tail_args a) {
   for (int i = tid; i < 2 * 2 * 2 * H; i += 128) hb[i] = 0.f;
   __syncthreads();
   cf_recurrence<true>(g, gxs, hb + dir * 2 * H, seq1, dir, unit, half);
-  gru_load_w(g, a.wh2, a.bh2, dir, unit, half);  // in flight during the projection
   __syncthreads();
   // layer-2 input projection: wave d owns n-tiles 6 d .. 6 d + 5, in two passes of three
 #pragma unroll 1
@@ -954,8 +953,12 @@ __global__ __launch_bounds__(128, 3) void gru_tail_kernel(tail_args a) {
       }
     }
   }
+  // layer-2 recurrent weights: requested only now, when the projection's operands are dead - the kernel fits 128 registers
+  // (four waves per SIMD instead of three); one L2 latency per window, partly behind the barrier
+  gru_w g2;
+  gru_load_w(g2, a.wh2, a.bh2, dir, unit, half);
   __syncthreads();
-  const float h_last = cf_recurrence<false>(g, gxs, hb + (2 + dir) * 2 * H, nullptr, dir, unit, half);
+  const float h_last = cf_recurrence<false>(g2, gxs, hb + (2 + dir) * 2 * H, nullptr, dir, unit, half);
   if (half == 0) {
     encs[dir * H + unit] = h_last;
     if (a.enc) a.enc[(size_t)w * 2 * H + dir * H + unit] = h_last;

@@ -32,6 +32,8 @@
 // spokestack/wakeword/tflite.py:175-176, result cast to float32); REAL = float is the fast mode.
 #include "common.h"
 
+#include <vector>
+
 #include "fft_device.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -70,7 +72,22 @@ struct logmel_args {
   const float *frames;
   float *mag_out;
   int64_t n_frames_direct;
+  long long *stamps;  // development (-DWW_FE_STAMPS=1): [workgroups][4 waves][12] s_memtime at the phase boundaries
 };
+
+#ifndef WW_FE_STAMPS
+#define WW_FE_STAMPS 0
+#endif
+#if WW_FE_STAMPS
+#define FE_STAMP(i_)                                                                                         \
+  {                                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wave) * 12 + (i_)] = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+  }
+#else
+#define FE_STAMP(i_)
+#endif
 
 // int16 / divisor, correctly rounded (reference: frame.astype(np.float32) / 32767, tflite.py:150).
 // For the two divisors in use (32767, 32768) the quotient of ANY int16 is obtained exactly by
@@ -219,6 +236,7 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? 4 : 5) void logmel_kernel(log
   const int64_t f0 = (int64_t)tile_idx * FPB;
   if (f0 >= nf) return;
   const int nfb = (int)((nf - f0) < FPB ? (nf - f0) : FPB);
+  FE_STAMP(0)
 
   // ---- LDS carve-up
   size_t off = 0;
@@ -361,7 +379,9 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? 4 : 5) void logmel_kernel(log
       if (VEC == 8) dst[1] = make_float4(o[4], o[5], o[6], o[7]);
     }
   }
+  FE_STAMP(1)
   __syncthreads();
+  FE_STAMP(2)
 
   // ---- FFT: every 16-lane row of a wave owns one frame (4 frames per wave at a time)
   unsigned char *wb = wave == WAVES - 1 ? (unsigned char *)tile : wbuf + (size_t)wave * wbuf_bytes<R>();
@@ -399,11 +419,14 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? 4 : 5) void logmel_kernel(log
       }
     }
   }
+  FE_STAMP(3)
   __syncthreads();  // the sample tile is dead now - wave 3's transposes and magnitudes move in
+  FE_STAMP(4)
   // From here on the four waves never meet again: each one carries its own 4 frames to the output.
   if (!active) return;
   {
     dft16<R>(v);
+    FE_STAMP(5)
     if (TW_LDS) {
 #pragma unroll
       for (int pos = 1; pos < 16; ++pos) v[pos] = cmul(v[pos], tb_tw[k_of(pos) * 16 + j]);
@@ -426,6 +449,7 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? 4 : 5) void logmel_kernel(log
 #pragma unroll
       for (int pos = 1; pos < 16; ++pos) v[pos] = cmul(v[pos], p[k_of(pos)]);
     }
+    FE_STAMP(6)
     // 16x16 transpose through LDS, real parts then imaginary parts (same buffer)
     cplx<R> w[16];
     R *trs = tr + sub * 16 * TR_LD;
@@ -458,8 +482,10 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? 4 : 5) void logmel_kernel(log
       for (int n2 = 0; n2 < 16; ++n2) w[n2].im = trs[j * TR_LD + n2];
       lds_fence();
     }
+    FE_STAMP(7)
     // pass 2: lane j = k1 holds Y[n2][k1]; output w[pos] = Z[k1 + 16 k_of(pos)]
     dft16<R>(w);
+    FE_STAMP(8)
     // untangle: with a = Z[k], b = conj Z[256-k]:  2E = a+b, 2O = (a-b)/i, 2T = W512^k 2O and
     //   2X[k] = 2E + 2T,   2X[256-k] = conj(2E - 2T)   ->  two magnitudes per evaluation, k < 128 only;
     //   the factor 2 leaves as an exact 0.5 after the fp32 square root.
@@ -487,6 +513,7 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? 4 : 5) void logmel_kernel(log
 #pragma unroll
     for (int k2 = 1; k2 < 8; ++k2) pz[k2].im = prow[-k2 * TR_LD];
     lds_fence();
+    FE_STAMP(9)
     float *mrow = mg + sub * MAG_LD;
 #pragma unroll
     for (int k2 = 0; k2 < 8; ++k2) {
@@ -525,6 +552,7 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? 4 : 5) void logmel_kernel(log
   //   a group start on different slots mod 4 - conflict-free.  (The fp32 MFMA form of this contraction kept
   //   the SIMD's vector ALU idle for 32 cycles per instruction - fp32 MFMA and VALU share a datapath on gfx950
   //   - and needed three workgroup barriers for the partial sums; this form needs none.)
+  FE_STAMP(10)
   lds_fence();
   {
     const int j = lane >> 2, sub = lane & 3;  // mel phase only: (slot, frame) of this lane
@@ -609,6 +637,7 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? 4 : 5) void logmel_kernel(log
       for (int i = lane; i < nv * a.n_mel; i += 64) dstf[i] = mt[i];
     }
   }
+  FE_STAMP(11)
 }
 
 // STFT magnitude of explicit frames [n][512] -> [n][257]; one wave per frame.
@@ -671,6 +700,37 @@ int ww_k_logmel(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, const floa
   if (n_ids > 0x7fffffff) return ww_fail(ctx, WW_EINVAL, "front-end launch too large (%lld workgroups): split the batch", (long long)n_ids);
   a.tiles_per_utt = (int)tiles;
   dim3 grid((unsigned)n_ids);
+#if WW_FE_STAMPS
+  // development build: WWHIP_FE_STAMPS=1 prints the mean phase timeline of the launch (cycles since the wave's first stamp)
+  const bool want_stamps = getenv("WWHIP_FE_STAMPS") != nullptr;
+  if (want_stamps) {
+    WW_HIP(ctx, hipMalloc((void **)&a.stamps, (size_t)n_ids * 48 * sizeof(long long)));
+    WW_HIP(ctx, hipMemsetAsync(a.stamps, 0, (size_t)n_ids * 48 * sizeof(long long), ctx->stream));
+  }
+  struct stamp_dump {
+    ww_ctx *ctx; long long *d; int64_t n;
+    ~stamp_dump() {
+      if (!d) return;
+      std::vector<long long> h((size_t)n * 48);
+      hipStreamSynchronize(ctx->stream);
+      hipMemcpy(h.data(), d, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+      hipFree(d);
+      double sum[12] = {0};
+      long long cnt = 0, tmin = 0, tmax = 0;
+      for (int64_t w = 0; w < n * 4; ++w) {
+        const long long *t = &h[(size_t)w * 12];
+        if (!t[0] || !t[11]) continue;  // inactive wave / workgroup
+        for (int i = 0; i < 12; ++i) sum[i] += (double)(t[i] - t[0]);
+        if (!cnt || t[0] < tmin) tmin = t[0];
+        if (!cnt || t[11] > tmax) tmax = t[11];
+        ++cnt;
+      }
+      fprintf(stderr, "fe stamps: %lld waves, mean cycles since entry:", cnt);
+      for (int i = 0; i < 12; ++i) fprintf(stderr, " %.0f", sum[i] / (cnt ? cnt : 1));
+      fprintf(stderr, "  | first entry -> last exit (clocks of different XCDs differ): %lld\n", tmax - tmin);
+    }
+  } dump{ctx, a.stamps, n_ids};
+#endif
   ww_launch_scope scope(ctx, fp->precise ? "logmel_kernel<f64>" : "logmel_kernel<f32>");
   if (fp->precise) {
     size_t sm = logmel_smem<double>(fp->hop);
