@@ -613,9 +613,12 @@ static int load_wave(ww_ctx *ctx, ww_model *m, const blob_view &bv) {
           const int ch = 4 * kg + (q & 3);
           for (int ks = 0; ks < 2; ++ks)
             for (int mt = 0; mt < 2; ++mt) {
-              const int tap = ks == 0 ? (q < 4 ? 2 : 1) : (q < 4 ? 0 : -1);
+              const int tap = ks == 0 ? (q < 4 ? 2 : -1) : (q < 4 ? 0 : 1);
               float wv = tap < 0 ? 0.f : (mt == 0 ? w_sig : w_tanh)[(((size_t)b * 3 + tap) * C + ch) * C + i];
-              if (ks == 1 && q == 4 && kg == 0) wv = (mt == 0 ? b_sig : b_tanh)[(size_t)b * C + i];  // bias slot (B = 1.0)
+              if (ks == 0 && q == 4 && kg == 0) wv = (mt == 0 ? b_sig : b_tanh)[(size_t)b * C + i];  // bias slot (B = 1.0)
+              // the gates are evaluated with v_exp_f32 (= exp2): sigmoid(s) = 1 / (1 + exp2(-log2e s)),
+              // tanh(t) = 1 - 2 / (1 + exp2(2 log2e t)) - the factors ride in the weights and biases
+              wv *= mt == 0 ? -1.4426950408889634f : 2.8853900817779268f;
               const uint16_t hi = bf16_rne(wv), lo = bf16_rne(wv - bf16_f(hi));
               pk[((((size_t)b * 14 + (ks * 2 + mt) * 2 + 0) * 64) + lane) * 8 + q] = hi;
               pk[((((size_t)b * 14 + (ks * 2 + mt) * 2 + 1) * 64) + lane) * 8 + q] = lo;

@@ -171,6 +171,14 @@ __device__ __forceinline__ bf16x8 cat8(s16x4 first, s16x4 second) {
   return __builtin_bit_cast(bf16x8, p);
 }
 #define MFMA_BF(acc, av, bv) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc, 0, 0, 0)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// max(x, 0) as ONE instruction: fmaxf compiles to a canonicalising v_max (x, x) in front of the v_max (0, x).  On the bit
+// pattern a signed-integer max does the same job (negative floats, -0 included, are negative integers).  Not inline
+// asm: the compiler does not see an MFMA -> VALU read hazard through it and omits the wait states.
+__device__ __forceinline__ float relu1(float x) {
+  const int b = __float_as_int(x);
+  return __int_as_float(b > 0 ? b : 0);
+}
 #define WV_SLOTS 14  // A-operand slots per block: gate (2 k-steps x {sig,tanh} x {hi,lo}) = 8, res | skip (3 m-tiles x {hi,lo}) = 6
 #define WV_PAGE_U4 (WV_SLOTS * 64)  // one block's parameter page in 16-byte units (the conv biases sit in padded k-slots)
 
@@ -327,18 +335,27 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
 
   } else {
     // ---- split-bf16 block loop (transposed: lane = time column n = lane & 15, rows = channels 4 kk + r).
-    //      LDS: u as two bf16 planes (hi, lo), each [2][WV_T + WV_PAD][16 ch], for the delayed taps only.
+    //      LDS: u for the delayed taps only, [2 buffers][4 channel groups kk][WV_T + WV_PAD rows][hi 4 x bf16 | lo 4 x bf16]:
+    //      a lane's (hi, lo) of one row are 16 contiguous bytes (one ds_write2_b64), the two delayed rows t - 2d and t - d of
+    //      one plane are ONE ds_read2_b64 whose result IS the B operand (tap 0 | tap 1) - no address arithmetic beyond one
+    //      add per block, no register moves.
     // One row tile per wave, 12 waves.  (4 waves x 3 tiles, written tile-major so that the scheduler could
     // overlap one tile's gate VALU with the next tile's MFMAs, measured 45 % slower: it does not interleave.)
+    // The loop is bound by vector-instruction ISSUE (each of the 3 waves of a SIMD issues its ~80 vector instructions per
+    // block, and every bf16 MFMA holds the SIMD's vector issue for 8 of its 16 cycles), so the block body carries no
+    // instruction it can avoid: ReLU is one v_max (fmaxf costs a canonicalising v_max in front), the exp2 scale factors
+    // of the gates sit in the packed weights, the dilation comes out of two SGPR pairs read before the loop.
     static_assert(!SPLIT_BF16 || WV_MPW == 1, "the split-bf16 loop handles one row tile per wave");
-    unsigned short *uh = (unsigned short *)lds;                                   // [2][WV_T + WV_PAD][16]
-    unsigned short *ul = uh + 2 * (WV_T + WV_PAD) * WV_C;
-    for (int i = tid; i < 2 * WV_PAD * WV_C; i += WV_THREADS) {                   // causal zero rows, both planes
-      int b = i / (WV_PAD * WV_C), o = i - b * (WV_PAD * WV_C);
-      uh[b * (WV_T + WV_PAD) * WV_C + o] = 0;
-      ul[b * (WV_T + WV_PAD) * WV_C + o] = 0;
+    constexpr int U_ROW_B = 16, U_KK_B = (WV_T + WV_PAD) * U_ROW_B, U_BUF_B = 4 * U_KK_B;   // bytes
+    static_assert(2 * U_BUF_B == 2 * (WV_T + WV_PAD) * WV_C * 4, "u planes must fill exactly the fp32 u buffers' bytes");
+    unsigned char *ldsb = (unsigned char *)lds;
+    const unsigned lds0 = (unsigned)(uintptr_t)lds;  // low 32 bits of a flat LDS pointer = the LDS byte address
+    for (int i = tid; i < 2 * 4 * WV_PAD; i += WV_THREADS) {                      // causal zero rows: [buffer][kk][row < PAD]
+      const int b = i / (4 * WV_PAD), k = (i / WV_PAD) & 3, r = i % WV_PAD;
+      *(uint4 *)(ldsb + b * U_BUF_B + k * U_KK_B + r * U_ROW_B) = make_uint4(0u, 0u, 0u, 0u);
     }
     const int t0 = wave * 16;
+    const int ub = kk * U_KK_B + (WV_PAD + t0 + j) * U_ROW_B;                     // this lane's (row t, channel group kk)
     // Block parameters (14 A-operand slots = one 14 KB "page") are identical for all 12 waves: the workgroup
     // fetches page b+2 with one or two 16-byte loads per thread at the top of block b and parks it in LDS at
     // the end of the block (three buffers).  The barrier of block b+1 publishes it, so in block b+2 every
@@ -366,16 +383,19 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
       bnall[i] = *(const float4 *)((v ? a.bn_t : a.bn_s) + b * WV_C + 4 * q);
     }
     __syncthreads();
+    const unsigned long long dil_lo = a.dil4[0], dil_hi = a.dil4[1];             // kernel-argument SGPRs: no load inside the loop
+    const s16x4 z4 = {0, 0, 0, 0};
+    const s16x4 one4 = {(short)(kk == 0 ? 0x3F80 : 0), 0, 0, 0};                  // k-slot 4 of lane group 0 = 1.0: the bias slot
     int pbuf = 0;  // blk % 3
     for (int blk = 0; blk < a.NB; ++blk) {
-      const int boff = (blk & 1) * (WV_T + WV_PAD) * WV_C + WV_PAD * WV_C;      // row 0 of this block's u planes
-      const int d = (int)((a.dil4[blk >> 4] >> (4 * (blk & 15))) & 15);
+      const int bo = (blk & 1) * U_BUF_B;
+      const int d = (int)(((blk < 16 ? dil_lo : dil_hi) >> (4 * (blk & 15))) & 15);
       const int nblk = blk + 2 < a.NB ? blk + 2 : a.NB - 1;                      // unconditional prefetch target
       const uint4 np0 = gpage[(size_t)nblk * WV_PAGE_U4 + tid], np1 = gpage[(size_t)nblk * WV_PAGE_U4 + pi1];
       __builtin_amdgcn_sched_barrier(0);  // keep the loads HERE (the scheduler would sink them to their use)
       const uint4 *pg = pages + pbuf * WV_PAGE_U4;
       const bf16x8 *wsl = (const bf16x8 *)pg + lane;                             // slot q: wsl[q * 64]
-      // this block's operands (published one barrier ago): issued now, consumed after the barrier
+      // this block's operands (published one barrier ago): issued now, the delayed-tap half consumed after the barrier
       const bf16x8 w0 = wsl[0 * 64], w1 = wsl[1 * 64], w2 = wsl[2 * 64], w3 = wsl[3 * 64];
       const bf16x8 w4 = wsl[4 * 64], w5 = wsl[5 * 64], w6 = wsl[6 * 64], w7 = wsl[7 * 64];
       const bf16x8 r0 = wsl[8 * 64], r1 = wsl[9 * 64], r2 = wsl[10 * 64], r3 = wsl[11 * 64], r4 = wsl[12 * 64], r5 = wsl[13 * 64];
@@ -384,39 +404,47 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
       const float uv[4] = {x[0][0] * bn_s.x + bn_t.x, x[0][1] * bn_s.y + bn_t.y, x[0][2] * bn_s.z + bn_t.z, x[0][3] * bn_s.w + bn_t.w};
       s16x4 u2h, u2l;
       split4(uv, u2h, u2l);
-      // [time t][8-byte chunk (kk + t / 4) % 4]: a row is 32 bytes, so without the rotation the 16 lanes of a
-      // write group (one kk, 16 rows) would share 8 banks (4-way conflict) and a 32-lane read group 2-way
-      const int trow = t0 + j;
-      auto uoff = [&](int t) { return boff + t * WV_C + 4 * ((kk + (t >> 2)) & 3); };  // t may be < 0: zero pad rows
-      const int orow = uoff(trow);
-      *(s16x4 *)(uh + orow) = u2h;
-      *(s16x4 *)(ul + orow) = u2l;
-      __syncthreads();  // u complete (all rows, all waves); this block's page complete
-      // delayed taps: tap k reads u[t - (2 - k) d]; rows < 0 hit the zero pad (d <= 8)
-      const int o1 = uoff(trow - d), o0 = uoff(trow - 2 * d);
-      const s16x4 u1h = *(const s16x4 *)(uh + o1), u1l = *(const s16x4 *)(ul + o1);
-      const s16x4 u0h = *(const s16x4 *)(uh + o0), u0l = *(const s16x4 *)(ul + o0);
+      // one ds_write2_b64 straight from the two operand register pairs (written as plain stores the compiler merges
+      // them into a 16-byte store, for which it first gathers the pairs into four consecutive registers)
+      asm volatile("ds_write2_b64 %0, %1, %2 offset1:1" : : "v"(lds0 + (unsigned)(bo + ub)), "v"(u2h), "v"(u2l) : "memory");
+      // k-step 0 = (tap 2 | bias slot): operands in registers - these six MFMAs run while the other waves arrive
+      // slot = (kstep * 2 + {sig, tanh}) * 2 + {hi, lo}; the host put (b_hi, b_lo) into k-slot 4 of lane group 0
       f32x4 as = {0.f, 0.f, 0.f, 0.f}, at = {0.f, 0.f, 0.f, 0.f};
-      // k-step 0 = (tap 2 | tap 1), k-step 1 = (tap 0 | zeros); slot = (kstep * 2 + {sig, tanh}) * 2 + {hi, lo}
-      // the zero half of k-step 1 carries the conv biases: k-slot 4 of lane group 0 is 1.0 in the hi operand
-      // (0 in the lo operand) and the host put (b_hi, b_lo) into that slot of the weight operands
-      const s16x4 z4 = {0, 0, 0, 0};
-      const s16x4 one4 = {(short)(kk == 0 ? 0x3F80 : 0), 0, 0, 0};
-      const bf16x8 x0h = cat8(u2h, u1h), x0l = cat8(u2l, u1l), x1h = cat8(u0h, one4), x1l = cat8(u0l, z4);
+      const bf16x8 xuh = cat8(u2h, one4), xul = cat8(u2l, z4);
+      MFMA_BF(as, w0, xuh); MFMA_BF(at, w2, xuh);
+      MFMA_BF(as, w1, xuh); MFMA_BF(at, w3, xuh);
+      MFMA_BF(as, w0, xul); MFMA_BF(at, w2, xul);
+      __syncthreads();  // u complete (all rows, all waves); this block's page complete
+      // k-step 1 = (tap 0 | tap 1) = rows t - 2d and t - d (rows < 0 hit the zero pad, d <= 8)
+      u32x4 xdh_, xdl_;
       {
-        MFMA_BF(as, w0, x0h); MFMA_BF(at, w2, x0h);
-        MFMA_BF(as, w1, x0h); MFMA_BF(at, w3, x0h);
-        MFMA_BF(as, w0, x0l); MFMA_BF(at, w2, x0l);
-        MFMA_BF(as, w4, x1h); MFMA_BF(at, w6, x1h);
-        MFMA_BF(as, w5, x1h); MFMA_BF(at, w7, x1h);
-        MFMA_BF(as, w4, x1l); MFMA_BF(at, w6, x1l);
+        const unsigned ra = lds0 + (unsigned)(bo + ub - 2 * U_ROW_B * d);
+#define WV_RD2(o1_)                                                                                              \
+  asm volatile("ds_read2_b64 %0, %2 offset1:%3\n\tds_read2_b64 %1, %2 offset0:1 offset1:%4\n\ts_waitcnt lgkmcnt(0)" \
+               : "=&v"(xdh_), "=&v"(xdl_)                                                                        \
+               : "v"(ra), "n"(o1_), "n"((o1_) + 1)                                                               \
+               : "memory")
+        if (d == 1) { WV_RD2(2); }
+        else if (d == 2) { WV_RD2(4); }
+        else if (d == 4) { WV_RD2(8); }
+        else if (d == 8) { WV_RD2(16); }
+        else {  // any other dilation: the two rows separately
+          const uint4 q0 = *(const uint4 *)(ldsb + bo + ub - 2 * U_ROW_B * d), q1 = *(const uint4 *)(ldsb + bo + ub - U_ROW_B * d);
+          xdh_ = (u32x4){q0.x, q0.y, q1.x, q1.y};
+          xdl_ = (u32x4){q0.z, q0.w, q1.z, q1.w};
+        }
+#undef WV_RD2
       }
-      // gate: tanh(t) * sigmoid(s), biases already inside the accumulators
+      const bf16x8 xdh = __builtin_bit_cast(bf16x8, xdh_), xdl = __builtin_bit_cast(bf16x8, xdl_);
+      MFMA_BF(as, w4, xdh); MFMA_BF(at, w6, xdh);
+      MFMA_BF(as, w5, xdh); MFMA_BF(at, w7, xdh);
+      MFMA_BF(as, w4, xdl); MFMA_BF(at, w6, xdl);
+      // gate: tanh(t) * sigmoid(s); biases AND the exp2 scale factors (-log2 e, 2 log2 e) are inside the accumulators
       float gv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float et = __builtin_amdgcn_exp2f(2.8853900817779268f * at[r]);    // exp(2 t): inf -> tanh 1, 0 -> -1
-        const float es = __builtin_amdgcn_exp2f(-1.4426950408889634f * as[r]);   // exp(-s)
+        const float et = __builtin_amdgcn_exp2f(at[r]);    // exp(2 t): inf -> tanh 1, 0 -> -1
+        const float es = __builtin_amdgcn_exp2f(as[r]);    // exp(-s)
         gv[r] = (1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + et)) * __builtin_amdgcn_rcpf(1.0f + es);
       }
       s16x4 g_h, g_l;
@@ -432,9 +460,9 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
       // res weights and bias (relu(0) = 0), so no special case
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        x[0][r] = fmaxf(ar[r], 0.f) + x[0][r];
-        skip[0][0][r] = skip[0][0][r] + fmaxf(s0[r], 0.f);
-        skip[0][1][r] = skip[0][1][r] + fmaxf(s1[r], 0.f);
+        x[0][r] = relu1(ar[r]) + x[0][r];
+        skip[0][0][r] = skip[0][0][r] + relu1(s0[r]);
+        skip[0][1][r] = skip[0][1][r] + relu1(s1[r]);
       }
       // park page blk+2 (loaded a whole block ago) in the buffer that held page blk-1: every wave is past its
       // reads of that one (they precede the barrier of block blk, which everyone here has passed)
