@@ -29,6 +29,8 @@
 // The detect head (ReLU, 1x1 32->32 ReLU, 1x1 32->2, max over time, softmax) runs in the same launch.
 #include "common.h"
 
+#include <vector>
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define WV_T 192      // padded time (12 tiles of 16)
@@ -72,7 +74,24 @@ struct wave_args {
   float *enc;           // optional [Nw][T][32]
   const float *enc_in;  // HEAD_ONLY: encoder output to run the detect graph on
   const uint4 *wpk;     // split-bf16 mode: parameter pages [NB][WV_PAGE_U4] (A operands of v_mfma_f32_16x16x32_bf16, then the vectors)
+  long long *stamps;    // development (-DWV_STAMPS=1): [windows][12 waves][12] s_memtime inside block WV_STAMP_BLK of the split-bf16 loop
 };
+
+#ifndef WV_STAMPS
+#define WV_STAMPS 0
+#endif
+#define WV_STAMP_BLK 10
+#if WV_STAMPS
+#define WV_STAMP(i_)                                                                                                   \
+  {                                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    if (a.stamps && blk == WV_STAMP_BLK + ((i_) == 11 ? 1 : 0) && lane == 0)                                           \
+      a.stamps[((size_t)blockIdx.x * 12 + wave) * 12 + (i_)] = __builtin_amdgcn_s_memtime();                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+  }
+#else
+#define WV_STAMP(i_)
+#endif
 
 __device__ __forceinline__ float sigmoid_w(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -335,10 +354,15 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
 
   } else {
     // ---- split-bf16 block loop (transposed: lane = time column n = lane & 15, rows = channels 4 kk + r).
-    //      LDS: u for the delayed taps only, [2 buffers][4 channel groups kk][WV_T + WV_PAD rows][hi 4 x bf16 | lo 4 x bf16]:
-    //      a lane's (hi, lo) of one row are 16 contiguous bytes (one ds_write2_b64), the two delayed rows t - 2d and t - d of
-    //      one plane are ONE ds_read2_b64 whose result IS the B operand (tap 0 | tap 1) - no address arithmetic beyond one
-    //      add per block, no register moves.
+    //      LDS: u for the delayed taps only, [plane hi | lo][2 buffers][4 channel groups kk][WV_T + WV_PAD rows][4 x bf16]:
+    //      16 lanes of one kk touch 128 contiguous bytes and the kk chunks sit 128 bytes apart mod 256, so the 8-byte
+    //      accesses are conflict-free at the full ds_read_b64 rate (2 LDS cycles per wave-instruction; right after the
+    //      barrier all 12 waves fetch their delayed taps at once and that burst is on every wave's critical path).  One
+    //      address add per block: the four reads (rows t - 2d and t - d, hi and lo) are immediate offsets from it.
+    // LDS instruction ORDER is part of the design (a wave's LDS operations complete in issue order): BatchNorm vectors, the
+    // u write, the gate operands - barrier - the delayed taps, and only then the res | skip operands, which are not needed
+    // for another ~600 cycles.  The wait in front of the barrier is counted (only the u write has to be complete), so
+    // nobody waits at the barrier for 14 KB of operands per wave to stream out of LDS.
     // One row tile per wave, 12 waves.  (4 waves x 3 tiles, written tile-major so that the scheduler could
     // overlap one tile's gate VALU with the next tile's MFMAs, measured 45 % slower: it does not interleave.)
     // The loop is bound by vector-instruction ISSUE (each of the 3 waves of a SIMD issues its ~80 vector instructions per
@@ -346,16 +370,18 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
     // instruction it can avoid: ReLU is one v_max (fmaxf costs a canonicalising v_max in front), the exp2 scale factors
     // of the gates sit in the packed weights, the dilation comes out of two SGPR pairs read before the loop.
     static_assert(!SPLIT_BF16 || WV_MPW == 1, "the split-bf16 loop handles one row tile per wave");
-    constexpr int U_ROW_B = 16, U_KK_B = (WV_T + WV_PAD) * U_ROW_B, U_BUF_B = 4 * U_KK_B;   // bytes
-    static_assert(2 * U_BUF_B == 2 * (WV_T + WV_PAD) * WV_C * 4, "u planes must fill exactly the fp32 u buffers' bytes");
+    constexpr int U_KK_B = (WV_T + WV_PAD) * 8, U_BUF_B = 4 * U_KK_B, U_PLANE_B = 2 * U_BUF_B;   // bytes
+    static_assert(2 * U_PLANE_B == 2 * (WV_T + WV_PAD) * WV_C * 4, "u planes must fill exactly the fp32 u buffers' bytes");
+    static_assert(U_KK_B % 256 == 128, "the two channel groups of a 32-lane read group must sit 128 bytes apart (mod 256): conflict-free ds_read_b64");
+    static_assert(U_PLANE_B % 512 == 0 && U_PLANE_B / 512 < 256, "lo plane reachable by ds_write2st64_b64's second offset");
     unsigned char *ldsb = (unsigned char *)lds;
     const unsigned lds0 = (unsigned)(uintptr_t)lds;  // low 32 bits of a flat LDS pointer = the LDS byte address
-    for (int i = tid; i < 2 * 4 * WV_PAD; i += WV_THREADS) {                      // causal zero rows: [buffer][kk][row < PAD]
-      const int b = i / (4 * WV_PAD), k = (i / WV_PAD) & 3, r = i % WV_PAD;
-      *(uint4 *)(ldsb + b * U_BUF_B + k * U_KK_B + r * U_ROW_B) = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < 2 * 2 * 4 * WV_PAD; i += WV_THREADS) {                  // causal zero rows: [plane][buffer][kk][row < PAD]
+      const int pl = i / (2 * 4 * WV_PAD), b = (i / (4 * WV_PAD)) & 1, k = (i / WV_PAD) & 3, r = i % WV_PAD;
+      *(uint2 *)(ldsb + pl * U_PLANE_B + b * U_BUF_B + k * U_KK_B + r * 8) = make_uint2(0u, 0u);
     }
     const int t0 = wave * 16;
-    const int ub = kk * U_KK_B + (WV_PAD + t0 + j) * U_ROW_B;                     // this lane's (row t, channel group kk)
+    const int ub = kk * U_KK_B + (WV_PAD + t0 + j) * 8;                           // this lane's (row t, channel group kk), hi plane
     // Block parameters (14 A-operand slots = one 14 KB "page") are identical for all 12 waves: the workgroup
     // fetches page b+2 with one or two 16-byte loads per thread at the top of block b and parks it in LDS at
     // the end of the block (three buffers).  The barrier of block b+1 publishes it, so in block b+2 every
@@ -388,6 +414,7 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
     const s16x4 one4 = {(short)(kk == 0 ? 0x3F80 : 0), 0, 0, 0};                  // k-slot 4 of lane group 0 = 1.0: the bias slot
     int pbuf = 0;  // blk % 3
     for (int blk = 0; blk < a.NB; ++blk) {
+      WV_STAMP(0) WV_STAMP(11)
       const int bo = (blk & 1) * U_BUF_B;
       const int d = (int)(((blk < 16 ? dil_lo : dil_hi) >> (4 * (blk & 15))) & 15);
       const int nblk = blk + 2 < a.NB ? blk + 2 : a.NB - 1;                      // unconditional prefetch target
@@ -395,18 +422,19 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
       __builtin_amdgcn_sched_barrier(0);  // keep the loads HERE (the scheduler would sink them to their use)
       const uint4 *pg = pages + pbuf * WV_PAGE_U4;
       const bf16x8 *wsl = (const bf16x8 *)pg + lane;                             // slot q: wsl[q * 64]
-      // this block's operands (published one barrier ago): issued now, the delayed-tap half consumed after the barrier
-      const bf16x8 w0 = wsl[0 * 64], w1 = wsl[1 * 64], w2 = wsl[2 * 64], w3 = wsl[3 * 64];
-      const bf16x8 w4 = wsl[4 * 64], w5 = wsl[5 * 64], w6 = wsl[6 * 64], w7 = wsl[7 * 64];
-      const bf16x8 r0 = wsl[8 * 64], r1 = wsl[9 * 64], r2 = wsl[10 * 64], r3 = wsl[11 * 64], r4 = wsl[12 * 64], r5 = wsl[13 * 64];
+      WV_STAMP(1)
       const float4 bn_s = bnall[blk * 8 + kk], bn_t = bnall[blk * 8 + 4 + kk];
       // BatchNorm affine (wavenet_model.py:57): this tile's u = the undelayed tap's B operand
       const float uv[4] = {x[0][0] * bn_s.x + bn_t.x, x[0][1] * bn_s.y + bn_t.y, x[0][2] * bn_s.z + bn_t.z, x[0][3] * bn_s.w + bn_t.w};
       s16x4 u2h, u2l;
       split4(uv, u2h, u2l);
-      // one ds_write2_b64 straight from the two operand register pairs (written as plain stores the compiler merges
-      // them into a 16-byte store, for which it first gathers the pairs into four consecutive registers)
-      asm volatile("ds_write2_b64 %0, %1, %2 offset1:1" : : "v"(lds0 + (unsigned)(bo + ub)), "v"(u2h), "v"(u2l) : "memory");
+      WV_STAMP(2)
+      // hi and lo planes in one instruction, straight from the two operand register pairs
+      asm volatile("ds_write2st64_b64 %0, %1, %2 offset1:%3" : : "v"(lds0 + (unsigned)(bo + ub)), "v"(u2h), "v"(u2l), "n"(U_PLANE_B / 512) : "memory");
+      // this block's gate operands (the page was published one barrier ago)
+      const bf16x8 w0 = wsl[0 * 64], w1 = wsl[1 * 64], w2 = wsl[2 * 64], w3 = wsl[3 * 64];
+      const bf16x8 w4 = wsl[4 * 64], w5 = wsl[5 * 64], w6 = wsl[6 * 64], w7 = wsl[7 * 64];
+      WV_STAMP(3)
       // k-step 0 = (tap 2 | bias slot): operands in registers - these six MFMAs run while the other waves arrive
       // slot = (kstep * 2 + {sig, tanh}) * 2 + {hi, lo}; the host put (b_hi, b_lo) into k-slot 4 of lane group 0
       f32x4 as = {0.f, 0.f, 0.f, 0.f}, at = {0.f, 0.f, 0.f, 0.f};
@@ -414,31 +442,39 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
       MFMA_BF(as, w0, xuh); MFMA_BF(at, w2, xuh);
       MFMA_BF(as, w1, xuh); MFMA_BF(at, w3, xuh);
       MFMA_BF(as, w0, xul); MFMA_BF(at, w2, xul);
-      __syncthreads();  // u complete (all rows, all waves); this block's page complete
+      WV_STAMP(4)
+      // u complete (all rows, all waves).  At most the 8 operand reads above are younger than the u write, so "at most 8
+      // LDS operations outstanding" means the write has landed; the operands keep streaming across the barrier.
+      asm volatile("s_waitcnt lgkmcnt(8)\n\ts_barrier" ::: "memory");
+      WV_STAMP(5)
       // k-step 1 = (tap 0 | tap 1) = rows t - 2d and t - d (rows < 0 hit the zero pad, d <= 8)
-      u32x4 xdh_, xdl_;
+      s16x4 u0h, u1h, u0l, u1l;
       {
-        const unsigned ra = lds0 + (unsigned)(bo + ub - 2 * U_ROW_B * d);
-#define WV_RD2(o1_)                                                                                              \
-  asm volatile("ds_read2_b64 %0, %2 offset1:%3\n\tds_read2_b64 %1, %2 offset0:1 offset1:%4\n\ts_waitcnt lgkmcnt(0)" \
-               : "=&v"(xdh_), "=&v"(xdl_)                                                                        \
-               : "v"(ra), "n"(o1_), "n"((o1_) + 1)                                                               \
+        const unsigned ra = lds0 + (unsigned)(bo + ub - 16 * d);
+#define WV_RD4(d_)                                                                                                          \
+  asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:%5\n\tds_read_b64 %2, %4 offset:%6\n\tds_read_b64 %3, %4 offset:%7" \
+               : "=&v"(u0h), "=&v"(u1h), "=&v"(u0l), "=&v"(u1l)                                                             \
+               : "v"(ra), "n"(8 * (d_)), "n"(U_PLANE_B), "n"(U_PLANE_B + 8 * (d_))                                         \
                : "memory")
-        if (d == 1) { WV_RD2(2); }
-        else if (d == 2) { WV_RD2(4); }
-        else if (d == 4) { WV_RD2(8); }
-        else if (d == 8) { WV_RD2(16); }
-        else {  // any other dilation: the two rows separately
-          const uint4 q0 = *(const uint4 *)(ldsb + bo + ub - 2 * U_ROW_B * d), q1 = *(const uint4 *)(ldsb + bo + ub - U_ROW_B * d);
-          xdh_ = (u32x4){q0.x, q0.y, q1.x, q1.y};
-          xdl_ = (u32x4){q0.z, q0.w, q1.z, q1.w};
+        if (d == 1) { WV_RD4(1); }
+        else if (d == 2) { WV_RD4(2); }
+        else if (d == 4) { WV_RD4(4); }
+        else if (d == 8) { WV_RD4(8); }
+        else {  // any other dilation: plain loads
+          u0h = *(const s16x4 *)(ldsb + bo + ub - 16 * d); u1h = *(const s16x4 *)(ldsb + bo + ub - 8 * d);
+          u0l = *(const s16x4 *)(ldsb + U_PLANE_B + bo + ub - 16 * d); u1l = *(const s16x4 *)(ldsb + U_PLANE_B + bo + ub - 8 * d);
         }
-#undef WV_RD2
+#undef WV_RD4
       }
-      const bf16x8 xdh = __builtin_bit_cast(bf16x8, xdh_), xdl = __builtin_bit_cast(bf16x8, xdl_);
+      // res | skip operands: behind the taps in the LDS queue, in front of their use by a whole gate evaluation
+      const bf16x8 r0 = wsl[8 * 64], r1 = wsl[9 * 64], r2 = wsl[10 * 64], r3 = wsl[11 * 64], r4 = wsl[12 * 64], r5 = wsl[13 * 64];
+      asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(u0h), "+v"(u1h), "+v"(u0l), "+v"(u1l) : : "memory");  // the taps (6 younger reads may be in flight)
+      WV_STAMP(6)
+      const bf16x8 xdh = cat8(u0h, u1h), xdl = cat8(u0l, u1l);
       MFMA_BF(as, w4, xdh); MFMA_BF(at, w6, xdh);
       MFMA_BF(as, w5, xdh); MFMA_BF(at, w7, xdh);
       MFMA_BF(as, w4, xdl); MFMA_BF(at, w6, xdl);
+      WV_STAMP(7)
       // gate: tanh(t) * sigmoid(s); biases AND the exp2 scale factors (-log2 e, 2 log2 e) are inside the accumulators
       float gv[4];
 #pragma unroll
@@ -447,6 +483,7 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
         const float es = __builtin_amdgcn_exp2f(as[r]);    // exp(-s)
         gv[r] = (1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + et)) * __builtin_amdgcn_rcpf(1.0f + es);
       }
+      WV_STAMP(8)
       s16x4 g_h, g_l;
       split4(gv, g_h, g_l);  // the gate product is the res / skip conv's B operand as it stands
       f32x4 ar = {0.f, 0.f, 0.f, 0.f}, s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
@@ -456,6 +493,7 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
         MFMA_BF(ar, r1, gh8); MFMA_BF(s0, r3, gh8); MFMA_BF(s1, r5, gh8);
         MFMA_BF(ar, r0, gl8); MFMA_BF(s0, r2, gl8); MFMA_BF(s1, r4, gl8);
       }
+      WV_STAMP(9)
       // residual / skip update; biases ride in the MFMA, and a block without a residual conv has zero
       // res weights and bias (relu(0) = 0), so no special case
 #pragma unroll
@@ -464,6 +502,7 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
         skip[0][0][r] = skip[0][0][r] + relu1(s0[r]);
         skip[0][1][r] = skip[0][1][r] + relu1(s1[r]);
       }
+      WV_STAMP(10)
       // park page blk+2 (loaded a whole block ago) in the buffer that held page blk-1: every wave is past its
       // reads of that one (they precede the barrier of block blk, which everyone here has passed)
       const int nbuf = pbuf == 0 ? 2 : pbuf - 1;  // (blk + 2) % 3
@@ -592,6 +631,36 @@ int ww_k_wave_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
   a.out = d_out; a.enc = d_enc;
   ww_launch_scope scope(ctx, m->precision == WW_PRECISION_BF16X3 ? "wavenet_kernel<bf16x3>" : "wavenet_kernel");
   a.wpk = (const uint4 *)v.wpk;
+#if WV_STAMPS
+  // development build: WWHIP_WV_STAMPS=1 prints the mean phase timeline of block WV_STAMP_BLK (cycles since its first stamp;
+  // the last column is the top of the next block)
+  struct stamp_dump {
+    ww_ctx *ctx; long long *d; int n;
+    ~stamp_dump() {
+      if (!d) return;
+      std::vector<long long> h((size_t)n * 144);
+      hipStreamSynchronize(ctx->stream);
+      hipMemcpy(h.data(), d, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+      hipFree(d);
+      double sum[12] = {0};
+      long long cnt = 0;
+      for (size_t w = 0; w < (size_t)n * 12; ++w) {
+        const long long *t = &h[w * 12];
+        if (!t[0] || !t[11]) continue;
+        for (int i = 0; i < 12; ++i) sum[i] += (double)(t[i] - t[0]);
+        ++cnt;
+      }
+      fprintf(stderr, "wavenet stamps: %lld waves, mean cycles since the top of block %d:", cnt, WV_STAMP_BLK);
+      for (int i = 0; i < 12; ++i) fprintf(stderr, " %.0f", sum[i] / (cnt ? cnt : 1));
+      fprintf(stderr, "\n");
+    }
+  } dump{ctx, nullptr, nw};
+  if (getenv("WWHIP_WV_STAMPS") && m->precision == WW_PRECISION_BF16X3) {
+    WW_HIP(ctx, hipMalloc((void **)&a.stamps, (size_t)nw * 144 * sizeof(long long)));
+    WW_HIP(ctx, hipMemsetAsync(a.stamps, 0, (size_t)nw * 144 * sizeof(long long), ctx->stream));
+    dump.d = a.stamps;
+  }
+#endif
   if (m->precision == WW_PRECISION_BF16X3)
     hipLaunchKernelGGL((wavenet_kernel<false, true>), dim3(nw), dim3(WV_THREADS), 0, ctx->stream, a);
   else
