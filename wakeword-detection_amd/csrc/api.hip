@@ -589,9 +589,11 @@ static int load_wave(ww_ctx *ctx, ww_model *m, const blob_view &bv) {
   }
   for (int col = 0; col < v.NOUT; ++col) d2b[col] = db2[col];
   // split-bf16 A operands (wavenet.hip, SPLIT_BF16; transposed formulation: rows = output channels).
-  // slot = (kstep*2 + {sig,tanh})*2 + {hi,lo} for the gate conv (k-step 0 = tap 2 | tap 1, k-step 1 = tap 0 |
-  // zeros), 8 + mtile*2 + {hi,lo} for res | skip (g | zeros).  Lane (i = lane & 15, kg = lane >> 4) holds, in
-  // k-slots 0..3, W[first tap][ch = 4 kg .. 4 kg + 3][out = 16 mtile + i] and in k-slots 4..7 the second tap's.
+  // slot = (kstep*2 + {sig,tanh})*2 + {0,1} for the gate conv (k-step 0 = tap 2, k-step 1 = tap 0 | tap 1: the two
+  // delayed taps), 8 + mtile*2 + {0,1} for res | skip.  Lane (i = lane & 15, kg = lane >> 4) holds 8 k-slots = two
+  // groups of the 4 channels 4 kg .. 4 kg + 3 for output row 16 mtile + i.  Where only one tap (or the gate product) is at
+  // hand the second group carries the hi x lo product instead of zeros: 5 MFMAs per gate and 2 per res | skip m-tile give
+  // all three split products plus the bias (16 MFMAs per block and tile, not 21).
   {
     auto bf16_rne = [](float f) -> uint16_t {
       uint32_t u;
@@ -606,32 +608,52 @@ static int load_wave(ww_ctx *ctx, ww_model *m, const blob_view &bv) {
       return f;
     };
     std::vector<uint16_t> pk((size_t)NB * 14 * 64 * 8, 0);
+    auto split = [&](float wv, uint16_t &hi, uint16_t &lo) {
+      hi = bf16_rne(wv);
+      lo = bf16_rne(wv - bf16_f(hi));
+    };
+    auto put = [&](int b, int slot, int lane, int q, uint16_t val) { pk[((((size_t)b * 14 + slot) * 64) + lane) * 8 + q] = val; };
     for (int b = 0; b < NB; ++b) {
       for (int lane = 0; lane < 64; ++lane) {
         const int i = lane & 15, kg = lane >> 4;
         for (int q = 0; q < 8; ++q) {
           const int ch = 4 * kg + (q & 3);
-          for (int ks = 0; ks < 2; ++ks)
-            for (int mt = 0; mt < 2; ++mt) {
-              const int tap = ks == 0 ? (q < 4 ? 2 : -1) : (q < 4 ? 0 : 1);
-              float wv = tap < 0 ? 0.f : (mt == 0 ? w_sig : w_tanh)[(((size_t)b * 3 + tap) * C + ch) * C + i];
-              if (ks == 0 && q == 4 && kg == 0) wv = (mt == 0 ? b_sig : b_tanh)[(size_t)b * C + i];  // bias slot (B = 1.0)
-              // the gates are evaluated with v_exp_f32 (= exp2): sigmoid(s) = 1 / (1 + exp2(-log2e s)),
-              // tanh(t) = 1 - 2 / (1 + exp2(2 log2e t)) - the factors ride in the weights and biases
-              wv *= mt == 0 ? -1.4426950408889634f : 2.8853900817779268f;
-              const uint16_t hi = bf16_rne(wv), lo = bf16_rne(wv - bf16_f(hi));
-              pk[((((size_t)b * 14 + (ks * 2 + mt) * 2 + 0) * 64) + lane) * 8 + q] = hi;
-              pk[((((size_t)b * 14 + (ks * 2 + mt) * 2 + 1) * 64) + lane) * 8 + q] = lo;
+          for (int mt = 0; mt < 2; ++mt) {
+            // the gates are evaluated with v_exp_f32 (= exp2): sigmoid(s) = 1 / (1 + exp2(-log2e s)),
+            // tanh(t) = 1 - 2 / (1 + exp2(2 log2e t)) - the factors ride in the weights and biases
+            const float sc = mt == 0 ? -1.4426950408889634f : 2.8853900817779268f;
+            const float *wsrc = mt == 0 ? w_sig : w_tanh;
+            auto wt = [&](int tap) { return wsrc[(((size_t)b * 3 + tap) * C + ch) * C + i] * sc; };
+            uint16_t hi, lo;
+            // k-step 0, slot "hh": (hi of tap 2 | hi of tap 2) against B = (u_hi | u_lo);
+            //           slot "lb": (lo of tap 2 | bias hi, bias lo in k-slots 4, 5 of lane group 0) against B = (u_hi | 1, 1, 0, 0)
+            split(wt(2), hi, lo);
+            put(b, (0 * 2 + mt) * 2 + 0, lane, q, hi);
+            if (q < 4) {
+              put(b, (0 * 2 + mt) * 2 + 1, lane, q, lo);
+            } else if (kg == 0 && q < 6) {
+              uint16_t bh, bl;
+              split((mt == 0 ? b_sig : b_tanh)[(size_t)b * C + i] * sc, bh, bl);
+              put(b, (0 * 2 + mt) * 2 + 1, lane, q, q == 4 ? bh : bl);
             }
+            // k-step 1: (tap 0 | tap 1), hi and lo slots, against B = the two delayed rows (hi plane, then lo plane)
+            split(wt(q < 4 ? 0 : 1), hi, lo);
+            put(b, (1 * 2 + mt) * 2 + 0, lane, q, hi);
+            put(b, (1 * 2 + mt) * 2 + 1, lane, q, lo);
+          }
           for (int mt = 0; mt < 3; ++mt) {
-            float wv = q >= 4 ? 0.f
-                              : (mt == 0 ? (has_res[b] ? w_res[((size_t)b * C + ch) * C + i] : 0.f)
-                                         : w_skip[((size_t)b * C + ch) * S + (mt - 1) * 16 + i]);
-            if (q == 4 && kg == 0)  // bias slot (B = 1.0)
-              wv = mt == 0 ? (has_res[b] ? b_res[(size_t)b * C + i] : 0.f) : b_skip[(size_t)b * S + (mt - 1) * 16 + i];
-            const uint16_t hi = bf16_rne(wv), lo = bf16_rne(wv - bf16_f(hi));
-            pk[((((size_t)b * 14 + 8 + mt * 2 + 0) * 64) + lane) * 8 + q] = hi;
-            pk[((((size_t)b * 14 + 8 + mt * 2 + 1) * 64) + lane) * 8 + q] = lo;
+            // res | skip: slot "hh" = (hi | hi) against B = (g_hi | g_lo), slot "lb" = (lo | bias hi, bias lo) against (g_hi | 1, 1, 0, 0)
+            const float wv = mt == 0 ? (has_res[b] ? w_res[((size_t)b * C + ch) * C + i] : 0.f) : w_skip[((size_t)b * C + ch) * S + (mt - 1) * 16 + i];
+            uint16_t hi, lo;
+            split(wv, hi, lo);
+            put(b, 8 + mt * 2 + 0, lane, q, hi);
+            if (q < 4) {
+              put(b, 8 + mt * 2 + 1, lane, q, lo);
+            } else if (kg == 0 && q < 6) {
+              uint16_t bh, bl;
+              split(mt == 0 ? (has_res[b] ? b_res[(size_t)b * C + i] : 0.f) : b_skip[(size_t)b * S + (mt - 1) * 16 + i], bh, bl);
+              put(b, 8 + mt * 2 + 1, lane, q, q == 4 ? bh : bl);
+            }
           }
         }
       }

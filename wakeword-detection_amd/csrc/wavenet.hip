@@ -198,7 +198,7 @@ __device__ __forceinline__ float relu1(float x) {
   const int b = __float_as_int(x);
   return __int_as_float(b > 0 ? b : 0);
 }
-#define WV_SLOTS 14  // A-operand slots per block: gate (2 k-steps x {sig,tanh} x {hi,lo}) = 8, res | skip (3 m-tiles x {hi,lo}) = 6
+#define WV_SLOTS 14  // A-operand slots per block: gate (2 k-steps x {sig,tanh} x 2) = 8, res | skip (3 m-tiles x 2) = 6
 #define WV_PAGE_U4 (WV_SLOTS * 64)  // one block's parameter page in 16-byte units (the conv biases sit in padded k-slots)
 
 template <bool HEAD_ONLY, bool SPLIT_BF16>
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
     //      address add per block: the four reads (rows t - 2d and t - d, hi and lo) are immediate offsets from it.
     // LDS instruction ORDER is part of the design (a wave's LDS operations complete in issue order): BatchNorm vectors, the
     // u write, the gate operands - barrier - the delayed taps, and only then the res | skip operands, which are not needed
-    // for another ~600 cycles.  The wait in front of the barrier is counted (only the u write has to be complete), so
+    // for another ~600 cycles (requested after the tap MFMAs instead: no gain, measured).  The wait in front of the barrier is counted (only the u write has to be complete), so
     // nobody waits at the barrier for 14 KB of operands per wave to stream out of LDS.
     // One row tile per wave, 12 waves.  (4 waves x 3 tiles, written tile-major so that the scheduler could
     // overlap one tile's gate VALU with the next tile's MFMAs, measured 45 % slower: it does not interleave.)
@@ -410,8 +410,8 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
     }
     __syncthreads();
     const unsigned long long dil_lo = a.dil4[0], dil_hi = a.dil4[1];             // kernel-argument SGPRs: no load inside the loop
-    const s16x4 z4 = {0, 0, 0, 0};
-    const s16x4 one4 = {(short)(kk == 0 ? 0x3F80 : 0), 0, 0, 0};                  // k-slot 4 of lane group 0 = 1.0: the bias slot
+    const short one = (short)(kk == 0 ? 0x3F80 : 0);
+    const s16x4 one2 = {one, one, 0, 0};                                          // k-slots 4, 5 of lane group 0 = 1.0: the bias slots (hi, lo)
     int pbuf = 0;  // blk % 3
     for (int blk = 0; blk < a.NB; ++blk) {
       WV_STAMP(0) WV_STAMP(11)
@@ -435,13 +435,13 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
       const bf16x8 w0 = wsl[0 * 64], w1 = wsl[1 * 64], w2 = wsl[2 * 64], w3 = wsl[3 * 64];
       const bf16x8 w4 = wsl[4 * 64], w5 = wsl[5 * 64], w6 = wsl[6 * 64], w7 = wsl[7 * 64];
       WV_STAMP(3)
-      // k-step 0 = (tap 2 | bias slot): operands in registers - these six MFMAs run while the other waves arrive
-      // slot = (kstep * 2 + {sig, tanh}) * 2 + {hi, lo}; the host put (b_hi, b_lo) into k-slot 4 of lane group 0
+      // k-step 0 = tap 2, operands in registers - these four MFMAs run while the other waves arrive.  The 8 k-slots of a lane
+      // group hold TWO 4-channel groups: (w_hi | w_hi) x (u_hi | u_lo) is hi*hi + hi*lo in one MFMA, (w_lo | bias) x (u_hi | 1, 1)
+      // the lo*hi product plus the bias (hi and lo halves in k-slots 4, 5 of lane group 0): api.hip, load_wavenet
       f32x4 as = {0.f, 0.f, 0.f, 0.f}, at = {0.f, 0.f, 0.f, 0.f};
-      const bf16x8 xuh = cat8(u2h, one4), xul = cat8(u2l, z4);
-      MFMA_BF(as, w0, xuh); MFMA_BF(at, w2, xuh);
-      MFMA_BF(as, w1, xuh); MFMA_BF(at, w3, xuh);
-      MFMA_BF(as, w0, xul); MFMA_BF(at, w2, xul);
+      const bf16x8 xua = cat8(u2h, u2l), xub = cat8(u2h, one2);
+      MFMA_BF(as, w0, xua); MFMA_BF(at, w2, xua);
+      MFMA_BF(as, w1, xub); MFMA_BF(at, w3, xub);
       WV_STAMP(4)
       // u complete (all rows, all waves).  At most the 8 operand reads above are younger than the u write, so "at most 8
       // LDS operations outstanding" means the write has landed; the operands keep streaming across the barrier.
@@ -487,11 +487,10 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
       s16x4 g_h, g_l;
       split4(gv, g_h, g_l);  // the gate product is the res / skip conv's B operand as it stands
       f32x4 ar = {0.f, 0.f, 0.f, 0.f}, s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-      const bf16x8 gh8 = cat8(g_h, one4), gl8 = cat8(g_l, z4);
+      const bf16x8 ga8 = cat8(g_h, g_l), gb8 = cat8(g_h, one2);
       {
-        MFMA_BF(ar, r0, gh8); MFMA_BF(s0, r2, gh8); MFMA_BF(s1, r4, gh8);
-        MFMA_BF(ar, r1, gh8); MFMA_BF(s0, r3, gh8); MFMA_BF(s1, r5, gh8);
-        MFMA_BF(ar, r0, gl8); MFMA_BF(s0, r2, gl8); MFMA_BF(s1, r4, gl8);
+        MFMA_BF(ar, r0, ga8); MFMA_BF(s0, r2, ga8); MFMA_BF(s1, r4, ga8);
+        MFMA_BF(ar, r1, gb8); MFMA_BF(s0, r3, gb8); MFMA_BF(s1, r5, gb8);
       }
       WV_STAMP(9)
       // residual / skip update; biases ride in the MFMA, and a block without a residual conv has zero
