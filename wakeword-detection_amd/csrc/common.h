@@ -219,3 +219,14 @@ int ww_k_wave_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
 int ww_k_far_frr(ww_ctx *ctx, const float *d_pos, int64_t n_pos, const float *d_neg, int64_t n_neg, int win,
                  const double *d_thr, int n_thr, double *d_smoothed, unsigned long long *d_pos_cnt,
                  unsigned long long *d_fa_cnt);
+
+#ifdef __HIPCC__
+// max(x, 0) as ONE instruction: fmaxf compiles to a canonicalising v_max (x, x) in front of the v_max (0, x) when its
+// argument comes out of an MFMA.  On the bit pattern a signed-integer max does the same job (negative floats, -0
+// included, are negative integers).  Not inline asm: the compiler does not see an MFMA -> VALU read hazard through it
+// and omits the wait states.
+__device__ __forceinline__ float relu1(float x) {
+  const int b = __float_as_int(x);
+  return __int_as_float(b > 0 ? b : 0);
+}
+#endif

@@ -522,8 +522,8 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (i < 5 || o_off[i][r] >= 0) {  // only the last tile of wave 3 has rows past M
-          feat[o_off[i][r]] = fmaxf(r0[r], 0.f);
-          feat[o_off[i][r] + 16] = fmaxf(r1[r], 0.f);
+          feat[o_off[i][r]] = relu1(r0[r]);
+          feat[o_off[i][r] + 16] = relu1(r1[r]);
         }
       }
     };

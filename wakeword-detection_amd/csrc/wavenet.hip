@@ -191,13 +191,6 @@ __device__ __forceinline__ bf16x8 cat8(s16x4 first, s16x4 second) {
 }
 #define MFMA_BF(acc, av, bv) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc, 0, 0, 0)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-// max(x, 0) as ONE instruction: fmaxf compiles to a canonicalising v_max (x, x) in front of the v_max (0, x).  On the bit
-// pattern a signed-integer max does the same job (negative floats, -0 included, are negative integers).  Not inline
-// asm: the compiler does not see an MFMA -> VALU read hazard through it and omits the wait states.
-__device__ __forceinline__ float relu1(float x) {
-  const int b = __float_as_int(x);
-  return __int_as_float(b > 0 ? b : 0);
-}
 #define WV_SLOTS 14  // A-operand slots per block: gate (2 k-steps x {sig,tanh} x 2) = 8, res | skip (3 m-tiles x 2) = 6
 #define WV_PAGE_U4 (WV_SLOTS * 64)  // one block's parameter page in 16-byte units (the conv biases sit in padded k-slots)
 
