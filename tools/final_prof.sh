@@ -24,4 +24,5 @@ python tools/slide_throughput.py 10 > $O/slide_throughput_10min.json 2> /dev/nul
 bash tools/pmc_crnn.sh 256 > $O/sq_crnn_256.txt 2>&1
 bash tools/pmc_crnn.sh 4096 > $O/sq_crnn_4096.txt 2>&1
 bash tools/pmc_fe.sh > $O/sq_logmel_256.txt 2>&1
-for f in sq_crnn_256 sq_crnn_4096 sq_logmel_256; do echo $f; tail -n 6 $O/$f.txt; done
+bash tools/pmc_wavenet.sh 256 > $O/sq_wavenet_bf16x3_256.txt 2>&1
+for f in sq_crnn_256 sq_crnn_4096 sq_logmel_256 sq_wavenet_bf16x3_256; do echo $f; tail -n 6 $O/$f.txt; done
