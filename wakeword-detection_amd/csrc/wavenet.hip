@@ -38,11 +38,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define WV_S 32
 #define WV_PAD 16     // causal zero rows in front of u
 #define WV_INLD 48    // staged input row stride (40 mel + zero pad to 3 k-blocks)
-#ifndef WV_NW
-#define WV_NW 12      // wavefronts per workgroup (3 per SIMD): 12 row tiles of 16 frames, one per wave
+// wavefronts per workgroup = template parameter NW of the kernel: the 12 row tiles of 16 frames are dealt 12 / NW per wave.
+// Both modes run 12 waves x 1 tile (3 waves per SIMD).  The split-bf16 loop is written over the tiles of a wave, so
+// -DWV_BF16_NW=6 or 4 builds the 2- and 3-tile forms (independent MFMAs / gate evaluations back to back in one wave, a third of
+// the operand reads): measured 45.2 and 44.6 us against 38.9 us for 12 x 1 - a wave's LDS and MFMA -> VALU latencies are
+// covered better by two more waves on the SIMD than by two more tiles in the wave.
+#ifndef WV_BF16_NW
+#define WV_BF16_NW 12
 #endif
-#define WV_MPW (12 / WV_NW)  // row tiles per wave
-#define WV_THREADS (WV_NW * 64)
+#ifndef WV_BF16_OCC
+#define WV_BF16_OCC 3   // waves per SIMD the split-bf16 kernel is compiled for (3 = one workgroup per CU)
+#endif
 
 struct win_addr_w {
   const int64_t *row;
@@ -194,8 +200,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define WV_SLOTS 14  // A-operand slots per block: gate (2 k-steps x {sig,tanh} x 2) = 8, res | skip (3 m-tiles x 2) = 6
 #define WV_PAGE_U4 (WV_SLOTS * 64)  // one block's parameter page in 16-byte units (the conv biases sit in padded k-slots)
 
-template <bool HEAD_ONLY, bool SPLIT_BF16>
-__global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
+template <bool HEAD_ONLY, bool SPLIT_BF16, int WV_NW>
+__global__ __launch_bounds__(WV_NW * 64, WV_NW == 12 ? (SPLIT_BF16 ? WV_BF16_OCC : 3) : 2) void wavenet_kernel(wave_args a) {
+  constexpr int WV_MPW = 12 / WV_NW, WV_THREADS = WV_NW * 64;
+  static_assert(WV_MPW * WV_NW == 12, "12 row tiles");
   // LDS: region A = staged input [192][48] (prologue only), later u[2][208][16] + g[192][16]
   // split-bf16: u planes (same bytes as the fp32 u buffers) + two parameter pages (next to / under the head's tile)
   constexpr int LDS_FP32 = WV_T * WV_INLD > (2 * (WV_T + WV_PAD) * WV_C + WV_T * WV_S) ? WV_T * WV_INLD
@@ -356,42 +364,40 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
     // u write, the gate operands - barrier - the delayed taps, and only then the res | skip operands, which are not needed
     // for another ~600 cycles (requested after the tap MFMAs instead: no gain, measured).  The wait in front of the barrier is counted (only the u write has to be complete), so
     // nobody waits at the barrier for 14 KB of operands per wave to stream out of LDS.
-    // One row tile per wave, 12 waves.  (4 waves x 3 tiles, written tile-major so that the scheduler could
-    // overlap one tile's gate VALU with the next tile's MFMAs, measured 45 % slower: it does not interleave.)
+    // 12 / NW row tiles per wave (template parameter): every statement of the block body runs over the wave's tiles, so a
+    // wave with several tiles issues independent MFMAs / gate evaluations back to back.
     // The loop is bound by vector-instruction ISSUE (each of the 3 waves of a SIMD issues its ~80 vector instructions per
     // block, and every bf16 MFMA holds the SIMD's vector issue for 8 of its 16 cycles), so the block body carries no
     // instruction it can avoid: ReLU is one v_max (fmaxf costs a canonicalising v_max in front), the exp2 scale factors
     // of the gates sit in the packed weights, the dilation comes out of two SGPR pairs read before the loop.
-    static_assert(!SPLIT_BF16 || WV_MPW == 1, "the split-bf16 loop handles one row tile per wave");
     constexpr int U_KK_B = (WV_T + WV_PAD) * 8, U_BUF_B = 4 * U_KK_B, U_PLANE_B = 2 * U_BUF_B;   // bytes
     static_assert(2 * U_PLANE_B == 2 * (WV_T + WV_PAD) * WV_C * 4, "u planes must fill exactly the fp32 u buffers' bytes");
     static_assert(U_KK_B % 256 == 128, "the two channel groups of a 32-lane read group must sit 128 bytes apart (mod 256): conflict-free ds_read_b64");
-    static_assert(U_PLANE_B % 512 == 0 && U_PLANE_B / 512 < 256, "lo plane reachable by ds_write2st64_b64's second offset");
     unsigned char *ldsb = (unsigned char *)lds;
     const unsigned lds0 = (unsigned)(uintptr_t)lds;  // low 32 bits of a flat LDS pointer = the LDS byte address
     for (int i = tid; i < 2 * 2 * 4 * WV_PAD; i += WV_THREADS) {                  // causal zero rows: [plane][buffer][kk][row < PAD]
       const int pl = i / (2 * 4 * WV_PAD), b = (i / (4 * WV_PAD)) & 1, k = (i / WV_PAD) & 3, r = i % WV_PAD;
       *(uint2 *)(ldsb + pl * U_PLANE_B + b * U_BUF_B + k * U_KK_B + r * 8) = make_uint2(0u, 0u);
     }
-    const int t0 = wave * 16;
-    const int ub = kk * U_KK_B + (WV_PAD + t0 + j) * 8;                           // this lane's (row t, channel group kk), hi plane
-    // Block parameters (14 A-operand slots = one 14 KB "page") are identical for all 12 waves: the workgroup
-    // fetches page b+2 with one or two 16-byte loads per thread at the top of block b and parks it in LDS at
-    // the end of the block (three buffers).  The barrier of block b+1 publishes it, so in block b+2 every
-    // wave may read its operands BEFORE that block's barrier - their LDS latency and the burst of 12 waves
-    // reading 14 KB each hide behind the BatchNorm / split / barrier part of the block.  (Per-wave register
-    // prefetch cost 1 us per block: the loads can only be issued once the registers are free, i.e. late;
+    // this wave's tiles are consecutive: tile mi starts 16 rows = 128 bytes behind tile mi - 1 in every plane
+    const int t0 = wave * WV_MPW * 16;
+    const int ub = kk * U_KK_B + (WV_PAD + t0 + j) * 8;                           // this lane's (row t of tile 0, channel group kk), hi plane
+    // Block parameters (14 A-operand slots = one 14 KB "page") are identical for all waves: the workgroup
+    // fetches page b+2 at the top of block b and parks it in LDS at the end of the block (three buffers).  The barrier of
+    // block b+1 publishes it, so in block b+2 every wave may read its operands BEFORE that block's barrier.
+    // (Per-wave register prefetch cost 1 us per block: the loads can only be issued once the registers are free, i.e. late;
     // double-buffered pages read after the barrier left ~1000 cycles of operand reads on the critical path.)
     uint4 *pages = (uint4 *)(lds + 2 * (WV_T + WV_PAD) * WV_C);                  // [3][WV_PAGE_U4]
     const uint4 *gpage = a.wpk;
-    const int pi1 = tid + WV_THREADS < WV_PAGE_U4 ? tid + WV_THREADS : WV_PAGE_U4 - 1;
+    constexpr int NPL = (WV_PAGE_U4 + WV_THREADS - 1) / WV_THREADS;               // page pieces per thread (the last one partial)
+    static_assert(NPL >= 2 && NPL <= 4, "page pieces per thread");
+    auto pclamp = [&](int q) { return tid + q * WV_THREADS < WV_PAGE_U4 ? tid + q * WV_THREADS : WV_PAGE_U4 - 1; };
+    const int pidx0 = pclamp(0), pidx1 = pclamp(1), pidx2 = pclamp(2), pidx3 = pclamp(3);
     {
       const int second = a.NB > 1 ? 1 : 0;
-      pages[tid] = gpage[tid];
-      pages[WV_PAGE_U4 + tid] = gpage[(size_t)second * WV_PAGE_U4 + tid];
-      if (tid + WV_THREADS < WV_PAGE_U4) {
-        pages[tid + WV_THREADS] = gpage[pi1];
-        pages[WV_PAGE_U4 + tid + WV_THREADS] = gpage[(size_t)second * WV_PAGE_U4 + pi1];
+      for (int i = tid; i < WV_PAGE_U4; i += WV_THREADS) {
+        pages[i] = gpage[i];
+        pages[WV_PAGE_U4 + i] = gpage[(size_t)second * WV_PAGE_U4 + i];
       }
     }
     // The BatchNorm vectors are needed BEFORE a block's barrier (they produce u), i.e. before that block's
@@ -411,96 +417,135 @@ __global__ __launch_bounds__(WV_THREADS) void wavenet_kernel(wave_args a) {
       const int bo = (blk & 1) * U_BUF_B;
       const int d = (int)(((blk < 16 ? dil_lo : dil_hi) >> (4 * (blk & 15))) & 15);
       const int nblk = blk + 2 < a.NB ? blk + 2 : a.NB - 1;                      // unconditional prefetch target
-      const uint4 np0 = gpage[(size_t)nblk * WV_PAGE_U4 + tid], np1 = gpage[(size_t)nblk * WV_PAGE_U4 + pi1];
+      // (named registers, not an array: the array form stayed in scratch memory and every block waited for its own prefetch)
+      const uint4 *gnext = gpage + (size_t)nblk * WV_PAGE_U4;
+      uint4 np0 = gnext[pidx0], np1 = gnext[pidx1], np2 = np0, np3 = np0;
+      if (NPL > 2) np2 = gnext[pidx2];
+      if (NPL > 3) np3 = gnext[pidx3];
       __builtin_amdgcn_sched_barrier(0);  // keep the loads HERE (the scheduler would sink them to their use)
       const uint4 *pg = pages + pbuf * WV_PAGE_U4;
       const bf16x8 *wsl = (const bf16x8 *)pg + lane;                             // slot q: wsl[q * 64]
       WV_STAMP(1)
       const float4 bn_s = bnall[blk * 8 + kk], bn_t = bnall[blk * 8 + 4 + kk];
-      // BatchNorm affine (wavenet_model.py:57): this tile's u = the undelayed tap's B operand
-      const float uv[4] = {x[0][0] * bn_s.x + bn_t.x, x[0][1] * bn_s.y + bn_t.y, x[0][2] * bn_s.z + bn_t.z, x[0][3] * bn_s.w + bn_t.w};
-      s16x4 u2h, u2l;
-      split4(uv, u2h, u2l);
+      // BatchNorm affine (wavenet_model.py:57): a tile's u = the undelayed tap's B operand
+      s16x4 u2h[WV_MPW], u2l[WV_MPW];
+      const unsigned wa = lds0 + (unsigned)(bo + ub);
+#pragma unroll
+      for (int mi = 0; mi < WV_MPW; ++mi) {
+        const float uv[4] = {x[mi][0] * bn_s.x + bn_t.x, x[mi][1] * bn_s.y + bn_t.y, x[mi][2] * bn_s.z + bn_t.z, x[mi][3] * bn_s.w + bn_t.w};
+        split4(uv, u2h[mi], u2l[mi]);
+      }
       WV_STAMP(2)
-      // hi and lo planes in one instruction, straight from the two operand register pairs
-      asm volatile("ds_write2st64_b64 %0, %1, %2 offset1:%3" : : "v"(lds0 + (unsigned)(bo + ub)), "v"(u2h), "v"(u2l), "n"(U_PLANE_B / 512) : "memory");
+      // hi and lo planes straight from the operand register pairs (immediate offsets: tile, plane)
+#define WV_WR(mi_)                                                                                                   \
+  if ((mi_) < WV_MPW)                                                                                                \
+    asm volatile("ds_write_b64 %0, %1 offset:%3\n\tds_write_b64 %0, %2 offset:%4"                                   \
+                 : : "v"(wa), "v"(u2h[(mi_) < WV_MPW ? (mi_) : 0]), "v"(u2l[(mi_) < WV_MPW ? (mi_) : 0]), "n"((mi_) * 128), "n"(U_PLANE_B + (mi_) * 128) : "memory");
+      WV_WR(0) WV_WR(1) WV_WR(2)
+#undef WV_WR
       // this block's gate operands (the page was published one barrier ago)
       const bf16x8 w0 = wsl[0 * 64], w1 = wsl[1 * 64], w2 = wsl[2 * 64], w3 = wsl[3 * 64];
       const bf16x8 w4 = wsl[4 * 64], w5 = wsl[5 * 64], w6 = wsl[6 * 64], w7 = wsl[7 * 64];
       WV_STAMP(3)
-      // k-step 0 = tap 2, operands in registers - these four MFMAs run while the other waves arrive.  The 8 k-slots of a lane
+      // k-step 0 = tap 2, operands in registers - these MFMAs run while the other waves arrive.  The 8 k-slots of a lane
       // group hold TWO 4-channel groups: (w_hi | w_hi) x (u_hi | u_lo) is hi*hi + hi*lo in one MFMA, (w_lo | bias) x (u_hi | 1, 1)
       // the lo*hi product plus the bias (hi and lo halves in k-slots 4, 5 of lane group 0): api.hip, load_wavenet
-      f32x4 as = {0.f, 0.f, 0.f, 0.f}, at = {0.f, 0.f, 0.f, 0.f};
-      const bf16x8 xua = cat8(u2h, u2l), xub = cat8(u2h, one2);
-      MFMA_BF(as, w0, xua); MFMA_BF(at, w2, xua);
-      MFMA_BF(as, w1, xub); MFMA_BF(at, w3, xub);
+      f32x4 as[WV_MPW], at[WV_MPW];
+#pragma unroll
+      for (int mi = 0; mi < WV_MPW; ++mi) {
+        as[mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        at[mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const bf16x8 xua = cat8(u2h[mi], u2l[mi]), xub = cat8(u2h[mi], one2);
+        MFMA_BF(as[mi], w0, xua); MFMA_BF(at[mi], w2, xua);
+        MFMA_BF(as[mi], w1, xub); MFMA_BF(at[mi], w3, xub);
+      }
       WV_STAMP(4)
-      // u complete (all rows, all waves).  At most the 8 operand reads above are younger than the u write, so "at most 8
-      // LDS operations outstanding" means the write has landed; the operands keep streaming across the barrier.
+      // u complete (all rows, all waves).  At most the 8 operand reads above are younger than the u writes, so "at most 8
+      // LDS operations outstanding" means the writes have landed; the operands keep streaming across the barrier.
       asm volatile("s_waitcnt lgkmcnt(8)\n\ts_barrier" ::: "memory");
       WV_STAMP(5)
       // k-step 1 = (tap 0 | tap 1) = rows t - 2d and t - d (rows < 0 hit the zero pad, d <= 8)
-      s16x4 u0h, u1h, u0l, u1l;
+      s16x4 u0h[WV_MPW], u1h[WV_MPW], u0l[WV_MPW], u1l[WV_MPW];
       {
-        const unsigned ra = lds0 + (unsigned)(bo + ub - 16 * d);
-#define WV_RD4(d_)                                                                                                          \
-  asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:%5\n\tds_read_b64 %2, %4 offset:%6\n\tds_read_b64 %3, %4 offset:%7" \
-               : "=&v"(u0h), "=&v"(u1h), "=&v"(u0l), "=&v"(u1l)                                                             \
-               : "v"(ra), "n"(8 * (d_)), "n"(U_PLANE_B), "n"(U_PLANE_B + 8 * (d_))                                         \
-               : "memory")
-        if (d == 1) { WV_RD4(1); }
-        else if (d == 2) { WV_RD4(2); }
-        else if (d == 4) { WV_RD4(4); }
-        else if (d == 8) { WV_RD4(8); }
+        const unsigned ra = wa - 16u * (unsigned)d;
+#define WV_RD4(mi_, d_)                                                                                                     \
+  if ((mi_) < WV_MPW)                                                                                                       \
+    asm volatile("ds_read_b64 %0, %4 offset:%5\n\tds_read_b64 %1, %4 offset:%6\n\tds_read_b64 %2, %4 offset:%7\n\tds_read_b64 %3, %4 offset:%8" \
+                 : "=&v"(u0h[(mi_) < WV_MPW ? (mi_) : 0]), "=&v"(u1h[(mi_) < WV_MPW ? (mi_) : 0]),                           \
+                   "=&v"(u0l[(mi_) < WV_MPW ? (mi_) : 0]), "=&v"(u1l[(mi_) < WV_MPW ? (mi_) : 0])                            \
+                 : "v"(ra), "n"((mi_) * 128), "n"((mi_) * 128 + 8 * (d_)), "n"(U_PLANE_B + (mi_) * 128),                     \
+                   "n"(U_PLANE_B + (mi_) * 128 + 8 * (d_))                                                                  \
+                 : "memory");
+#define WV_RD(d_) WV_RD4(0, d_) WV_RD4(1, d_) WV_RD4(2, d_)
+        if (d == 1) { WV_RD(1) }
+        else if (d == 2) { WV_RD(2) }
+        else if (d == 4) { WV_RD(4) }
+        else if (d == 8) { WV_RD(8) }
         else {  // any other dilation: plain loads
-          u0h = *(const s16x4 *)(ldsb + bo + ub - 16 * d); u1h = *(const s16x4 *)(ldsb + bo + ub - 8 * d);
-          u0l = *(const s16x4 *)(ldsb + U_PLANE_B + bo + ub - 16 * d); u1l = *(const s16x4 *)(ldsb + U_PLANE_B + bo + ub - 8 * d);
+#pragma unroll
+          for (int mi = 0; mi < WV_MPW; ++mi) {
+            const unsigned char *base = ldsb + bo + ub + mi * 128;
+            u0h[mi] = *(const s16x4 *)(base - 16 * d); u1h[mi] = *(const s16x4 *)(base - 8 * d);
+            u0l[mi] = *(const s16x4 *)(base + U_PLANE_B - 16 * d); u1l[mi] = *(const s16x4 *)(base + U_PLANE_B - 8 * d);
+          }
         }
+#undef WV_RD
 #undef WV_RD4
       }
       // res | skip operands: behind the taps in the LDS queue, in front of their use by a whole gate evaluation
       const bf16x8 r0 = wsl[8 * 64], r1 = wsl[9 * 64], r2 = wsl[10 * 64], r3 = wsl[11 * 64], r4 = wsl[12 * 64], r5 = wsl[13 * 64];
-      asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(u0h), "+v"(u1h), "+v"(u0l), "+v"(u1l) : : "memory");  // the taps (6 younger reads may be in flight)
+      // the taps (6 younger reads may be in flight)
+#pragma unroll
+      for (int mi = 0; mi < WV_MPW; ++mi)
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(u0h[mi]), "+v"(u1h[mi]), "+v"(u0l[mi]), "+v"(u1l[mi]) : : "memory");
       WV_STAMP(6)
-      const bf16x8 xdh = cat8(u0h, u1h), xdl = cat8(u0l, u1l);
-      MFMA_BF(as, w4, xdh); MFMA_BF(at, w6, xdh);
-      MFMA_BF(as, w5, xdh); MFMA_BF(at, w7, xdh);
-      MFMA_BF(as, w4, xdl); MFMA_BF(at, w6, xdl);
+#pragma unroll
+      for (int mi = 0; mi < WV_MPW; ++mi) {
+        const bf16x8 xdh = cat8(u0h[mi], u1h[mi]), xdl = cat8(u0l[mi], u1l[mi]);
+        MFMA_BF(as[mi], w4, xdh); MFMA_BF(at[mi], w6, xdh);
+        MFMA_BF(as[mi], w5, xdh); MFMA_BF(at[mi], w7, xdh);
+        MFMA_BF(as[mi], w4, xdl); MFMA_BF(at[mi], w6, xdl);
+      }
       WV_STAMP(7)
       // gate: tanh(t) * sigmoid(s); biases AND the exp2 scale factors (-log2 e, 2 log2 e) are inside the accumulators
-      float gv[4];
+      f32x4 ar[WV_MPW], s0[WV_MPW], s1[WV_MPW];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float et = __builtin_amdgcn_exp2f(at[r]);    // exp(2 t): inf -> tanh 1, 0 -> -1
-        const float es = __builtin_amdgcn_exp2f(as[r]);    // exp(-s)
-        gv[r] = (1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + et)) * __builtin_amdgcn_rcpf(1.0f + es);
-      }
-      WV_STAMP(8)
-      s16x4 g_h, g_l;
-      split4(gv, g_h, g_l);  // the gate product is the res / skip conv's B operand as it stands
-      f32x4 ar = {0.f, 0.f, 0.f, 0.f}, s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-      const bf16x8 ga8 = cat8(g_h, g_l), gb8 = cat8(g_h, one2);
-      {
-        MFMA_BF(ar, r0, ga8); MFMA_BF(s0, r2, ga8); MFMA_BF(s1, r4, ga8);
-        MFMA_BF(ar, r1, gb8); MFMA_BF(s0, r3, gb8); MFMA_BF(s1, r5, gb8);
+      for (int mi = 0; mi < WV_MPW; ++mi) {
+        float gv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float et = __builtin_amdgcn_exp2f(at[mi][r]);    // exp(2 t): inf -> tanh 1, 0 -> -1
+          const float es = __builtin_amdgcn_exp2f(as[mi][r]);    // exp(-s)
+          gv[r] = (1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + et)) * __builtin_amdgcn_rcpf(1.0f + es);
+        }
+        WV_STAMP(8)
+        s16x4 g_h, g_l;
+        split4(gv, g_h, g_l);  // the gate product is the res / skip conv's B operand as it stands
+        ar[mi] = (f32x4){0.f, 0.f, 0.f, 0.f}; s0[mi] = ar[mi]; s1[mi] = ar[mi];
+        const bf16x8 ga8 = cat8(g_h, g_l), gb8 = cat8(g_h, one2);
+        MFMA_BF(ar[mi], r0, ga8); MFMA_BF(s0[mi], r2, ga8); MFMA_BF(s1[mi], r4, ga8);
+        MFMA_BF(ar[mi], r1, gb8); MFMA_BF(s0[mi], r3, gb8); MFMA_BF(s1[mi], r5, gb8);
       }
       WV_STAMP(9)
       // residual / skip update; biases ride in the MFMA, and a block without a residual conv has zero
       // res weights and bias (relu(0) = 0), so no special case
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        x[0][r] = relu1(ar[r]) + x[0][r];
-        skip[0][0][r] = skip[0][0][r] + relu1(s0[r]);
-        skip[0][1][r] = skip[0][1][r] + relu1(s1[r]);
-      }
+      for (int mi = 0; mi < WV_MPW; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          x[mi][r] = relu1(ar[mi][r]) + x[mi][r];
+          skip[mi][0][r] = skip[mi][0][r] + relu1(s0[mi][r]);
+          skip[mi][1][r] = skip[mi][1][r] + relu1(s1[mi][r]);
+        }
       WV_STAMP(10)
       // park page blk+2 (loaded a whole block ago) in the buffer that held page blk-1: every wave is past its
       // reads of that one (they precede the barrier of block blk, which everyone here has passed)
       const int nbuf = pbuf == 0 ? 2 : pbuf - 1;  // (blk + 2) % 3
       uint4 *pn = pages + nbuf * WV_PAGE_U4;
-      pn[tid] = np0;
-      if (tid + WV_THREADS < WV_PAGE_U4) pn[tid + WV_THREADS] = np1;
+      pn[pidx0] = np0;
+      if (tid + WV_THREADS < WV_PAGE_U4) pn[pidx1] = np1;
+      if (NPL > 2 && tid + 2 * WV_THREADS < WV_PAGE_U4) pn[pidx2] = np2;
+      if (NPL > 3 && tid + 3 * WV_THREADS < WV_PAGE_U4) pn[pidx3] = np3;
       pbuf = pbuf == 2 ? 0 : pbuf + 1;
     }
     __syncthreads();
@@ -654,9 +699,9 @@ int ww_k_wave_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
   }
 #endif
   if (m->precision == WW_PRECISION_BF16X3)
-    hipLaunchKernelGGL((wavenet_kernel<false, true>), dim3(nw), dim3(WV_THREADS), 0, ctx->stream, a);
+    hipLaunchKernelGGL((wavenet_kernel<false, true, WV_BF16_NW>), dim3(nw), dim3(WV_BF16_NW * 64), 0, ctx->stream, a);
   else
-    hipLaunchKernelGGL((wavenet_kernel<false, false>), dim3(nw), dim3(WV_THREADS), 0, ctx->stream, a);
+    hipLaunchKernelGGL((wavenet_kernel<false, false, 12>), dim3(nw), dim3(12 * 64), 0, ctx->stream, a);
   WW_HIP(ctx, hipGetLastError());
   return WW_OK;
 }
@@ -669,7 +714,7 @@ int ww_k_wave_detect(ww_ctx *ctx, const ww_model *m, const float *d_enc, int nw,
   a.d_w1_4 = v.d_w1; a.d_b1 = v.d_b1; a.d_w2_4 = v.d_w2; a.d_b2 = v.d_b2;
   a.out = d_out; a.enc = nullptr; a.enc_in = d_enc;
   ww_launch_scope scope(ctx, "wavenet_detect_kernel");
-  hipLaunchKernelGGL((wavenet_kernel<true, false>), dim3(nw), dim3(WV_THREADS), 0, ctx->stream, a);
+  hipLaunchKernelGGL((wavenet_kernel<true, false, 12>), dim3(nw), dim3(12 * 64), 0, ctx->stream, a);
   WW_HIP(ctx, hipGetLastError());
   return WW_OK;
 }
