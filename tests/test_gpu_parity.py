@@ -519,3 +519,26 @@ def test_logmel_with_other_filterbanks(assets, monkeypatch):
         _engine_with_filter(assets, monkeypatch, bank([(10, 37)] + [(4 * i, 4) for i in range(39)]))
     with pytest.raises(Exception, match="mel band"):
         _engine_with_filter(assets, monkeypatch, bank([(7 * i, 20) for i in range(17)] + [(4 * i, 4) for i in range(23)]))
+
+
+@pytest.mark.parametrize("name", ["CRNN", "Wavenet"])
+def test_degenerate_sizes_through_the_c_abi(engines, oracles, name):
+    """Empty and minimal inputs: zero windows, a mel stream shorter than / exactly one window, empty posterior sets in the
+    sweep - the entry points return empty results (status 0), not errors, and the one-window cases equal the oracle."""
+    e = engines[name]
+    rng = np.random.default_rng(41)
+    out, enc = e.forward(np.zeros((0, e.window, 40), np.float32), want_enc=True)
+    assert out.shape == (0, e.n_out) and enc.shape[0] == 0
+    assert e.slide_forward(np.zeros((e.window - 1, 40), np.float32), 2).shape == (0, e.n_out)
+    assert e.slide_forward(np.zeros((0, 40), np.float32), 2).shape == (0, e.n_out)
+    mel = rng.uniform(0, 6.5, (e.window, 40)).astype(np.float32)
+    one = e.slide_forward(mel, 2)
+    assert one.shape == (1, e.n_out)
+    assert np.abs(one - oracles[name].forward(mel[None])).max() < TOL_POST
+    assert np.abs(e.slide_forward(np.concatenate([mel, mel[:1]]), 2) - one).max() == 0   # one extra row: still one window at hop 2
+    assert e.logmel([]) == []
+    thr = np.arange(0.5, 0.99999, 0.005)
+    frr, fa, cnt = e.far_frr(np.zeros(0, np.float32), np.zeros(0, np.float32), thr, 1.0, 1.0)
+    assert frr.shape == fa.shape == cnt.shape == thr.shape and not cnt.any() and not fa.any()
+    frr, fa, cnt = e.far_frr(np.array([0.9], np.float32), np.zeros(0, np.float32), thr, 1.0, 1.0)
+    assert frr[0] == 0.0 and frr[-1] == 1.0 and not fa.any()   # 0.9 > 0.5, 0.9 < 0.995
