@@ -85,14 +85,21 @@ __global__ __launch_bounds__(128) void stream_frontend_kernel(stream_fe_args a) 
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int s = blockIdx.x;
-  const int fill = a.ctl[s * 4 + 0], n_frames = a.ctl[s * 4 + 1], flags = a.ctl[s * 4 + 2], pos = a.ctl[s * 4 + 3];
+  // the tick's 320 samples (40 x 16 bytes) are requested from pinned host memory BEFORE the control words are looked at:
+  // one trip over the bus instead of two in a row (control words -> branch -> samples)
+  static_assert(WW_CHUNK * 2 == 40 * 16, "a tick is 40 sixteen-byte pieces");
+  uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+  if (tid < 40) raw = ((const uint4 *)(a.frames + (size_t)s * WW_CHUNK))[tid];
+  const int4 cw = ((const int4 *)a.ctl)[s];
+  const int fill = cw.x, n_frames = cw.y, flags = cw.z, pos = cw.w;
   const bool speech = flags & 1, skip = flags & 2;
 
   size_t off = 0;
   cplx<R> *fbuf = (cplx<R> *)(smem + off); off += 2 * FFT_LD * sizeof(cplx<R>);
   float *mag = (float *)(smem + off); off += 2 * 260 * sizeof(float);
   float *wl = (float *)(smem + off); off += WW_MEL_TAPS * 64 * sizeof(float);
-  float *x = (float *)(smem + off);  // [ST_RING]
+  float *x = (float *)(smem + off); off += ST_RING * sizeof(float);  // [ST_RING]
+  short *xs = (short *)(smem + off);  // [WW_CHUNK] raw samples of the tick
 
   // ---- this tick's window descriptors: host-pinned -> device arrays (read by the model kernels that follow)
   for (int i = s * 128 + tid; i < a.nw; i += a.S * 128) {
@@ -106,21 +113,23 @@ __global__ __launch_bounds__(128) void stream_frontend_kernel(stream_fe_args a) 
   float *ring = a.ring + (size_t)s * ST_RING;
   for (int i = tid; i < fill; i += 128) x[i] = ring[i];
   const float carry = a.prev[s];
+  if (tid < 40) ((uint4 *)xs)[tid] = raw;
+  __syncthreads();
   for (int i = tid; i < WW_CHUNK; i += 128) {
-    float v = __fdiv_rn((float)a.frames[(size_t)s * WW_CHUNK + i], a.divisor);
+    float v = __fdiv_rn((float)xs[i], a.divisor);
     if (a.clip) v = fminf(fmaxf(v, -1.0f), 1.0f);
     float p;
     if (i == 0) {
       p = carry;
     } else {
-      p = __fdiv_rn((float)a.frames[(size_t)s * WW_CHUNK + i - 1], a.divisor);
+      p = __fdiv_rn((float)xs[i - 1], a.divisor);
       if (a.clip) p = fminf(fmaxf(p, -1.0f), 1.0f);
     }
     x[fill + i] = (a.preemph != 0.0f) ? __fsub_rn(v, __fmul_rn(a.preemph, p)) : v;
   }
   __syncthreads();
   if (tid == 0) {
-    float v = __fdiv_rn((float)a.frames[(size_t)s * WW_CHUNK + WW_CHUNK - 1], a.divisor);
+    float v = __fdiv_rn((float)xs[WW_CHUNK - 1], a.divisor);
     if (a.clip) v = fminf(fmaxf(v, -1.0f), 1.0f);
     a.prev[s] = v;  // tflite.py:156-158: carry is the un-emphasised last sample
   }
@@ -301,10 +310,10 @@ int ww_stream_step(ww_streams *st, const int16_t *frames, const uint8_t *is_spee
   {
     ww_launch_scope scope(ctx, "stream_frontend_kernel");
     if (st->fp.precise) {
-      size_t sm = 2 * FFT_LD * 16 + 2 * 260 * 4 + WW_MEL_TAPS * 64 * 4 + ST_RING * 4;
+      size_t sm = 2 * FFT_LD * 16 + 2 * 260 * 4 + WW_MEL_TAPS * 64 * 4 + ST_RING * 4 + WW_CHUNK * 2;
       hipLaunchKernelGGL((stream_frontend_kernel<double>), dim3(S), dim3(128), sm, ctx->stream, a);
     } else {
-      size_t sm = 2 * FFT_LD * 8 + 2 * 260 * 4 + WW_MEL_TAPS * 64 * 4 + ST_RING * 4;
+      size_t sm = 2 * FFT_LD * 8 + 2 * 260 * 4 + WW_MEL_TAPS * 64 * 4 + ST_RING * 4 + WW_CHUNK * 2;
       hipLaunchKernelGGL((stream_frontend_kernel<float>), dim3(S), dim3(128), sm, ctx->stream, a);
     }
   }
