@@ -106,13 +106,28 @@ __global__ __launch_bounds__(128) void stream_frontend_kernel(stream_fe_args a) 
     a.d_row[i] = a.h_row[i];
     a.d_valid[i] = a.h_valid[i];
   }
+  // device-side inputs that do not depend on the control words are requested before the branch on them, i.e. while
+  // the control words and samples are still crossing the bus: mel weights, the whole sample ring (fill <= 511 of its
+  // 832 slots are meaningful; the rest is never read), the pre-emphasis carry, the transform's constants
+  constexpr int WLQ = (WW_MEL_TAPS * 64 / 4 + 127) / 128;
+  float4 wlq[WLQ];
+#pragma unroll
+  for (int q = 0; q < WLQ; ++q) {
+    const int i = tid + q * 128;
+    wlq[q] = ((const float4 *)a.wpad)[i < WW_MEL_TAPS * 64 / 4 ? i : 0];
+  }
+  float *ring = a.ring + (size_t)s * ST_RING;
+  const float4 ringq = ((const float4 *)ring)[tid];  // samples 4 tid .. 4 tid + 3 (128 threads x 4 = 512 >= fill)
+  const float carry = a.prev[s];
+  fft_consts<R> fc;
+  fft_load_consts<R>(fc, lane, a.hann, a.tw256, a.tw512);
   if (skip) return;  // context.is_active: the frame is not sampled at all (tflite.py:139-140)
 
-  for (int i = tid; i < WW_MEL_TAPS * 64 / 4; i += 128) ((float4 *)wl)[i] = ((const float4 *)a.wpad)[i];
+#pragma unroll
+  for (int q = 0; q < WLQ; ++q)
+    if (tid + q * 128 < WW_MEL_TAPS * 64 / 4) ((float4 *)wl)[tid + q * 128] = wlq[q];
   // ---- [ring | new samples] in LDS
-  float *ring = a.ring + (size_t)s * ST_RING;
-  for (int i = tid; i < fill; i += 128) x[i] = ring[i];
-  const float carry = a.prev[s];
+  ((float4 *)x)[tid] = ringq;
   if (tid < 40) ((uint4 *)xs)[tid] = raw;
   __syncthreads();
   for (int i = tid; i < WW_CHUNK; i += 128) {
@@ -135,8 +150,6 @@ __global__ __launch_bounds__(128) void stream_frontend_kernel(stream_fe_args a) 
   }
   // ---- new frames (wave k handles frame k); only analysed while is_speech (tflite.py:166)
   if (speech && wave < n_frames) {
-    fft_consts<R> fc;
-    fft_load_consts<R>(fc, lane, a.hann, a.tw256, a.tw512);
     const float *src = x + wave * a.hop;
     auto x2 = [&](int n) -> float2 { return make_float2(src[2 * n], src[2 * n + 1]); };
     float *mg = mag + wave * 260;
