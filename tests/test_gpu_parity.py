@@ -542,3 +542,45 @@ def test_degenerate_sizes_through_the_c_abi(engines, oracles, name):
     assert frr.shape == fa.shape == cnt.shape == thr.shape and not cnt.any() and not fa.any()
     frr, fa, cnt = e.far_frr(np.array([0.9], np.float32), np.zeros(0, np.float32), thr, 1.0, 1.0)
     assert frr[0] == 0.0 and frr[-1] == 1.0 and not fa.any()   # 0.9 > 0.5, 0.9 < 0.995
+
+
+@pytest.mark.parametrize("name", ["CRNN", "CRNN_softmax"])
+def test_stream_incremental_kernel_matches_full_recompute(assets, name, monkeypatch):
+    """Streaming CRNN: crnn_stream_kernel (three of the nineteen time positions per new window, the other sixteen projected
+    rows from the per-stream ring) against the full recompute of every window (WWHIP_STREAM_FULL=1) - 300 ticks with
+    the speech bit going on and off, resets of single streams and of the whole bank, from an empty history."""
+    from wwhip.engine import Engine, StreamBank
+    e = Engine(os.path.join(assets, name))
+    S, ticks = 7, 300
+    rng = np.random.default_rng(77)
+    pcm = np.clip(rng.normal(0, 2500, (ticks, S, 320)), -32768, 32767).astype(np.int16)
+    speech = (rng.uniform(size=(ticks, S)) < 0.9).astype(np.uint8)
+    speech[:, 0] = 1
+
+    def run(full):
+        if full:
+            monkeypatch.setenv("WWHIP_STREAM_FULL", "1")
+        else:
+            monkeypatch.delenv("WWHIP_STREAM_FULL", raising=False)
+        bank = StreamBank(e, S)
+        out = []
+        for t in range(ticks):
+            if t == 120:
+                bank.reset([2, 5])
+            if t == 200:
+                bank.reset()
+            p, n = bank.step(pcm[t], speech[t])
+            out.append((p.copy(), n.copy()))
+        bank.close()
+        return out
+
+    try:
+        inc, full = run(False), run(True)
+        worst = 0.0
+        for (p0, n0), (p1, n1) in zip(inc, full):
+            np.testing.assert_array_equal(n0, n1)
+            worst = max(worst, float(np.abs(p0 - p1).max()))
+        assert worst < 2e-6, worst   # the two kernels associate the projection's k sum differently for some rows
+        assert sum(int(n.sum()) for _, n in inc) > 3000
+    finally:
+        e.close()

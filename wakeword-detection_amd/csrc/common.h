@@ -212,6 +212,9 @@ size_t ww_crnn_workspace(const ww_model *m, int n_windows);
 int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *d_win_row,
                       const int32_t *d_win_valid, int64_t row0, int hop, int valid_const, int n_windows, void *ws,
                       float *d_out, float *d_enc);
+bool ww_crnn_stream_capable(const ww_model *m);
+int ww_k_crnn_stream_forward(ww_ctx *ctx, const ww_model *m, const float *d_hist, int64_t hist_rows, const int64_t *d_win_row,
+                             const int32_t *d_win_valid, const int32_t *d_win_aux, float *d_gxc, int n_windows, float *d_out);
 size_t ww_wave_workspace(const ww_model *m, int n_windows);
 int ww_k_wave_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *d_win_row,
                       const int32_t *d_win_valid, int64_t row0, int hop, int valid_const, int n_windows, void *ws,
@@ -219,6 +222,10 @@ int ww_k_wave_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
 int ww_k_far_frr(ww_ctx *ctx, const float *d_pos, int64_t n_pos, const float *d_neg, int64_t n_neg, int win,
                  const double *d_thr, int n_thr, double *d_smoothed, unsigned long long *d_pos_cnt,
                  unsigned long long *d_fa_cnt);
+
+// streaming CRNN: slots of the per-stream ring of projected rows (crnn.hip, crnn_stream_kernel): a row written for the window
+// that ends at stream row r is last read by the window that ends at r + 128, and overwritten at r + WW_STREAM_GXC
+#define WW_STREAM_GXC 144
 
 #ifdef __HIPCC__
 // max(x, 0) as ONE instruction: fmaxf compiles to a canonicalising v_max (x, x) in front of the v_max (0, x) when its

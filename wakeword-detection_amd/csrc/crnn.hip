@@ -638,6 +638,196 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
 }
 
 // ------------------------------------------------------------------------------------------
+// crnn_stream_kernel: crnn_fused_kernel for the streaming mode (spokestack/wakeword/tflite.py:187-188: the window slides
+// by ONE mel row per posterior).  The conv and the layer-1 input projection act on each of the 19 time positions of a
+// window separately, and position t looks at mel rows 8 t - 6 .. 8 t + 13 of the window: positions 1..17 never see the
+// window's zero padding, so their projected rows gx1[t] are functions of 20 consecutive mel rows of the STREAM - the row
+// that is position 17 of the window ending at stream row r is position 16 of the window ending at r + 8, ... position 1
+// at r + 128.  Per stream a ring of WW_STREAM_GXC rows of gx1 (keyed by r mod ring size) keeps them: a new window
+// computes THREE positions (0 and 18, which touch the padding, and the new interior one, 17, which it also stores) instead
+// of 19, fetches the other sixteen rows (12 KB, L2) and runs the recurrences and the head as crnn_fused_kernel does.
+// 1.3 instead of 8.0 MFLOP per posterior; what remains of the kernel's time is the recurrences (phases D..G).
+// After a reset every slot holds the row of an all-zero field (the mel history is zeros), which is what the positions
+// in front of the stream's first rows must see.  Rows differ from the batch kernel's in the last bits where the batch
+// kernel computes a position on the 16-row MFMA tile and this one on the 4x4x1 form (different association of the k sum).
+// ------------------------------------------------------------------------------------------
+struct stream_args {
+  fused_args f;
+  const int32_t *aux;  // [nw] stream * WW_STREAM_GXC + (stream rows incl. this window's newest) % WW_STREAM_GXC
+  float *gxc;          // [S][WW_STREAM_GXC][192]
+};
+
+__global__ __launch_bounds__(CF_THREADS, 2) void crnn_stream_kernel(stream_args sa) {
+  const fused_args &a = sa.f;
+  extern __shared__ __align__(16) float cf_smem[];
+  float *img = cf_smem, *feat = cf_smem + CF_IMG_FLOATS;
+  constexpr int H = GR_H, OT = CV_OT, RA = WW_STREAM_GXC;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kk = lane >> 4;
+  const int w = blockIdx.x;
+  int64_t row;
+  int valid;
+  window_span(a.wa, w, a.T, row, valid);
+  const int aux = sa.aux[w];
+  const int q0 = aux % RA;
+  float *cache = sa.gxc + (size_t)(aux - q0) * (6 * H);
+
+  float4 wreg[CV_KB][2];
+#pragma unroll
+  for (int kb = 0; kb < CV_KB; ++kb)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) wreg[kb][n] = *(const float4 *)(a.w4 + ((size_t)(kb * 4 + kk) * 32 + n * 16 + j) * 4);
+  const float cb0 = a.cbias[j], cb1 = a.cbias[16 + j];
+
+  // ---- the sixteen cached rows (positions 1..16): requested first, parked in LDS once the image is dead
+  // (three named registers: as an array they stayed in scratch memory)
+  auto cached = [&](int q) {
+    const int i = tid + q * CF_THREADS, tr = i / 48, c4 = i - tr * 48;  // 16 rows x 48 float4
+    int slot = q0 + 8 * tr;
+    slot = slot >= RA ? slot - RA : slot;
+    return *(const float4 *)(cache + (size_t)slot * (6 * H) + c4 * 4);
+  };
+  const float4 crow0 = cached(0), crow1 = cached(1), crow2 = cached(2);
+  // ---- A: mel rows 0..13 (position 0) and 130..150 (positions 17, 18) of the window -> the transposed image
+  int a_off, o_off[4];
+  {
+    const float *src = a.mel + row * CV_NMEL;  // 160-byte rows of a hipMalloc'ed history: 16-byte aligned
+    float4 stage[2];
+    int sidx[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int i = tid + q * CF_THREADS;            // 140 + 210 float4
+      const int f4 = i < 140 ? i : 1300 + (i - 140);  // float4 index inside the [151][40] window
+      const bool in = i < 350 && f4 / 10 < valid;
+      sidx[q] = in ? f4 : -1;
+      stage[q] = in ? *(const float4 *)(src + (size_t)f4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int i = tid; i < CF_IMG_FLOATS / 4; i += CF_THREADS) ((float4 *)img)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+      // the three positions as 60 rows (p, f) of ONE m-tile per wave: p = 0, 1, 2 <-> t = 0, 17, 18
+      constexpr int M = 3 * CV_OF;
+      int m = wave * 16 + j;
+      m = m < M ? m : M - 1;
+      const int p = m / CV_OF, f = m - p * CV_OF, t = p ? 16 + p : 0;
+      a_off = (f * CV_SF) * CV_LDT + t * CV_ST;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mo = wave * 16 + kk * 4 + r, po = mo / CV_OF, fo = mo - po * CV_OF;
+        o_off[r] = mo < M ? po * CF_FLD + fo * 32 + j : -1;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (sidx[q] >= 0) {
+        const int it = sidx[q] / 10, im = (sidx[q] - it * 10) * 4;
+        const float e[4] = {stage[q].x, stage[q].y, stage[q].z, stage[q].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) img[(im + c + CV_PF) * CV_LDT + it + CV_PT] = e[c];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- B: conv of the 60 rows -> feat[p][f * 32 + channel]
+  {
+    float4 av[CV_KB];
+    const float *abase = img + a_off;
+#pragma unroll
+    for (int kb = 0; kb < CV_KB; ++kb) {
+      const int k4 = kb * 16 + kk * 4;
+      const int kf = k4 / CV_KT, kt = k4 - kf * CV_KT;
+      av[kb] = *(const float4 *)(abase + kf * CV_LDT + kt);
+    }
+    f32x4 acc0 = {cb0, cb0, cb0, cb0}, acc1 = {cb1, cb1, cb1, cb1};
+#pragma unroll
+    for (int kb = 0; kb < CV_KB; ++kb) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb].x, wreg[kb][0].x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb].x, wreg[kb][1].x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb].y, wreg[kb][0].y, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb].y, wreg[kb][1].y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb].z, wreg[kb][0].z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb].z, wreg[kb][1].z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb].w, wreg[kb][0].w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb].w, wreg[kb][1].w, acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (o_off[r] >= 0) {
+        feat[o_off[r]] = relu1(acc0[r]);
+        feat[o_off[r] + 16] = relu1(acc1[r]);
+      }
+    }
+  }
+  const float *wb = a.wx1s + ((size_t)kk * 192 + wave * 48 + j) * 4;
+  constexpr size_t KS_STRIDE = (size_t)4 * 192 * 4;
+  auto w_ld = [&](int ks, int n) { return *(const float4 *)(wb + ks * KS_STRIDE + n * 64); };
+  float4 bq[4][3];
+#pragma unroll
+  for (int s2 = 0; s2 < 3; ++s2)
+#pragma unroll
+    for (int n = 0; n < 3; ++n) bq[s2][n] = w_ld(s2, n);
+  __syncthreads();  // feat complete; the image is dead from here on
+  float *gxs = img + CF_GX, *seq1 = img + CF_SEQ, *hb = img + CF_HB;
+  for (int i = tid; i < 32 * GR_SEQ_LD; i += CF_THREADS) seq1[i] = 0.f;
+  if (tid < 2 * 2 * 2 * H) hb[tid] = 0.f;
+  auto park = [&](int q, const float4 v) {
+    const int i = tid + q * CF_THREADS, tr = i / 48, c4 = i - tr * 48;
+    *(float4 *)(&gxs[(tr + 1) * GR_GX_LD + c4 * 4]) = v;
+  };
+  park(0, crow0); park(1, crow1); park(2, crow2);
+
+  // ---- C: layer-1 input projection of the three rows on v_mfma_f32_4x4x1_16b_f32 (the batch kernel's 3-row remainder form)
+  const int unit = lane >> 1, half = lane & 1, dir = wave & 1;
+  gru_w g;
+  {
+    const int r1 = lane & 3;
+    const float *a1p = feat + (r1 < 3 ? r1 : 2) * CF_FLD + kk * 4;  // lane % 4 == 3: no fourth row, its sums are never stored
+    f32x4 rem[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float4 rvq[2];
+    rvq[0] = *(const float4 *)(a1p);
+#pragma unroll
+    for (int ks = 0; ks < 40; ++ks) {
+      if (ks + 3 < 40) {
+#pragma unroll
+        for (int n = 0; n < 3; ++n) bq[(ks + 3) & 3][n] = w_ld(ks + 3, n);
+      }
+      if (ks + 1 < 40) rvq[(ks + 1) & 1] = *(const float4 *)(a1p + (ks + 1) * 16);
+      __builtin_amdgcn_sched_barrier(0);
+      const float4 rv = rvq[ks & 1];
+      const float4 *b = bq[ks & 3];
+#define CS_ROUND(e_)                                                                 \
+  rem[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(rv.e_, b[0].e_, rem[0], 0, 0, 0);     \
+  rem[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(rv.e_, b[1].e_, rem[1], 0, 0, 0);     \
+  rem[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(rv.e_, b[2].e_, rem[2], 0, 0, 0);
+      CS_ROUND(x) CS_ROUND(y) CS_ROUND(z) CS_ROUND(w)
+#undef CS_ROUND
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    gru_load_w(g, wave < 2 ? a.wh1 : a.wh2, wave < 2 ? a.bh1 : a.bh2, dir, unit, half);
+    int nslot = q0 + 128;
+    nslot = nslot >= RA ? nslot - RA : nslot;
+    float *crow_new = cache + (size_t)nslot * (6 * H);
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+      const int col = wave * 48 + n * 16 + j;
+      const float bv = a.bx1[col];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        float v = rem[n][i];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (kk == 0) {
+          gxs[(i ? 16 + i : 0) * GR_GX_LD + col] = v + bv;
+          if (i == 1) crow_new[col] = v + bv;  // position 17: position 16 of the window 8 rows on, ... position 1 of the one 128 on
+        }
+      }
+    }
+  }
+  __syncthreads();  // gx complete; nobody reads feat any more
+  cf_phases_d_to_g(a, img, feat, g, w);
+}
+
+// ------------------------------------------------------------------------------------------
 // crnn_fused_bf16_kernel (WW_PRECISION_BF16X3): phases A..C of crnn_fused_kernel on the bf16 matrix pipe with split
 // operands, x = hi + lo (two bf16, 16 mantissa bits) and a*b = ah*bh + ah*bl + al*bh on v_mfma_f32_16x16x32_bf16 with
 // fp32 accumulate - the arithmetic of the split-bf16 Wavenet (wavenet.hip).  48 matrix cycles per 16x16x32 products
@@ -1175,6 +1365,30 @@ static int crnn_split_threshold() {
   static const char *e = getenv("WWHIP_CRNN_SPLIT_AT");  // development: 0 = always fused
   static const int v = e ? atoi(e) : 1024;
   return v;
+}
+
+// streaming form (crnn_stream_kernel): standard geometry, fp32 contractions
+bool ww_crnn_stream_capable(const ww_model *m) { return m->kind == WW_KIND_CRNN && !m->crnn.generic; }
+
+int ww_k_crnn_stream_forward(ww_ctx *ctx, const ww_model *m, const float *d_hist, int64_t hist_rows, const int64_t *d_win_row,
+                             const int32_t *d_win_valid, const int32_t *d_win_aux, float *d_gxc, int nw, float *d_out) {
+  if (nw <= 0) return WW_OK;
+  const ww_crnn_dev &c = m->crnn;
+  if (c.generic) return ww_fail(ctx, WW_EINVAL, "streaming CRNN kernel: standard conv geometry only");
+  stream_args sa = {};
+  sa.f = {d_hist, {d_win_row, d_win_valid, 0, 0, 0, hist_rows}, c.conv_w, c.conv_b, c.wx1s, c.bx1, c.wh1, c.bh1, c.wx2s, c.bx2, c.wh2, c.bh2,
+          c.w1, c.b1, c.w2, c.b2, nullptr, d_out, c.T, c.NOUT, c.HEAD, nullptr, nullptr, c.cwb, c.wx1b};
+  sa.aux = d_win_aux;
+  sa.gxc = d_gxc;
+  static bool attr_set = false;
+  if (!attr_set) {
+    WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
+    attr_set = true;
+  }
+  ww_launch_scope scope(ctx, "crnn_stream_kernel");
+  hipLaunchKernelGGL(crnn_stream_kernel, dim3(nw), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, sa);
+  WW_HIP(ctx, hipGetLastError());
+  return WW_OK;
 }
 
 size_t ww_crnn_workspace(const ww_model *m, int nw) {

@@ -55,6 +55,12 @@ struct ww_streams {
   char *h_pack = nullptr, *d_pack = nullptr, *h_pack_dev = nullptr;  // h_pack_dev: the device's address of h_pack
   size_t pack_bytes = 0;
   std::vector<int> fill, pos;
+  // incremental CRNN (crnn.hip, crnn_stream_kernel): per-stream ring of projected interior rows, the row of an all-zero
+  // field every slot holds after a reset, and the number of mel rows since the reset modulo the ring size
+  float *gxc = nullptr, *gx_zero = nullptr;  // [S][WW_STREAM_GXC][192], [192]
+  int32_t *h_win_aux = nullptr, *d_win_aux = nullptr;
+  std::vector<int> rowq;
+  bool incremental = false;
 };
 
 struct stream_fe_args {
@@ -62,8 +68,9 @@ struct stream_fe_args {
   const int32_t *ctl;      // pinned host memory
   const int64_t *h_row;    // pinned host: this tick's window rows / valid counts, copied to d_row / d_valid here
   const int32_t *h_valid;  //   for the model kernels that follow on the stream
+  const int32_t *h_aux;    //   (+ the cache slots of the incremental CRNN kernel)
   int64_t *d_row;
-  int32_t *d_valid;
+  int32_t *d_valid, *d_aux;
   int nw, S;
   float *ring;
   float *hist;
@@ -105,6 +112,7 @@ __global__ __launch_bounds__(128) void stream_frontend_kernel(stream_fe_args a) 
   for (int i = s * 128 + tid; i < a.nw; i += a.S * 128) {
     a.d_row[i] = a.h_row[i];
     a.d_valid[i] = a.h_valid[i];
+    a.d_aux[i] = a.h_aux[i];
   }
   // device-side inputs that do not depend on the control words are requested before the branch on them, i.e. while
   // the control words and samples are still crossing the bus: mel weights, the whole sample ring (fill <= 511 of its
@@ -172,11 +180,15 @@ __global__ __launch_bounds__(128) void stream_frontend_kernel(stream_fe_args a) 
   for (int i = tid; i < keep; i += 128) ring[i] = x[n_frames * a.hop + i];
 }
 
-__global__ void stream_reset_kernel(float *hist, const int32_t *ids, int S, int HR, int F) {
+__global__ void stream_reset_kernel(float *hist, const int32_t *ids, int S, int HR, int F, float *gxc, const float *gx_zero) {
   const int b = blockIdx.x;
   const int s = ids ? ids[b] : b;
   if (s < 0 || s >= S) return;
   for (int i = threadIdx.x; i < HR * F; i += blockDim.x) hist[(size_t)s * HR * F + i] = 0.f;
+  if (gxc) {  // every cached row = the row of an all-zero field (what lies in front of the stream's first mel rows)
+    float *c = gxc + (size_t)s * WW_STREAM_GXC * 192;
+    for (int i = threadIdx.x; i < WW_STREAM_GXC * 192; i += blockDim.x) c[i] = gx_zero[i % 192];
+  }
 }
 
 extern "C" {
@@ -185,7 +197,7 @@ int ww_stream_destroy(ww_streams *st) {
   if (!st) return WW_OK;
   ww_device_scope dev_scope(st->ctx->device);
   hipStreamSynchronize(st->ctx->stream);
-  void *dev[] = {st->ring, st->hist, st->prev, st->d_pack, st->ws};
+  void *dev[] = {st->ring, st->hist, st->prev, st->d_pack, st->ws, st->gxc, st->gx_zero};
   for (void *p : dev)
     if (p) hipFree(p);
   void *host[] = {st->h_pack, st->h_out};
@@ -214,8 +226,8 @@ int ww_stream_create(ww_ctx *ctx, const ww_model *model, int32_t S, const ww_fro
             hipHostMalloc((void **)&st->h_out, (size_t)2 * S * st->NO * 4) == hipSuccess;
   {
     const size_t o_frames = 0, o_row = o_frames + (size_t)S * WW_CHUNK * 2, o_ctl = o_row + (size_t)2 * S * 8,
-                 o_valid = o_ctl + (size_t)S * 16;
-    st->pack_bytes = o_valid + (size_t)2 * S * 4;
+                 o_valid = o_ctl + (size_t)S * 16, o_aux = o_valid + (size_t)2 * S * 4;
+    st->pack_bytes = o_aux + (size_t)2 * S * 4;
     ok = ok && hipMalloc((void **)&st->d_pack, st->pack_bytes) == hipSuccess &&
          hipHostMalloc((void **)&st->h_pack, st->pack_bytes) == hipSuccess;
     if (ok) {
@@ -223,6 +235,7 @@ int ww_stream_create(ww_ctx *ctx, const ww_model *model, int32_t S, const ww_fro
       st->h_win_row = (int64_t *)(st->h_pack + o_row);   st->d_win_row = (int64_t *)(st->d_pack + o_row);
       st->h_ctl = (int32_t *)(st->h_pack + o_ctl);       st->d_ctl = (int32_t *)(st->d_pack + o_ctl);
       st->h_win_valid = (int32_t *)(st->h_pack + o_valid); st->d_win_valid = (int32_t *)(st->d_pack + o_valid);
+      st->h_win_aux = (int32_t *)(st->h_pack + o_aux);     st->d_win_aux = (int32_t *)(st->d_pack + o_aux);
     }
   }
   if (!ok) {
@@ -237,9 +250,38 @@ int ww_stream_create(ww_ctx *ctx, const ww_model *model, int32_t S, const ww_fro
   hipMemsetAsync(st->ring, 0, (size_t)S * ST_RING * 4, ctx->stream);
   hipMemsetAsync(st->hist, 0, hist_elems * 4, ctx->stream);
   hipMemsetAsync(st->prev, 0, (size_t)S * 4, ctx->stream);
+  hipMemsetAsync(st->d_pack, 0, st->pack_bytes, ctx->stream);
+  memset(st->h_pack, 0, st->pack_bytes);
   WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
   st->fill.assign(S, 0);
   st->pos.assign(S, 0);
+  st->rowq.assign(S, 0);
+  // CRNN, standard geometry, fp32 contractions: three positions per new window instead of nineteen (crnn_stream_kernel).
+  // WWHIP_STREAM_FULL=1 (development) keeps the full recompute.
+  st->incremental = ww_crnn_stream_capable(model) && model->precision == WW_PRECISION_FP32 && !getenv("WWHIP_STREAM_FULL");
+  if (st->incremental) {
+    if (hipMalloc((void **)&st->gxc, (size_t)S * WW_STREAM_GXC * 192 * 4) != hipSuccess ||
+        hipMalloc((void **)&st->gx_zero, 192 * 4) != hipSuccess) {
+      ww_stream_destroy(st);
+      return ww_fail(ctx, WW_ENOMEM, "cannot allocate the projected-row cache of %d streams", S);
+    }
+    // the row of an all-zero field: position 17 of one window over the (all-zero) history of stream 0, which the kernel
+    // stores into slot (0 + 128) % ring of stream 0's cache
+    hipMemsetAsync(st->gxc, 0, (size_t)WW_STREAM_GXC * 192 * 4, ctx->stream);
+    int rc = ww_k_crnn_stream_forward(ctx, model, st->hist, (int64_t)S * st->HR, st->d_win_row, st->d_win_valid, st->d_win_aux,
+                                      st->gxc, 1, st->h_out_dev);  // d_pack is zeroed: window row 0, aux 0 (valid 0 = all-zero window)
+    if (rc) {
+      ww_stream_destroy(st);
+      return rc;
+    }
+    hipMemcpyAsync(st->gx_zero, st->gxc + (size_t)(128 % WW_STREAM_GXC) * 192, 192 * 4, hipMemcpyDeviceToDevice, ctx->stream);
+    hipLaunchKernelGGL(stream_reset_kernel, dim3(S), dim3(256), 0, ctx->stream, st->hist, (const int32_t *)nullptr, S, st->HR, st->F,
+                       st->gxc, (const float *)st->gx_zero);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+      ww_stream_destroy(st);
+      return ww_fail(ctx, WW_EHIP, "streaming CRNN set-up failed");
+    }
+  }
   *out = st;
   return WW_OK;
 }
@@ -261,7 +303,8 @@ int ww_stream_reset(ww_streams *st, const int32_t *ids, int32_t n) {
     WW_HIP(ctx, hipMemcpyAsync(st->d_win_valid, st->h_win_valid, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     d_ids = st->d_win_valid;
   }
-  hipLaunchKernelGGL(stream_reset_kernel, dim3(count), dim3(256), 0, ctx->stream, st->hist, d_ids, st->S, st->HR, st->F);
+  hipLaunchKernelGGL(stream_reset_kernel, dim3(count), dim3(256), 0, ctx->stream, st->hist, (const int32_t *)d_ids, st->S, st->HR, st->F,
+                     st->gxc, (const float *)st->gx_zero);
   WW_HIP(ctx, hipGetLastError());
   WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
   // WakewordTrigger.reset (tflite.py:241-246): sample window emptied, frame window zeroed;
@@ -270,6 +313,7 @@ int ww_stream_reset(ww_streams *st, const int32_t *ids, int32_t n) {
     const int s = ids ? ids[i] : i;
     st->fill[s] = 0;
     st->pos[s] = 0;
+    st->rowq[s] = 0;
   }
   return WW_OK;
 }
@@ -298,10 +342,12 @@ int ww_stream_step(ww_streams *st, const int16_t *frames, const uint8_t *is_spee
       // the T rows that end at this tick's new row k are the contiguous block that starts at (pos + k + 2) % R
       st->h_win_row[nw] = (int64_t)s * st->HR + (st->pos[s] + k + 2) % (st->T + 1);
       st->h_win_valid[nw] = st->T;
+      st->h_win_aux[nw] = s * WW_STREAM_GXC + (st->rowq[s] + k + 1) % WW_STREAM_GXC;  // rows since the reset incl. this window's newest
       ++nw;
     }
     if (!(flags & 2)) st->fill[s] = st->fill[s] + WW_CHUNK - nf * hop;
     st->pos[s] = (st->pos[s] + np) % (st->T + 1);
+    st->rowq[s] = (st->rowq[s] + np) % WW_STREAM_GXC;
   }
   memcpy(st->h_frames, frames, (size_t)S * WW_CHUNK * 2);
   const ww_model *m = st->model;
@@ -312,7 +358,8 @@ int ww_stream_step(ww_streams *st, const int16_t *frames, const uint8_t *is_spee
   a.ctl = (const int32_t *)(st->h_pack_dev + ((char *)st->h_ctl - st->h_pack));
   a.h_row = (const int64_t *)(st->h_pack_dev + ((char *)st->h_win_row - st->h_pack));
   a.h_valid = (const int32_t *)(st->h_pack_dev + ((char *)st->h_win_valid - st->h_pack));
-  a.d_row = st->d_win_row; a.d_valid = st->d_win_valid; a.nw = nw; a.S = S;
+  a.h_aux = (const int32_t *)(st->h_pack_dev + ((char *)st->h_win_aux - st->h_pack));
+  a.d_row = st->d_win_row; a.d_valid = st->d_win_valid; a.d_aux = st->d_win_aux; a.nw = nw; a.S = S;
   a.ring = st->ring;
   a.hist = st->hist; a.prev = st->prev;
   a.T = st->T; a.F = st->F; a.HR = st->HR;
@@ -333,7 +380,12 @@ int ww_stream_step(ww_streams *st, const int16_t *frames, const uint8_t *is_spee
   WW_HIP(ctx, hipGetLastError());
   if (nw) {
     const float *d_hist = st->hist;
-    int rc = m->kind == WW_KIND_CRNN
+    // the cache holds fp32-path rows: a model switched to another precision after the bank was created goes back to the
+    // full recompute for good (the cache would be stale if it were switched back)
+    if (st->incremental && m->precision != WW_PRECISION_FP32) st->incremental = false;
+    int rc = st->incremental
+                 ? ww_k_crnn_stream_forward(ctx, m, d_hist, (int64_t)S * st->HR, st->d_win_row, st->d_win_valid, st->d_win_aux, st->gxc, nw, st->h_out_dev)
+             : m->kind == WW_KIND_CRNN
                  ? ww_k_crnn_forward(ctx, m, d_hist, (int64_t)S * st->HR, st->d_win_row, st->d_win_valid, 0, 0, 0, nw, st->ws, st->h_out_dev, nullptr)
                  : ww_k_wave_forward(ctx, m, d_hist, (int64_t)S * st->HR, st->d_win_row, st->d_win_valid, 0, 0, 0, nw, st->ws, st->h_out_dev, nullptr);
     if (rc) return rc;
