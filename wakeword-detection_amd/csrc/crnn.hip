@@ -651,6 +651,9 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
 // in front of the stream's first rows must see.  Rows differ from the batch kernel's in the last bits where the batch
 // kernel computes a position on the 16-row MFMA tile and this one on the 4x4x1 form (different association of the k sum).
 // ------------------------------------------------------------------------------------------
+#ifndef CS_DEPTH
+#define CS_DEPTH 8
+#endif
 struct stream_args {
   fused_args f;
   const int32_t *aux;  // [nw] stream * WW_STREAM_GXC + (stream rows incl. this window's newest) % WW_STREAM_GXC
@@ -665,6 +668,7 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_stream_kernel(stream_args 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kk = lane >> 4;
   const int w = blockIdx.x;
+  CF_STAMP(0)
   int64_t row;
   int valid;
   window_span(a.wa, w, a.T, row, valid);
@@ -728,6 +732,7 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_stream_kernel(stream_args 
     }
   }
   __syncthreads();
+  CF_STAMP(1)
   // ---- B: conv of the 60 rows -> feat[p][f * 32 + channel]
   {
     float4 av[CV_KB];
@@ -761,12 +766,16 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_stream_kernel(stream_args 
   const float *wb = a.wx1s + ((size_t)kk * 192 + wave * 48 + j) * 4;
   constexpr size_t KS_STRIDE = (size_t)4 * 192 * 4;
   auto w_ld = [&](int ks, int n) { return *(const float4 *)(wb + ks * KS_STRIDE + n * 64); };
-  float4 bq[4][3];
+  // W_x1 ring: with three rows the projection is bound by how many bytes of W are in flight, not by the matrix pipe
+  // (3.8 k cycles of MFMAs against 491 KB per workgroup): CS_DEPTH - 1 k-steps ahead instead of the batch kernel's three
+  float4 bq[CS_DEPTH][3];
 #pragma unroll
-  for (int s2 = 0; s2 < 3; ++s2)
+  for (int s2 = 0; s2 < CS_DEPTH - 1; ++s2)
 #pragma unroll
     for (int n = 0; n < 3; ++n) bq[s2][n] = w_ld(s2, n);
+  CF_STAMP(2)
   __syncthreads();  // feat complete; the image is dead from here on
+  CF_STAMP(3)
   float *gxs = img + CF_GX, *seq1 = img + CF_SEQ, *hb = img + CF_HB;
   for (int i = tid; i < 32 * GR_SEQ_LD; i += CF_THREADS) seq1[i] = 0.f;
   if (tid < 2 * 2 * 2 * H) hb[tid] = 0.f;
@@ -787,14 +796,14 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_stream_kernel(stream_args 
     rvq[0] = *(const float4 *)(a1p);
 #pragma unroll
     for (int ks = 0; ks < 40; ++ks) {
-      if (ks + 3 < 40) {
+      if (ks + CS_DEPTH - 1 < 40) {
 #pragma unroll
-        for (int n = 0; n < 3; ++n) bq[(ks + 3) & 3][n] = w_ld(ks + 3, n);
+        for (int n = 0; n < 3; ++n) bq[(ks + CS_DEPTH - 1) % CS_DEPTH][n] = w_ld(ks + CS_DEPTH - 1, n);
       }
       if (ks + 1 < 40) rvq[(ks + 1) & 1] = *(const float4 *)(a1p + (ks + 1) * 16);
       __builtin_amdgcn_sched_barrier(0);
       const float4 rv = rvq[ks & 1];
-      const float4 *b = bq[ks & 3];
+      const float4 *b = bq[ks % CS_DEPTH];
 #define CS_ROUND(e_)                                                                 \
   rem[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(rv.e_, b[0].e_, rem[0], 0, 0, 0);     \
   rem[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(rv.e_, b[1].e_, rem[1], 0, 0, 0);     \
@@ -823,7 +832,9 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_stream_kernel(stream_args 
       }
     }
   }
+  CF_STAMP(4)
   __syncthreads();  // gx complete; nobody reads feat any more
+  CF_STAMP(5)
   cf_phases_d_to_g(a, img, feat, g, w);
 }
 
@@ -1385,9 +1396,28 @@ int ww_k_crnn_stream_forward(ww_ctx *ctx, const ww_model *m, const float *d_hist
     WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
     attr_set = true;
   }
-  ww_launch_scope scope(ctx, "crnn_stream_kernel");
-  hipLaunchKernelGGL(crnn_stream_kernel, dim3(nw), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, sa);
+  static const bool want_stamps = getenv("WWHIP_CF_STAMPS") != nullptr;  // development: phase timeline (as ww_k_crnn_forward)
+  if (want_stamps) {
+    WW_HIP(ctx, hipMalloc((void **)&sa.f.stamps, (size_t)nw * 40 * sizeof(long long)));
+    WW_HIP(ctx, hipMemsetAsync(sa.f.stamps, 0, (size_t)nw * 40 * sizeof(long long), ctx->stream));
+  }
+  {
+    ww_launch_scope scope(ctx, "crnn_stream_kernel");
+    hipLaunchKernelGGL(crnn_stream_kernel, dim3(nw), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, sa);
+  }
   WW_HIP(ctx, hipGetLastError());
+  if (want_stamps) {
+    std::vector<long long> h((size_t)nw * 40);
+    WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    WW_HIP(ctx, hipMemcpy(h.data(), sa.f.stamps, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    WW_HIP(ctx, hipFree(sa.f.stamps));
+    double sum[10] = {0};
+    for (int b = 0; b < nw; ++b)
+      for (int i = 0; i < 10; ++i) sum[i] += (double)(h[((size_t)b * 4 + 0) * 10 + i] - h[((size_t)b * 4 + 0) * 10]);
+    fprintf(stderr, "crnn_stream_kernel, %d windows, wave 0, mean cycles since entry:", nw);
+    for (int i = 0; i < 10; ++i) fprintf(stderr, " %.0f", sum[i] / nw);
+    fprintf(stderr, "\n");
+  }
   return WW_OK;
 }
 
