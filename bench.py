@@ -288,7 +288,9 @@ def stream_leg(torch, np, dist, comm_dev, local_rank, S, ticks, warm=100):
     stream and tick); latency = tick submitted on the host -> posteriors visible on the host."""
     from wwhip.engine import Engine, StreamBank
     out = {"streams_per_gpu": S, "ticks": ticks, "warmup_ticks": warm,
-           "note": "per-tick latency, host frames in -> host posteriors out; MAX over ranks of each rank's percentile"}
+           "note": "per-tick latency, host frames in -> host posteriors out; MAX over ranks of each rank's percentile; "
+                   "CRNN: crnn_stream_kernel (3 of the 19 time positions of a window are new per mel row, the other 16 "
+                   "projected rows come from a per-stream ring; results within 2e-6 of the full recompute)"}
     rng = np.random.default_rng(5)
     frames = np.clip(rng.normal(0, 2500, (64, S, 320)), -32768, 32767).astype(np.int16)
     speech = np.ones(S, np.uint8)
