@@ -584,3 +584,25 @@ def test_stream_incremental_kernel_matches_full_recompute(assets, name, monkeypa
         assert sum(int(n.sum()) for _, n in inc) > 3000
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("name", ["CRNN", "CRNN_softmax"])
+def test_crnn_sliding_rows_path_matches_per_window_kernels(engines, oracles, name):
+    """From 64 regular sliding windows on, the CRNN computes every projected row once per sequence (crnn_rows_kernel: one new
+    interior field and the two edge positions per window) and gru_tail_kernel gathers a window's 19 rows.  Same posteriors
+    as the per-window kernels on the same windows (stacked: hop = T takes crnn_fused_kernel), for every hop class
+    (gcd with 8 = 1, 2, 4, 8), a sequence that ends exactly with a window, and a chunk boundary."""
+    e = engines[name]
+    rng = np.random.default_rng(97)
+    T = e.window
+    for hop, nw in ((2, 300), (1, 130), (3, 77), (4, 64), (8, 100), (5, 65), (2, 1500)):
+        rows = (nw - 1) * hop + T + (0 if hop == 4 else 3)
+        mel = rng.uniform(0, 6.5, (rows, 40)).astype(np.float32)
+        mel[rng.integers(0, rows, 5)] = 0
+        got = e.slide_forward(mel, hop)
+        assert got.shape[0] == (rows - T) // hop + 1 >= nw
+        wins = np.stack([mel[i * hop:i * hop + T] for i in range(got.shape[0])])
+        ref = np.concatenate([e.forward(wins[i:i + 512]) for i in range(0, len(wins), 512)])
+        assert np.abs(got - ref).max() < 2e-6, (hop, nw, float(np.abs(got - ref).max()))
+        idx = rng.choice(len(wins), 24, replace=False)
+        assert np.abs(got[idx] - oracles[name].forward(wins[idx])).max() < TOL_POST

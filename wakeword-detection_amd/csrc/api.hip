@@ -407,6 +407,20 @@ static int load_crnn(ww_ctx *ctx, ww_model *m, const blob_view &bv) {
     for (int ch = 0; ch < c.C; ++ch)
       for (int k = 0; k < K; ++k) w4[((size_t)(k / 4) * 32 + ch) * 4 + (k % 4)] = cw[(size_t)ch * K + k];
     c.conv_w = upload(m, w4);
+    // the positions at a window's edges see its zero padding: the same conv with the taps over the padding cleared
+    // (left: frames kt < PT; right: kt >= KT - (KT - PT - 1) = PT + 7), applied to the stream's real rows (crnn_rows_kernel)
+    std::vector<float> wl(w4), wr(w4);
+    for (int k = 0; k < K; ++k) {
+      const int kt = k % c.KT;
+      for (int ch = 0; ch < c.C; ++ch) {
+        const size_t o = ((size_t)(k / 4) * 32 + ch) * 4 + (k % 4);
+        if (kt < c.PT) wl[o] = 0.f;
+        if (kt >= c.T - (c.OT - 1) * c.ST + c.PT) wr[o] = 0.f;   // frames past the window's last row: kt >= 151 - 144 + 6 = 13
+      }
+    }
+    c.conv_wL = upload(m, wl);
+    c.conv_wR = upload(m, wr);
+    if (!c.conv_wL || !c.conv_wR) return ww_fail(ctx, WW_ENOMEM, "CRNN upload failed");
   } else {
     std::vector<float> wt((size_t)K * c.C);
     for (int ch = 0; ch < c.C; ++ch)

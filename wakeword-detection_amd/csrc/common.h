@@ -111,6 +111,7 @@ struct ww_crnn_dev {
   bool generic = false;
   int FEATP = 0;               // OF*C rounded up to the GEMM's K tile (64)
   float *conv_wt = nullptr;    // [KF*KT][C]
+  float *conv_wL = nullptr, *conv_wR = nullptr;  // conv_w with the taps that meet a window's zero padding cleared (first 6 / last 7 frames): crnn_rows_kernel
   float *wx1p = nullptr;       // [2*3H][FEATP], zero padded
 };
 

@@ -839,6 +839,181 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_stream_kernel(stream_args 
 }
 
 // ------------------------------------------------------------------------------------------
+// crnn_rows_kernel: conv + layer-1 input projection of SIXTEEN time positions per workgroup, for windows that slide over
+// one mel sequence with a regular hop (utils/evaluate_models.py:66-73: hop 2).  Positions 1..17 of a window do not see
+// its zero padding, so their projected rows are functions of 20 consecutive rows of the sequence and are shared by
+// the windows that lie 8, 16, ... rows further on (crnn_stream_kernel is the one-row-at-a-time form of the same fact):
+// per window 1 + 2 instead of 19 positions are computed - the new interior field and the two edge positions 0 and 18,
+// which are the same conv with the taps over the padding cleared (conv_wL / conv_wR) applied to the sequence's real rows.
+// Three position lists ("kinds"): interior fields at stride g = gcd(hop, 8) rows, left edges and right edges at stride hop.
+// A workgroup stages the union of its 16 fields (15 stride + 20 <= 140 rows) once, runs the conv as 20 m-tiles
+// (position, frequency) and the projection as ONE full 16-row MFMA tile per n-tile - no 3-row remainder, and W_x1 is
+// streamed once per 16 rows that are then used by 16 x 17 / 3 windows.  gru_tail_kernel gathers a window's 19 rows.
+// ------------------------------------------------------------------------------------------
+struct rows_args {
+  const float *mel;
+  int64_t mel_rows;
+  const float *w4[3];  // conv weights per kind: interior, left edge, right edge
+  const float *cbias, *wx1s, *bx1;
+  float *out[3];       // [count][192] per kind (b_x included)
+  int64_t start[3];    // mel row of position 0's field (may lie outside the sequence: rows outside read as zeros)
+  int stride[3], count[3], tiles[3];
+};
+
+__global__ __launch_bounds__(CF_THREADS, 2) void crnn_rows_kernel(rows_args a) {
+  extern __shared__ __align__(16) float cf_smem[];
+  float *img = cf_smem, *feat = cf_smem + CF_IMG_FLOATS;  // feat: [16][CF_FLD]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kk = lane >> 4;
+  int kind = 0, tile = blockIdx.x;
+  if (tile >= a.tiles[0]) { tile -= a.tiles[0]; kind = 1; }
+  if (kind == 1 && tile >= a.tiles[1]) { tile -= a.tiles[1]; kind = 2; }
+  const int stride = a.stride[kind], p0 = tile * 16;
+  const int np = a.count[kind] - p0 < 16 ? a.count[kind] - p0 : 16;
+  const int64_t field0 = a.start[kind] + (int64_t)p0 * stride;
+  const float *w4 = a.w4[kind];
+
+  float4 wreg[CV_KB][2];
+#pragma unroll
+  for (int kb = 0; kb < CV_KB; ++kb)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) wreg[kb][n] = *(const float4 *)(w4 + ((size_t)(kb * 4 + kk) * 32 + n * 16 + j) * 4);
+  const float cb0 = a.cbias[j], cb1 = a.cbias[16 + j];
+
+  // ---- stage the union of the 16 fields: image[(mel + PF)][row - field0]
+  int a_off[5], o_off[5][4];
+  {
+    constexpr int MAXV = 6;  // 6 * 256 float4 >= 140 * 40 / 4
+    const int ncols = 15 * stride + CV_KT;
+    const bool al16 = ((((uintptr_t)a.mel) & 15) == 0);
+    float4 stage[MAXV];
+#pragma unroll
+    for (int q = 0; q < MAXV; ++q) {
+      const int f4 = q * CF_THREADS + tid, it = f4 / 10;
+      const int64_t r = field0 + it;
+      if (it < ncols && r >= 0 && r < a.mel_rows) {
+        const float *src = a.mel + r * CV_NMEL + (f4 - it * 10) * 4;
+        stage[q] = al16 ? *(const float4 *)src : make_float4(src[0], src[1], src[2], src[3]);
+      } else {
+        stage[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    for (int i = tid; i < CF_IMG_FLOATS / 4; i += CF_THREADS) ((float4 *)img)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int mt = wave + 4 * i, m = mt * 16 + j;   // 20 m-tiles: (position, frequency) rows
+      const int p = m / CV_OF, f = m - p * CV_OF;
+      a_off[i] = (f * CV_SF) * CV_LDT + p * stride;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mo = mt * 16 + kk * 4 + r, po = mo / CV_OF, fo = mo - po * CV_OF;
+        o_off[i][r] = po * CF_FLD + fo * 32 + j;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < MAXV; ++q) {
+      const int f4 = q * CF_THREADS + tid, it = f4 / 10, im = (f4 - it * 10) * 4;
+      if (it < ncols) {
+        const float e[4] = {stage[q].x, stage[q].y, stage[q].z, stage[q].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) img[(im + c + CV_PF) * CV_LDT + it] = e[c];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- conv: five m-tiles per wave, pipelined as in crnn_fused_kernel
+  {
+    auto load_a = [&](float4(&av)[CV_KB], int i) {
+      const float *abase = img + a_off[i];
+#pragma unroll
+      for (int kb = 0; kb < CV_KB; ++kb) {
+        const int k4 = kb * 16 + kk * 4;
+        const int kf = k4 / CV_KT, kt = k4 - kf * CV_KT;
+        av[kb] = *(const float4 *)(abase + kf * CV_LDT + kt);
+      }
+    };
+    auto store_tile = [&](int i, const f32x4 &r0, const f32x4 &r1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        feat[o_off[i][r]] = relu1(r0[r]);
+        feat[o_off[i][r] + 16] = relu1(r1[r]);
+      }
+    };
+#define CR_CONV_KB(kb_)                                                                              \
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i & 1][kb_].x, wreg[kb_][0].x, acc0, 0, 0, 0);       \
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i & 1][kb_].x, wreg[kb_][1].x, acc1, 0, 0, 0);       \
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i & 1][kb_].y, wreg[kb_][0].y, acc0, 0, 0, 0);       \
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i & 1][kb_].y, wreg[kb_][1].y, acc1, 0, 0, 0);       \
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i & 1][kb_].z, wreg[kb_][0].z, acc0, 0, 0, 0);       \
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i & 1][kb_].z, wreg[kb_][1].z, acc1, 0, 0, 0);       \
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i & 1][kb_].w, wreg[kb_][0].w, acc0, 0, 0, 0);       \
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i & 1][kb_].w, wreg[kb_][1].w, acc1, 0, 0, 0);
+    float4 av[2][CV_KB];
+    f32x4 prev0 = {0.f, 0.f, 0.f, 0.f}, prev1 = {0.f, 0.f, 0.f, 0.f};
+    load_a(av[0], 0);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      if (i + 1 < 5) load_a(av[(i + 1) & 1], i + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 acc0 = {cb0, cb0, cb0, cb0}, acc1 = {cb1, cb1, cb1, cb1};
+      CR_CONV_KB(0) CR_CONV_KB(1) CR_CONV_KB(2)
+      __builtin_amdgcn_sched_barrier(0);
+      if (i > 0) store_tile(i - 1, prev0, prev1);
+      __builtin_amdgcn_sched_barrier(0);
+      CR_CONV_KB(3) CR_CONV_KB(4) CR_CONV_KB(5) CR_CONV_KB(6)
+      prev0 = acc0;
+      prev1 = acc1;
+    }
+    store_tile(4, prev0, prev1);
+#undef CR_CONV_KB
+  }
+  const float *wb = a.wx1s + ((size_t)kk * 192 + wave * 48 + j) * 4;
+  constexpr size_t KS_STRIDE = (size_t)4 * 192 * 4;
+  auto w_ld = [&](int ks, int n) { return *(const float4 *)(wb + ks * KS_STRIDE + n * 64); };
+  float4 bq[4][3];
+#pragma unroll
+  for (int s2 = 0; s2 < 3; ++s2)
+#pragma unroll
+    for (int n = 0; n < 3; ++n) bq[s2][n] = w_ld(s2, n);
+  __syncthreads();  // feat complete
+  // ---- projection: 16 rows = one MFMA tile per n-tile, 3 n-tiles per wave
+  {
+    const float *a0p = feat + j * CF_FLD + kk * 4;
+    f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float4 avq[2];
+    avq[0] = *(const float4 *)(a0p);
+#pragma unroll
+    for (int ks = 0; ks < 40; ++ks) {
+      if (ks + 3 < 40) {
+#pragma unroll
+        for (int n = 0; n < 3; ++n) bq[(ks + 3) & 3][n] = w_ld(ks + 3, n);
+      }
+      if (ks + 1 < 40) avq[(ks + 1) & 1] = *(const float4 *)(a0p + (ks + 1) * 16);
+      __builtin_amdgcn_sched_barrier(0);
+      const float4 av = avq[ks & 1];
+      const float4 *b = bq[ks & 3];
+#define CR_ROUND(e_)                                                                  \
+  acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.e_, b[0].e_, acc[0], 0, 0, 0);    \
+  acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.e_, b[1].e_, acc[1], 0, 0, 0);    \
+  acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.e_, b[2].e_, acc[2], 0, 0, 0);
+      CR_ROUND(x) CR_ROUND(y) CR_ROUND(z) CR_ROUND(w)
+#undef CR_ROUND
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float *out = a.out[kind] + (size_t)p0 * 192;
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+      const int col = wave * 48 + n * 16 + j;
+      const float bv = a.bx1[col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (kk * 4 + r < np) out[(size_t)(kk * 4 + r) * 192 + col] = acc[n][r] + bv;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // crnn_fused_bf16_kernel (WW_PRECISION_BF16X3): phases A..C of crnn_fused_kernel on the bf16 matrix pipe with split
 // operands, x = hi + lo (two bf16, 16 mantissa bits) and a*b = ah*bh + ah*bl + al*bh on v_mfma_f32_16x16x32_bf16 with
 // fp32 accumulate - the arithmetic of the split-bf16 Wavenet (wavenet.hip).  48 matrix cycles per 16x16x32 products
@@ -1085,12 +1260,14 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_bf16_kernel(fused_ar
 // Phases as D..G of crnn_fused_kernel; the layer-2 projection takes its B operands straight from L2.
 // ------------------------------------------------------------------------------------------
 struct tail_args {
-  const float *gx1;   // [Nw][OT][192]
+  const float *gx1;   // [Nw][OT][192], or nullptr: rows gathered from the three lists of crnn_rows_kernel
   const float *wh1, *bh1;
   const float *wx2s;  // B-operand order [16][192][4]
   const float *bx2, *wh2, *bh2, *w1, *b1, *w2, *b2;
   float *enc, *out;
   int NOUT, HEAD;
+  const float *gxI, *gxL, *gxR;  // interior fields [..][192], left / right edge rows [Nw][192]
+  int hop_g, eight_g;            // hop / g and 8 / g: position t of window w is interior field w * hop_g + (t - 1) * eight_g
 };
 // LDS (floats): gx [20][196] | seq1 [20][68] (rows 19 zero) | h [2][2][2][32] | enc [64] | hid [64] = 22.7 KB: seven per CU
 #define GT_SEQ (20 * GR_GX_LD)
@@ -1108,11 +1285,19 @@ __global__ __launch_bounds__(128, 4) void gru_tail_kernel(tail_args a) {
   const int w = blockIdx.x;
   gru_w g;
   gru_load_w(g, a.wh1, a.bh1, dir, unit, half);
-  {
+  if (a.gx1) {
     const float4 *src = (const float4 *)(a.gx1 + (size_t)w * OT * 6 * H);
     for (int q = tid; q < OT * 6 * H / 4; q += 128) {
       const int e = q * 4, t = e / (6 * H), c = e - t * 6 * H;
       *(float4 *)(&gxs[t * GR_GX_LD + c]) = src[q];
+    }
+  } else {
+    for (int q = tid; q < OT * 6 * H / 4; q += 128) {
+      const int t = q / 48, c4 = q - t * 48;
+      const float *row = t == 0 ? a.gxL + (size_t)w * 6 * H
+                       : t == OT - 1 ? a.gxR + (size_t)w * 6 * H
+                                     : a.gxI + ((size_t)w * a.hop_g + (size_t)(t - 1) * a.eight_g) * 6 * H;
+      *(float4 *)(&gxs[t * GR_GX_LD + c4 * 4]) = ((const float4 *)row)[c4];
     }
   }
   for (int i = tid; i < 20 * GR_SEQ_LD; i += 128) seq1[i] = 0.f;
@@ -1421,12 +1606,28 @@ int ww_k_crnn_stream_forward(ww_ctx *ctx, const ww_model *m, const float *d_hist
   return WW_OK;
 }
 
+// Regular sliding windows (hop <= 8 over one mel sequence, every window complete) take crnn_rows_kernel + gru_tail_kernel from
+// this many windows on (WWHIP_CRNN_SLIDE=0, development: never).
+static int crnn_slide_min() {
+  static const char *e = getenv("WWHIP_CRNN_SLIDE");
+  static const int v = e ? (atoi(e) > 0 ? atoi(e) : 0x7fffffff) : 64;
+  return v;
+}
+static int gcd8(int hop) { return hop % 8 == 0 ? 8 : hop % 4 == 0 ? 4 : hop % 2 == 0 ? 2 : 1; }
+
 size_t ww_crnn_workspace(const ww_model *m, int nw) {
   const ww_crnn_dev &c = m->crnn;
   if (c.generic) return crnn_generic_workspace(c, nw);
   const int thr = crnn_split_threshold();
-  if (thr > 0 && nw > thr) return ww_bump::need((size_t)nw * c.OT * 6 * c.H, 4) + 1024;
-  return 1024;  // crnn_fused_kernel keeps every intermediate in LDS
+  // sliding form: (fields + 2 edge rows per window) x 192 floats; fields <= 7 nw + 130 (hop 7), i.e. never more than the
+  // 19 rows per window of the front/tail form
+  size_t need = 1024;  // crnn_fused_kernel keeps every intermediate in LDS
+  if (nw >= crnn_slide_min()) need = ww_bump::need(((size_t)9 * nw + 160) * 6 * c.H, 4) + 1024;
+  if (thr > 0 && nw > thr) {
+    const size_t split = ww_bump::need((size_t)nw * c.OT * 6 * c.H, 4) + 1024;
+    need = split > need ? split : need;
+  }
+  return need;
 }
 
 int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *d_win_row,
@@ -1439,6 +1640,40 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
   fused_args a = {d_mel, wa, c.conv_w, c.conv_b, c.wx1s, c.bx1, c.wh1, c.bh1, c.wx2s, c.bx2, c.wh2, c.bh2,
                   c.w1, c.b1, c.w2, c.b2, d_enc, d_out, c.T, c.NOUT, c.HEAD, nullptr, nullptr, c.cwb, c.wx1b};
   const bool bf16 = m->precision == WW_PRECISION_BF16X3;
+  if (!bf16 && !d_win_row && !d_win_valid && valid_const >= c.T && hop >= 1 && hop <= 8 && nw >= crnn_slide_min() && row0 >= 0 &&
+      row0 + (int64_t)(nw - 1) * hop + c.T <= mel_rows) {
+    // windows sliding over one sequence: 1 + 2 positions per window instead of 19 (crnn_rows_kernel)
+    static bool rows_attr = false;
+    if (!rows_attr) {
+      WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
+      rows_attr = true;
+    }
+    const int g = gcd8(hop);
+    const int64_t n_int = ((int64_t)(nw - 1) * hop + 128) / g + 1;
+    ww_bump b(ws, ~size_t(0));
+    float *gI = b.take<float>((size_t)n_int * 6 * c.H), *gL = b.take<float>((size_t)nw * 6 * c.H), *gR = b.take<float>((size_t)nw * 6 * c.H);
+    rows_args r = {};
+    r.mel = d_mel; r.mel_rows = mel_rows;
+    r.w4[0] = c.conv_w; r.w4[1] = c.conv_wL; r.w4[2] = c.conv_wR;
+    r.cbias = c.conv_b; r.wx1s = c.wx1s; r.bx1 = c.bx1;
+    r.out[0] = gI; r.out[1] = gL; r.out[2] = gR;
+    r.start[0] = row0 + 2; r.start[1] = row0 - c.PT; r.start[2] = row0 + (int64_t)(c.OT - 1) * c.ST - c.PT;
+    r.stride[0] = g; r.stride[1] = hop; r.stride[2] = hop;
+    r.count[0] = (int)n_int; r.count[1] = nw; r.count[2] = nw;
+    for (int k = 0; k < 3; ++k) r.tiles[k] = (r.count[k] + 15) / 16;
+    {
+      ww_launch_scope scope(ctx, "crnn_rows_kernel");
+      hipLaunchKernelGGL(crnn_rows_kernel, dim3(r.tiles[0] + r.tiles[1] + r.tiles[2]), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, r);
+    }
+    tail_args t = {nullptr, c.wh1, c.bh1, c.wx2s, c.bx2, c.wh2, c.bh2, c.w1, c.b1, c.w2, c.b2, d_enc, d_out, c.NOUT, c.HEAD,
+                   gI, gL, gR, hop / g, 8 / g};
+    {
+      ww_launch_scope scope(ctx, "gru_tail_kernel");
+      hipLaunchKernelGGL(gru_tail_kernel, dim3(nw), dim3(128), 0, ctx->stream, t);
+    }
+    WW_HIP(ctx, hipGetLastError());
+    return WW_OK;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
@@ -1456,7 +1691,7 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
       if (bf16) hipLaunchKernelGGL(crnn_fused_bf16_kernel<true>, dim3(nw), dim3(CF_THREADS), CFB_SMEM_BYTES, ctx->stream, a);
       else hipLaunchKernelGGL(crnn_fused_kernel<true>, dim3(nw), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, a);
     }
-    tail_args t = {a.gx_out, c.wh1, c.bh1, c.wx2s, c.bx2, c.wh2, c.bh2, c.w1, c.b1, c.w2, c.b2, d_enc, d_out, c.NOUT, c.HEAD};
+    tail_args t = {a.gx_out, c.wh1, c.bh1, c.wx2s, c.bx2, c.wh2, c.bh2, c.w1, c.b1, c.w2, c.b2, d_enc, d_out, c.NOUT, c.HEAD, nullptr, nullptr, nullptr, 0, 0};
     {
       ww_launch_scope scope(ctx, "gru_tail_kernel");
       hipLaunchKernelGGL(gru_tail_kernel, dim3(nw), dim3(128), 0, ctx->stream, t);
