@@ -177,6 +177,14 @@ int ww_slide_forward(ww_ctx *ctx, const ww_model *model, const float *mel, int64
 int ww_forward_windows_dev(ww_ctx *ctx, const ww_model *model, const float *d_mel, int64_t mel_rows,
                            const int64_t *d_win_row, const int32_t *d_win_valid, int32_t n_windows, float *d_out);
 
+/* Several mel sequences in one device buffer (the padded clips of a test set), each slid over with the same hop:
+ * sequence s has seg_nw[s] complete windows, window k of it covers rows [seg_row0[s] + k*hop, + window).
+ * seg_row0 / seg_nw are HOST arrays; d_out receives the detect rows sequence by sequence.  This is the window loop of
+ * utils/evaluate_models.py:66-88 over many files at once; for the CRNN the conv and the layer-1 projection of a time
+ * position are computed once per sequence instead of once per window that contains it. */
+int ww_forward_segments_dev(ww_ctx *ctx, const ww_model *model, const float *d_mel, int64_t mel_rows, const int64_t *seg_row0,
+                            const int32_t *seg_nw, int32_t n_seg, int32_t hop, float *d_out);
+
 /* Whole hot path for a batch of equal-length clips resident in HBM (BASELINE configs 2/3):
  * PCM [n_clips][samples_per_clip] -> log-mel -> one zero-padded window per clip ->
  * encode + detect -> d_out [n_clips][n_out].  d_mel_scratch may be NULL (ctx workspace). */

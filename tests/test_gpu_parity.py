@@ -606,3 +606,36 @@ def test_crnn_sliding_rows_path_matches_per_window_kernels(engines, oracles, nam
         assert np.abs(got - ref).max() < 2e-6, (hop, nw, float(np.abs(got - ref).max()))
         idx = rng.choice(len(wins), 24, replace=False)
         assert np.abs(got[idx] - oracles[name].forward(wins[idx])).max() < TOL_POST
+
+
+@pytest.mark.parametrize("name", ["CRNN", "Wavenet"])
+def test_forward_segments_dev_matches_explicit_windows(engines, name):
+    """ww_forward_segments_dev (several sequences in one mel buffer, each slid over with the same hop) against the same
+    windows given one by one - CRNN: crnn_rows_kernel by tile descriptors + the gathering gru_tail_kernel; Wavenet: the
+    entry point's explicit-list fallback.  Sequences of 0, 1, 15, 16, 17 and many windows, odd and even first rows."""
+    import torch
+    e = engines[name]
+    T = e.window
+    rng = np.random.default_rng(123)
+    for hop in (2, 3):
+        seg_nw = np.array([40, 0, 1, 15, 16, 17, 333, 2], np.int32)
+        gaps = np.array([0, 5, 3, 0, 7, 1, 2, 9])
+        rows, r = [], 0
+        for nw, gap in zip(seg_nw, gaps):
+            r += int(gap)
+            rows.append(r)
+            r += ((int(nw) - 1) * hop + T) if nw else 11
+        mel = rng.uniform(0, 6.5, (r + 4, 40)).astype(np.float32)
+        seg_row0 = np.array(rows, np.int64)
+        d_mel = torch.from_numpy(mel).cuda()
+        n = int(seg_nw.sum())
+        d_out = torch.zeros((n, e.n_out), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        e.forward_segments_dev(d_mel.data_ptr(), len(mel), seg_row0, seg_nw, hop, d_out.data_ptr())
+        e.ctx.synchronize()
+        got = d_out.cpu().numpy()
+        wins = np.stack([mel[r0 + k * hop: r0 + k * hop + T] for r0, nw in zip(seg_row0, seg_nw) for k in range(nw)])
+        ref = e.forward(wins)
+        assert np.abs(got - ref).max() < 2e-6, (hop, float(np.abs(got - ref).max()))
+    with pytest.raises(ValueError):
+        e.forward_segments_dev(d_mel.data_ptr(), len(mel), np.array([len(mel) - 10], np.int64), np.array([3], np.int32), 2, d_out.data_ptr())

@@ -1067,6 +1067,47 @@ int ww_forward_windows_dev(ww_ctx *ctx, const ww_model *m, const float *d_mel, i
   return WW_OK;
 }
 
+int ww_forward_segments_dev(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *seg_row0,
+                            const int32_t *seg_nw, int32_t n_seg, int32_t hop, float *d_out) {
+  if (!ctx || !m || !d_mel || !d_out) return ww_fail(ctx, WW_EINVAL, "NULL argument");
+  if (n_seg < 0) return ww_fail(ctx, WW_EINVAL, "negative sequence count");
+  if (hop <= 0) return ww_fail(ctx, WW_EINVAL, "hop must be positive");
+  if (n_seg == 0) return WW_OK;
+  if (!seg_row0 || !seg_nw) return ww_fail(ctx, WW_EINVAL, "sequence descriptors are NULL");
+  ww_device_scope dev(ctx->device);
+  if (ww_crnn_segments_capable(m, hop)) return ww_k_crnn_segments_forward(ctx, m, d_mel, mel_rows, seg_row0, seg_nw, n_seg, hop, d_out);
+  // every other model / mode: the same windows as an explicit list through the per-window kernels
+  const int T = m->info.window, NO = m->info.n_out;
+  std::vector<int64_t> rows;
+  for (int s = 0; s < n_seg; ++s) {
+    if (seg_nw[s] < 0) return ww_fail(ctx, WW_EINVAL, "negative window count in sequence %d", s);
+    if (seg_nw[s] && (seg_row0[s] < 0 || seg_row0[s] + (int64_t)(seg_nw[s] - 1) * hop + T > mel_rows))
+      return ww_fail(ctx, WW_EINVAL, "sequence %d: windows leave the mel buffer", s);
+    for (int k = 0; k < seg_nw[s]; ++k) rows.push_back(seg_row0[s] + (int64_t)k * hop);
+  }
+  const int64_t nw = (int64_t)rows.size();
+  if (nw == 0) return WW_OK;
+  if (nw > 0x7fffffff) return ww_fail(ctx, WW_EINVAL, "too many windows in one call");
+  std::vector<int32_t> valid((size_t)nw, T);
+  const int chunk = nw < WW_MAX_CHUNK ? (int)nw : WW_MAX_CHUNK;
+  const size_t b_rows = ww_bump::need((size_t)nw, 8), b_valid = ww_bump::need((size_t)nw, 4), b_ws = model_ws(m, chunk);
+  int rc = ww_ensure(ctx, ctx->dev, b_rows + b_valid + b_ws + 1024, false);
+  if (rc) return rc;
+  ww_bump bump(ctx->dev.ptr, ctx->dev.cap);
+  int64_t *d_rows = bump.take<int64_t>((size_t)nw);
+  int32_t *d_valid = bump.take<int32_t>((size_t)nw);
+  void *ws = bump.take<char>(b_ws);
+  WW_HIP(ctx, hipMemcpyAsync(d_rows, rows.data(), (size_t)nw * 8, hipMemcpyHostToDevice, ctx->stream));
+  WW_HIP(ctx, hipMemcpyAsync(d_valid, valid.data(), (size_t)nw * 4, hipMemcpyHostToDevice, ctx->stream));
+  WW_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the host vectors go out of scope
+  for (int64_t w0 = 0; w0 < nw; w0 += chunk) {
+    const int n = (int)((nw - w0) < chunk ? (nw - w0) : chunk);
+    rc = model_forward(ctx, m, d_mel, mel_rows, d_rows + w0, d_valid + w0, 0, 0, 0, n, ws, d_out + (size_t)w0 * NO, nullptr);
+    if (rc) return rc;
+  }
+  return WW_OK;
+}
+
 int ww_clips_forward_dev(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, int32_t n_clips, int32_t samples,
                          const ww_frontend_params *fp, float *d_out) {
   if (!ctx || !m || !d_pcm || !d_out) return ww_fail(ctx, WW_EINVAL, "NULL argument");

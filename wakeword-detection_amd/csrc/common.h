@@ -213,6 +213,9 @@ size_t ww_crnn_workspace(const ww_model *m, int n_windows);
 int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *d_win_row,
                       const int32_t *d_win_valid, int64_t row0, int hop, int valid_const, int n_windows, void *ws,
                       float *d_out, float *d_enc);
+bool ww_crnn_segments_capable(const ww_model *m, int hop);
+int ww_k_crnn_segments_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *seg_row0,
+                               const int32_t *seg_nw, int n_seg, int hop, float *d_out);
 bool ww_crnn_stream_capable(const ww_model *m);
 int ww_k_crnn_stream_forward(ww_ctx *ctx, const ww_model *m, const float *d_hist, int64_t hist_rows, const int64_t *d_win_row,
                              const int32_t *d_win_valid, const int32_t *d_win_aux, float *d_gxc, int n_windows, float *d_out);

@@ -858,6 +858,12 @@ struct rows_args {
   float *out[3];       // [count][192] per kind (b_x included)
   int64_t start[3];    // mel row of position 0's field (may lie outside the sequence: rows outside read as zeros)
   int stride[3], count[3], tiles[3];
+  const struct rows_tile *desc;  // or: one descriptor per workgroup (several sequences in one buffer: ww_k_crnn_segments_forward)
+};
+struct rows_tile {
+  int64_t start;    // mel row of the tile's first field
+  int64_t out_row;  // row of out[kind] its first position goes to
+  int32_t stride, count, kind, pad;
 };
 
 __global__ __launch_bounds__(CF_THREADS, 2) void crnn_rows_kernel(rows_args a) {
@@ -865,12 +871,21 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_rows_kernel(rows_args a) {
   float *img = cf_smem, *feat = cf_smem + CF_IMG_FLOATS;  // feat: [16][CF_FLD]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kk = lane >> 4;
-  int kind = 0, tile = blockIdx.x;
-  if (tile >= a.tiles[0]) { tile -= a.tiles[0]; kind = 1; }
-  if (kind == 1 && tile >= a.tiles[1]) { tile -= a.tiles[1]; kind = 2; }
-  const int stride = a.stride[kind], p0 = tile * 16;
-  const int np = a.count[kind] - p0 < 16 ? a.count[kind] - p0 : 16;
-  const int64_t field0 = a.start[kind] + (int64_t)p0 * stride;
+  int kind = 0, stride, np;
+  int64_t field0, out_row;
+  if (a.desc) {
+    const rows_tile d = a.desc[blockIdx.x];
+    kind = d.kind; stride = d.stride; np = d.count; field0 = d.start; out_row = d.out_row;
+  } else {
+    int tile = blockIdx.x;
+    if (tile >= a.tiles[0]) { tile -= a.tiles[0]; kind = 1; }
+    if (kind == 1 && tile >= a.tiles[1]) { tile -= a.tiles[1]; kind = 2; }
+    stride = a.stride[kind];
+    const int p0 = tile * 16;
+    np = a.count[kind] - p0 < 16 ? a.count[kind] - p0 : 16;
+    field0 = a.start[kind] + (int64_t)p0 * stride;
+    out_row = p0;
+  }
   const float *w4 = a.w4[kind];
 
   float4 wreg[CV_KB][2];
@@ -1001,7 +1016,7 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_rows_kernel(rows_args a) {
 #undef CR_ROUND
       __builtin_amdgcn_sched_barrier(0);
     }
-    float *out = a.out[kind] + (size_t)p0 * 192;
+    float *out = a.out[kind] + (size_t)out_row * 192;
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
       const int col = wave * 48 + n * 16 + j;
@@ -1268,6 +1283,7 @@ struct tail_args {
   int NOUT, HEAD;
   const float *gxI, *gxL, *gxR;  // interior fields [..][192], left / right edge rows [Nw][192]
   int hop_g, eight_g;            // hop / g and 8 / g: position t of window w is interior field w * hop_g + (t - 1) * eight_g
+  const int64_t *iI0;            // or: window w's first interior field explicitly (several sequences)
 };
 // LDS (floats): gx [20][196] | seq1 [20][68] (rows 19 zero) | h [2][2][2][32] | enc [64] | hid [64] = 22.7 KB: seven per CU
 #define GT_SEQ (20 * GR_GX_LD)
@@ -1296,7 +1312,7 @@ __global__ __launch_bounds__(128, 4) void gru_tail_kernel(tail_args a) {
       const int t = q / 48, c4 = q - t * 48;
       const float *row = t == 0 ? a.gxL + (size_t)w * 6 * H
                        : t == OT - 1 ? a.gxR + (size_t)w * 6 * H
-                                     : a.gxI + ((size_t)w * a.hop_g + (size_t)(t - 1) * a.eight_g) * 6 * H;
+                                     : a.gxI + ((size_t)(a.iI0 ? a.iI0[w] : (int64_t)w * a.hop_g) + (size_t)(t - 1) * a.eight_g) * 6 * H;
       *(float4 *)(&gxs[t * GR_GX_LD + c4 * 4]) = ((const float4 *)row)[c4];
     }
   }
@@ -1615,6 +1631,89 @@ static int crnn_slide_min() {
 }
 static int gcd8(int hop) { return hop % 8 == 0 ? 8 : hop % 4 == 0 ? 4 : hop % 2 == 0 ? 2 : 1; }
 
+// Several mel sequences in one buffer (the clips of a test set, wwhip/evaluate.py), each slid over with the same hop:
+// crnn_rows_kernel by tile descriptors (no tile straddles two sequences), gru_tail_kernel with each window's first
+// interior field given explicitly.  seg_row0 / seg_nw are HOST arrays; windows are numbered sequence by sequence.
+bool ww_crnn_segments_capable(const ww_model *m, int hop) {
+  return m->kind == WW_KIND_CRNN && !m->crnn.generic && m->precision == WW_PRECISION_FP32 && hop >= 1 && hop <= 8 &&
+         crnn_slide_min() != 0x7fffffff;
+}
+
+int ww_k_crnn_segments_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *seg_row0,
+                               const int32_t *seg_nw, int n_seg, int hop, float *d_out) {
+  const ww_crnn_dev &c = m->crnn;
+  const int g = gcd8(hop);
+  static bool rows_attr = false;
+  if (!rows_attr) {
+    WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
+    rows_attr = true;
+  }
+  // groups of whole sequences of at most ~WW_SEG_GROUP windows bound the workspace
+  constexpr int64_t WW_SEG_GROUP = 32768;
+  std::vector<rows_tile> tiles;
+  std::vector<int64_t> i0;
+  int64_t w_done = 0;
+  for (int s0 = 0; s0 < n_seg;) {
+    tiles.clear();
+    i0.clear();
+    int64_t nI = 0, nW = 0;
+    int s1 = s0;
+    for (; s1 < n_seg && (s1 == s0 || nW + seg_nw[s1] <= WW_SEG_GROUP); ++s1) {
+      const int nw = seg_nw[s1];
+      if (nw < 0) return ww_fail(ctx, WW_EINVAL, "negative window count in sequence %d", s1);
+      if (nw == 0) continue;
+      const int64_t r0 = seg_row0[s1];
+      if (r0 < 0 || r0 + (int64_t)(nw - 1) * hop + c.T > mel_rows)
+        return ww_fail(ctx, WW_EINVAL, "sequence %d: windows leave the mel buffer", s1);
+      const int64_t n_int = ((int64_t)(nw - 1) * hop + 128) / g + 1;
+      for (int64_t p0 = 0; p0 < n_int; p0 += 16)
+        tiles.push_back({r0 + 2 + (int64_t)g * p0, nI + p0, g, (int32_t)(n_int - p0 < 16 ? n_int - p0 : 16), 0, 0});
+      for (int p0 = 0; p0 < nw; p0 += 16) {
+        const int32_t cnt = nw - p0 < 16 ? nw - p0 : 16;
+        tiles.push_back({r0 - c.PT + (int64_t)hop * p0, nW + p0, hop, cnt, 1, 0});
+        tiles.push_back({r0 + (int64_t)(c.OT - 1) * c.ST - c.PT + (int64_t)hop * p0, nW + p0, hop, cnt, 2, 0});
+      }
+      for (int k = 0; k < nw; ++k) i0.push_back(nI + (int64_t)k * hop / g);
+      nI += n_int;
+      nW += nw;
+    }
+    if (nW > 0) {
+      const size_t b_tiles = ww_bump::need(tiles.size() * sizeof(rows_tile), 1), b_i0 = ww_bump::need(i0.size() * 8, 1);
+      const size_t b_rows = ww_bump::need((size_t)(nI + 2 * nW) * 6 * c.H, 4);
+      int rc = ww_ensure(ctx, ctx->dev, b_tiles + b_i0 + b_rows + 4096, false);
+      if (rc) return rc;
+      ww_bump b(ctx->dev.ptr, ctx->dev.cap);
+      rows_tile *d_tiles = (rows_tile *)b.take<char>(tiles.size() * sizeof(rows_tile));
+      int64_t *d_i0 = b.take<int64_t>(i0.size());
+      float *gI = b.take<float>((size_t)nI * 6 * c.H), *gL = b.take<float>((size_t)nW * 6 * c.H), *gR = b.take<float>((size_t)nW * 6 * c.H);
+      WW_HIP(ctx, hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(rows_tile), hipMemcpyHostToDevice, ctx->stream));
+      WW_HIP(ctx, hipMemcpyAsync(d_i0, i0.data(), i0.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+      rows_args r = {};
+      r.mel = d_mel; r.mel_rows = mel_rows;
+      r.w4[0] = c.conv_w; r.w4[1] = c.conv_wL; r.w4[2] = c.conv_wR;
+      r.cbias = c.conv_b; r.wx1s = c.wx1s; r.bx1 = c.bx1;
+      r.out[0] = gI; r.out[1] = gL; r.out[2] = gR;
+      r.desc = d_tiles;
+      {
+        ww_launch_scope scope(ctx, "crnn_rows_kernel");
+        hipLaunchKernelGGL(crnn_rows_kernel, dim3((unsigned)tiles.size()), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, r);
+      }
+      tail_args t = {nullptr, c.wh1, c.bh1, c.wx2s, c.bx2, c.wh2, c.bh2, c.w1, c.b1, c.w2, c.b2, nullptr,
+                     d_out + (size_t)w_done * c.NOUT, c.NOUT, c.HEAD, gI, gL, gR, hop / g, 8 / g, d_i0};
+      {
+        ww_launch_scope scope(ctx, "gru_tail_kernel");
+        hipLaunchKernelGGL(gru_tail_kernel, dim3((unsigned)nW), dim3(128), 0, ctx->stream, t);
+      }
+      WW_HIP(ctx, hipGetLastError());
+      // the host vectors are reused by the next group: the copies out of them must have been taken
+      WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      w_done += nW;
+    }
+    s0 = s1;
+  }
+  return WW_OK;
+}
+
 size_t ww_crnn_workspace(const ww_model *m, int nw) {
   const ww_crnn_dev &c = m->crnn;
   if (c.generic) return crnn_generic_workspace(c, nw);
@@ -1666,7 +1765,7 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
       hipLaunchKernelGGL(crnn_rows_kernel, dim3(r.tiles[0] + r.tiles[1] + r.tiles[2]), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, r);
     }
     tail_args t = {nullptr, c.wh1, c.bh1, c.wx2s, c.bx2, c.wh2, c.bh2, c.w1, c.b1, c.w2, c.b2, d_enc, d_out, c.NOUT, c.HEAD,
-                   gI, gL, gR, hop / g, 8 / g};
+                   gI, gL, gR, hop / g, 8 / g, nullptr};
     {
       ww_launch_scope scope(ctx, "gru_tail_kernel");
       hipLaunchKernelGGL(gru_tail_kernel, dim3(nw), dim3(128), 0, ctx->stream, t);
@@ -1691,7 +1790,7 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
       if (bf16) hipLaunchKernelGGL(crnn_fused_bf16_kernel<true>, dim3(nw), dim3(CF_THREADS), CFB_SMEM_BYTES, ctx->stream, a);
       else hipLaunchKernelGGL(crnn_fused_kernel<true>, dim3(nw), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, a);
     }
-    tail_args t = {a.gx_out, c.wh1, c.bh1, c.wx2s, c.bx2, c.wh2, c.bh2, c.w1, c.b1, c.w2, c.b2, d_enc, d_out, c.NOUT, c.HEAD, nullptr, nullptr, nullptr, 0, 0};
+    tail_args t = {a.gx_out, c.wh1, c.bh1, c.wx2s, c.bx2, c.wh2, c.bh2, c.w1, c.b1, c.w2, c.b2, d_enc, d_out, c.NOUT, c.HEAD, nullptr, nullptr, nullptr, 0, 0, nullptr};
     {
       ww_launch_scope scope(ctx, "gru_tail_kernel");
       hipLaunchKernelGGL(gru_tail_kernel, dim3(nw), dim3(128), 0, ctx->stream, t);

@@ -64,6 +64,7 @@ SYMBOLS: Dict[str, tuple] = {
     "ww_forward_enc": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp]),
     "ww_slide_forward": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _P(_i64)]),
     "ww_forward_windows_dev": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp]),
+    "ww_forward_segments_dev": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp]),
     "ww_clips_forward_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _P(FrontendParams), _vp]),
     "ww_stream_create": (C.c_int, [_vp, _vp, _i32, _P(FrontendParams), _P(_vp)]),
     "ww_stream_destroy": (C.c_int, [_vp]),

@@ -197,6 +197,18 @@ class Engine:
                                                    C.c_void_p(d_win_row_ptr), C.c_void_p(d_win_valid_ptr), int(n_windows),
                                                    C.c_void_p(d_out_ptr)))
 
+    def forward_segments_dev(self, d_mel_ptr: int, mel_rows: int, seg_row0: np.ndarray, seg_nw: np.ndarray, hop: int,
+                             d_out_ptr: int) -> None:
+        """Several mel sequences in one device buffer, each slid over with ``hop`` (``ww_forward_segments_dev``): sequence
+        ``s`` has ``seg_nw[s]`` complete windows starting at row ``seg_row0[s]``; detect rows go to ``d_out`` sequence by
+        sequence.  The descriptor arrays are host arrays."""
+        r0 = np.ascontiguousarray(seg_row0, dtype=np.int64)
+        nw = np.ascontiguousarray(seg_nw, dtype=np.int32)
+        if r0.shape != nw.shape or r0.ndim != 1:
+            raise ValueError("seg_row0 and seg_nw must be 1-D arrays of the same length")
+        self._chk(self._lib.ww_forward_segments_dev(self.ctx.handle, self._model, C.c_void_p(d_mel_ptr), int(mel_rows),
+                                                    _lib.ptr(r0), _lib.ptr(nw), int(r0.size), int(hop), C.c_void_p(d_out_ptr)))
+
 
 class StreamBank:
     """S device-resident streams advanced 20 ms per :meth:`step` (``ww_stream_*``)."""

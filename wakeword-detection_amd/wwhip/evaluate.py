@@ -272,18 +272,22 @@ def clip_posteriors(engine: Engine, clips: Sequence[np.ndarray], hop: int = 2, f
     # windows: one per clip (rows of the bare clip), then the sliding ones of the padded clip
     nw = np.where(nf_pad >= T, (nf_pad - T) // hop + 1, 0)
     woffs = np.concatenate(([0], np.cumsum(nw)))
-    slide_row = np.repeat(foffs[:-1] - hop * woffs[:-1], nw) + hop * np.arange(int(woffs[-1]), dtype=np.int64)
-    win_row = np.concatenate((foffs[:-1] + PAD // hop_s, slide_row)).astype(np.int64)
-    win_valid = np.concatenate((np.minimum(nf_bare, T), np.full(int(woffs[-1]), T))).astype(np.int32)
+    # the n single windows (ragged: valid < T) as an explicit list; the sliding ones as n sequences of one buffer, which
+    # lets the CRNN compute every time position once per clip instead of once per window (ww_forward_segments_dev)
+    win_row = (foffs[:-1] + PAD // hop_s).astype(np.int64)
+    win_valid = np.minimum(nf_bare, T).astype(np.int32)
+    n_slide = int(woffs[-1])
     dev = torch.device("cuda", engine.ctx.device)  # the engine's GPU, whatever torch's current device is
     d_pcm = pin.to(dev, non_blocking=True)
     d_so, d_fo = torch.from_numpy(soffs).to(dev), torch.from_numpy(foffs).to(dev)
     d_mel = torch.empty((max(total_f, 1), engine.n_mel), dtype=torch.float32, device=dev)
     d_row, d_valid = torch.from_numpy(win_row).to(dev), torch.from_numpy(win_valid).to(dev)
-    d_out = torch.empty((len(win_row), engine.n_out), dtype=torch.float32, device=dev)
+    d_out = torch.empty((n + n_slide, engine.n_out), dtype=torch.float32, device=dev)
     torch.cuda.synchronize(dev)
     engine.logmel_dev(d_pcm.data_ptr(), d_so.data_ptr(), d_fo.data_ptr(), n, total_f, int(nf_pad.max()), d_mel.data_ptr(), fp)
-    engine.forward_windows_dev(d_mel.data_ptr(), total_f, d_row.data_ptr(), d_valid.data_ptr(), len(win_row), d_out.data_ptr())
+    engine.forward_windows_dev(d_mel.data_ptr(), total_f, d_row.data_ptr(), d_valid.data_ptr(), n, d_out.data_ptr())
+    if n_slide:
+        engine.forward_segments_dev(d_mel.data_ptr(), total_f, foffs[:-1], nw, hop, d_out[n:].data_ptr())
     engine.ctx.synchronize()
     post = d_out.cpu().numpy()[:, pidx]
     p_one, slide = post[:n], post[n:]
