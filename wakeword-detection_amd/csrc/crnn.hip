@@ -1635,7 +1635,7 @@ static int gcd8(int hop) { return hop % 8 == 0 ? 8 : hop % 4 == 0 ? 4 : hop % 2 
 // crnn_rows_kernel by tile descriptors (no tile straddles two sequences), gru_tail_kernel with each window's first
 // interior field given explicitly.  seg_row0 / seg_nw are HOST arrays; windows are numbered sequence by sequence.
 bool ww_crnn_segments_capable(const ww_model *m, int hop) {
-  return m->kind == WW_KIND_CRNN && !m->crnn.generic && m->precision == WW_PRECISION_FP32 && hop >= 1 && hop <= 8 &&
+  return m->kind == WW_KIND_CRNN && !m->crnn.generic && hop >= 1 && hop <= 8 &&
          crnn_slide_min() != 0x7fffffff;
 }
 
@@ -1739,7 +1739,8 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
   fused_args a = {d_mel, wa, c.conv_w, c.conv_b, c.wx1s, c.bx1, c.wh1, c.bh1, c.wx2s, c.bx2, c.wh2, c.bh2,
                   c.w1, c.b1, c.w2, c.b2, d_enc, d_out, c.T, c.NOUT, c.HEAD, nullptr, nullptr, c.cwb, c.wx1b};
   const bool bf16 = m->precision == WW_PRECISION_BF16X3;
-  if (!bf16 && !d_win_row && !d_win_valid && valid_const >= c.T && hop >= 1 && hop <= 8 && nw >= crnn_slide_min() && row0 >= 0 &&
+  // (also in split-bf16 mode: the mode permits bf16 products, and computing a seventh of them in fp32 is both faster and closer)
+  if (!d_win_row && !d_win_valid && valid_const >= c.T && hop >= 1 && hop <= 8 && nw >= crnn_slide_min() && row0 >= 0 &&
       row0 + (int64_t)(nw - 1) * hop + c.T <= mel_rows) {
     // windows sliding over one sequence: 1 + 2 positions per window instead of 19 (crnn_rows_kernel)
     static bool rows_attr = false;

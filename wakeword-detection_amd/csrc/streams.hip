@@ -256,9 +256,10 @@ int ww_stream_create(ww_ctx *ctx, const ww_model *model, int32_t S, const ww_fro
   st->fill.assign(S, 0);
   st->pos.assign(S, 0);
   st->rowq.assign(S, 0);
-  // CRNN, standard geometry, fp32 contractions: three positions per new window instead of nineteen (crnn_stream_kernel).
+  // CRNN, standard geometry: three positions per new window instead of nineteen (crnn_stream_kernel, fp32 contractions - also
+  // for a model in split-bf16 mode: a seventh of the products in fp32 is both faster and closer).
   // WWHIP_STREAM_FULL=1 (development) keeps the full recompute.
-  st->incremental = ww_crnn_stream_capable(model) && model->precision == WW_PRECISION_FP32 && !getenv("WWHIP_STREAM_FULL");
+  st->incremental = ww_crnn_stream_capable(model) && !getenv("WWHIP_STREAM_FULL");
   if (st->incremental) {
     if (hipMalloc((void **)&st->gxc, (size_t)S * WW_STREAM_GXC * 192 * 4) != hipSuccess ||
         hipMalloc((void **)&st->gx_zero, 192 * 4) != hipSuccess) {
@@ -380,9 +381,6 @@ int ww_stream_step(ww_streams *st, const int16_t *frames, const uint8_t *is_spee
   WW_HIP(ctx, hipGetLastError());
   if (nw) {
     const float *d_hist = st->hist;
-    // the cache holds fp32-path rows: a model switched to another precision after the bank was created goes back to the
-    // full recompute for good (the cache would be stale if it were switched back)
-    if (st->incremental && m->precision != WW_PRECISION_FP32) st->incremental = false;
     int rc = st->incremental
                  ? ww_k_crnn_stream_forward(ctx, m, d_hist, (int64_t)S * st->HR, st->d_win_row, st->d_win_valid, st->d_win_aux, st->gxc, nw, st->h_out_dev)
              : m->kind == WW_KIND_CRNN
