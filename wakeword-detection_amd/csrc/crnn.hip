@@ -1285,8 +1285,9 @@ struct tail_args {
   int hop_g, eight_g;            // hop / g and 8 / g: position t of window w is interior field w * hop_g + (t - 1) * eight_g
   const int64_t *iI0;            // or: window w's first interior field explicitly (several sequences)
 };
-// LDS (floats): gx [20][196] | seq1 [20][68] (rows 19 zero) | h [2][2][2][32] | enc [64] | hid [64] = 22.7 KB: seven per CU
-#define GT_SEQ (20 * GR_GX_LD)
+// LDS (floats): gx [19][196] | seq1 [20][68] (row 19 zero) | h [2][2][2][32] | enc [64] | hid [64] = 21.9 KB: seven per CU whatever
+// the allocation granularity (22.7 KB with a 20th gx row was seven only if LDS is handed out in units below 1 KB)
+#define GT_SEQ (19 * GR_GX_LD)
 #define GT_HB (GT_SEQ + 20 * GR_SEQ_LD)
 #define GT_ENC (GT_HB + 2 * 2 * 2 * GR_H)
 #define GT_HID (GT_ENC + 2 * GR_H)
