@@ -272,6 +272,12 @@ def roofline_of(eng, prof, clips, fast_frontend):
         t = rec["total_ms"] / max(rec["calls"], 1) * 1e-3
         if b == "hbm":
             every[name] = {"bound": "hbm", "achieved": nb / t / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": nb / t / PEAK_HBM}
+            if not fast_frontend and fl:
+                # SURVEY 8(d) prices the front end against HBM; what its instructions run on is the fp64 vector ALU
+                every[name]["fp64_valu"] = {"achieved_TFLOPs": fl / t / 1e12, "peak_TFLOPs": PEAK_F64_VALU / 1e12,
+                                            "frac": fl / t / PEAK_F64_VALU,
+                                            "note": "13.9 kFLOP per frame (SURVEY 8d), mostly adds: half of the FMA peak is the ceiling; "
+                                                    "vector ALUs 58 % busy over the kernel (profiles/r02/sq_logmel_256_*.txt)"}
         elif name.endswith("<bf16x3>"):
             every[name] = {"bound": "mfma", "achieved": 3.0 * fl / t / 1e12, "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s",
                            "frac": 3.0 * fl / t / PEAK_BF16_MFMA}
