@@ -137,21 +137,26 @@ struct wave_blk {
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0); \
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
 
+// (block-uniform base pointers + one 32-bit per-lane offset each: the loads take SGPR base + VGPR offset + immediate, no
+//  64-bit address arithmetic on the vector ALU - in the fp32 kernel every vector instruction costs matrix time)
 __device__ __forceinline__ void wave_blk_load(const wave_args &a, int blk, int j, int kk, wave_blk &p) {
+  const float *wg = a.w_gate4 + (size_t)blk * 3 * 4 * 32 * 4, *wrs = a.w_rs4 + (size_t)blk * 4 * 48 * 4;
+  const unsigned og = (unsigned)(kk * 32 + j) * 4, ors = (unsigned)(kk * 48 + j) * 4;
 #pragma unroll
   for (int kb = 0; kb < 3; ++kb)
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
-      p.wg[kb][n] = *(const float4 *)(a.w_gate4 + (((size_t)blk * 3 + kb) * 4 + kk) * 32 * 4 + (n * 16 + j) * 4);
+    for (int n = 0; n < 2; ++n) p.wg[kb][n] = *(const float4 *)(wg + og + kb * 4 * 32 * 4 + n * 16 * 4);
 #pragma unroll
-  for (int n = 0; n < 3; ++n) p.wrs[n] = *(const float4 *)(a.w_rs4 + ((size_t)blk * 4 + kk) * 48 * 4 + (n * 16 + j) * 4);
-  p.bn_s = a.bn_s[blk * WV_C + j];
-  p.bn_t = a.bn_t[blk * WV_C + j];
-  p.bsig = a.b_gate[blk * 32 + j];
-  p.btanh = a.b_gate[blk * 32 + 16 + j];
-  p.bres = a.b_rs[blk * 48 + j];
-  p.bsk0 = a.b_rs[blk * 48 + 16 + j];
-  p.bsk1 = a.b_rs[blk * 48 + 32 + j];
+  for (int n = 0; n < 3; ++n) p.wrs[n] = *(const float4 *)(wrs + ors + n * 16 * 4);
+  const float *bn_s = a.bn_s + blk * WV_C, *bn_t = a.bn_t + blk * WV_C, *bg = a.b_gate + blk * 32, *brs = a.b_rs + blk * 48;
+  const unsigned uj = (unsigned)j;
+  p.bn_s = bn_s[uj];
+  p.bn_t = bn_t[uj];
+  p.bsig = bg[uj];
+  p.btanh = bg[uj + 16];
+  p.bres = brs[uj];
+  p.bsk0 = brs[uj + 16];
+  p.bsk1 = brs[uj + 32];
 }
 
 
