@@ -250,17 +250,17 @@ __device__ __forceinline__ void wsync_g() {
 //      column meet in two cross-lane adds at the very end - 20 rows of matrix time for 19 instead of 32.
 //      Each wave owns 3 of the 12 n-tiles over the whole K.  W_x1 (491 KB) streams from L2 straight into registers
 //      in B-operand order ([k/4][192][4], one contiguous KB per wave load), three k-steps ahead of its use.
-//   D  layer-1 recurrence (wave 0 forward, wave 1 backward) | waves 2, 3 copy W_x2 (B-operand order, 48 KB) into the
-//      dead feat space
-//   E  layer-2 input projection, the same 16 + 3 row split, both operands out of LDS
-//   F  layer-2 recurrence (waves 2, 3) | waves 0, 1 stage the detect head over W_x2
+//   D  layer-1 recurrence (wave 0 forward, wave 1 backward); every wave's W_x2 operands (B-operand order) on their way
+//      from L2 into registers
+//   E  layer-2 input projection, the same 16 + 3 row split, A operand out of LDS
+//   F  layer-2 recurrence (waves 2, 3) | waves 0, 1 stage the detect head in the dead feat space
 //   G  detect head (wave 0)
 //
 // One wave per SIMD: v_mfma_f32_16x16x4_f32 reaches its issue rate from a single wave with independent accumulators,
 // while two such waves on a SIMD got in each other's way (8-wave form of this kernel: the older wave of a SIMD took
 // 14.8k cycles over 9.6k cycles of MFMAs and its partner advanced only once it was alone).
 // LDS: the window image (28.9 KB; after B it holds gx, seq1, h, the head's small vectors) + feat (49.2 KB; after C
-// W_x2, then the head's first layer) = 78.1 KB, two workgroups per CU: one's recurrences and staging run beside
+// the head's first layer) = 78.1 KB, two workgroups per CU: one's recurrences and staging run beside
 // the other's MFMA phases.
 // ------------------------------------------------------------------------------------------
 #define CF_THREADS 256
@@ -340,16 +340,18 @@ __device__ __forceinline__ void cf_phases_d_to_g(const fused_args &a, float *img
   const int j = lane & 15, kk = lane >> 4;
   const int unit = lane >> 1, half = lane & 1, dir = wave & 1;
   float *gxs = img + CF_GX, *seq1 = img + CF_SEQ, *hb = img + CF_HB, *encs = img + CF_ENC, *hid = img + CF_HID, *w2s = img + CF_W2S;
-  // ---- D: layer-1 recurrence (waves 0, 1) | waves 2, 3: W_x2 (B-operand order) -> the feat space
-  float *wx2l = feat;  // [16 k-quads][192][4]
+  // ---- D: layer-1 recurrence (waves 0, 1).  Every wave first requests its B operands of the layer-2 projection (W_x2 in
+  //      B-operand order, 12 x 16 bytes per lane, L2): they arrive during the recurrence, and phase E reads nothing but
+  //      its A operand from LDS (W_x2 used to be staged through the feat space by waves 2, 3; phase E 4.3 k -> 4.0 k cycles for 1.9 k of MFMAs)
+  float4 bq2[4][3];
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+    for (int n = 0; n < 3; ++n) bq2[kb][n] = *(const float4 *)(a.wx2s + ((size_t)(kb * 4 + kk) * 192 + (wave * 3 + n) * 16 + j) * 4);
   if (wave < 2) {
     __builtin_amdgcn_s_setprio(3);  // the serial chain issues ahead of a co-resident workgroup's MFMA stream (+1.5 % at scale)
     cf_recurrence<true>(g, gxs, hb + dir * 2 * H, seq1, dir, unit, half);
     __builtin_amdgcn_s_setprio(0);
-  } else {
-    const float4 *src = (const float4 *)a.wx2s;
-#pragma unroll 4
-    for (int i = tid - 128; i < 16 * 192; i += 128) ((float4 *)wx2l)[i] = src[i];
   }
   __syncthreads();
   CF_STAMP(6)
@@ -363,9 +365,7 @@ __device__ __forceinline__ void cf_phases_d_to_g(const fused_args &a, float *img
     for (int kb = 0; kb < 4; ++kb) {
       const float4 av = *(const float4 *)(&seq1[j * GR_SEQ_LD + kb * 16 + kk * 4]);
       const float4 rv = *(const float4 *)(&seq1[(16 + (lane & 3)) * GR_SEQ_LD + kb * 16 + kk * 4]);  // row 19 is zero
-      float4 b[3];
-#pragma unroll
-      for (int n = 0; n < 3; ++n) b[n] = *(const float4 *)(&wx2l[((kb * 4 + kk) * 192 + (wave * 3 + n) * 16 + j) * 4]);
+      const float4 *b = bq2[kb];
       CF_ROUND(av, rv, b, x) CF_ROUND(av, rv, b, y) CF_ROUND(av, rv, b, z) CF_ROUND(av, rv, b, w)
     }
 #pragma unroll
@@ -387,7 +387,7 @@ __device__ __forceinline__ void cf_phases_d_to_g(const fused_args &a, float *img
   CF_STAMP(7)
 
   // ---- F: layer-2 recurrence (waves 2, 3): only the last state of each direction is kept | waves 0, 1: head -> LDS
-  float *w1s = feat;  // [64][GR_W1_LD], over W_x2
+  float *w1s = feat;  // [64][GR_W1_LD]
   if (wave >= 2) {
     __builtin_amdgcn_s_setprio(3);  // the serial chain issues ahead of a co-resident workgroup's MFMA stream (+1.5 % at scale)
     const float h_last = cf_recurrence<false>(g, gxs, hb + (2 + dir) * 2 * H, nullptr, dir, unit, half);
