@@ -178,7 +178,7 @@ def test_wavenet_split_bf16_mode(assets, oracles, golden, name):
 
 @pytest.mark.parametrize("name", ["CRNN", "CRNN_softmax"])
 def test_crnn_large_batch_path(engines, oracles, name):
-    """Above 1,024 windows per launch the CRNN runs as crnn_fused_kernel<front> + gru_tail_kernel (the recurrences of six
+    """Above 1,024 windows per launch the CRNN runs as crnn_fused_kernel<front> + gru_tail_kernel (the recurrences of seven
     windows share a CU): same results as the one-kernel path bit for bit, and the oracle's within tolerance - windows
     with partial validity included, encoder output too."""
     rng = np.random.default_rng(31)
