@@ -335,7 +335,7 @@ __device__ __forceinline__ float cf_recurrence(const gru_w &g, const float *gxs,
 // Phases D..G of the fused kernels (fp32 and split-bf16 front halves share them): gx1 is in LDS, g holds this wave's
 // recurrent weights (waves 0, 1: layer 1; waves 2, 3: layer 2).
 __device__ __forceinline__ void cf_phases_d_to_g(const fused_args &a, float *img, float *feat, const gru_w &g, int w) {
-  constexpr int H = GR_H, OT = CV_OT;
+  constexpr int H = GR_H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kk = lane >> 4;
   const int unit = lane >> 1, half = lane & 1, dir = wave & 1;
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
   CF_STAMP(2)
   __syncthreads();  // feat complete; the image is dead from here on
   CF_STAMP(3)
-  float *gxs = img + CF_GX, *seq1 = img + CF_SEQ, *hb = img + CF_HB, *encs = img + CF_ENC, *hid = img + CF_HID, *w2s = img + CF_W2S;
+  float *gxs = img + CF_GX, *seq1 = img + CF_SEQ, *hb = img + CF_HB;
   for (int i = tid; i < 32 * GR_SEQ_LD; i += CF_THREADS) seq1[i] = 0.f;
   if (tid < 2 * 2 * 2 * H) hb[tid] = 0.f;
 
@@ -664,7 +664,7 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_stream_kernel(stream_args 
   const fused_args &a = sa.f;
   extern __shared__ __align__(16) float cf_smem[];
   float *img = cf_smem, *feat = cf_smem + CF_IMG_FLOATS;
-  constexpr int H = GR_H, OT = CV_OT, RA = WW_STREAM_GXC;
+  constexpr int H = GR_H, RA = WW_STREAM_GXC;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kk = lane >> 4;
   const int w = blockIdx.x;
