@@ -31,9 +31,11 @@ Rank 0 prints ONE JSON line (schema in the task contract) that also carries
   single_stream - the same job on ONE context (strict batch-256 latency chain, --pipeline 1)
   wavenet       - BASELINE configs[2]: split-bf16 MFMA and the fp32-MFMA parity mode
   streaming     - BASELINE configs[4]: 128 streams per GPU in lock step, tick latency p50/p99
-  eval_testset  - BASELINE configs[0]/[3]: the 2,048-clip stand-in of the hey-snips test split,
-                  utterance-sharded over the N ranks, FRR @ 0.5 FA/h (the second half of the
-                  metric) next to the C-oracle value of the same flow (N = 1 only).
+  eval_testset  - BASELINE configs[0]/[3]: the reference evaluator's own flow on the 2,048-clip
+                  stand-in of the hey-snips test split - positives utterance-sharded, the ONE joined
+                  negative stream cut into contiguous posterior ranges over the N ranks - FRR @ 0.5
+                  FA/h (the second half of the metric) next to the C-oracle value of the same flow
+                  (N = 1 only).
 """
 import argparse
 import json
@@ -91,6 +93,29 @@ def synth_pcm(rng, n_clips):
     return np.clip(np.rint(x), -32768, 32767).astype(np.int16)
 
 
+def kernel_source_sha():
+    """sha256 over the kernel sources the library is built from: PMC figures measured on other sources are not evidence for
+    this build (there is no .git on the GPU box, so the sources themselves are the key)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(PKG, "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_counters():
+    """profiles/r03/pmc_counters.json (tools/pmc_collect.py: rocprofv3 --pmc passes, mean per launch and kernel) if it
+    was measured on THESE kernel sources, else None."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03", "pmc_counters.json")))
+    except (OSError, ValueError):
+        return None
+    return pmc if pmc.get("source_sha") == kernel_source_sha() else None
+
+
 def kernel_work(eng, n_clips):
     """name -> (bound, algorithmic HBM bytes, algorithmic FLOPs (2*MAC)) per launch; DESIGN.md section 4."""
     nf = (SAMPLES - 512) // 160 + 1
@@ -118,13 +143,37 @@ def kernel_work(eng, n_clips):
     return out
 
 
+def granted_cpus():
+    """CPUs this job may actually use: the affinity mask, capped by the cgroup CPU quota when there is one."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            elif int(txt[0]) > 0:
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                n = min(n, max(1, int(int(txt[0]) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(eng, pcm_sample, budget_s=10.0):
-    """Time the C restatement (oracle/ww_oracle.c, all host threads) on a bounded sample."""
+    """Time the C restatement (oracle/ww_oracle.c) on a bounded sample, as SURVEY 8(d) defines the CPU baseline when TFLite
+    is absent: ONE thread (the reference path is one TFLite interpreter, default threads = 1, batch 1:
+    spokestack/models/tensorflow.py:26-28) and all the cores this job is granted."""
     import numpy as np
     from oracle import cpu as ocpu
     ora = ocpu.CpuOracle(eng.blob)
-    # a 1-GPU box grants this job 16 CPUs (of many more logical ones): use exactly that share
-    threads = ocpu.set_threads(max(1, min(16, os.cpu_count() or 1)))
+    nproc, granted = os.cpu_count() or 1, granted_cpus()
+    # a 1-GPU box grants this job 16 CPUs of many more logical ones: use exactly that share
+    all_threads = max(1, min(16, granted))
 
     def one_pass(clips):
         wins = np.zeros((len(clips), eng.window, 40), np.float32)
@@ -134,23 +183,31 @@ def cpu_baseline(eng, pcm_sample, budget_s=10.0):
             wins[i, :n] = mel[:n]
         return ora.forward(wins)
 
-    one_pass(pcm_sample[:threads])  # warm up (thread pool, tables)
-    t0 = time.perf_counter()
-    done = 0
-    n = len(pcm_sample)
-    while True:
-        one_pass(pcm_sample)
-        done += n
-        el = time.perf_counter() - t0
-        if el > budget_s:
-            break
+    def timed(threads, sample, budget):
+        used = ocpu.set_threads(threads)
+        one_pass(sample[:used])  # warm up (thread pool, tables)
+        t0 = time.perf_counter()
+        done = 0
+        while True:
+            one_pass(sample)
+            done += len(sample)
+            el = time.perf_counter() - t0
+            if el > budget:
+                return used, done, el
+
+    t_all, n_all, el_all = timed(all_threads, pcm_sample, 0.6 * budget_s)
+    t_one, n_one, el_one = timed(1, pcm_sample[:16], 0.4 * budget_s)
     return {
-        "value": done * FRAMES_PER_CLIP / el,
+        "value": n_all * FRAMES_PER_CLIP / el_all,
         "unit": "audio frames/s",
-        "cores": threads,
+        "cores": t_all,
         "kind": "port",
-        "sample": f"{done} clips x 1.5 s ({n}-clip sample of the same synthetic batch, repeated), "
-                  f"{el:.1f} s wall; C restatement oracle/ww_oracle.c with OpenMP over clips, NOT TFLite",
+        "sample": f"{n_all} clips x 1.5 s ({len(pcm_sample)}-clip sample of the same synthetic batch, repeated), "
+                  f"{el_all:.1f} s wall on {t_all} threads; C restatement oracle/ww_oracle.c with OpenMP over clips, NOT TFLite",
+        "one_thread": {"value": n_one * FRAMES_PER_CLIP / el_one, "unit": "audio frames/s", "cores": t_one,
+                       "sample": f"{n_one} clips x 1.5 s (16-clip sample, repeated), {el_one:.1f} s wall; the reference's own "
+                                 "shape: one interpreter, one thread, one clip at a time"},
+        "host": {"nproc": nproc, "granted_cpus": granted},
     }
 
 
@@ -248,18 +305,16 @@ def roofline_of(eng, prof, clips, fast_frontend):
         roof["fp64_valu"] = {"achieved_TFLOPs": tf64, "peak_TFLOPs": PEAK_F64_VALU / 1e12, "frac": tf64 * 1e12 / PEAK_F64_VALU,
                              "note": "13.9 kFLOP per frame (SURVEY 8d); mostly adds, so half of the FMA peak is the ceiling"}
     roof["traffic"] = None
-    for rnd in ("r02", "r01"):  # HBM-side bytes per launch from the committed PMC passes of the same workload
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")))["kernels"].get(dom)
-        except (OSError, KeyError, ValueError):
-            continue
-        if pmc and clips == 256:
-            roof["traffic"] = (2 * pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024
-            roof["traffic_note"] = ("2 x FETCH_SIZE + WRITE_SIZE (gfx950 reports half of 16-byte-per-lane streaming reads: "
-                                    "MI355X_MICROARCH.md), rocprofv3 --pmc in separate passes, bytes per launch "
-                                    f"(profiles/{rnd}/pmc_traffic.json)")
-            roof["algorithmic_bytes"] = nbytes
-            break
+    pmc = pmc_counters()
+    rec = (pmc or {}).get("workloads", {}).get(f"clips{clips}", {}).get(dom)
+    if rec and "FETCH_SIZE" in rec and "WRITE_SIZE" in rec:
+        roof["traffic"] = (2 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024
+        roof["traffic_note"] = ("2 x FETCH_SIZE + WRITE_SIZE (KiB; gfx950 reports half of 16-byte-per-lane streaming reads: "
+                                "MI355X_MICROARCH.md), rocprofv3 --pmc in separate passes, mean bytes per launch "
+                                f"(profiles/r03/pmc_counters.json, kernel sources {pmc['source_sha']})")
+        roof["algorithmic_bytes"] = nbytes
+    elif pmc is None:
+        roof["traffic_note"] = "no PMC pass on these kernel sources (profiles/r03/pmc_counters.json absent or of another source_sha)"
     roof["kernel"] = dom
     roof["kernel_avg_us"] = round(dom_ms * 1e3, 3)
     roof["all_kernels_avg_us"] = per_kernel
@@ -326,52 +381,80 @@ def stream_leg(torch, np, dist, comm_dev, local_rank, S, ticks, warm=100):
 
 
 def eval_leg(torch, np, dist, comm_dev, rank, world, local_rank, n_clips, with_oracle):
-    """BASELINE configs[0] stand-in / configs[3]: 2,048 ragged clips, utterances dealt longest-first round-robin to the
-    ranks, sliding posteriors (hop 2) + one window per clip, gather, rank 0 smooths + sweeps: FRR @ 0.5 FA/h."""
-    from wwhip.evaluate import synth_testset, evaluate_testset_sharded, frr_at_fa
+    """BASELINE configs[0] stand-in / configs[3]: the reference evaluator's own flow (utils/evaluate_models.py main()) on
+    2,048 synthetic labelled clips, sharded over the ranks: wake-word clips file by file through one never-reset Filter
+    (utterance-sharded), the first num_wakewords other clips joined by 100 ms of silence into ONE negative stream that is
+    cut into `world` contiguous posterior ranges; posterior gather; rank 0 smooths + sweeps: FRR @ 0.5 FA/h.
+    Next to it the per-clip variant of round 2 (every clip on its own grid, all negatives)."""
+    from wwhip.evaluate import (synth_testset, evaluate_testset_sharded, evaluate_reference_flow_sharded, frr_at_fa,
+                                join_negatives, StreamPlan)
     from wwhip.models import engine_for
     eng = engine_for(os.path.join(PKG, "assets", "tf_lite_models", "CRNN_softmax"), local_rank)
     clips, labels = synth_testset(n_clips)
-    res = None
-    for attempt in range(2):  # the second pass is the timed one (page-locked staging exists, workspaces sized)
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        r = evaluate_testset_sharded(eng, clips, labels, rank, world, comm_dev)
-        el = time.perf_counter() - t0
+
+    def timed(fn):
+        for attempt in range(2):  # the second pass is the timed one (page-locked staging exists, workspaces sized)
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = fn()
+            el = time.perf_counter() - t0
+        return r, el
+
+    r, el = timed(lambda: evaluate_reference_flow_sharded(eng, clips, labels, rank, world, comm_dev))
+    pc, el_pc = timed(lambda: evaluate_testset_sharded(eng, clips, labels, rank, world, comm_dev))
     if rank != 0:
         return None
-    audio_frames = sum((len(c) + 16000) // 160 for c in clips)
-    res = {"workload": f"{len(clips)} synthetic clips 0.8-2.5 s (SURVEY 8d cfg 1 stand-in, seed 1234), CRNN_softmax, "
-                       "0.5 s zero padding, sliding hop 2 + one window per clip, 30-tap smoothing, 100 thresholds",
-           "world_size": world, "seconds_host_pcm_in_to_curves_out": el, "audio_frames_per_s": audio_frames / el,
+    lab = labels.astype(bool)
+    wake = [c for c, l in zip(clips, lab) if l]
+    other = [c for c, l in zip(clips, lab) if not l]
+    stream = join_negatives(other, len(wake))
+    audio_frames = (len(stream) + sum(len(c) for c in wake)) // 160
+    res = {"workload": f"{len(clips)} synthetic clips 0.8-2.5 s (SURVEY 8d cfg 1 stand-in, seed 1234), CRNN_softmax; the reference "
+                       "evaluator's flow: wake-word clips through one never-reset Filter (0.5 s zero padding, C2 carry), the first "
+                       "num_wakewords other clips joined by 100 ms of silence into ONE stream slid over continuously (hop 2, one "
+                       "inference per 20 ms chunk), 30-tap smoothing, 100 thresholds",
+           "flow": "utils/evaluate_models.py main(): concatenate_FA + get_posterior x 2 + plot_FRR_FAR",
+           "sharding": "positives: whole files longest-first round-robin; negative stream: contiguous posterior ranges "
+                       "(each rank re-reads a T-2-frame overlap); posterior all_gather; rank 0 sweeps",
+           "world_size": world, "num_wakewords": r["num_wakewords"], "negative_clips_joined": r["negative_clips_joined"],
+           "seconds_host_pcm_in_to_curves_out": el, "audio_frames_per_s": audio_frames / el,
            "windows": r["windows"], "negative_hours": r["hours"],
            "frr_at_0.5_fa_per_hour": r["frr_at_0.5_fa_per_hour"], "fa_count_at_threshold_0.5": int(r["fa_count"][0]),
-           "one_window_accuracy": r["one_window_accuracy"], "posterior_checksum": r["posterior_checksum"]}
+           "posterior_checksum": r["posterior_checksum"],
+           "per_clip_variant": {"note": "round 2's stand-in: every clip evaluated on its own (ring reset, 0.5 s of zeros each side), ALL "
+                                        "negatives concatenated as posteriors, + one end-padded window per clip (evaluate_tf_lite_opts.py)",
+                                "seconds_host_pcm_in_to_curves_out": el_pc, "windows": pc["windows"], "negative_hours": pc["hours"],
+                                "audio_frames_per_s": sum((len(c) + 16000) // 160 for c in clips) / el_pc,
+                                "frr_at_0.5_fa_per_hour": pc["frr_at_0.5_fa_per_hour"], "fa_count_at_threshold_0.5": int(pc["fa_count"][0]),
+                                "one_window_accuracy": pc["one_window_accuracy"], "posterior_checksum": pc["posterior_checksum"]}}
     if with_oracle:
-        # the same flow on the C oracle (the checker), all clips: posteriors -> the same sweep in NumPy
+        # the same flow on the C oracle (the checker): ONE framing grid over the padded wake-word files / over the padded
+        # stream, windows where StreamPlan (pinned on the literal reference loop in tests/test_host_logic.py) puts them
         from oracle import cpu as ocpu
         from oracle import numpy_ref as NR
         ora = ocpu.CpuOracle(eng.blob)
-        ocpu.set_threads(max(1, min(16, os.cpu_count() or 1)))
+        ocpu.set_threads(max(1, min(16, granted_cpus())))
         t0 = time.perf_counter()
-        lab, offs, pidx = labels.astype(bool), r["sliding_offsets"], eng.posterior_index
-        z = np.zeros(8000, np.int16)
-        o_pos, o_neg, maxdiff = [], [], 0.0
-        for i, c in enumerate(clips):
-            p = ora.slide_forward(ora.logmel(np.concatenate((z, c, z))), 2)[:, pidx]
-            if len(p):
-                maxdiff = max(maxdiff, float(np.abs(p - r["sliding"][offs[i]:offs[i + 1]]).max()))
-            if lab[i]:
-                o_pos.append(p.max() if len(p) else 0.0)
-            else:
-                o_neg.append(p)
-        of, oa, oc, _ = NR.far_frr(np.array(o_pos, np.float32), np.concatenate(o_neg), int(lab.sum()), r["hours"])
+        pidx = eng.posterior_index
+        plan = StreamPlan([len(stream)], eng.window)
+        padded = np.zeros(int(plan.padded[0]), np.int16)
+        padded[8000:8000 + len(stream)] = stream
+        o_neg = ora.slide_forward(ora.logmel(padded, 32768.0, False), 2)[:plan.total, pidx]
+        plan = StreamPlan([len(c) for c in wake], eng.window)
+        whole = np.zeros(int(plan.padded.sum()), np.int16)
+        for k, c in enumerate(wake):
+            whole[plan.pos[k] + 8000: plan.pos[k] + 8000 + len(c)] = c
+        mel = ora.logmel(whole, 32768.0, False)
+        o_pos = np.array([ora.slide_forward(mel[plan.F[k]: plan.F[k] + plan.n_frames[k]], 2)[:plan.n_win[k], pidx].max()
+                          for k in range(len(wake))], np.float32)
+        of, oa, oc, _ = NR.far_frr(o_pos, o_neg, len(wake), r["hours"])
         res["oracle"] = {"frr_at_0.5_fa_per_hour": frr_at_fa(of, oa, 0.5), "fa_count_at_threshold_0.5": int(oc[0]),
                          "fa_counts_identical": bool(np.array_equal(oc, r["fa_count"])),
                          "frr_identical": bool(np.array_equal(of, r["frr"])),
-                         "max_abs_posterior_diff": maxdiff, "seconds": time.perf_counter() - t0,
+                         "max_abs_posterior_diff": float(max(np.abs(o_neg - r["negatives"]).max(), np.abs(o_pos - r["positives"]).max())),
+                         "seconds": time.perf_counter() - t0,
                          "kind": "oracle/ww_oracle.c + oracle/numpy_ref.py (C restatement, NOT TFLite)"}
     return res
 

@@ -77,7 +77,8 @@ int ww_ctx_create(int device, void *external_stream, ww_ctx **out);
 int ww_ctx_destroy(ww_ctx *ctx);
 int ww_ctx_synchronize(ww_ctx *ctx);
 void *ww_ctx_stream(ww_ctx *ctx);
-const char *ww_last_error(const ww_ctx *ctx); /* ctx may be NULL: error of a failed create */
+/* ctx may be NULL: the error of the calling THREAD's last failed ww_ctx_create (thread-local text). */
+const char *ww_last_error(const ww_ctx *ctx);
 const char *ww_version(void);
 /* Which HIP runtime the library actually runs on.  libwwhip.so links libamdhip64 by soname; a host program that has
  * already loaded another copy (PyTorch-ROCm wheels bundle their own) decides which one that is.  built_hip_version =
@@ -120,6 +121,16 @@ int ww_model_get_info(const ww_model *model, ww_model_info *out);
 #define WW_PRECISION_FP32 0
 #define WW_PRECISION_BF16X3 1
 int ww_model_set_precision(ww_model *model, int precision);
+
+/* Dispatch options of one model object (they select between kernels that compute the same windows; results agree to
+ * <= 2e-6, tests/test_gpu_parity.py).  These replace round 2's process-wide WWHIP_CRNN_* environment variables.
+ *   WW_OPT_CRNN_SPLIT_AT   explicit-window launches above this many windows run crnn_fused_kernel<front> + gru_tail_kernel
+ *                          instead of one crnn_fused_kernel (default 1024; 0 = always one fused kernel)
+ *   WW_OPT_CRNN_SLIDE_MIN  regular sliding windows (ww_slide_forward, ww_forward_segments_dev) take the once-per-sequence
+ *                          form crnn_rows_kernel + gru_tail_kernel from this many windows on (default 64; 0 = never) */
+#define WW_OPT_CRNN_SPLIT_AT 1
+#define WW_OPT_CRNN_SLIDE_MIN 2
+int ww_model_set_option(ww_model *model, int key, int64_t value);
 
 /* ---- front end: PCM -> log-mel ---------------------------------------------------------
  * Replaces the per-sample RingBuffer loop + np.fft.rfft + filter.tflite invoke of
@@ -201,7 +212,10 @@ int ww_clips_forward_dev(ww_ctx *ctx, const ww_model *model, const int16_t *d_pc
  * active (context.is_active): the reference does not sample an active stream at all (tflite.py:139-140), so its
  * rings stand still and it yields no posterior until the flag is cleared.  frames = [n_streams][320] int16
  * (20 ms at 16 kHz). */
-int ww_stream_create(ww_ctx *ctx, const ww_model *model, int32_t n_streams, const ww_frontend_params *fp,
+/* flags: WW_STREAM_FULL_RECOMPUTE = every streaming CRNN window recomputed from its mel rows by the batch kernels instead of
+ * the incremental crnn_stream_kernel (3 new time positions per window); results agree to 2e-6.  0 = default. */
+#define WW_STREAM_FULL_RECOMPUTE 1u
+int ww_stream_create(ww_ctx *ctx, const ww_model *model, int32_t n_streams, const ww_frontend_params *fp, uint32_t flags,
                      ww_streams **out);
 int ww_stream_destroy(ww_streams *st);
 int ww_stream_step(ww_streams *st, const int16_t *frames, const uint8_t *is_speech, float *post, int32_t *n_post);

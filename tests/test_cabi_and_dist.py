@@ -99,6 +99,44 @@ def test_posterior_gather_gloo_world2(tmp_path):
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
 
 
+_PLAN_WORKER = """
+import os, sys
+sys.path[:0] = [{root!r}, os.path.join({root!r}, "wakeword-detection_amd")]
+import numpy as np, torch.distributed as dist
+from wwhip import dist as D
+from wwhip.evaluate import StreamPlan
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+plan = StreamPlan([30000, 41000, 4000, 24000, 51234], 151)
+for eval_type in ("false_negatives", "false_accepts"):
+    slots, vals = [], []
+    for k, i0, i1 in plan.shares(eval_type, world)[rank]:
+        s0, s1 = plan.sample_range(k, i0, i1)
+        assert (s1 - s0 - 512) // 160 + 1 == 2 * (i1 - i0 - 1) + 151      # the frames this rank's piece yields = what its windows need
+        slots.append(np.arange(plan.offs[k] + i0, plan.offs[k] + i1))
+        vals.append((plan.F[k] + 2 * np.arange(i0, i1)) * 0.25)           # a "posterior" that names its first global frame
+    slots = np.concatenate(slots) if slots else np.zeros(0, np.int64)
+    vals = np.concatenate(vals) if vals else np.zeros(0)
+    full = D.gather_posteriors(vals.astype(np.float32), slots, plan.total)
+    want = np.concatenate([(plan.F[k] + 2 * np.arange(plan.n_win[k])) * 0.25 for k in range(5)]).astype(np.float32)
+    assert np.array_equal(full, want), eval_type
+dist.barrier(); dist.destroy_process_group()
+open(os.path.join({out!r}, f"plan{{rank}}.ok"), "w").write("ok")
+"""
+
+
+def test_stream_plan_shares_and_gather_gloo_world3(tmp_path):
+    """SURVEY 8(e) on CPU: the window shares of the sharded reference flow (whole files for the positives, contiguous
+    posterior ranges of the negative stream) + the posterior gather reassemble the full list on every rank (3 ranks)."""
+    script = tmp_path / "plan_worker.py"
+    script.write_text(_PLAN_WORKER.format(root=ROOT, out=str(tmp_path)))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3",
+                        "--master-addr", "127.0.0.1", "--master-port", "29543", str(script)],
+                       capture_output=True, text=True, env=dict(os.environ), timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert all((tmp_path / f"plan{k}.ok").exists() for k in range(3))
+
+
 def test_bench_parent_starts_ranks_without_touching_a_gpu():
     """`bench.py --gpus 2` with no WORLD_SIZE spawns its ranks itself.  Without a GPU the children refuse to run
     ("no CPU fallback"), and the parent must report that as a failure instead of printing a line."""

@@ -139,6 +139,99 @@ def test_cfg1_full_size_vs_oracle(testset_one_rank):
     assert one["frr_at_0.5_fa_per_hour"] == frr_at_fa(wf, wa, 0.5)
 
 
+@pytest.fixture(scope="module")
+def reference_flow_one_rank(assets):
+    from wwhip.evaluate import synth_testset, evaluate_reference_flow_sharded
+    from wwhip.models import engine_for
+    eng = engine_for(os.path.join(assets, "CRNN_softmax"))
+    clips, labels = synth_testset(2048)
+    return eng, clips, labels, evaluate_reference_flow_sharded(eng, clips, labels)
+
+
+def _write_wav(path, pcm):
+    import wave
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(np.asarray(pcm, np.int16).tobytes())
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_reference_flow_sharded_identical_for_any_rank_count(reference_flow_one_rank, tmp_path, world):
+    """SURVEY 8(e), the reference's own false-accept flow (utils/evaluate_models.py main()): the first num_wakewords
+    negative clips joined by 100 ms of silence into ONE stream, evaluated continuously and cut into `world` contiguous
+    posterior ranges (each rank front-ends only its samples + the T-2-frame overlap), positives utterance-sharded with
+    the never-reset ring's carry (quirk C2): every posterior, the FA counts and the FRR array are bit-identical to 1 rank."""
+    _, _, _, one = reference_flow_one_rank
+    dump = tmp_path / f"ranks{world}.npz"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(29660 + world), os.path.join(ROOT, "tools", "eval_testset.py"),
+                        "--flow", "reference", "--backend", "gloo", "--dump", str(dump)], capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["world_size"] == world and line["flow"] == "reference"
+    got = np.load(dump)
+    np.testing.assert_array_equal(got["negatives"], one["negatives"])
+    np.testing.assert_array_equal(got["positives"], one["positives"])
+    np.testing.assert_array_equal(got["fa_count"], one["fa_count"])
+    np.testing.assert_array_equal(got["frr"], one["frr"])
+    assert float(got["checksum"]) == one["posterior_checksum"] == line["posterior_checksum"]
+    assert line["frr_at_0.5_fa_per_hour"] == one["frr_at_0.5_fa_per_hour"]
+
+
+def test_reference_flow_equals_get_posterior_and_oracle(reference_flow_one_rank, tmp_path):
+    """The sharded flow's arrays against (a) the unsharded drop-in `get_posterior` on the same wavs (the whole stream in one
+    front-end pass): bit-identical; (b) the C oracle over the same stream + the NumPy restatement of plot_FRR_FAR:
+    posteriors within 1e-4, FA counts / FRR array / FRR @ 0.5 FA/h identical."""
+    from oracle import cpu as ocpu
+    from oracle import numpy_ref as NR
+    from wwhip.evaluate import get_posterior, join_negatives, frr_at_fa, StreamPlan
+    eng, clips, labels, one = reference_flow_one_rank
+    lab = labels.astype(bool)
+    wake = [c for c, l in zip(clips, lab) if l]
+    other = [c for c, l in zip(clips, lab) if not l]
+    assert one["num_wakewords"] == len(wake) > 100
+    stream = join_negatives(other, len(wake))
+    assert len(stream) == sum(len(c) for c in other[:len(wake)]) + 1600 * (len(wake) - 1)
+    assert one["hours"] == len(stream) / 16000 / 3600                       # duration_test: the wav's own length
+    far = tmp_path / "not_hey_snips_long.wav"
+    _write_wav(far, stream)
+    neg = np.asarray(get_posterior(eng.model_dir, "CRNN", "false_accepts", [str(far)], 20, 16000), np.float32)
+    np.testing.assert_array_equal(neg, one["negatives"])
+    files = []
+    for i, c in enumerate(wake[:40]):
+        files.append(str(tmp_path / f"w{i}.wav"))
+        _write_wav(files[-1], c)
+    pos = np.asarray(get_posterior(eng.model_dir, "CRNN", "false_negatives", files, 20, 16000), np.float32)
+    np.testing.assert_array_equal(pos, one["positives"][:40])
+    # (b) the oracle
+    ora = ocpu.CpuOracle(eng.blob)
+    ocpu.set_threads(max(1, min(16, os.cpu_count() or 1)))
+    pidx = eng.posterior_index
+    plan = StreamPlan([len(stream)], eng.window)
+    padded = np.zeros(int(plan.padded[0]), np.int16)
+    padded[8000:8000 + len(stream)] = stream
+    o_neg = ora.slide_forward(ora.logmel(padded, 32768.0, False), 2)[:, pidx]
+    assert len(o_neg) == len(one["negatives"]) == plan.total
+    assert np.abs(o_neg - one["negatives"]).max() < TOL
+    plan = StreamPlan([len(c) for c in wake], eng.window)
+    whole = np.zeros(int(plan.padded.sum()), np.int16)
+    for k, c in enumerate(wake):
+        whole[plan.pos[k] + 8000: plan.pos[k] + 8000 + len(c)] = c
+    mel = ora.logmel(whole, 32768.0, False)                                  # ONE grid over all files: the never-reset ring
+    o_pos = []
+    for k in range(len(wake)):
+        rows = mel[plan.F[k]: plan.F[k] + plan.n_frames[k]]
+        p = ora.slide_forward(rows, 2)[:plan.n_win[k], pidx]                 # windows still pending at end of file are dropped
+        assert len(p) == plan.n_win[k]
+        o_pos.append(p.max())
+    assert np.abs(np.array(o_pos) - one["positives"]).max() < TOL
+    wf, wa, wc, _ = NR.far_frr(np.array(o_pos, np.float32), o_neg, len(wake), one["hours"])
+    np.testing.assert_array_equal(one["fa_count"], wc)
+    np.testing.assert_array_equal(one["frr"], wf)
+    assert one["frr_at_0.5_fa_per_hour"] == frr_at_fa(wf, wa, 0.5)
+
+
 def test_bench_rccl_path_at_world_size_one():
     """The multi-GPU runs use the `nccl` (= RCCL) backend with device tensors in the posterior gather and the timing
     reductions; a one-GPU box can at least run that code at world size 1 (WW_BENCH_FORCE_DIST=1)."""

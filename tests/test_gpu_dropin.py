@@ -348,27 +348,34 @@ def test_superframe_smoothing_matches_the_reference_lattice(assets):
     assert fired == [False] * 9 + [True]
 
 
-def test_evaluator_command_line_flow(assets, tmp_path):
+def test_evaluator_command_line_flow(assets, oracle_dirs, tmp_path):
     """tools/evaluate_models.py = utils/evaluate_models.py main(): test.json -> concatenated negative wav ->
-    cached posteriors -> FRR / FA-per-hour; second run must come from the pickle caches."""
+    cached posteriors -> FRR / FA-per-hour.  Its numbers are compared with the literal restatement of main() (one
+    never-reset Filter per get_posterior call, the per-file loop, plot_FRR_FAR's sweep) on the op-by-op oracle; a second run
+    must come from the pickle caches; a 2-rank run (torchrun, gloo, the ranks share the card: wake-word files dealt over the
+    ranks, the long negative wav cut into two posterior ranges) must print the same arrays."""
     import json
     import shutil
     import subprocess
     import sys
+    from oracle import numpy_ref as NR
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     data = tmp_path / "snips"
     (data / "audio_files").mkdir(parents=True)
     rng = np.random.default_rng(23)
-    meta = []
+    meta, pcms = [], []
     for i in range(6):
         pcm = np.clip(rng.normal(0, 2500, int(rng.integers(30000, 42000))), -32768, 32767).astype(np.int16)
+        pcms.append(pcm)
         _write_wav(str(data / "audio_files" / f"c{i}.wav"), pcm)
         meta.append({"audio_file_path": f"audio_files/c{i}.wav", "is_hotword": int(i < 2), "worker_id": "w"})
     (data / "test.json").write_text(json.dumps(meta))
     models = tmp_path / "models"
     shutil.copytree(os.path.join(assets, "CRNN_softmax"), models)
-    cmd = [sys.executable, os.path.join(root, "tools", "evaluate_models.py"), "--model_type", "CRNN", "--models_dir", str(models) + "/",
-           "--data_dir", str(data) + "/", "--eval_dir", str(tmp_path / "evaluation") + "/"]
+    script = os.path.join(root, "tools", "evaluate_models.py")
+    args = ["--model_type", "CRNN", "--models_dir", str(models) + "/", "--data_dir", str(data) + "/",
+            "--eval_dir", str(tmp_path / "evaluation") + "/"]
+    cmd = [sys.executable, script] + args
     out1 = json.loads(subprocess.run(cmd, capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
     assert out1["num_wakewords"] == 2 and len(out1["FRR"]) == 100 and len(out1["FA_per_hour"]) == 100
     assert all(0.0 <= v <= 1.0 for v in out1["FRR"])
@@ -376,11 +383,38 @@ def test_evaluator_command_line_flow(assets, tmp_path):
     assert far.exists() and (models / "CRNN_all_wakeword.pkl").exists() and (models / "CRNN_no_wakeword.pkl").exists()
     # the negative wav holds the first num_wakewords (= 2) negative clips joined by 100 ms of silence
     from wwhip.evaluate import read_wav
-    n_expect = sum(len(read_wav(str(data / "audio_files" / f"c{i}.wav"))) for i in (2, 3)) + 1600
+    n_expect = len(pcms[2]) + len(pcms[3]) + 1600
     assert len(read_wav(str(far))) == n_expect
     assert abs(out1["fa_hours"] - n_expect / 16000 / 3600) < 1e-12
+    # the restatement of main() on the oracle
+    mdir = oracle_dirs["CRNN_softmax"]
+    window_fn = lambda w: float(mdir.window(w)[1])  # noqa: E731
+    filt = NR.RefFilter(lambda a: mdir.filter(a)[0])            # get_posterior(..., "false_negatives", wakeword_paths): ONE Filter
+    want_pos = [max(NR.sliding_posteriors(filt, p.astype(np.float32) / np.float32(32768), 151, window_fn)) for p in pcms[:2]]
+    filt = NR.RefFilter(lambda a: mdir.filter(a)[0])            # get_posterior(..., "false_accepts", [FAR_path]): a new one
+    want_neg = NR.sliding_posteriors(filt, read_wav(str(far)), 151, window_fn)
+    import pickle
+    got_pos = np.atleast_1d(np.squeeze(np.array(pickle.load(open(models / "CRNN_all_wakeword.pkl", "rb")))))
+    got_neg = np.array(pickle.load(open(models / "CRNN_no_wakeword.pkl", "rb")))
+    assert len(got_neg) == len(want_neg) and np.abs(got_neg - np.array(want_neg)).max() < TOL
+    assert np.abs(got_pos - np.array(want_pos)).max() < TOL
+    wf, wa, wc, _ = NR.far_frr(np.array(want_pos, np.float32), np.array(want_neg, np.float32), 2, n_expect / 16000 / 3600)
+    assert out1["FA_count"] == wc.tolist()
+    np.testing.assert_array_equal(np.array(out1["FRR"]), wf)
+    np.testing.assert_allclose(np.array(out1["FA_per_hour"]), wa, rtol=1e-15)
     out2 = json.loads(subprocess.run(cmd, capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
     assert out2 == out1
+    # two ranks, no caches
+    for f in ("CRNN_all_wakeword.pkl", "CRNN_no_wakeword.pkl"):
+        (models / f).unlink()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29655", script] + args, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out3 = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out3["world_size"] == 2
+    assert {k: v for k, v in out3.items() if k != "world_size"} == {k: v for k, v in out1.items() if k != "world_size"}
+    np.testing.assert_array_equal(np.array(pickle.load(open(models / "CRNN_no_wakeword.pkl", "rb"))), got_neg)
 
 
 def test_fp16_weight_variant_and_opts_script(assets, tmp_path):

@@ -545,9 +545,10 @@ def test_degenerate_sizes_through_the_c_abi(engines, oracles, name):
 
 
 @pytest.mark.parametrize("name", ["CRNN", "CRNN_softmax"])
-def test_stream_incremental_kernel_matches_full_recompute(assets, name, monkeypatch):
+def test_stream_incremental_kernel_matches_full_recompute(assets, name):
     """Streaming CRNN: crnn_stream_kernel (three of the nineteen time positions per new window, the other sixteen projected
-    rows from the per-stream ring) against the full recompute of every window (WWHIP_STREAM_FULL=1) - 300 ticks with
+    rows from the per-stream ring) against the full recompute of every window (a bank created with
+    WW_STREAM_FULL_RECOMPUTE) - 300 ticks with
     the speech bit going on and off, resets of single streams and of the whole bank, from an empty history."""
     from wwhip.engine import Engine, StreamBank
     e = Engine(os.path.join(assets, name))
@@ -558,11 +559,7 @@ def test_stream_incremental_kernel_matches_full_recompute(assets, name, monkeypa
     speech[:, 0] = 1
 
     def run(full):
-        if full:
-            monkeypatch.setenv("WWHIP_STREAM_FULL", "1")
-        else:
-            monkeypatch.delenv("WWHIP_STREAM_FULL", raising=False)
-        bank = StreamBank(e, S)
+        bank = StreamBank(e, S, full_recompute=full)
         out = []
         for t in range(ticks):
             if t == 120:
@@ -609,7 +606,7 @@ def test_crnn_sliding_rows_path_matches_per_window_kernels(engines, oracles, nam
 
 
 @pytest.mark.parametrize("name", ["CRNN", "Wavenet"])
-def test_forward_segments_dev_matches_explicit_windows(engines, name):
+def test_forward_segments_dev_matches_explicit_windows(engines, oracles, name):
     """ww_forward_segments_dev (several sequences in one mel buffer, each slid over with the same hop) against the same
     windows given one by one - CRNN: crnn_rows_kernel by tile descriptors + the gathering gru_tail_kernel; Wavenet: the
     entry point's explicit-list fallback.  Sequences of 0, 1, 15, 16, 17 and many windows, odd and even first rows."""
@@ -637,5 +634,79 @@ def test_forward_segments_dev_matches_explicit_windows(engines, name):
         wins = np.stack([mel[r0 + k * hop: r0 + k * hop + T] for r0, nw in zip(seg_row0, seg_nw) for k in range(nw)])
         ref = e.forward(wins)
         assert np.abs(got - ref).max() < 2e-6, (hop, float(np.abs(got - ref).max()))
+        idx = rng.choice(len(wins), 16, replace=False)  # and against the CPU oracle, not only the library's other kernels
+        assert np.abs(got[idx] - oracles[name].forward(wins[idx])).max() < TOL_POST
     with pytest.raises(ValueError):
         e.forward_segments_dev(d_mel.data_ptr(), len(mel), np.array([len(mel) - 10], np.int64), np.array([3], np.int32), 2, d_out.data_ptr())
+
+
+def test_two_host_threads_through_the_c_abi(assets, oracles):
+    """include/wwhip.h: "one ww_ctx per host thread".  Two Python threads (ctypes releases the GIL inside every call, so
+    the library really runs concurrently), each with its OWN context, model and stream bank - one CRNN, one Wavenet -
+    interleave ww_logmel / ww_forward / ww_slide_forward / ww_stream_step calls; every result equals the same calls made
+    from one thread, and the oracle.  A failed ww_ctx_create in each thread leaves its own message in that thread's
+    ww_last_error(NULL) (thread-local text)."""
+    import ctypes as C
+    import threading
+    from wwhip import _lib
+    from wwhip.engine import Engine, StreamBank, frontend_params
+    rounds = 12
+
+    def job(name, seed, barrier=None):
+        ctx = _lib.Context(0)
+        eng = Engine(os.path.join(assets, name), ctx=ctx)
+        bank = StreamBank(eng, 5)
+        rng = np.random.default_rng(seed)
+        out = []
+        for r in range(rounds):
+            if barrier is not None:
+                barrier.wait()
+            pcm = [np.clip(rng.normal(0, 2500, n), -32768, 32767).astype(np.int16) for n in (24000, 9000 + 37 * r)]
+            mels = eng.logmel(pcm, frontend_params())
+            win = np.zeros((3, eng.window, 40), np.float32)
+            win[0, :min(len(mels[0]), eng.window)] = mels[0][:eng.window]
+            win[1] = rng.uniform(0, 6.5, (eng.window, 40))
+            post = eng.forward(win)
+            slide = eng.slide_forward(rng.uniform(0, 6.5, (eng.window + 2 * (70 + r), 40)).astype(np.float32), 2)
+            ticks = [bank.step(np.clip(rng.normal(0, 2500, (5, 320)), -32768, 32767).astype(np.int16), np.ones(5, np.uint8))
+                     for _ in range(4)]
+            out.append((mels, win, post, slide, ticks))
+        bank.close()
+        eng.close()
+        ctx.close()
+        return out
+
+    want = {name: job(name, seed) for name, seed in (("CRNN", 41), ("Wavenet", 42))}   # one thread, one after the other
+    got, errs, texts = {}, [], {}
+    barrier = threading.Barrier(2)
+
+    def worker(name, seed, bad_device):
+        try:
+            h = C.c_void_p()
+            rc = _lib.load().ww_ctx_create(bad_device, None, C.byref(h))
+            barrier.wait()                                                 # both creates have failed before either text is read
+            texts[name] = (rc, _lib.load().ww_last_error(None).decode())
+            got[name] = job(name, seed, barrier)
+        except Exception as e:  # pragma: no cover - reported below
+            errs.append((name, repr(e)))
+            barrier.abort()
+
+    th = [threading.Thread(target=worker, args=a) for a in (("CRNN", 41, 1234), ("Wavenet", 42, -7))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(600)
+    assert not errs, errs
+    assert texts["CRNN"][0] == _lib.WW_EINVAL and "1234" in texts["CRNN"][1]
+    assert texts["Wavenet"][0] == _lib.WW_EINVAL and "-7" in texts["Wavenet"][1]
+    for name in ("CRNN", "Wavenet"):
+        for (m0, w0, p0, s0, t0), (m1, w1, p1, s1, t1) in zip(want[name], got[name]):
+            for a, b in zip(m0, m1):
+                np.testing.assert_array_equal(a, b)
+            np.testing.assert_array_equal(p0, p1)
+            np.testing.assert_array_equal(s0, s1)
+            for (pa, na), (pb, nb) in zip(t0, t1):
+                np.testing.assert_array_equal(na, nb)
+                np.testing.assert_array_equal(pa, pb)
+        _, win, post, _, _ = got[name][-1]
+        assert np.abs(post - oracles[name].forward(win)).max() < TOL_POST

@@ -202,6 +202,69 @@ def test_window_schedule_matches_reference_loop():
             assert ws.tolist() == (2 * np.arange(len(ws))).tolist()
 
 
+def test_stream_plan_matches_reference_loop_over_files():
+    """wwhip.evaluate.StreamPlan (the arithmetic every rank of the sharded evaluation shares) against the literal per-file
+    loop of utils/evaluate_models.py:45-88 driven by ONE never-reset Filter (quirk C2): the "mel row" of global frame j is
+    filled with j, so every window reports which global frames it was made of."""
+    rng = np.random.default_rng(3)
+    for T in (151, 182):
+        lens = [30000, 41000, 4000, 24000, 51234]
+        counter = [0]
+
+        def filter_model(mag):
+            counter[0] += 1
+            return np.full((1, 40), counter[0] - 1, np.float32)
+
+        filt = NR.RefFilter(filter_model)
+        filt.stft_mag = lambda: np.zeros(257, np.float32)
+        per_file = []
+        for n in lens:
+            wins = []
+            NR.sliding_posteriors(filt, rng.normal(0, 0.1, n).astype(np.float32), T,
+                                  lambda w: wins.append((int(w[0, 0]), int(w[-1, 0]), len(w))) or 0.0)
+            per_file.append(wins)
+        plan = E.StreamPlan(lens, T)
+        assert plan.n_win.tolist() == [len(w) for w in per_file]
+        assert plan.n_win[2] == 0                                   # a 0.25 s clip never fills a window
+        for k, wins in enumerate(per_file):
+            for i, (first, last, rows) in enumerate(wins):
+                assert rows == T and first == plan.F[k] + 2 * i and last == first + T - 1
+                s0, s1 = plan.sample_range(k, i, i + 1)
+                assert s0 == 160 * first and s1 == 160 * last + 512
+                assert s0 >= plan.pos[k] - 511 and s1 <= plan.pos[k] + plan.padded[k]   # at most the predecessor's tail
+        # every window lands in exactly one rank's share, whatever the world size
+        for world in (1, 2, 3, 5, 8):
+            for eval_type in ("false_negatives", "false_accepts"):
+                seen = np.zeros(plan.total, int)
+                for share in plan.shares(eval_type, world):
+                    for k, i0, i1 in share:
+                        assert 0 <= i0 < i1 <= plan.n_win[k]
+                        seen[plan.offs[k] + i0: plan.offs[k] + i1] += 1
+                assert (seen == 1).all()
+            sizes = [sum(i1 - i0 for _, i0, i1 in sh) for sh in plan.shares("false_accepts", world)]
+            assert max(sizes) - min(sizes) <= 1                     # contiguous ranges of equal size (dist.split_stream)
+
+
+def test_join_negatives_is_concatenate_FA(tmp_path):
+    """join_negatives (in memory) == concatenate_FA (wav files): first num_files clips, 100 ms of silence between."""
+    import wave
+    rng = np.random.default_rng(4)
+    clips = [np.clip(rng.normal(0, 3000, n), -32768, 32767).astype(np.int16) for n in (5000, 7000, 3000, 9000)]
+    paths = []
+    for i, c in enumerate(clips):
+        paths.append(str(tmp_path / f"n{i}.wav"))
+        with wave.open(paths[-1], "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(c.tobytes())
+    for num in (3, 1, 0, 9):
+        E.concatenate_FA(paths, num, str(tmp_path / "far.wav"))
+        want = E.read_wav_pcm(str(tmp_path / "far.wav"))
+        got = E.join_negatives(clips, num)
+        np.testing.assert_array_equal(got, want)
+        assert E.wav_length(str(tmp_path / "far.wav")) == len(got)
+    z = np.zeros(1600, np.int16)
+    np.testing.assert_array_equal(E.join_negatives(clips, 3), np.concatenate([clips[0], z, clips[1], z, clips[2]]))
+
+
 def test_read_wav_roundtrip(tmp_path):
     import wave
     p = str(tmp_path / "a.wav")

@@ -6,7 +6,11 @@
 
 Same arguments, same caches (<models_dir>/<model_type>_all_wakeword.pkl / _no_wakeword.pkl, the concatenated
 negative wav under --eval_dir).  Instead of opening three matplotlib windows it prints the curves' summary as
-JSON (add --plot for the windows when matplotlib is available)."""
+JSON (add --plot for the windows when matplotlib is available).
+
+Several GPUs: start it under `python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/evaluate_models.py ...`:
+the wake-word files are dealt over the ranks, the ONE long negative wav is cut into N contiguous posterior ranges
+(wwhip.evaluate.get_posterior_sharded), posteriors are gathered (RCCL; gloo when the ranks share a card), rank 0 sweeps."""
 import argparse
 import json
 import os
@@ -39,21 +43,41 @@ def parse_args():
 
 
 def main(args) -> int:
+    rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")))
+    dist, comm_dev, dev = None, None, 0
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        ndev = torch.cuda.device_count()
+        dev = local % max(ndev, 1)
+        backend = "nccl" if ndev >= world else "gloo"  # fewer GPUs than ranks: the ranks share the card
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(dev)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        comm_dev = "cuda" if backend == "nccl" else "cpu"
     FAR_path = Path(os.path.join(args.eval_dir, args.neg_samples))
     wakeword_paths, not_wakeword_paths = E.testset_files(args.data_dir)
     num_wakewords = len(wakeword_paths)
-    if not FAR_path.exists():
+    if rank == 0 and not FAR_path.exists():
         os.makedirs(args.eval_dir, exist_ok=True)
         E.concatenate_FA(not_wakeword_paths, num_wakewords, str(FAR_path), args.sample_rate)
+    if dist is not None:
+        dist.barrier()
     total_duration_hrs = E.duration_test(str(FAR_path), args.sample_rate) / 3600
     pos = E.load_posteriors(args.models_dir, args.model_type, args.frame_width, args.sample_rate, "false_negatives",
                             wakeword_paths, Path(os.path.join(args.models_dir, args.model_type + "_all_wakeword.pkl")),
-                            args.examine_audio)
+                            args.examine_audio, rank, world, comm_dev, dev)
     neg = E.load_posteriors(args.models_dir, args.model_type, args.frame_width, args.sample_rate, "false_accepts",
                             [str(FAR_path)], Path(os.path.join(args.models_dir, args.model_type + "_no_wakeword.pkl")),
-                            args.examine_audio)
+                            args.examine_audio, rank, world, comm_dev, dev)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return 0
     res = E.plot_FRR_FAR(pos, neg, num_wakewords, total_duration_hrs, args.model_type, models_dir=args.models_dir, show=args.plot)
-    print(json.dumps({"model_type": args.model_type, "num_wakewords": num_wakewords, "fa_hours": total_duration_hrs,
+    print(json.dumps({"model_type": args.model_type, "num_wakewords": num_wakewords, "fa_hours": total_duration_hrs, "world_size": world,
+                      "FA_count": [int(x) for x in res["FA_count"]],
                       "frr_at_0.5_fa_per_hour": res["frr_at_0.5_fa_per_hour"],
                       "FRR": [float(x) for x in res["FRR"]], "FA_per_hour": [float(x) for x in res["FAR"]],
                       "thresholds": [float(x) for x in res["thresholds"]]}))

@@ -1,0 +1,59 @@
+# Round-3 profile set (development tool): rocprofv3 kernel-trace stats for every hot kernel (clip batch, sliding evaluation,
+# streaming), PMC passes (HBM traffic + SQ) of the same commands, counter calibration.  Everything goes to gpurun_out/r03p;
+# tools/pmc_collect.py turns the PMC directories into profiles/r03/pmc_counters.json.  Programs directly after `--`.
+set -e
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r03p
+mkdir -p $O
+STATS="--kernel-trace --stats --output-format csv"
+WHAT=${1:-all}   # kt | pmc | all  (two gpurun calls when one would run past the time limit)
+if [ $WHAT = kt ] || [ $WHAT = all ]; then
+# 1. kernel-trace stats
+rocprofv3 $STATS -d $O/kt_bench_single -o run -- python3 $R/bench.py --pipeline 1 --no-cpu-baseline --no-extra > $O/bench_single_under_rocprof.json 2> $O/kt_bench_single.err
+echo "kt bench single done"
+rocprofv3 $STATS -d $O/kt_bench_default -o run -- python3 $R/bench.py --no-cpu-baseline --no-extra > $O/bench_default_under_rocprof.json 2> $O/kt_bench_default.err
+echo "kt bench default done"
+rocprofv3 $STATS -d $O/kt_bench_wavenet -o run -- python3 $R/bench.py --model wavenet --pipeline 1 --no-cpu-baseline --no-extra > $O/bench_wavenet_under_rocprof.json 2> $O/kt_bench_wavenet.err
+echo "kt bench wavenet done"
+rocprofv3 $STATS -d $O/kt_slide -o run -- python3 $R/tools/slide_throughput.py 10 > $O/slide_under_rocprof.json 2> $O/kt_slide.err
+echo "kt slide done"
+rocprofv3 $STATS -d $O/kt_stream -o run -- python3 $R/tools/stream_prof.py > $O/stream_under_rocprof.txt 2> $O/kt_stream.err
+echo "kt stream done"
+fi
+if [ $WHAT = pmc ] || [ $WHAT = all ]; then
+# 2. PMC passes: one TCC counter per pass, SQ counters up to 8 per pass
+SQ1="SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY"
+SQ2="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD"
+pmc() {  # name, counters, program...
+  local name=$1 ctrs=$2; shift 2
+  rocprofv3 --pmc $ctrs -d $O/pmc_$name -o run --output-format csv -- "$@" > $O/pmc_$name.log 2>&1 || echo "pmc pass $name failed"
+  echo "pmc $name done"
+}
+for wl in "clips256 python3 $R/tools/kbench.py crnn 256 5" "wave256 python3 $R/tools/kbench.py wavenet 256 5 bf16x3" \
+          "wave256f python3 $R/tools/kbench.py wavenet 256 5" "slide10 python3 $R/tools/slide_throughput.py 2" \
+          "stream128 python3 $R/tools/stream_prof.py"; do
+  set -- $wl; name=$1; shift
+  pmc ${name}_fetch FETCH_SIZE "$@"
+  pmc ${name}_write WRITE_SIZE "$@"
+  pmc ${name}_sq1 "$SQ1" "$@"
+  pmc ${name}_sq2 "$SQ2" "$@"
+done
+# 3. what the SQ counters count (known instruction streams)
+pmc calib "SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" $R/tools/build/pmc_calib
+$R/tools/build/pmc_calib > $O/pmc_calib_memtime.jsonl
+cd $R
+mkdir -p $O/summary
+python3 tools/pmc_collect.py $O/summary/pmc_counters.json clips256=$O/pmc_clips256_fetch clips256=$O/pmc_clips256_write clips256=$O/pmc_clips256_sq1 clips256=$O/pmc_clips256_sq2 \
+  wave256=$O/pmc_wave256_fetch wave256=$O/pmc_wave256_write wave256=$O/pmc_wave256_sq1 wave256=$O/pmc_wave256_sq2 \
+  wave256f=$O/pmc_wave256f_fetch wave256f=$O/pmc_wave256f_write wave256f=$O/pmc_wave256f_sq1 wave256f=$O/pmc_wave256f_sq2 \
+  slide=$O/pmc_slide10_fetch slide=$O/pmc_slide10_write slide=$O/pmc_slide10_sq1 slide=$O/pmc_slide10_sq2 \
+  stream128=$O/pmc_stream128_fetch stream128=$O/pmc_stream128_write stream128=$O/pmc_stream128_sq1 stream128=$O/pmc_stream128_sq2 \
+  calib=$O/pmc_calib
+fi
+cd $R
+mkdir -p $O/summary
+for d in kt_bench_single kt_bench_default kt_bench_wavenet kt_slide kt_stream; do
+  f=$(ls $O/$d/*/*kernel_stats.csv $O/$d/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/summary/${d}_kernel_stats.csv
+done
+ls $O/summary

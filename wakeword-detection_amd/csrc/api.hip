@@ -5,7 +5,9 @@
 #include <cmath>
 #include <mutex>
 
-static char g_err[512] = {0};
+// message of a failure that has no context to carry it (ww_ctx_create, NULL handles): one buffer per host thread, so that
+// two threads creating contexts concurrently each read their own text through ww_last_error(NULL)
+static thread_local char g_err[512] = {0};
 
 int ww_fail(ww_ctx *ctx, int code, const char *fmt, ...) {
   va_list ap;
@@ -18,11 +20,6 @@ int ww_fail(ww_ctx *ctx, int code, const char *fmt, ...) {
 
 int ww_ensure(ww_ctx *ctx, ww_arena &a, size_t bytes, bool pinned) {
   if (bytes <= a.cap) return WW_OK;
-  // growing invalidates pointers baked into a cached graph
-  if (!pinned && !ctx->clip_graphs.empty()) {
-    hipStreamSynchronize(ctx->stream);
-    ctx->drop_graphs(nullptr);
-  }
   if (a.ptr) {
     hipStreamSynchronize(ctx->stream);
     if (pinned) hipHostFree(a.ptr); else hipFree(a.ptr);
@@ -95,6 +92,7 @@ int ww_ctx_create(int device, void *external_stream, ww_ctx **out) {
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return ww_fail(nullptr, WW_ENODEVICE, "device %d is %s; libwwhip.so carries gfx950 code only", device, prop.gcnArchName);
   ww_device_scope dev_scope(device);  // the stream and events below are created on `device`; the caller's current device is restored
+  if (!dev_scope.ok()) return ww_fail(nullptr, WW_EHIP, "cannot switch to device %d: %s", device, hipGetErrorString(dev_scope.err));
   ww_ctx *c = new ww_ctx();
   c->device = device;
   if (external_stream) {
@@ -108,6 +106,12 @@ int ww_ctx_create(int device, void *external_stream, ww_ctx **out) {
   }
   hipEventCreate(&c->t0);
   hipEventCreate(&c->t1);
+  // kernel attributes are per device: set them for this context's device (a second GPU of the process gets its own)
+  if (int rc = ww_k_crnn_init_device(c)) {
+    snprintf(g_err, sizeof g_err, "%s", c->err);
+    ww_ctx_destroy(c);
+    return rc;
+  }
   *out = c;
   return WW_OK;
 }
@@ -116,7 +120,6 @@ int ww_ctx_destroy(ww_ctx *ctx) {
   if (!ctx) return WW_OK;
   ww_device_scope dev_scope(ctx->device);
   hipStreamSynchronize(ctx->stream);
-  ctx->drop_graphs(nullptr);
   for (auto &co : ctx->clip_offs) {
     hipFree(co.d_so);
     hipFree(co.d_fo);
@@ -700,7 +703,7 @@ int ww_model_load(ww_ctx *ctx, const void *blob, size_t len, ww_model **out) {
   blob_view bv = {(const uint8_t *)blob, len, h[3], h[2]};
   if (16 + 32 * (size_t)bv.n > len) return ww_fail(ctx, WW_EBLOB, "section table exceeds blob");
   if (bv.kind != WW_KIND_CRNN && bv.kind != WW_KIND_WAVENET) return ww_fail(ctx, WW_EBLOB, "unknown model kind %u", bv.kind);
-  ww_device_scope dev_scope(ctx->device);  // the caller's current device is left as it was
+  WW_ON_DEVICE(ctx, dev_scope);  // the caller's current device is left as it was
   ww_model *m = new ww_model();
   m->ctx = ctx;
   m->kind = (int)bv.kind;
@@ -722,7 +725,6 @@ int ww_model_free(ww_model *m) {
   if (m->ctx) {
     ww_device_scope dev_scope(m->ctx->device);
     hipStreamSynchronize(m->ctx->stream);
-    m->ctx->drop_graphs(m);
   }
   for (void *p : m->allocs) hipFree(p);
   delete m;
@@ -741,6 +743,16 @@ int ww_model_set_precision(ww_model *m, int precision) {
     return ww_fail(m->ctx, WW_EINVAL, "unknown precision %d", precision);
   m->precision = precision;
   return WW_OK;
+}
+
+int ww_model_set_option(ww_model *m, int key, int64_t value) {
+  if (!m) return WW_EINVAL;
+  if (value < 0 || value > 0x7fffffff) return ww_fail(m->ctx, WW_EINVAL, "option value %lld out of range", (long long)value);
+  switch (key) {
+    case WW_OPT_CRNN_SPLIT_AT: m->opt_split_at = (int)value; return WW_OK;
+    case WW_OPT_CRNN_SLIDE_MIN: m->opt_slide_min = (int)value; return WW_OK;
+    default: return ww_fail(m->ctx, WW_EINVAL, "unknown model option %d", key);
+  }
 }
 
 int64_t ww_num_frames(int64_t n, int32_t hop) {
@@ -766,7 +778,7 @@ static int logmel_host(ww_ctx *ctx, const ww_model *m, const void *samples, size
   if (n_utt < 0) return ww_fail(ctx, WW_EINVAL, "negative utterance count");
   int rc = check_fp(ctx, fp, elt == 2);
   if (rc) return rc;
-  ww_device_scope dev_scope(ctx->device);  // the caller's current device is left as it was
+  WW_ON_DEVICE(ctx, dev_scope);  // the caller's current device is left as it was
   frame_offs[0] = 0;
   int64_t max_f = 0;
   for (int u = 0; u < n_utt; ++u) {
@@ -836,7 +848,7 @@ int ww_logmel_dev(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, const in
   if (((uintptr_t)d_pcm & 15) != 0) return ww_fail(ctx, WW_EINVAL, "d_pcm must be 16-byte aligned");
   int rc = check_fp(ctx, fp, true);
   if (rc) return rc;
-  ww_device_scope dev(ctx->device);
+  WW_ON_DEVICE(ctx, dev);
   return ww_k_logmel(ctx, m, d_pcm, nullptr, d_sample_offs, d_frame_offs, n_utt, total_frames, max_frames_per_utt, fp, d_mel);
 }
 
@@ -845,7 +857,7 @@ int ww_stft_mag(ww_ctx *ctx, const ww_model *m, const float *frames, int64_t n, 
   if (n < 0) return ww_fail(ctx, WW_EINVAL, "negative frame count");
   if (n == 0) return WW_OK;
   if (!frames || !mag) return ww_fail(ctx, WW_EINVAL, "NULL buffer");
-  ww_device_scope dev_scope(ctx->device);  // the caller's current device is left as it was
+  WW_ON_DEVICE(ctx, dev_scope);  // the caller's current device is left as it was
   const size_t b_f = ww_bump::need((size_t)n * WW_FFT_WINDOW, 4), b_m = ww_bump::need((size_t)n * WW_FFT_BINS, 4);
   int rc;
   if (b_f + b_m <= WW_SMALL_IO_BYTES) {
@@ -878,7 +890,7 @@ int ww_filter_apply(ww_ctx *ctx, const ww_model *m, const float *mag, int64_t n,
   if (n < 0) return ww_fail(ctx, WW_EINVAL, "negative row count");
   if (n == 0) return WW_OK;
   if (!mag || !mel) return ww_fail(ctx, WW_EINVAL, "NULL buffer");
-  ww_device_scope dev_scope(ctx->device);  // the caller's current device is left as it was
+  WW_ON_DEVICE(ctx, dev_scope);  // the caller's current device is left as it was
   const int NBN = m->filt.n_bins, F = m->filt.n_mel;
   const size_t b_a = ww_bump::need((size_t)n * NBN, 4), b_b = ww_bump::need((size_t)n * F, 4);
   int rc;
@@ -908,7 +920,7 @@ int ww_detect(ww_ctx *ctx, const ww_model *m, const float *enc, int32_t n, float
   if (n < 0) return ww_fail(ctx, WW_EINVAL, "negative row count");
   if (n == 0) return WW_OK;
   if (!enc || !out) return ww_fail(ctx, WW_EINVAL, "NULL buffer");
-  ww_device_scope dev_scope(ctx->device);  // the caller's current device is left as it was
+  WW_ON_DEVICE(ctx, dev_scope);  // the caller's current device is left as it was
   const size_t per = (size_t)m->info.enc_rows * m->info.enc_width;
   const size_t b_a = ww_bump::need((size_t)n * per, 4), b_b = ww_bump::need((size_t)n * m->info.n_out, 4);
   int rc;
@@ -959,7 +971,7 @@ static int forward_host(ww_ctx *ctx, const ww_model *m, const float *mel, int64_
                         float *enc) {
   const int T = m->info.window, F = m->info.n_mel, NO = m->info.n_out;
   const size_t enc_per = (size_t)m->info.enc_rows * m->info.enc_width;
-  ww_device_scope dev_scope(ctx->device);  // the caller's current device is left as it was
+  WW_ON_DEVICE(ctx, dev_scope);  // the caller's current device is left as it was
   // Small calls (the reference's per-frame use: one window in, one posterior out, utils/time_tf_models.py) are
   // latency-bound, and a copy-engine operation costs more than the few KB are worth: the window is staged in pinned
   // host memory and the kernels read it over the bus themselves; the posteriors (and the encoder output) are stored
@@ -1053,7 +1065,7 @@ int ww_forward_windows_dev(ww_ctx *ctx, const ww_model *m, const float *d_mel, i
   if (nw < 0) return ww_fail(ctx, WW_EINVAL, "negative window count");
   if (nw == 0) return WW_OK;
   if (!d_win_row || !d_win_valid) return ww_fail(ctx, WW_EINVAL, "window descriptors are NULL");
-  ww_device_scope dev(ctx->device);
+  WW_ON_DEVICE(ctx, dev);
   const int NO = m->info.n_out;
   const int chunk = nw < WW_MAX_CHUNK ? nw : WW_MAX_CHUNK;
   int rc = ww_ensure(ctx, ctx->dev, model_ws(m, chunk) + 1024, false);
@@ -1074,7 +1086,7 @@ int ww_forward_segments_dev(ww_ctx *ctx, const ww_model *m, const float *d_mel, 
   if (hop <= 0) return ww_fail(ctx, WW_EINVAL, "hop must be positive");
   if (n_seg == 0) return WW_OK;
   if (!seg_row0 || !seg_nw) return ww_fail(ctx, WW_EINVAL, "sequence descriptors are NULL");
-  ww_device_scope dev(ctx->device);
+  WW_ON_DEVICE(ctx, dev);
   if (ww_crnn_segments_capable(m, hop)) return ww_k_crnn_segments_forward(ctx, m, d_mel, mel_rows, seg_row0, seg_nw, n_seg, hop, d_out);
   // every other model / mode: the same windows as an explicit list through the per-window kernels
   const int T = m->info.window, NO = m->info.n_out;
@@ -1117,7 +1129,7 @@ int ww_clips_forward_dev(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, i
   if (((uintptr_t)d_pcm & 15) != 0) return ww_fail(ctx, WW_EINVAL, "d_pcm must be 16-byte aligned");
   int rc = check_fp(ctx, fp, true);
   if (rc) return rc;
-  ww_device_scope dev(ctx->device);
+  WW_ON_DEVICE(ctx, dev);
   const int64_t nf = ww_num_frames(samples, fp->hop);
   const int F = m->info.n_mel, T = m->info.window;
   // offset tables for this batch geometry: built once, outside any capture
@@ -1143,15 +1155,6 @@ int ww_clips_forward_dev(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, i
   const size_t b_mel = ww_bump::need((size_t)n_clips * (nf > 0 ? nf : 1) * F, 4);
   const size_t b_ws = model_ws(m, n_clips);
   if ((rc = ww_ensure(ctx, ctx->dev, b_mel + b_ws + 1024, false))) return rc;
-  if (!ctx->profiling && getenv("WWHIP_USE_GRAPH") != nullptr) {
-    for (auto &cg : ctx->clip_graphs) {
-      if (cg.model == m && cg.pcm == d_pcm && cg.out == d_out && cg.n_clips == n_clips && cg.samples == samples &&
-          cg.ws == ctx->dev.ptr && memcmp(&cg.fp, fp, sizeof *fp) == 0) {
-        WW_HIP(ctx, hipGraphLaunch(cg.exec, ctx->stream));
-        return WW_OK;
-      }
-    }
-  }
   auto enqueue = [&]() -> int {
     ww_bump bump(ctx->dev.ptr, ctx->dev.cap);
     float *d_mel = bump.take<float>((size_t)n_clips * (nf > 0 ? nf : 1) * F);
@@ -1162,34 +1165,9 @@ int ww_clips_forward_dev(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, i
     return model_forward(ctx, m, d_mel, (int64_t)n_clips * nf, nullptr, nullptr, 0, (int)nf, (int)(nf < T ? nf : T),
                          n_clips, ws, d_out, nullptr);
   };
-  // Plain stream launches by default: measured on MI355X the 4-kernel chain replays in 93 us as a
-  // hipGraph but in 88 us as ordinary launches (the queue stays full, so launch latency is hidden,
-  // while a graph replay has a 10-16 us floor).  WWHIP_USE_GRAPH=1 turns the capture path on.
-  static const bool use_graph = getenv("WWHIP_USE_GRAPH") != nullptr;
-  if (ctx->profiling || !use_graph) return enqueue();
-  // capture the launch chain once per distinct (input, output) pair, replay afterwards: the chain
-  // is launch-latency bound at these batch sizes
-  if (ctx->clip_graphs.size() >= 128) {
-    WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->drop_graphs(nullptr);
-  }
-  hipGraph_t graph = nullptr;
-  WW_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-  rc = enqueue();
-  hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
-  if (rc) {
-    if (graph) hipGraphDestroy(graph);
-    return rc;
-  }
-  if (e != hipSuccess) return ww_fail(ctx, WW_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
-  ww_ctx::clip_graph_t cg;
-  e = hipGraphInstantiate(&cg.exec, graph, nullptr, nullptr, 0);
-  hipGraphDestroy(graph);
-  if (e != hipSuccess) return ww_fail(ctx, WW_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
-  cg.model = m; cg.pcm = d_pcm; cg.out = d_out; cg.n_clips = n_clips; cg.samples = samples; cg.fp = *fp; cg.ws = ctx->dev.ptr;
-  ctx->clip_graphs.push_back(cg);
-  WW_HIP(ctx, hipGraphLaunch(cg.exec, ctx->stream));
-  return WW_OK;
+  // Plain stream launches: measured on MI355X (round 1) the chain replays slower as a hipGraph (93 vs 88 us: the queue stays
+  // full, so launch latency is hidden, while a graph replay has a 10-16 us floor); the capture path was removed in round 3.
+  return enqueue();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1203,7 +1181,7 @@ int ww_far_frr(ww_ctx *ctx, const float *pos, int64_t n_pos, const float *neg, i
   if ((n_pos && !pos) || (n_neg && !neg)) return ww_fail(ctx, WW_EINVAL, "NULL posterior buffer");
   if (win > 0 && n_neg > 0 && n_neg < win)
     return ww_fail(ctx, WW_EINVAL, "negative stream shorter than the smoothing window (np.convolve 'same' would change its length)");
-  ww_device_scope dev_scope(ctx->device);  // the caller's current device is left as it was
+  WW_ON_DEVICE(ctx, dev_scope);  // the caller's current device is left as it was
   const size_t b_p = ww_bump::need((size_t)n_pos + 1, 4), b_n = ww_bump::need((size_t)n_neg + 1, 4);
   const size_t b_s = ww_bump::need((size_t)n_neg + 1, 8), b_t = ww_bump::need((size_t)n_thr, 8);
   int rc = ww_ensure(ctx, ctx->dev, b_p + b_n + b_s + 3 * b_t + 1024, false);
@@ -1234,7 +1212,7 @@ int ww_superframe_smooth(ww_ctx *ctx, const float *in, int64_t n, int32_t T, flo
   if (!ctx || (n > 0 && (!in || !wake))) return ww_fail(ctx, WW_EINVAL, "NULL argument");
   if (n < 0) return ww_fail(ctx, WW_EINVAL, "bad sizes");
   if (n == 0) return WW_OK;
-  ww_device_scope dev_scope(ctx->device);  // the caller's current device is left as it was
+  WW_ON_DEVICE(ctx, dev_scope);  // the caller's current device is left as it was
   const size_t b_in = ww_bump::need((size_t)n * T * 2, 4), b_p = ww_bump::need((size_t)n * T, 1), b_w = ww_bump::need((size_t)n, 1);
   int rc = ww_ensure(ctx, ctx->dev, b_in + b_p + b_w + 1024, false);
   if (rc) return rc;

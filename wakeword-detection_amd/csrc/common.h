@@ -21,8 +21,7 @@ struct ww_prof_entry {
   double total_ms = 0.0;
 };
 
-// Growable device / pinned-host arenas.  Never (re)allocated inside a captured region:
-// ensure() is called by the entry points before they start enqueueing.
+// Growable device / pinned-host arenas: ensure() is called by the entry points before they start enqueueing.
 struct ww_arena {
   void *ptr = nullptr;
   size_t cap = 0;
@@ -38,33 +37,12 @@ struct ww_ctx {
   bool profiling = false;
   std::map<std::string, ww_prof_entry> prof;
   hipEvent_t t0 = nullptr, t1 = nullptr;
-  // cached graphs for ww_clips_forward_dev, keyed by every pointer/size baked into them
-  struct clip_graph_t {
-    hipGraphExec_t exec = nullptr;
-    const void *model = nullptr;
-    const void *pcm = nullptr;
-    void *out = nullptr;
-    int n_clips = 0, samples = 0;
-    ww_frontend_params fp = {};
-    void *ws = nullptr;
-  };
-  std::vector<clip_graph_t> clip_graphs;
   // sample/frame offset tables of the equal-length clip batches seen so far (tiny, built once)
   struct clip_offs_t {
     int n_clips = 0, samples = 0, hop = 0;
     int64_t *d_so = nullptr, *d_fo = nullptr;
   };
   std::vector<clip_offs_t> clip_offs;
-  void drop_graphs(const void *model_or_null) {
-    for (size_t i = 0; i < clip_graphs.size();) {
-      if (!model_or_null || clip_graphs[i].model == model_or_null) {
-        hipGraphExecDestroy(clip_graphs[i].exec);
-        clip_graphs.erase(clip_graphs.begin() + i);
-      } else {
-        ++i;
-      }
-    }
-  }
 };
 
 // Device-resident mel filterbank in banded form: band m covers bins [start[m], start[m]+len[m])
@@ -135,6 +113,8 @@ struct ww_model {
   ww_crnn_dev crnn;
   ww_wave_dev wave;
   int precision = 0;  // WW_PRECISION_*
+  int opt_split_at = 1024;  // WW_OPT_CRNN_SPLIT_AT
+  int opt_slide_min = 64;   // WW_OPT_CRNN_SLIDE_MIN
   std::vector<void *> allocs;
 };
 
@@ -153,13 +133,24 @@ int ww_ensure(ww_ctx *ctx, ww_arena &a, size_t bytes, bool pinned);
 struct ww_device_scope {
   int prev = -1;
   bool changed = false;
+  hipError_t err = hipSuccess;  // why the switch to `dev` failed; entry points check ok() before they allocate or launch
   explicit ww_device_scope(int dev) {
-    if (hipGetDevice(&prev) == hipSuccess && prev != dev) changed = hipSetDevice(dev) == hipSuccess;
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) {
+      err = hipSetDevice(dev);
+      changed = err == hipSuccess;
+    }
   }
+  bool ok() const { return err == hipSuccess; }
   ~ww_device_scope() {
     if (changed) (void)hipSetDevice(prev);
   }
 };
+// Declares the scope and leaves the entry point with WW_EHIP if the context's device could not be made current.
+#define WW_ON_DEVICE(ctx_, name_)                                                                                   \
+  ww_device_scope name_((ctx_)->device);                                                                            \
+  if (!name_.ok())                                                                                                  \
+    return ww_fail((ctx_), WW_EHIP, "cannot switch to device %d: %s", (ctx_)->device, hipGetErrorString(name_.err))
 
 // Bracket a kernel launch with profiling events when enabled.
 struct ww_launch_scope {
@@ -209,7 +200,9 @@ int ww_k_wave_detect(ww_ctx *ctx, const ww_model *m, const float *d_enc, int nw,
 int ww_k_viterbi2(ww_ctx *ctx, const float *d_in, int64_t n, int T, float stay_bonus, int in_is_cost, unsigned char *d_path,
                   unsigned char *d_wake);
 
-size_t ww_crnn_workspace(const ww_model *m, int n_windows);
+// `sliding`: the caller may pass regular sliding windows (row0 + w*hop), for which the scratch of crnn_rows_kernel is reserved too
+size_t ww_crnn_workspace(const ww_model *m, int n_windows, bool sliding = true);
+int ww_k_crnn_init_device(ww_ctx *ctx);  // per-device kernel attributes (dynamic LDS above 64 KB)
 int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *d_win_row,
                       const int32_t *d_win_valid, int64_t row0, int hop, int valid_const, int n_windows, void *ws,
                       float *d_out, float *d_enc);

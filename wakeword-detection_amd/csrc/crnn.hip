@@ -1574,10 +1574,19 @@ static int crnn_forward_generic(ww_ctx *ctx, const ww_model *m, const win_addr &
 // ------------------------------------------------------------------------------------------
 // Above this many windows per launch the recurrences move to gru_tail_kernel (one more kernel boundary and 14.6 KB per
 // window through memory buy a CU-filling mix; below it one workgroup per window end to end is the shorter path).
-static int crnn_split_threshold() {
-  static const char *e = getenv("WWHIP_CRNN_SPLIT_AT");  // development: 0 = always fused
-  static const int v = e ? atoi(e) : 1024;
-  return v;
+// (ww_model_set_option(WW_OPT_CRNN_SPLIT_AT): 0 = always fused.)
+static int crnn_split_threshold(const ww_model *m) { return m->opt_split_at; }
+
+// Every CRNN kernel that asks for more than the default 64 KB of dynamic LDS.  The attribute is per device, so it is set
+// for the device of every new context (ww_ctx_create, under its device scope) instead of once per process.
+int ww_k_crnn_init_device(ww_ctx *ctx) {
+  WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
+  WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
+  WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
+  WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
+  WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, CFB_SMEM_BYTES));
+  WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, CFB_SMEM_BYTES));
+  return WW_OK;
 }
 
 // streaming form (crnn_stream_kernel): standard geometry, fp32 contractions
@@ -1593,11 +1602,6 @@ int ww_k_crnn_stream_forward(ww_ctx *ctx, const ww_model *m, const float *d_hist
           c.w1, c.b1, c.w2, c.b2, nullptr, d_out, c.T, c.NOUT, c.HEAD, nullptr, nullptr, c.cwb, c.wx1b};
   sa.aux = d_win_aux;
   sa.gxc = d_gxc;
-  static bool attr_set = false;
-  if (!attr_set) {
-    WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
-    attr_set = true;
-  }
   static const bool want_stamps = getenv("WWHIP_CF_STAMPS") != nullptr;  // development: phase timeline (as ww_k_crnn_forward)
   if (want_stamps) {
     WW_HIP(ctx, hipMalloc((void **)&sa.f.stamps, (size_t)nw * 40 * sizeof(long long)));
@@ -1624,12 +1628,8 @@ int ww_k_crnn_stream_forward(ww_ctx *ctx, const ww_model *m, const float *d_hist
 }
 
 // Regular sliding windows (hop <= 8 over one mel sequence, every window complete) take crnn_rows_kernel + gru_tail_kernel from
-// this many windows on (WWHIP_CRNN_SLIDE=0, development: never).
-static int crnn_slide_min() {
-  static const char *e = getenv("WWHIP_CRNN_SLIDE");
-  static const int v = e ? (atoi(e) > 0 ? atoi(e) : 0x7fffffff) : 64;
-  return v;
-}
+// this many windows on (ww_model_set_option(WW_OPT_CRNN_SLIDE_MIN): 0 = never).
+static int crnn_slide_min(const ww_model *m) { return m->opt_slide_min > 0 ? m->opt_slide_min : 0x7fffffff; }
 static int gcd8(int hop) { return hop % 8 == 0 ? 8 : hop % 4 == 0 ? 4 : hop % 2 == 0 ? 2 : 1; }
 
 // Several mel sequences in one buffer (the clips of a test set, wwhip/evaluate.py), each slid over with the same hop:
@@ -1637,18 +1637,13 @@ static int gcd8(int hop) { return hop % 8 == 0 ? 8 : hop % 4 == 0 ? 4 : hop % 2 
 // interior field given explicitly.  seg_row0 / seg_nw are HOST arrays; windows are numbered sequence by sequence.
 bool ww_crnn_segments_capable(const ww_model *m, int hop) {
   return m->kind == WW_KIND_CRNN && !m->crnn.generic && hop >= 1 && hop <= 8 &&
-         crnn_slide_min() != 0x7fffffff;
+         crnn_slide_min(m) != 0x7fffffff;
 }
 
 int ww_k_crnn_segments_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *seg_row0,
                                const int32_t *seg_nw, int n_seg, int hop, float *d_out) {
   const ww_crnn_dev &c = m->crnn;
   const int g = gcd8(hop);
-  static bool rows_attr = false;
-  if (!rows_attr) {
-    WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
-    rows_attr = true;
-  }
   // groups of whole sequences of at most ~WW_SEG_GROUP windows bound the workspace
   constexpr int64_t WW_SEG_GROUP = 32768;
   std::vector<rows_tile> tiles;
@@ -1715,14 +1710,14 @@ int ww_k_crnn_segments_forward(ww_ctx *ctx, const ww_model *m, const float *d_me
   return WW_OK;
 }
 
-size_t ww_crnn_workspace(const ww_model *m, int nw) {
+size_t ww_crnn_workspace(const ww_model *m, int nw, bool sliding) {
   const ww_crnn_dev &c = m->crnn;
   if (c.generic) return crnn_generic_workspace(c, nw);
-  const int thr = crnn_split_threshold();
+  const int thr = crnn_split_threshold(m);
   // sliding form: (fields + 2 edge rows per window) x 192 floats; fields <= 7 nw + 130 (hop 7), i.e. never more than the
   // 19 rows per window of the front/tail form
   size_t need = 1024;  // crnn_fused_kernel keeps every intermediate in LDS
-  if (nw >= crnn_slide_min()) need = ww_bump::need(((size_t)9 * nw + 160) * 6 * c.H, 4) + 1024;
+  if (sliding && nw >= crnn_slide_min(m)) need = ww_bump::need(((size_t)9 * nw + 160) * 6 * c.H, 4) + 1024;
   if (thr > 0 && nw > thr) {
     const size_t split = ww_bump::need((size_t)nw * c.OT * 6 * c.H, 4) + 1024;
     need = split > need ? split : need;
@@ -1741,14 +1736,9 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
                   c.w1, c.b1, c.w2, c.b2, d_enc, d_out, c.T, c.NOUT, c.HEAD, nullptr, nullptr, c.cwb, c.wx1b};
   const bool bf16 = m->precision == WW_PRECISION_BF16X3;
   // (also in split-bf16 mode: the mode permits bf16 products, and computing a seventh of them in fp32 is both faster and closer)
-  if (!d_win_row && !d_win_valid && valid_const >= c.T && hop >= 1 && hop <= 8 && nw >= crnn_slide_min() && row0 >= 0 &&
+  if (!d_win_row && !d_win_valid && valid_const >= c.T && hop >= 1 && hop <= 8 && nw >= crnn_slide_min(m) && row0 >= 0 &&
       row0 + (int64_t)(nw - 1) * hop + c.T <= mel_rows) {
     // windows sliding over one sequence: 1 + 2 positions per window instead of 19 (crnn_rows_kernel)
-    static bool rows_attr = false;
-    if (!rows_attr) {
-      WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
-      rows_attr = true;
-    }
     const int g = gcd8(hop);
     const int64_t n_int = ((int64_t)(nw - 1) * hop + 128) / g + 1;
     ww_bump b(ws, ~size_t(0));
@@ -1775,15 +1765,7 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
     WW_HIP(ctx, hipGetLastError());
     return WW_OK;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
-    WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
-    WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, CFB_SMEM_BYTES));
-    WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, CFB_SMEM_BYTES));
-    attr_set = true;
-  }
-  const int thr = crnn_split_threshold();
+  const int thr = crnn_split_threshold(m);
   if (thr > 0 && nw > thr) {
     ww_bump b(ws, ~size_t(0));
     a.gx_out = b.take<float>((size_t)nw * c.OT * 6 * c.H);

@@ -207,18 +207,26 @@ int ww_stream_destroy(ww_streams *st) {
   return WW_OK;
 }
 
-int ww_stream_create(ww_ctx *ctx, const ww_model *model, int32_t S, const ww_frontend_params *fp, ww_streams **out) {
+int ww_stream_create(ww_ctx *ctx, const ww_model *model, int32_t S, const ww_frontend_params *fp, uint32_t flags,
+                     ww_streams **out) {
   if (!ctx || !model || !fp || !out) return ww_fail(ctx, WW_EINVAL, "NULL argument");
   *out = nullptr;
+  if (flags & ~(uint32_t)WW_STREAM_FULL_RECOMPUTE) return ww_fail(ctx, WW_EINVAL, "unknown stream flags 0x%x", flags);
   if (S <= 0 || S > 65535) return ww_fail(ctx, WW_EINVAL, "stream count %d out of range (1..65535)", S);
   if (fp->hop != 160) return ww_fail(ctx, WW_EINVAL, "streaming mode supports hop 160 (10 ms @ 16 kHz) only, got %d", fp->hop);
   if (!(fp->pcm_divisor > 0.f)) return ww_fail(ctx, WW_EINVAL, "pcm_divisor must be positive");
-  ww_device_scope dev_scope(ctx->device);  // the caller's current device is left as it was
+  WW_ON_DEVICE(ctx, dev_scope);  // the caller's current device is left as it was
   ww_streams *st = new ww_streams();
   st->ctx = ctx; st->model = model; st->S = S; st->fp = *fp;
   st->T = model->info.window; st->F = model->info.n_mel; st->NO = model->info.n_out; st->HR = 2 * (st->T + 1);
   const size_t hist_elems = (size_t)S * st->HR * st->F;
-  size_t ws_bytes = (model->kind == WW_KIND_CRNN ? ww_crnn_workspace(model, 2 * S) : ww_wave_workspace(model, 2 * S));
+  // CRNN, standard geometry: three positions per new window instead of nineteen (crnn_stream_kernel, fp32 contractions - also
+  // for a model in split-bf16 mode: a seventh of the products in fp32 is both faster and closer).
+  // WW_STREAM_FULL_RECOMPUTE keeps the per-window kernels (every window recomputed from its mel rows).
+  st->incremental = ww_crnn_stream_capable(model) && !(flags & WW_STREAM_FULL_RECOMPUTE);
+  // model scratch of the per-window kernels (explicit window rows: never the sliding form); the incremental CRNN needs none
+  size_t ws_bytes = st->incremental ? 256
+                    : (model->kind == WW_KIND_CRNN ? ww_crnn_workspace(model, 2 * S, false) : ww_wave_workspace(model, 2 * S));
   bool ok = hipMalloc((void **)&st->ring, (size_t)S * ST_RING * 4) == hipSuccess &&
             hipMalloc((void **)&st->hist, hist_elems * 4) == hipSuccess &&
             hipMalloc((void **)&st->prev, (size_t)S * 4) == hipSuccess &&
@@ -256,10 +264,6 @@ int ww_stream_create(ww_ctx *ctx, const ww_model *model, int32_t S, const ww_fro
   st->fill.assign(S, 0);
   st->pos.assign(S, 0);
   st->rowq.assign(S, 0);
-  // CRNN, standard geometry: three positions per new window instead of nineteen (crnn_stream_kernel, fp32 contractions - also
-  // for a model in split-bf16 mode: a seventh of the products in fp32 is both faster and closer).
-  // WWHIP_STREAM_FULL=1 (development) keeps the full recompute.
-  st->incremental = ww_crnn_stream_capable(model) && !getenv("WWHIP_STREAM_FULL");
   if (st->incremental) {
     if (hipMalloc((void **)&st->gxc, (size_t)S * WW_STREAM_GXC * 192 * 4) != hipSuccess ||
         hipMalloc((void **)&st->gx_zero, 192 * 4) != hipSuccess) {
@@ -293,7 +297,7 @@ int ww_stream_reset(ww_streams *st, const int32_t *ids, int32_t n) {
   if (ids && n < 0) return ww_fail(ctx, WW_EINVAL, "negative id count");
   const int count = ids ? n : st->S;
   if (count == 0) return WW_OK;
-  ww_device_scope dev_scope(ctx->device);  // the caller's current device is left as it was
+  WW_ON_DEVICE(ctx, dev_scope);  // the caller's current device is left as it was
   int32_t *d_ids = nullptr;
   if (ids) {
     for (int i = 0; i < n; ++i)
@@ -323,7 +327,7 @@ int ww_stream_step(ww_streams *st, const int16_t *frames, const uint8_t *is_spee
   if (!st) return WW_EINVAL;
   ww_ctx *ctx = st->ctx;
   if (!frames || !is_speech || !post || !n_post) return ww_fail(ctx, WW_EINVAL, "NULL argument");
-  ww_device_scope dev_scope(ctx->device);  // the caller's current device is left as it was
+  WW_ON_DEVICE(ctx, dev_scope);  // the caller's current device is left as it was
   const int S = st->S, hop = st->fp.hop;
   int nw = 0;
   for (int s = 0; s < S; ++s) {

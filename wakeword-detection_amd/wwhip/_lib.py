@@ -22,6 +22,8 @@ LIB_PATH = os.environ.get("WWHIP_LIB") or os.path.join(_PKG, "libwwhip.so")
 WW_OK, WW_EINVAL, WW_EBLOB, WW_EHIP, WW_ENOMEM, WW_ESTATE, WW_ENODEVICE = 0, -1, -2, -3, -4, -5, -6
 KIND_CRNN, KIND_WAVENET = 1, 2
 PRECISION_FP32, PRECISION_BF16X3 = 0, 1
+OPT_CRNN_SPLIT_AT, OPT_CRNN_SLIDE_MIN = 1, 2
+STREAM_FULL_RECOMPUTE = 1
 
 
 class ModelInfo(C.Structure):
@@ -53,6 +55,7 @@ SYMBOLS: Dict[str, tuple] = {
     "ww_model_free": (C.c_int, [_vp]),
     "ww_model_get_info": (C.c_int, [_vp, _P(ModelInfo)]),
     "ww_model_set_precision": (C.c_int, [_vp, C.c_int]),
+    "ww_model_set_option": (C.c_int, [_vp, C.c_int, _i64]),
     "ww_num_frames": (_i64, [_i64, _i32]),
     "ww_logmel": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _P(FrontendParams), _vp, _vp]),
     "ww_logmel_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _P(FrontendParams), _vp, _vp]),
@@ -66,7 +69,7 @@ SYMBOLS: Dict[str, tuple] = {
     "ww_forward_windows_dev": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp]),
     "ww_forward_segments_dev": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp]),
     "ww_clips_forward_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _P(FrontendParams), _vp]),
-    "ww_stream_create": (C.c_int, [_vp, _vp, _i32, _P(FrontendParams), _P(_vp)]),
+    "ww_stream_create": (C.c_int, [_vp, _vp, _i32, _P(FrontendParams), C.c_uint32, _P(_vp)]),
     "ww_stream_destroy": (C.c_int, [_vp]),
     "ww_stream_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "ww_stream_reset": (C.c_int, [_vp, _vp, _i32]),
@@ -235,14 +238,17 @@ class Context:
             pass
 
 
-_default_ctx: Dict[int, Context] = {}
+_default_ctx: Dict[tuple, Context] = {}
 
 
 def default_context(device: int = 0) -> Context:
-    """Process-wide context per device for the drop-in classes (single-threaded callers,
-    like the reference: SURVEY 8b 'Threading / ownership')."""
-    ctx = _default_ctx.get(device)
-    if ctx is None:
-        ctx = Context(device)
-        _default_ctx[device] = ctx
+    """The calling thread's context on ``device`` for the drop-in classes: include/wwhip.h asks for one ``ww_ctx`` per
+    host thread (the reference itself is single-threaded: SURVEY 8b 'Threading / ownership'), so two threads that use
+    the drop-in classes never share a stream or a workspace."""
+    key = (device, threading.get_ident())
+    with _lock:
+        ctx = _default_ctx.get(key)
+        if ctx is None or ctx.handle is None:
+            ctx = Context(device)
+            _default_ctx[key] = ctx
     return ctx

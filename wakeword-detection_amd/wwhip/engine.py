@@ -58,6 +58,15 @@ class Engine:
         self._chk(self._lib.ww_model_set_precision(self._model, modes[precision]))
         self.precision = precision
 
+    def set_option(self, key: str, value: int) -> None:
+        """Per-model dispatch options (``ww_model_set_option``): ``"crnn_split_at"`` - explicit-window launches above
+        this many windows take front + tail kernels (0 = always one fused kernel); ``"crnn_slide_min"`` - regular
+        sliding windows take the once-per-sequence form from this many windows on (0 = never)."""
+        keys = {"crnn_split_at": _lib.OPT_CRNN_SPLIT_AT, "crnn_slide_min": _lib.OPT_CRNN_SLIDE_MIN}
+        if key not in keys:
+            raise ValueError(f"option must be one of {sorted(keys)}")
+        self._chk(self._lib.ww_model_set_option(self._model, keys[key], int(value)))
+
     # ------------------------------------------------------------------ properties
     @property
     def handle(self):
@@ -213,13 +222,17 @@ class Engine:
 class StreamBank:
     """S device-resident streams advanced 20 ms per :meth:`step` (``ww_stream_*``)."""
 
-    def __init__(self, engine: Engine, n_streams: int, fp: Optional[_lib.FrontendParams] = None) -> None:
+    def __init__(self, engine: Engine, n_streams: int, fp: Optional[_lib.FrontendParams] = None,
+                 full_recompute: bool = False) -> None:
+        """``full_recompute``: every streaming CRNN window recomputed from its mel rows (``WW_STREAM_FULL_RECOMPUTE``)
+        instead of the incremental kernel."""
         self.engine = engine
         self.S = int(n_streams)
         self._lib = _lib.load()
         fp = fp or frontend_params()
         h = C.c_void_p()
-        _lib.raise_for(self._lib.ww_stream_create(engine.ctx.handle, engine.handle, self.S, C.byref(fp), C.byref(h)),
+        _lib.raise_for(self._lib.ww_stream_create(engine.ctx.handle, engine.handle, self.S, C.byref(fp),
+                                                  _lib.STREAM_FULL_RECOMPUTE if full_recompute else 0, C.byref(h)),
                        engine.ctx.handle)
         self._h = h
         _lib.register("streams", self)

@@ -25,6 +25,8 @@ from .engine import Engine, frontend_params
 from .models import engine_for
 
 WINDOW = 512
+CLIP_PAD = 8000  # 0.5 s of zeros each side of a clip (evaluate_models.py:52-53)
+CLIP_HOP = 2     # mel rows between windows (evaluate_models.py:42)
 _PIN = None  # page-locked staging buffer of clip_posteriors (torch tensor, grown on demand)
 
 
@@ -130,6 +132,247 @@ def get_posterior(models_dir, model_type, eval_type, test_files, frame_width, sa
         else:
             all_posterior.extend(p.tolist())
     return all_posterior
+
+
+# ----------------------------------------------------------------------------------------------
+# The same flow, sharded over ranks: utterance-sharded for the positives, ONE long
+# negative stream cut into contiguous posterior ranges for the false accepts.
+# ----------------------------------------------------------------------------------------------
+def wav_length(path: str, sample_rate: int = 16000) -> int:
+    """Samples ``read_wav(path)`` would return, from the header alone."""
+    with wave.open(path, "rb") as w:
+        if w.getframerate() != sample_rate:
+            raise ValueError(f"{path}: sample rate {w.getframerate()} != {sample_rate} (no resampler here)")
+        return w.getnframes()
+
+
+def read_wav_pcm(path: str, sample_rate: int = 16000) -> np.ndarray:
+    """Mono PCM16 wav as int16 (``librosa.load`` = these / 32768); anything else as :func:`read_wav`'s float32."""
+    with wave.open(path, "rb") as w:
+        if w.getsampwidth() == 2 and w.getnchannels() == 1 and w.getframerate() == sample_rate:
+            return np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16)
+    return read_wav(path, sample_rate)
+
+
+class StreamPlan:
+    """Window layout of ``get_posterior`` over a list of files, as pure arithmetic on the file lengths - identical on
+    every rank.  File ``k`` (padded by 0.5 s each side, then to whole chunks) starts at stream sample ``pos[k]``; the
+    never-reset ring (quirk C2) credits it the global frames ``[F[k], F[k] + n_frames[k])`` (global frame ``j`` = stream
+    samples ``[160 j, 160 j + 512)``; the first ones of a later file start in its predecessor's tail) and the
+    one-inference-per-chunk rule (``evaluate_models.py:70``) gives it ``n_win[k]`` windows, window ``i`` covering the
+    global frames ``[F[k] + hop i, F[k] + hop i + T)``."""
+
+    def __init__(self, lengths: Sequence[int], encoder_len: int, frame_length: int = 320, sample_rate: int = 16000,
+                 hop: int = 2, carry_over: bool = True) -> None:
+        self.T, self.hop, self.frame_length, self.pad, self.carry = int(encoder_len), int(hop), int(frame_length), sample_rate // 2, carry_over
+        self.lengths = np.asarray(lengths, np.int64)
+        padded = self.lengths + 2 * self.pad
+        self.padded = padded + (-padded) % frame_length
+        per_file, starts = frame_schedule(self.padded.tolist(), 160, frame_length, carry_over)
+        self.pos = np.asarray(starts, np.int64)
+        self.n_frames = np.array([int(f.sum()) for f in per_file], np.int64)
+        # first global frame credited to the file: the ring emits frames in order, so it is the count emitted before it
+        self.F = np.array([((p - WINDOW) // 160 + 1 if p >= WINDOW else 0) for p in self.pos], np.int64)
+        nw = []
+        for fpc in per_file:
+            ws = window_schedule(fpc, self.T, self.hop)
+            assert np.array_equal(ws, self.hop * np.arange(len(ws)))  # the schedule drops `hop` rows per inference
+            nw.append(len(ws))
+        self.n_win = np.asarray(nw, np.int64)
+        self.offs = np.concatenate(([0], np.cumsum(self.n_win)))
+
+    @property
+    def total(self) -> int:
+        return int(self.offs[-1])
+
+    def shares(self, eval_type: str, world: int) -> List[List[Tuple[int, int, int]]]:
+        """Per rank: ``(file, i0, i1)`` runs of windows.  Positives: whole files dealt longest-first round-robin
+        (``dist.shard_by_length``); the negative stream: contiguous posterior ranges (``dist.split_stream``), cut
+        where a range crosses a file boundary."""
+        from . import dist as D
+        out: List[List[Tuple[int, int, int]]] = [[] for _ in range(world)]
+        if eval_type == "false_negatives":
+            for r, files in enumerate(D.shard_by_length(self.lengths.tolist(), world)):
+                out[r] = [(k, 0, int(self.n_win[k])) for k in sorted(files) if self.n_win[k] > 0]
+        else:
+            for r, (lo, hi) in enumerate(D.split_stream(self.total, world)):
+                k = int(np.searchsorted(self.offs, lo, side="right")) - 1
+                while lo < hi:
+                    end = min(hi, int(self.offs[k + 1]))
+                    if end > lo:
+                        out[r].append((k, lo - int(self.offs[k]), end - int(self.offs[k])))
+                    lo, k = end, k + 1
+        return out
+
+    def sample_range(self, k: int, i0: int, i1: int) -> Tuple[int, int]:
+        """Stream samples the windows ``i0..i1-1`` of file ``k`` are functions of (with pre-emphasis 0, as ``Filter``'s
+        default: no sample before the first frame is needed)."""
+        g0 = int(self.F[k]) + self.hop * i0
+        g1 = int(self.F[k]) + self.hop * (i1 - 1) + self.T - 1
+        base = 0 if self.carry else int(self.pos[k])  # without carry every file has its own grid (F = 0, pos = 0)
+        return base + 160 * g0, base + 160 * g1 + WINDOW
+
+
+def _stream_slice(plan: StreamPlan, load: Callable[[int], np.ndarray], cache: dict, s0: int, s1: int, k_hint: int) -> np.ndarray:
+    """Samples ``[s0, s1)`` of the concatenated padded stream, touching only the files that overlap it."""
+    pos = plan.pos if plan.carry else np.zeros_like(plan.pos)
+    ks = [k_hint] if not plan.carry else [k for k in range(max(k_hint - 1, 0), len(pos)) if pos[k] < s1 and pos[k] + plan.padded[k] > s0]
+    parts, dt = [], np.int16
+    for k in ks:
+        if k not in cache:
+            cache[k] = np.asarray(load(k))
+        if cache[k].dtype != np.int16:
+            dt = np.float32
+    out = np.zeros(s1 - s0, dt)
+    for k in ks:
+        x = cache[k].astype(dt, copy=False)
+        a = int(pos[k]) + plan.pad  # stream sample of x[0]
+        lo, hi = max(s0, a), min(s1, a + len(x))
+        if hi > lo:
+            out[lo - s0: hi - s0] = x[lo - a: hi - a]
+    return out
+
+
+def _pieces_forward(eng: Engine, pieces: List[np.ndarray], n_win: List[int], hop: int, precise: bool = True) -> np.ndarray:
+    """One front-end launch over ``pieces`` (each its own framing grid, frame j = samples [160 j, 160 j + 512)) and one
+    model launch over their windows (piece p: ``n_win[p]`` windows at rows ``hop i``): detect rows, piece by piece."""
+    import torch  # only to hold the device buffers of the batched launch
+
+    n = len(pieces)
+    if n == 0 or sum(n_win) == 0:
+        return np.zeros((0, eng.n_out), np.float32)
+    dev = torch.device("cuda", eng.ctx.device)
+    nf = np.array([eng.num_frames(len(p)) for p in pieces], np.int64)
+    foffs = np.concatenate(([0], np.cumsum(nf)))
+    total_f = int(foffs[-1])
+    for p, f, w in zip(pieces, nf, n_win):
+        assert w == 0 or (w - 1) * hop + eng.window <= f, "piece too short for its windows"
+    d_mel = torch.empty((max(total_f, 1), eng.n_mel), dtype=torch.float32, device=dev)
+    if all(p.dtype == np.int16 for p in pieces):
+        # librosa's floats are int16 / 32768 exactly: the device front end divides (correctly rounded) by the same 32768
+        soffs = np.concatenate(([0], np.cumsum([len(p) for p in pieces]))).astype(np.int64)
+        pcm = np.zeros(int(soffs[-1]) + 16, np.int16)  # (the kernel's vector loads may run a few samples past the end)
+        for i, p in enumerate(pieces):
+            pcm[soffs[i]: soffs[i + 1]] = p
+        d_pcm, d_so, d_fo = torch.from_numpy(pcm).to(dev), torch.from_numpy(soffs).to(dev), torch.from_numpy(foffs).to(dev)
+        torch.cuda.synchronize(dev)
+        eng.logmel_dev(d_pcm.data_ptr(), d_so.data_ptr(), d_fo.data_ptr(), n, total_f, int(nf.max()), d_mel.data_ptr(),
+                       frontend_params(32768.0, False, 0.0, 160, precise))
+    else:
+        mels = eng.logmel([np.asarray(p, np.float32) for p in pieces], frontend_params(1.0, False, 0.0, 160, precise))
+        d_mel[:total_f] = torch.from_numpy(np.concatenate(mels)).to(dev)
+    n_tot = int(sum(n_win))
+    d_out = torch.empty((n_tot, eng.n_out), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize(dev)
+    eng.forward_segments_dev(d_mel.data_ptr(), total_f, foffs[:-1], np.asarray(n_win, np.int32), hop, d_out.data_ptr())
+    eng.ctx.synchronize()
+    return d_out.cpu().numpy()
+
+
+def get_posterior_sharded(models_dir, model_type, eval_type, test_files, frame_width, sample_rate, rank: int = 0,
+                          world: int = 1, comm_device: Optional[str] = None,
+                          loader: Optional[Callable[[str], np.ndarray]] = None, lengths: Optional[Sequence[int]] = None,
+                          carry_over: bool = True, device: int = 0, engine: Optional[Engine] = None,
+                          precise: bool = True) -> list:
+    """:func:`get_posterior` with its windows dealt to ``world`` ranks (one process per GPU; ``torch.distributed``
+    initialised by the caller when ``world > 1``).  ``"false_negatives"``: whole files, longest first round-robin;
+    ``"false_accepts"``: the window list - for the reference's evaluator ONE long wav (``evaluate_models.py:317-321``) -
+    cut into ``world`` contiguous posterior ranges (``dist.split_stream``).  A rank loads and front-ends only the samples
+    its windows are functions of: posterior ``i`` of a file needs the global frames ``[F + 2 i, F + 2 i + T)``, i.e. each
+    range re-reads a ``T - 2``-frame overlap and the results are exact.  The one exchange is the posterior gather.  Every
+    rank returns the full list :func:`get_posterior` returns.
+
+    ``test_files``: paths (default loader :func:`read_wav_pcm`; ``lengths`` default = wav headers) or arrays already in
+    memory (int16 PCM, or float32 samples in [-1, 1)).  ``precise=False``: the fp32-FFT front end (``ww_frontend_params.precise``
+    = 0) instead of the reference's float64 STFT."""
+    if model_type not in ("CRNN", "Wavenet"):
+        raise ValueError("model_type must be 'CRNN' or 'Wavenet'")
+    if eval_type not in ("false_negatives", "false_accepts"):
+        raise ValueError("eval_type must be 'false_negatives' or 'false_accepts'")
+    eng: Engine = engine or engine_for(models_dir, device)
+    frame_length = sample_rate // 1000 * frame_width
+    in_memory = len(test_files) > 0 and not isinstance(test_files[0], (str, bytes)) and not hasattr(test_files[0], "__fspath__")
+    if in_memory:
+        load = lambda k: np.asarray(test_files[k])  # noqa: E731
+        lengths = [len(x) for x in test_files] if lengths is None else lengths
+    else:
+        rd = loader or (lambda p: read_wav_pcm(p, sample_rate))
+        load = lambda k: rd(str(test_files[k]))  # noqa: E731
+        if lengths is None:
+            lengths = [wav_length(str(f), sample_rate) for f in test_files] if loader is None else [len(rd(str(f))) for f in test_files]
+    if len(test_files) == 0:
+        return []
+    plan = StreamPlan(lengths, eng.window, frame_length, sample_rate, 2, carry_over)
+    mine = plan.shares(eval_type, world)[rank]
+    cache: dict = {}
+    pieces, n_win, slots = [], [], []
+    for k, i0, i1 in mine:
+        s0, s1 = plan.sample_range(k, i0, i1)
+        pieces.append(_stream_slice(plan, load, cache, s0, s1, k))
+        n_win.append(i1 - i0)
+        slots.append(np.arange(plan.offs[k] + i0, plan.offs[k] + i1))
+        for j in [j for j in cache if j < k - 1]:
+            del cache[j]
+    vals = _pieces_forward(eng, pieces, n_win, plan.hop, precise)[:, eng.posterior_index]
+    slots = np.concatenate(slots) if slots else np.zeros(0, np.int64)
+    if world > 1:
+        from . import dist as D
+        post = D.gather_posteriors(vals, slots, plan.total, device=comm_device)
+    else:
+        post = np.zeros(plan.total, np.float32)
+        post[slots] = vals
+    if eval_type == "false_negatives":
+        return [np.max(post[plan.offs[k]:plan.offs[k + 1]]) for k in range(len(plan.n_win))]  # raises on an empty clip, like the reference
+    return post.tolist()
+
+
+def join_negatives(clips: Sequence[np.ndarray], num_files: int, sample_rate: int = 16000) -> np.ndarray:
+    """``concatenate_FA`` (``evaluate_models.py:150-160``) on PCM in memory: ``clips[0] + (100 ms silence + clip) for
+    clips[1:num_files]``."""
+    gap = np.zeros(sample_rate // 10, np.int16)
+    parts = [np.asarray(clips[0], np.int16)]
+    for c in clips[1:max(num_files, 0)]:
+        parts += [gap, np.asarray(c, np.int16)]
+    return np.concatenate(parts)
+
+
+def evaluate_negative_stream_sharded(engine: Engine, stream_pcm: np.ndarray, rank: int = 0, world: int = 1,
+                                     comm_device: Optional[str] = None, precise: bool = True) -> np.ndarray:
+    """The reference's false-accept leg (``evaluate_models.py:317-321``: ``get_posterior(..., "false_accepts",
+    [FAR_path])``) on one long PCM stream, cut into ``world`` contiguous posterior ranges; full posterior array on
+    every rank (smoothing across the cuts happens after the gather, :func:`far_frr`)."""
+    return np.asarray(get_posterior_sharded(engine.model_dir, "CRNN" if engine.is_crnn else "Wavenet", "false_accepts",
+                                            [np.asarray(stream_pcm)], 20, 16000, rank, world, comm_device, engine=engine,
+                                            precise=precise), np.float32)
+
+
+def evaluate_reference_flow_sharded(engine: Engine, clips: Sequence[np.ndarray], labels: Sequence[int], rank: int = 0,
+                                    world: int = 1, comm_device: Optional[str] = None, thresholds=None, windowsize: int = 30,
+                                    precise: bool = True):
+    """``utils/evaluate_models.py`` ``main()`` (``:281-326``) on labelled int16 clips in memory, sharded over ``world``
+    ranks: the wake-word clips go file by file through one never-reset ``Filter`` (quirk C2; utterance-sharded, a rank
+    re-reads the <= 511-sample tail of a file's predecessor), the first ``num_wakewords`` other clips are joined by 100 ms
+    of silence into ONE stream (``concatenate_FA``) that is evaluated continuously and cut into contiguous posterior ranges
+    (:func:`evaluate_negative_stream_sharded`), hours = the joined stream's duration; rank 0 smooths and sweeps.
+    Returns the result dict on rank 0 and ``None`` elsewhere."""
+    labels = np.asarray(labels).astype(bool)
+    wake = [np.asarray(c, np.int16) for c, l in zip(clips, labels) if l]
+    other = [np.asarray(c, np.int16) for c, l in zip(clips, labels) if not l]
+    mtype = "CRNN" if engine.is_crnn else "Wavenet"
+    num_wakewords = len(wake)
+    pos = np.asarray(get_posterior_sharded(engine.model_dir, mtype, "false_negatives", wake, 20, 16000, rank, world,
+                                           comm_device, engine=engine, precise=precise), np.float32)
+    stream = join_negatives(other, num_wakewords) if other else np.zeros(0, np.int16)
+    neg = (evaluate_negative_stream_sharded(engine, stream, rank, world, comm_device, precise) if len(stream)
+           else np.zeros(0, np.float32))
+    if rank != 0:
+        return None
+    hours = len(stream) / 16000.0 / 3600.0
+    thr, frr, fa, cnt = far_frr(pos, neg, max(num_wakewords, 1), hours, thresholds, windowsize, engine=engine)
+    return {"thresholds": thr, "frr": frr, "fa_per_hour": fa, "fa_count": cnt, "frr_at_0.5_fa_per_hour": frr_at_fa(frr, fa, 0.5),
+            "positives": pos, "negatives": neg, "hours": hours, "num_wakewords": num_wakewords,
+            "negative_clips_joined": min(len(other), max(num_wakewords, 1)), "windows": int(len(neg)) + int(num_wakewords),
+            "posterior_checksum": float(neg.sum(dtype=np.float64) + pos.sum(dtype=np.float64))}
 
 
 def _forward_rows(eng: Engine, rows: np.ndarray, win_row: np.ndarray) -> np.ndarray:
@@ -243,7 +486,7 @@ def clip_posteriors(engine: Engine, clips: Sequence[np.ndarray], hop: int = 2, f
 
     fp = fp or frontend_params()
     pidx = engine.posterior_index
-    T, hop_s, PAD = engine.window, int(fp.hop), 8000
+    T, hop_s, PAD = engine.window, int(fp.hop), CLIP_PAD
     n = len(clips)
     if n == 0:
         return np.zeros(0, np.float32), []
@@ -295,10 +538,10 @@ def clip_posteriors(engine: Engine, clips: Sequence[np.ndarray], hop: int = 2, f
 
 
 def evaluate_testset(engine: Engine, clips: Sequence[np.ndarray], labels: Sequence[int], thresholds=None,
-                     windowsize: int = 30):
+                     windowsize: int = 30, fp=None):
     """FRR / FA-per-hour curves + FRR@0.5FA/h + one-window accuracy for a labelled clip set."""
     labels = np.asarray(labels).astype(bool)
-    p_one, sliding = clip_posteriors(engine, clips)
+    p_one, sliding = clip_posteriors(engine, clips, fp=fp)
     pos = np.array([s.max() if len(s) else 0.0 for s, l in zip(sliding, labels) if l], np.float32)
     neg = np.concatenate([s for s, l in zip(sliding, labels) if not l]) if (~labels).any() else np.zeros(0, np.float32)
     hours = sum((len(c) + 16000) for c, l in zip(clips, labels) if not l) / 16000.0 / 3600.0
@@ -310,21 +553,29 @@ def evaluate_testset(engine: Engine, clips: Sequence[np.ndarray], labels: Sequen
 
 
 def evaluate_testset_sharded(engine: Engine, clips: Sequence[np.ndarray], labels: Sequence[int], rank: int = 0,
-                             world: int = 1, comm_device: Optional[str] = None, thresholds=None, windowsize: int = 30):
-    """SURVEY 8(d) cfg 4: :func:`evaluate_testset` with the utterances dealt longest-first round-robin to ``world``
-    ranks (one process per GPU, ``torch.distributed`` already initialised by the caller when ``world > 1``).  Each rank
-    runs its own clips; the one exchange is the posterior gather; rank 0 smooths and sweeps.  Every posterior is a full
-    recompute of its window (``utils/evaluate_models.py:70-88``), so the result is identical for every ``world``.
+                             world: int = 1, comm_device: Optional[str] = None, thresholds=None, windowsize: int = 30,
+                             fp=None):
+    """SURVEY 8(d) cfg 4, per-clip variant: :func:`evaluate_testset` with the utterances dealt longest-first round-robin to
+    ``world`` ranks (one process per GPU, ``torch.distributed`` already initialised by the caller when ``world > 1``).  Each
+    rank runs its own clips; the one exchange is the posterior gather; rank 0 smooths and sweeps.  A posterior is a function
+    of its own window's mel rows only (``utils/evaluate_models.py:70-88``; the CRNN's sliding form computes a time position
+    once per CLIP - ``ww_forward_segments_dev`` - never across clips), so the result is identical for every ``world``.
+    (The reference's own flow - one continuous negative stream - is :func:`evaluate_reference_flow_sharded`.)
     Returns the result dict on rank 0 and ``None`` elsewhere."""
     from . import dist as D
     labels = np.asarray(labels).astype(bool)
     T, n = engine.window, len(clips)
-    # global layout of the sliding posteriors: pure arithmetic, identical on every rank
-    n_frames = np.array([((len(c) + 16000) - WINDOW) // 160 + 1 for c in clips], np.int64)
-    n_win = np.where(n_frames >= T, (n_frames - T) // 2 + 1, 0)
+    hop_s = int(fp.hop) if fp is not None else 160
+    # global layout of the sliding posteriors: pure arithmetic, identical on every rank (the same PAD / front-end hop / window
+    # hop clip_posteriors uses; asserted per clip below)
+    n_frames = np.array([(((len(c) + 2 * CLIP_PAD) - WINDOW) // hop_s + 1 if len(c) + 2 * CLIP_PAD >= WINDOW else 0) for c in clips], np.int64)
+    n_win = np.where(n_frames >= T, (n_frames - T) // CLIP_HOP + 1, 0)
     offs = np.concatenate(([0], np.cumsum(n_win)))
     mine = D.shard_by_length([len(c) for c in clips], world)[rank]
-    p_one, sliding = clip_posteriors(engine, [clips[i] for i in mine])
+    p_one, sliding = clip_posteriors(engine, [clips[i] for i in mine], CLIP_HOP, fp)
+    for j, i in enumerate(mine):
+        if len(sliding[j]) != n_win[i]:
+            raise RuntimeError(f"clip {i}: {len(sliding[j])} sliding posteriors, the global layout expects {n_win[i]}")
     slots = np.concatenate([np.arange(offs[i], offs[i + 1]) for i in mine]) if mine else np.zeros(0, np.int64)
     vals = np.concatenate(sliding) if sliding else np.zeros(0, np.float32)
     if world > 1:
@@ -342,7 +593,7 @@ def evaluate_testset_sharded(engine: Engine, clips: Sequence[np.ndarray], labels
                     for i in range(n) if labels[i]], np.float32)
     neg = (np.concatenate([all_slide[offs[i]:offs[i + 1]] for i in range(n) if not labels[i]])
            if (~labels).any() else np.zeros(0, np.float32))
-    hours = sum(len(clips[i]) + 16000 for i in range(n) if not labels[i]) / 16000.0 / 3600.0
+    hours = sum(len(clips[i]) + 2 * CLIP_PAD for i in range(n) if not labels[i]) / 16000.0 / 3600.0
     thr, frr, fa, cnt = far_frr(pos, neg, max(int(labels.sum()), 1), hours, thresholds, windowsize, engine=engine)
     return {"thresholds": thr, "frr": frr, "fa_per_hour": fa, "fa_count": cnt, "frr_at_0.5_fa_per_hour": frr_at_fa(frr, fa, 0.5),
             "one_window_posteriors": all_one, "one_window_accuracy": float(((all_one >= 0.5) == labels).mean()),
@@ -389,17 +640,21 @@ def duration_test(FAR_path: str, sample_rate: int) -> float:
     return len(read_wav(str(FAR_path), sample_rate)) / sample_rate
 
 
-def load_posteriors(models_dir, model_type, frame_width, sample_rate, eval_type, input_path, out_path, examine_audio=False):
-    """Pickle-cached :func:`get_posterior` (``:163-175``)."""
+def load_posteriors(models_dir, model_type, frame_width, sample_rate, eval_type, input_path, out_path, examine_audio=False,
+                    rank: int = 0, world: int = 1, comm_device: Optional[str] = None, device: int = 0):
+    """Pickle-cached posteriors (``:163-175``), computed by :func:`get_posterior_sharded` (``world`` = 1: one GPU, the
+    same windows as :func:`get_posterior`); with ``world > 1`` every rank computes its share and rank 0 writes the cache."""
     import os
     import pickle
     if os.path.exists(str(out_path)):
         with open(str(out_path), "rb") as f:
             posteriors = pickle.load(f)
     else:
-        posteriors = get_posterior(models_dir, model_type, eval_type, input_path, frame_width, sample_rate, examine_audio)
-        with open(str(out_path), "wb") as f:
-            pickle.dump(posteriors, f)
+        posteriors = get_posterior_sharded(models_dir, model_type, eval_type, input_path, frame_width, sample_rate, rank,
+                                           world, comm_device, device=device)
+        if rank == 0:
+            with open(str(out_path), "wb") as f:
+                pickle.dump(posteriors, f)
     return np.squeeze(np.array(posteriors))
 
 

@@ -10,7 +10,7 @@ global heap.  This module implements that subset of the published HDF5 file form
 (https://docs.hdfgroup.org/hdf5/develop/_f_m_t3.html) and nothing else: anything outside it - superblock
 version 2/3 and version-2 object headers (``libver='latest'``), link-message groups, chunked or filtered
 (deflate / shuffle) dataset storage, compound / array / bitfield / reference datatypes - raises
-``NotImplementedError`` naming the feature, so that a file written with other h5py options fails loudly
+``H5UnsupportedError`` (an ``H5FormatError`` and a ``NotImplementedError``) naming the feature, so that a file written with other h5py options fails loudly
 instead of being half-read (install h5py for those: ``wwhip.evaluate.open_h5`` prefers it when present).
 Every line of the reader is exercised by tests/test_h5min.py on h5py-written files.
 
@@ -40,6 +40,13 @@ UNDEF = 0xFFFFFFFFFFFFFFFF
 
 class H5FormatError(ValueError):
     pass
+
+
+class H5UnsupportedError(H5FormatError, NotImplementedError):
+    """A valid HDF5 feature this reader does not implement (chunked / compact / filtered storage, superblock v2+, v2 object
+    headers, new-style groups, compound / array types).  A subclass of :class:`H5FormatError`, so callers that fall back on
+    that (``open_h5``, the checkpoint readers) catch it too; also a ``NotImplementedError``.  Files the reader handles are
+    what h5py writes with its defaults (``libver='earliest'``, contiguous, no compression): INTEGRATION.md."""
 
 
 def _pad8(n: int) -> int:
@@ -81,7 +88,7 @@ def _parse_dtype(buf: bytes, off: int) -> Tuple[_DType, int]:
     if cls == 3:  # fixed-length string
         return _DType(np.dtype(f"S{size}"), size=size, strpad=b0 & 0x0F), 8
     if cls in (4, 6, 7):  # bitfield, compound, reference: the feature files and Keras checkpoints hold none
-        raise NotImplementedError(f"HDF5 datatype class {cls} ({ {4: 'bitfield', 6: 'compound', 7: 'reference'}[cls] })")
+        raise H5UnsupportedError(f"HDF5 datatype class {cls} ({ {4: 'bitfield', 6: 'compound', 7: 'reference'}[cls] })")
     if cls == 8:  # enumeration
         n = b0 | (b1 << 8)
         base, used = _parse_dtype(buf, p)
@@ -102,7 +109,7 @@ def _parse_dtype(buf: bytes, off: int) -> Tuple[_DType, int]:
         kind = "vlen_str" if vtype == 1 else "vlen_seq"
         return _DType(np.dtype("V%d" % size), kind=kind, size=size, base=base), 8 + used
     if cls == 10:
-        raise NotImplementedError("HDF5 array datatype")
+        raise H5UnsupportedError("HDF5 array datatype")
     raise H5FormatError(f"unsupported datatype class {cls}")
 
 
@@ -111,7 +118,7 @@ def _parse_dataspace(buf: bytes, off: int) -> Tuple[Optional[Tuple[int, ...]], i
     if ver == 1:
         p = off + 8
     elif ver == 2:  # written with libver='latest'; h5py's default ('earliest') and this module's writer use version 1
-        raise NotImplementedError("HDF5 dataspace message version 2")
+        raise H5UnsupportedError("HDF5 dataspace message version 2")
     else:
         raise H5FormatError(f"dataspace version {ver}")
     dims = struct.unpack_from("<%dQ" % rank, buf, p)
@@ -171,7 +178,7 @@ class Dataset(_Object):
         self._dt, _ = _parse_dtype(dt.data, 0)
         self._layout = lay.data
         if self._find(0x000B) is not None:
-            raise NotImplementedError(f"{name}: filtered (deflate / shuffle / fletcher32) dataset storage")
+            raise H5UnsupportedError(f"{name}: filtered (deflate / shuffle / fletcher32) dataset storage")
 
     @property
     def shape(self) -> Tuple[int, ...]:
@@ -197,15 +204,15 @@ class Dataset(_Object):
         if ver == 3:
             cls = b[1]
             if cls == 0:
-                raise NotImplementedError(f"{self.name}: compact dataset storage")
+                raise H5UnsupportedError(f"{self.name}: compact dataset storage")
             if cls == 1:
                 addr, size = struct.unpack_from("<QQ", b, 2)
                 return b"\0" * nbytes if addr == UNDEF else f._buf[addr:addr + nbytes]
             if cls == 2:
-                raise NotImplementedError(f"{self.name}: chunked dataset storage")
+                raise H5UnsupportedError(f"{self.name}: chunked dataset storage")
             raise H5FormatError(f"layout class {cls}")
         if ver in (1, 2):  # libhdf5 older than 1.6
-            raise NotImplementedError(f"{self.name}: data layout message version {ver}")
+            raise H5UnsupportedError(f"{self.name}: data layout message version {ver}")
         raise H5FormatError(f"layout version {ver}")
 
     def __getitem__(self, key) -> Any:
@@ -234,7 +241,7 @@ class Group(_Object):
                     links[name] = addr
             if st is None and (self._find(0x0002) is not None or any(m.type == 0x0006 for m in self._msgs)):
                 # link-info / link messages: groups written with libver='latest'
-                raise NotImplementedError(f"{self.name}: new-style HDF5 groups (link messages / fractal-heap storage)")
+                raise H5UnsupportedError(f"{self.name}: new-style HDF5 groups (link messages / fractal-heap storage)")
             self._links = links
         return self._links
 
@@ -298,7 +305,7 @@ class File(Group):
             root = p + 32  # root group symbol table entry
             _, addr, cache = struct.unpack_from("<QQI", b, root)
         elif ver in (2, 3):  # written with libver='latest' (v2 object headers, link messages): not what the reference writes
-            raise NotImplementedError(f"{path}: HDF5 superblock version {ver}")
+            raise H5UnsupportedError(f"{path}: HDF5 superblock version {ver}")
         else:
             raise H5FormatError(f"superblock version {ver}")
         self._cache: Dict[int, _Object] = {}
@@ -326,7 +333,7 @@ class File(Group):
         addr += self._base if addr != UNDEF else 0
         msgs: List[_Message] = []
         if b[addr:addr + 4] == b"OHDR":
-            raise NotImplementedError("HDF5 version-2 object headers")
+            raise H5UnsupportedError("HDF5 version-2 object headers")
         ver, _, nmsg, _, hsize = struct.unpack_from("<BBHII", b, addr)
         if ver != 1:
             raise H5FormatError(f"object header version {ver} at {addr}")

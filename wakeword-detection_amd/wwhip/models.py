@@ -23,8 +23,10 @@ _ENGINES: Dict[str, Engine] = {}
 
 
 def engine_for(model_dir: str, device: int = 0) -> Engine:
-    """One resident :class:`Engine` per (model directory, device)."""
-    key = f"{os.path.abspath(model_dir)}@{device}"
+    """One resident :class:`Engine` per (model directory, device, host thread): an engine enqueues on its thread's own
+    context (``_lib.default_context``), which is never shared between threads."""
+    import threading
+    key = f"{os.path.abspath(model_dir)}@{device}@{threading.get_ident()}"
     eng = _ENGINES.get(key)
     if eng is None or eng.handle is None:
         eng = Engine(model_dir, device=device)
