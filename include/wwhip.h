@@ -127,9 +127,13 @@ int ww_model_set_precision(ww_model *model, int precision);
  *   WW_OPT_CRNN_SPLIT_AT   explicit-window launches above this many windows run crnn_fused_kernel<front> + gru_tail_kernel
  *                          instead of one crnn_fused_kernel (default 1024; 0 = always one fused kernel)
  *   WW_OPT_CRNN_SLIDE_MIN  regular sliding windows (ww_slide_forward, ww_forward_segments_dev) take the once-per-sequence
- *                          form crnn_rows_kernel + gru_tail_kernel from this many windows on (default 64; 0 = never) */
+ *                          form crnn_rows_kernel + gru_tail_kernel from this many windows on (default 64; 0 = never)
+ *   WW_OPT_CRNN_TAIL_MFMA  the recurrences of those two forms: 1 (default) = sixteen windows per workgroup, recurrent products
+ *                          on v_mfma_f32_16x16x4_f32 (gru_tail16_kernel); 0 = one window per workgroup on the vector ALU
+ *                          (gru_tail_kernel) */
 #define WW_OPT_CRNN_SPLIT_AT 1
 #define WW_OPT_CRNN_SLIDE_MIN 2
+#define WW_OPT_CRNN_TAIL_MFMA 3
 int ww_model_set_option(ww_model *model, int key, int64_t value);
 
 /* ---- front end: PCM -> log-mel ---------------------------------------------------------

@@ -148,3 +148,17 @@ def test_bench_parent_starts_ranks_without_touching_a_gpu():
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0 and r.stdout.strip() == ""
     assert "rank exit codes" in r.stderr and "needs an MI355X" in r.stderr
+
+
+@pytest.mark.timeout(120)
+def test_default_context_fails_fast_without_a_gpu(tmp_path):
+    """`_lib.default_context` (what every drop-in class goes through) must raise - not hang - when no device is usable; in a
+    child process with a deadline, because a lock-order mistake here would otherwise stall the whole suite."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the context is created for real by the -m gpu tests")
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "from wwhip import _lib\n"
+            "try:\n    _lib.default_context(0)\nexcept RuntimeError as e:\n    print('raised', e)\n" % (ROOT, os.path.join(ROOT, "wakeword-detection_amd")))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=90)
+    assert r.returncode == 0 and "raised" in r.stdout, r.stdout + r.stderr

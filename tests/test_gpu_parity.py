@@ -178,21 +178,33 @@ def test_wavenet_split_bf16_mode(assets, oracles, golden, name):
 
 @pytest.mark.parametrize("name", ["CRNN", "CRNN_softmax"])
 def test_crnn_large_batch_path(engines, oracles, name):
-    """Above 1,024 windows per launch the CRNN runs as crnn_fused_kernel<front> + gru_tail_kernel (the recurrences of seven
-    windows share a CU): same results as the one-kernel path bit for bit, and the oracle's within tolerance - windows
-    with partial validity included, encoder output too."""
+    """Above 1,024 windows per launch the CRNN runs as crnn_fused_kernel<front> + a tail kernel for the recurrences:
+    gru_tail16_kernel (default: sixteen windows per workgroup, recurrent products and the layer-2 projection on
+    v_mfma_f32_16x16x4_f32, a partial last workgroup: 1,500 = 93 x 16 + 12) within 2e-6 of the one-kernel path, and
+    gru_tail_kernel (option crnn_tail_mfma = 0: one window per workgroup on the vector ALU) bit for bit; the oracle's within
+    tolerance - windows with partial validity included, encoder output too."""
     rng = np.random.default_rng(31)
     e = engines[name]
     wins = rng.uniform(0, 6.5, (1500, e.window, 40)).astype(np.float32)
     wins[::13, 120:] = 0
     wins[7] = 0
-    big, big_enc = e.forward(wins, want_enc=True)           # one launch of 1,500 windows: front + tail
     small = np.concatenate([e.forward(wins[i:i + 500]) for i in range(0, 1500, 500)])  # three fused launches
-    np.testing.assert_array_equal(big, small)
     idx = rng.choice(1500, 96, replace=False)
     want, want_enc = oracles[name].forward(wins[idx], want_enc=True)
-    assert np.abs(big[idx] - want).max() < TOL_POST
-    assert np.abs(big_enc[idx].reshape(want_enc.shape) - want_enc).max() < 1e-4
+    try:
+        for mfma in (1, 0):
+            e.set_option("crnn_tail_mfma", mfma)
+            big, big_enc = e.forward(wins, want_enc=True)       # one launch of 1,500 windows: front + tail
+            if mfma:
+                assert np.abs(big - small).max() < 2e-6, float(np.abs(big - small).max())
+            else:
+                np.testing.assert_array_equal(big, small)
+            assert np.abs(big[idx] - want).max() < TOL_POST
+            assert np.abs(big_enc[idx].reshape(want_enc.shape) - want_enc).max() < 1e-4
+    finally:
+        e.set_option("crnn_tail_mfma", 1)
+    with pytest.raises(ValueError):
+        e.set_option("no_such_option", 1)
 
 
 def test_retired_precision_mode_is_refused(engines):
@@ -596,11 +608,17 @@ def test_crnn_sliding_rows_path_matches_per_window_kernels(engines, oracles, nam
         rows = (nw - 1) * hop + T + (0 if hop == 4 else 3)
         mel = rng.uniform(0, 6.5, (rows, 40)).astype(np.float32)
         mel[rng.integers(0, rows, 5)] = 0
-        got = e.slide_forward(mel, hop)
+        got = e.slide_forward(mel, hop)                     # gathering gru_tail16_kernel (16 windows per workgroup, MFMA)
+        e.set_option("crnn_tail_mfma", 0)
+        try:
+            got_valu = e.slide_forward(mel, hop)            # gathering gru_tail_kernel (one window per workgroup, vector ALU)
+        finally:
+            e.set_option("crnn_tail_mfma", 1)
         assert got.shape[0] == (rows - T) // hop + 1 >= nw
         wins = np.stack([mel[i * hop:i * hop + T] for i in range(got.shape[0])])
         ref = np.concatenate([e.forward(wins[i:i + 512]) for i in range(0, len(wins), 512)])
         assert np.abs(got - ref).max() < 2e-6, (hop, nw, float(np.abs(got - ref).max()))
+        assert np.abs(got_valu - ref).max() < 2e-6, (hop, nw, float(np.abs(got_valu - ref).max()))
         idx = rng.choice(len(wins), 24, replace=False)
         assert np.abs(got[idx] - oracles[name].forward(wins[idx])).max() < TOL_POST
 

@@ -115,6 +115,7 @@ struct ww_model {
   int precision = 0;  // WW_PRECISION_*
   int opt_split_at = 1024;  // WW_OPT_CRNN_SPLIT_AT
   int opt_slide_min = 64;   // WW_OPT_CRNN_SLIDE_MIN
+  int opt_tail_mfma = 1;    // WW_OPT_CRNN_TAIL_MFMA
   std::vector<void *> allocs;
 };
 

@@ -1284,6 +1284,7 @@ struct tail_args {
   const float *gxI, *gxL, *gxR;  // interior fields [..][192], left / right edge rows [Nw][192]
   int hop_g, eight_g;            // hop / g and 8 / g: position t of window w is interior field w * hop_g + (t - 1) * eight_g
   const int64_t *iI0;            // or: window w's first interior field explicitly (several sequences)
+  const float *wx2;              // W_x2 row-major [2*3H][2H] (gru_tail16_kernel)
 };
 // LDS (floats): gx [19][196] | seq1 [20][68] (row 19 zero) | h [2][2][2][32] | enc [64] | hid [64] = 21.9 KB: seven per CU whatever
 // the allocation granularity (22.7 KB with a 20th gx row was seven only if LDS is handed out in units below 1 KB)
@@ -1393,6 +1394,247 @@ __global__ __launch_bounds__(128, 4) void gru_tail_kernel(tail_args a) {
       float sum = e;
       for (int o = 1; o < 8; o <<= 1) sum += __shfl_xor(sum, o);
       if (lane < a.NOUT) a.out[(size_t)w * a.NOUT + lane] = e / sum;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// gru_tail16_kernel: the same work as gru_tail_kernel for SIXTEEN windows per two-wave workgroup (wave 0 forward, wave 1
+// backward), with the recurrent mat-vec of the sixteen windows as one matrix product per step on v_mfma_f32_16x16x4_f32:
+//   [16 windows x 32 units] x W_h^T [32 x 96]  =  6 n-tiles (z, r, c  x  unit half) x 8 k-steps = 48 MFMAs.
+// A tile's accumulator has its unit (column) on the lane and four windows (rows) in its registers, and so do the tiles
+// of the other gates - the gate arithmetic of a (window, unit) pair is lane-local, evaluated ONCE (gru_tail_kernel's lane
+// pairs each evaluate a unit's gates twice), the projected inputs gx[window][t][gate unit] are read straight from global
+// memory / L2 in that layout (one step ahead), and a step's new state goes through 2 KB of LDS to become the next step's A
+// operand (lane = window, its eight k's of every k-step = eight consecutive units: two 16-byte reads).
+// Layer 2's input projection (as many MFMAs as all four recurrences together) is computed per step in the same
+// accumulators: A = seq1[t] of the sixteen windows (global workspace, written by layer 1), B = this direction's 96 rows of
+// W_x2 held in registers (6 tiles x 16 k-steps), issued for step t+1 between writing h(t) and reading it back.
+// The contraction index of every product is dealt to the lanes as k = (k-steps per lane group) * (lane >> 4) + k-step, so
+// that a lane's operands of consecutive k-steps are consecutive in memory (the order of an fp32 sum is free within 1e-7).
+// ------------------------------------------------------------------------------------------
+#define GT16_LD 36   // h exchange row: 32 units + 4
+#define GT16_ELD 68  // enc / hid row: 64 + 4
+struct tail16_args {
+  tail_args t;
+  float *seq;  // [workgroup][OT][16][64] layer-1 outputs
+  int nw;      // windows in this launch (the last workgroup may be partial)
+};
+
+__global__ __launch_bounds__(128, 2) void gru_tail16_kernel(tail16_args aa) {
+  constexpr int H = GR_H, OT = CV_OT;
+  const tail_args &a = aa.t;
+  __shared__ __align__(16) float hs[2][2][16 * GT16_LD];
+  __shared__ __align__(16) float encs[16 * GT16_ELD];
+  __shared__ __align__(16) float hid[16 * GT16_ELD];
+  const int tid = threadIdx.x, lane = tid & 63, dir = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int w0 = blockIdx.x * 16;
+  float *seq = aa.seq + (size_t)blockIdx.x * OT * 16 * 2 * H;
+
+  // rows of the accumulator tiles = windows 4 g + r (clamped in a partial workgroup: computed twice, stored once)
+  int wi[4];
+  int64_t i0[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    wi[r] = min(w0 + 4 * g + r, aa.nw - 1);
+    i0[r] = a.gx1 ? 0 : (a.iI0 ? a.iI0[wi[r]] : (int64_t)wi[r] * a.hop_g);
+  }
+  auto gx_row = [&](int r, int t) -> const float * {
+    if (a.gx1) return a.gx1 + ((size_t)wi[r] * OT + t) * 6 * H;
+    if (t == 0) return a.gxL + (size_t)wi[r] * 6 * H;
+    if (t == OT - 1) return a.gxR + (size_t)wi[r] * 6 * H;
+    return a.gxI + (size_t)(i0[r] + (int64_t)(t - 1) * a.eight_g) * 6 * H;
+  };
+  // recurrent weights as B operands: tile nt = gate * 2 + unit half; k-step ks, lane group g <-> unit 8 g + ks
+  float wh[6][8];
+  float bh[6];
+  auto load_wh = [&](const float *whp, const float *bhp) {
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt) {
+      const int row = (nt >> 1) * H + (nt & 1) * 16 + c;
+      const float4 *p = (const float4 *)(whp + ((size_t)dir * 3 * H + row) * H + 8 * g);
+      const float4 v0 = p[0], v1 = p[1];
+      wh[nt][0] = v0.x; wh[nt][1] = v0.y; wh[nt][2] = v0.z; wh[nt][3] = v0.w;
+      wh[nt][4] = v1.x; wh[nt][5] = v1.y; wh[nt][6] = v1.z; wh[nt][7] = v1.w;
+      bh[nt] = bhp[dir * 3 * H + row];
+    }
+  };
+  load_wh(a.wh1, a.bh1);
+  for (int i = tid; i < 2 * 2 * 16 * GT16_LD; i += 128) (&hs[0][0][0])[i] = 0.f;
+
+  // ---- layer 1 ------------------------------------------------------------------------------
+  float h_own[4][2];  // [row r][unit half]: h of (window 4 g + r, unit 16 uh + c)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) h_own[r][0] = h_own[r][1] = 0.f;
+  float gxn[4][6];
+  {
+    const int t = dir ? OT - 1 : 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float *row = gx_row(r, t) + dir * 3 * H + c;
+#pragma unroll
+      for (int nt = 0; nt < 6; ++nt) gxn[r][nt] = row[(nt >> 1) * H + (nt & 1) * 16];
+    }
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int s = 0; s < OT; ++s) {
+    const int t = dir ? OT - 1 - s : s, cur = s & 1;
+    f32x4 acc[6];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = (f32x4){gxn[0][nt] + bh[nt], gxn[1][nt] + bh[nt], gxn[2][nt] + bh[nt], gxn[3][nt] + bh[nt]};
+    acc[4] = (f32x4){bh[4], bh[4], bh[4], bh[4]};
+    acc[5] = (f32x4){bh[5], bh[5], bh[5], bh[5]};
+    float gxc[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { gxc[r][0] = gxn[r][4]; gxc[r][1] = gxn[r][5]; }
+    if (s + 1 < OT) {  // next step's projected inputs: in flight during this step's products and gates
+      const int tn = dir ? t - 1 : t + 1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float *row = gx_row(r, tn) + dir * 3 * H + c;
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt) gxn[r][nt] = row[(nt >> 1) * H + (nt & 1) * 16];
+      }
+    }
+    if (s > 0) {  // h = 0 at the first step
+      const float4 *hp = (const float4 *)(&hs[dir][cur][c * GT16_LD + 8 * g]);
+      const float4 a0 = hp[0], a1 = hp[1];
+      const float ha[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[ks], wh[nt][ks], acc[nt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int uh = 0; uh < 2; ++uh)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float z = fast_sigmoid(acc[uh][r]);
+        const float rr = fast_sigmoid(acc[2 + uh][r]);
+        const float cc = fast_tanh(gxc[r][uh] + rr * acc[4 + uh][r]);
+        const float hn = z * h_own[r][uh] + (1.0f - z) * cc;
+        h_own[r][uh] = hn;
+        hs[dir][cur ^ 1][(4 * g + r) * GT16_LD + uh * 16 + c] = hn;
+        seq[((size_t)t * 16 + 4 * g + r) * 2 * H + dir * H + uh * 16 + c] = hn;
+      }
+    wsync_h();
+  }
+  __syncthreads();  // seq1 of both directions is in memory (workgroup scope)
+
+  // ---- layer 2: input projection per step in the recurrence's accumulators --------------------
+  load_wh(a.wh2, a.bh2);
+  float wx[6][16];  // W_x2 rows of this direction as B operands: k-step ks, lane group g <-> seq1 column 16 g + ks
+  float bx[6];
+#pragma unroll
+  for (int nt = 0; nt < 6; ++nt) {
+    const int row = dir * 3 * H + (nt >> 1) * H + (nt & 1) * 16 + c;
+    const float4 *p = (const float4 *)(a.wx2 + (size_t)row * 2 * H + 16 * g);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = p[q];
+      wx[nt][4 * q] = v.x; wx[nt][4 * q + 1] = v.y; wx[nt][4 * q + 2] = v.z; wx[nt][4 * q + 3] = v.w;
+    }
+    bx[nt] = a.bx2[row];
+  }
+  for (int i = tid; i < 2 * 2 * 16 * GT16_LD; i += 128) (&hs[0][0][0])[i] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) h_own[r][0] = h_own[r][1] = 0.f;
+  // acc2: tiles 0..3 = z, r (projection + recurrent part in one sum), 4..5 = projected c input, 6..7 = recurrent c part
+  f32x4 acc2[8];
+  auto project = [&](int t) {
+    const float4 *sp = (const float4 *)(seq + ((size_t)t * 16 + c) * 2 * H + 16 * g);
+    const float4 q0 = sp[0], q1 = sp[1], q2 = sp[2], q3 = sp[3];
+    const float sa[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) { const float b = bx[nt] + bh[nt]; acc2[nt] = (f32x4){b, b, b, b}; }
+    acc2[4] = (f32x4){bx[4], bx[4], bx[4], bx[4]};
+    acc2[5] = (f32x4){bx[5], bx[5], bx[5], bx[5]};
+    acc2[6] = (f32x4){bh[4], bh[4], bh[4], bh[4]};
+    acc2[7] = (f32x4){bh[5], bh[5], bh[5], bh[5]};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < 6; ++nt) acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[ks], wx[nt][ks], acc2[nt], 0, 0, 0);
+  };
+  project(dir ? OT - 1 : 0);
+  __syncthreads();
+#pragma unroll 1
+  for (int s = 0; s < OT; ++s) {
+    const int t = dir ? OT - 1 - s : s, cur = s & 1;
+    if (s > 0) {
+      const float4 *hp = (const float4 *)(&hs[dir][cur][c * GT16_LD + 8 * g]);
+      const float4 a0 = hp[0], a1 = hp[1];
+      const float ha[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[ks], wh[nt][ks], acc2[nt], 0, 0, 0);
+        acc2[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[ks], wh[4][ks], acc2[6], 0, 0, 0);
+        acc2[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[ks], wh[5][ks], acc2[7], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int uh = 0; uh < 2; ++uh)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float z = fast_sigmoid(acc2[uh][r]);
+        const float rr = fast_sigmoid(acc2[2 + uh][r]);
+        const float cc = fast_tanh(acc2[4 + uh][r] + rr * acc2[6 + uh][r]);
+        const float hn = z * h_own[r][uh] + (1.0f - z) * cc;
+        h_own[r][uh] = hn;
+        hs[dir][cur ^ 1][(4 * g + r) * GT16_LD + uh * 16 + c] = hn;
+      }
+    if (s + 1 < OT) project(dir ? t - 1 : t + 1);  // between the h write and its read-back: covers the LDS round trip
+    wsync_h();
+  }
+#pragma unroll
+  for (int uh = 0; uh < 2; ++uh)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      encs[(4 * g + r) * GT16_ELD + dir * H + uh * 16 + c] = h_own[r][uh];
+      if (a.enc && w0 + 4 * g + r < aa.nw) a.enc[(size_t)(w0 + 4 * g + r) * 2 * H + dir * H + uh * 16 + c] = h_own[r][uh];
+    }
+  __syncthreads();
+
+  // ---- detect head: wave d takes windows 8 d .. 8 d + 7; lane = hidden unit, its w1 row in registers -----
+  {
+    float4 w1r[16];
+    const float4 *wr = (const float4 *)(a.w1 + (size_t)lane * 2 * H);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) w1r[q] = wr[q];
+    const float b1v = a.b1[lane];
+#pragma unroll 1
+    for (int wq = dir * 8; wq < dir * 8 + 8; ++wq) {
+      float acc = 0.f;  // one chain in k order: bit-identical to crnn_fused_kernel's head
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float4 ev = *(const float4 *)(&encs[wq * GT16_ELD + q * 4]);
+        acc = fmaf(w1r[q].x, ev.x, acc); acc = fmaf(w1r[q].y, ev.y, acc);
+        acc = fmaf(w1r[q].z, ev.z, acc); acc = fmaf(w1r[q].w, ev.w, acc);
+      }
+      hid[wq * GT16_ELD + lane] = fmaxf(acc + b1v, 0.f);
+    }
+  }
+  __syncthreads();
+  {
+    const int wq = tid >> 3, o = tid & 7;  // 16 windows x up to 8 outputs
+    float y = 0.f;
+    if (o < a.NOUT) {
+      for (int k = 0; k < 2 * H; ++k) y = fmaf(a.w2[o * 64 + k], hid[wq * GT16_ELD + k], y);
+      y += a.b2[o];
+    }
+    const bool live = o < a.NOUT && w0 + wq < aa.nw;
+    if (a.HEAD == 0) {
+      if (live) a.out[(size_t)(w0 + wq) * a.NOUT + o] = sigmoid_f(y);
+    } else {
+      float mx = (o < a.NOUT) ? y : -INFINITY;
+      for (int d = 1; d < 8; d <<= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+      const float e = (o < a.NOUT) ? expf(y - mx) : 0.f;
+      float sum = e;
+      for (int d = 1; d < 8; d <<= 1) sum += __shfl_xor(sum, d);
+      if (live) a.out[(size_t)(w0 + wq) * a.NOUT + o] = e / sum;
     }
   }
 }
@@ -1627,6 +1869,21 @@ int ww_k_crnn_stream_forward(ww_ctx *ctx, const ww_model *m, const float *d_hist
   return WW_OK;
 }
 
+// Everything behind the layer-1 projections: sixteen windows per workgroup with the recurrent products on the matrix pipe
+// (gru_tail16_kernel, default), or one window per workgroup on the vector ALU (gru_tail_kernel: WW_OPT_CRNN_TAIL_MFMA = 0).
+static size_t tail_seq_bytes(int nw) { return ww_bump::need((size_t)((nw + 15) / 16) * CV_OT * 16 * 2 * GR_H, 4); }
+static void launch_tail(ww_ctx *ctx, const ww_model *m, tail_args t, int nw, float *seq) {
+  t.wx2 = m->crnn.wx2;
+  if (m->opt_tail_mfma) {
+    tail16_args a16 = {t, seq, nw};
+    ww_launch_scope scope(ctx, "gru_tail16_kernel");
+    hipLaunchKernelGGL(gru_tail16_kernel, dim3((unsigned)((nw + 15) / 16)), dim3(128), 0, ctx->stream, a16);
+  } else {
+    ww_launch_scope scope(ctx, "gru_tail_kernel");
+    hipLaunchKernelGGL(gru_tail_kernel, dim3((unsigned)nw), dim3(128), 0, ctx->stream, t);
+  }
+}
+
 // Regular sliding windows (hop <= 8 over one mel sequence, every window complete) take crnn_rows_kernel + gru_tail_kernel from
 // this many windows on (ww_model_set_option(WW_OPT_CRNN_SLIDE_MIN): 0 = never).
 static int crnn_slide_min(const ww_model *m) { return m->opt_slide_min > 0 ? m->opt_slide_min : 0x7fffffff; }
@@ -1676,12 +1933,13 @@ int ww_k_crnn_segments_forward(ww_ctx *ctx, const ww_model *m, const float *d_me
     if (nW > 0) {
       const size_t b_tiles = ww_bump::need(tiles.size() * sizeof(rows_tile), 1), b_i0 = ww_bump::need(i0.size() * 8, 1);
       const size_t b_rows = ww_bump::need((size_t)(nI + 2 * nW) * 6 * c.H, 4);
-      int rc = ww_ensure(ctx, ctx->dev, b_tiles + b_i0 + b_rows + 4096, false);
+      int rc = ww_ensure(ctx, ctx->dev, b_tiles + b_i0 + b_rows + tail_seq_bytes((int)nW) + 8192, false);
       if (rc) return rc;
       ww_bump b(ctx->dev.ptr, ctx->dev.cap);
       rows_tile *d_tiles = (rows_tile *)b.take<char>(tiles.size() * sizeof(rows_tile));
       int64_t *d_i0 = b.take<int64_t>(i0.size());
       float *gI = b.take<float>((size_t)nI * 6 * c.H), *gL = b.take<float>((size_t)nW * 6 * c.H), *gR = b.take<float>((size_t)nW * 6 * c.H);
+      float *seq = (float *)b.take<char>(tail_seq_bytes((int)nW));
       WW_HIP(ctx, hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(rows_tile), hipMemcpyHostToDevice, ctx->stream));
       WW_HIP(ctx, hipMemcpyAsync(d_i0, i0.data(), i0.size() * 8, hipMemcpyHostToDevice, ctx->stream));
       rows_args r = {};
@@ -1695,11 +1953,8 @@ int ww_k_crnn_segments_forward(ww_ctx *ctx, const ww_model *m, const float *d_me
         hipLaunchKernelGGL(crnn_rows_kernel, dim3((unsigned)tiles.size()), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, r);
       }
       tail_args t = {nullptr, c.wh1, c.bh1, c.wx2s, c.bx2, c.wh2, c.bh2, c.w1, c.b1, c.w2, c.b2, nullptr,
-                     d_out + (size_t)w_done * c.NOUT, c.NOUT, c.HEAD, gI, gL, gR, hop / g, 8 / g, d_i0};
-      {
-        ww_launch_scope scope(ctx, "gru_tail_kernel");
-        hipLaunchKernelGGL(gru_tail_kernel, dim3((unsigned)nW), dim3(128), 0, ctx->stream, t);
-      }
+                     d_out + (size_t)w_done * c.NOUT, c.NOUT, c.HEAD, gI, gL, gR, hop / g, 8 / g, d_i0, nullptr};
+      launch_tail(ctx, m, t, (int)nW, seq);
       WW_HIP(ctx, hipGetLastError());
       // the host vectors are reused by the next group: the copies out of them must have been taken
       WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1717,9 +1972,9 @@ size_t ww_crnn_workspace(const ww_model *m, int nw, bool sliding) {
   // sliding form: (fields + 2 edge rows per window) x 192 floats; fields <= 7 nw + 130 (hop 7), i.e. never more than the
   // 19 rows per window of the front/tail form
   size_t need = 1024;  // crnn_fused_kernel keeps every intermediate in LDS
-  if (sliding && nw >= crnn_slide_min(m)) need = ww_bump::need(((size_t)9 * nw + 160) * 6 * c.H, 4) + 1024;
+  if (sliding && nw >= crnn_slide_min(m)) need = ww_bump::need(((size_t)9 * nw + 160) * 6 * c.H, 4) + tail_seq_bytes(nw) + 2048;
   if (thr > 0 && nw > thr) {
-    const size_t split = ww_bump::need((size_t)nw * c.OT * 6 * c.H, 4) + 1024;
+    const size_t split = ww_bump::need((size_t)nw * c.OT * 6 * c.H, 4) + tail_seq_bytes(nw) + 2048;
     need = split > need ? split : need;
   }
   return need;
@@ -1743,6 +1998,7 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
     const int64_t n_int = ((int64_t)(nw - 1) * hop + 128) / g + 1;
     ww_bump b(ws, ~size_t(0));
     float *gI = b.take<float>((size_t)n_int * 6 * c.H), *gL = b.take<float>((size_t)nw * 6 * c.H), *gR = b.take<float>((size_t)nw * 6 * c.H);
+    float *seq = (float *)b.take<char>(tail_seq_bytes(nw));
     rows_args r = {};
     r.mel = d_mel; r.mel_rows = mel_rows;
     r.w4[0] = c.conv_w; r.w4[1] = c.conv_wL; r.w4[2] = c.conv_wR;
@@ -1757,11 +2013,8 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
       hipLaunchKernelGGL(crnn_rows_kernel, dim3(r.tiles[0] + r.tiles[1] + r.tiles[2]), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, r);
     }
     tail_args t = {nullptr, c.wh1, c.bh1, c.wx2s, c.bx2, c.wh2, c.bh2, c.w1, c.b1, c.w2, c.b2, d_enc, d_out, c.NOUT, c.HEAD,
-                   gI, gL, gR, hop / g, 8 / g, nullptr};
-    {
-      ww_launch_scope scope(ctx, "gru_tail_kernel");
-      hipLaunchKernelGGL(gru_tail_kernel, dim3(nw), dim3(128), 0, ctx->stream, t);
-    }
+                   gI, gL, gR, hop / g, 8 / g, nullptr, nullptr};
+    launch_tail(ctx, m, t, nw, seq);
     WW_HIP(ctx, hipGetLastError());
     return WW_OK;
   }
@@ -1769,16 +2022,14 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
   if (thr > 0 && nw > thr) {
     ww_bump b(ws, ~size_t(0));
     a.gx_out = b.take<float>((size_t)nw * c.OT * 6 * c.H);
+    float *seq = (float *)b.take<char>(tail_seq_bytes(nw));
     {
       ww_launch_scope scope(ctx, bf16 ? "crnn_fused_kernel<front,bf16x3>" : "crnn_fused_kernel<front>");
       if (bf16) hipLaunchKernelGGL(crnn_fused_bf16_kernel<true>, dim3(nw), dim3(CF_THREADS), CFB_SMEM_BYTES, ctx->stream, a);
       else hipLaunchKernelGGL(crnn_fused_kernel<true>, dim3(nw), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, a);
     }
-    tail_args t = {a.gx_out, c.wh1, c.bh1, c.wx2s, c.bx2, c.wh2, c.bh2, c.w1, c.b1, c.w2, c.b2, d_enc, d_out, c.NOUT, c.HEAD, nullptr, nullptr, nullptr, 0, 0, nullptr};
-    {
-      ww_launch_scope scope(ctx, "gru_tail_kernel");
-      hipLaunchKernelGGL(gru_tail_kernel, dim3(nw), dim3(128), 0, ctx->stream, t);
-    }
+    tail_args t = {a.gx_out, c.wh1, c.bh1, c.wx2s, c.bx2, c.wh2, c.bh2, c.w1, c.b1, c.w2, c.b2, d_enc, d_out, c.NOUT, c.HEAD, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr};
+    launch_tail(ctx, m, t, nw, seq);
     WW_HIP(ctx, hipGetLastError());
     return WW_OK;
   }

@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("WWHIP_LIB") or os.path.join(_PKG, "libwwhip.so")
 WW_OK, WW_EINVAL, WW_EBLOB, WW_EHIP, WW_ENOMEM, WW_ESTATE, WW_ENODEVICE = 0, -1, -2, -3, -4, -5, -6
 KIND_CRNN, KIND_WAVENET = 1, 2
 PRECISION_FP32, PRECISION_BF16X3 = 0, 1
-OPT_CRNN_SPLIT_AT, OPT_CRNN_SLIDE_MIN = 1, 2
+OPT_CRNN_SPLIT_AT, OPT_CRNN_SLIDE_MIN, OPT_CRNN_TAIL_MFMA = 1, 2, 3
 STREAM_FULL_RECOMPUTE = 1
 
 
@@ -239,6 +239,7 @@ class Context:
 
 
 _default_ctx: Dict[tuple, Context] = {}
+_ctx_lock = threading.Lock()  # not _lock: Context() itself goes through load(), which takes that one
 
 
 def default_context(device: int = 0) -> Context:
@@ -246,7 +247,7 @@ def default_context(device: int = 0) -> Context:
     host thread (the reference itself is single-threaded: SURVEY 8b 'Threading / ownership'), so two threads that use
     the drop-in classes never share a stream or a workspace."""
     key = (device, threading.get_ident())
-    with _lock:
+    with _ctx_lock:
         ctx = _default_ctx.get(key)
         if ctx is None or ctx.handle is None:
             ctx = Context(device)

@@ -61,8 +61,11 @@ class Engine:
     def set_option(self, key: str, value: int) -> None:
         """Per-model dispatch options (``ww_model_set_option``): ``"crnn_split_at"`` - explicit-window launches above
         this many windows take front + tail kernels (0 = always one fused kernel); ``"crnn_slide_min"`` - regular
-        sliding windows take the once-per-sequence form from this many windows on (0 = never)."""
-        keys = {"crnn_split_at": _lib.OPT_CRNN_SPLIT_AT, "crnn_slide_min": _lib.OPT_CRNN_SLIDE_MIN}
+        sliding windows take the once-per-sequence form from this many windows on (0 = never); ``"crnn_tail_mfma"`` - 1 (default):
+        the recurrences of those two forms for sixteen windows per workgroup on the matrix pipe, 0: one window per workgroup
+        on the vector ALU."""
+        keys = {"crnn_split_at": _lib.OPT_CRNN_SPLIT_AT, "crnn_slide_min": _lib.OPT_CRNN_SLIDE_MIN,
+                "crnn_tail_mfma": _lib.OPT_CRNN_TAIL_MFMA}
         if key not in keys:
             raise ValueError(f"option must be one of {sorted(keys)}")
         self._chk(self._lib.ww_model_set_option(self._model, keys[key], int(value)))
