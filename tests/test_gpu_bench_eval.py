@@ -180,8 +180,8 @@ def test_reference_flow_sharded_identical_for_any_rank_count(reference_flow_one_
 
 
 def test_reference_flow_equals_get_posterior_and_oracle(reference_flow_one_rank, tmp_path):
-    """The sharded flow's arrays against (a) the unsharded drop-in `get_posterior` on the same wavs (the whole stream in one
-    front-end pass): bit-identical; (b) the C oracle over the same stream + the NumPy restatement of plot_FRR_FAR:
+    """The sharded flow's arrays against (a) the drop-in `get_posterior` on the same audio as wav FILES (the world-size-1 case
+    of the same implementation, one piece per file instead of arrays in memory): bit-identical; (b) the C oracle over the same stream + the NumPy restatement of plot_FRR_FAR:
     posteriors within 1e-4, FA counts / FRR array / FRR @ 0.5 FA/h identical."""
     from oracle import cpu as ocpu
     from oracle import numpy_ref as NR

@@ -45,6 +45,7 @@ class Engine:
         self.enc_shape = (info.enc_rows, info.enc_width)
         self.model_dir = model_dir
         _lib.register("models", self)
+        self._options = {"crnn_split_at": 1024, "crnn_slide_min": 64, "crnn_tail_mfma": 1}  # the library's defaults
         self.precision = "fp32"
         if precision != "fp32":
             self.set_precision(precision)
@@ -69,6 +70,23 @@ class Engine:
         if key not in keys:
             raise ValueError(f"option must be one of {sorted(keys)}")
         self._chk(self._lib.ww_model_set_option(self._model, keys[key], int(value)))
+        self._options[key] = int(value)
+
+    def options(self, **kv):
+        """Context manager: the given options for the duration of a ``with`` block, the previous values afterwards."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            old = {k: self._options[k] for k in kv}
+            try:
+                for k, v in kv.items():
+                    self.set_option(k, v)
+                yield self
+            finally:
+                for k, v in old.items():
+                    self.set_option(k, v)
+        return scope()
 
     # ------------------------------------------------------------------ properties
     @property

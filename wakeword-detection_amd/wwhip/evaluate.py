@@ -83,55 +83,12 @@ def window_schedule(frames_per_chunk: np.ndarray, encoder_len: int, hop: int = 2
 def get_posterior(models_dir, model_type, eval_type, test_files, frame_width, sample_rate, examine_audio=False,
                   loader: Optional[Callable[[str], np.ndarray]] = None, carry_over: bool = True,
                   device: int = 0) -> list:
-    """Reference signature (``utils/evaluate_models.py:26-28``) plus ``loader`` (path -> float
-    samples; default :func:`read_wav`) and ``carry_over`` (False = reset the ring per file)."""
-    if model_type not in ("CRNN", "Wavenet"):
-        raise ValueError("model_type must be 'CRNN' or 'Wavenet'")
-    eng: Engine = engine_for(models_dir, device)
-    encoder_len = eng.window
-    frame_length = sample_rate // 1000 * frame_width
-    hop = 2
-    load = loader or (lambda p: read_wav(p, sample_rate))
-    pidx = eng.posterior_index
-    pad = sample_rate // 2
-    # the ring is continuous over all files: build one stream, remember the file boundaries
-    signals = []
-    for f in test_files:
-        x = np.asarray(load(f), dtype=np.float32)
-        x = np.pad(x, (pad, pad), mode="constant")
-        if len(x) % frame_length:
-            x = np.pad(x, (0, frame_length - len(x) % frame_length), mode="constant")
-        signals.append(x)
-    if not signals:
-        return []
-    per_file, starts = frame_schedule([len(s) for s in signals], 160, frame_length, carry_over)
-    if carry_over:
-        stream = [np.concatenate(signals)]
-    else:
-        stream = signals
-    mels = eng.logmel(stream, frontend_params(1.0, False, 0.0, 160, True))
-    # every window of every file in ONE model launch: start rows within the concatenated mel rows
-    rows = np.concatenate(mels) if len(mels) > 1 else mels[0]
-    win_rows, counts = [], []
-    frame_cursor = 0
-    for i, fpc in enumerate(per_file):
-        n_frames = int(fpc.sum())
-        ws = window_schedule(fpc, encoder_len, hop)
-        win_rows.append(frame_cursor + ws)
-        counts.append(len(ws))
-        frame_cursor += n_frames if carry_over else len(mels[i])
-    win_row = np.concatenate(win_rows) if win_rows else np.zeros(0, np.int64)
-    post = _forward_rows(eng, rows, win_row)[:, pidx] if len(win_row) else np.zeros(0, np.float32)
-    all_posterior: list = []
-    o = 0
-    for nw in counts:
-        p = post[o:o + nw]
-        o += nw
-        if eval_type == "false_negatives":
-            all_posterior.append(np.max(p))  # raises on an empty clip, like the reference
-        else:
-            all_posterior.extend(p.tolist())
-    return all_posterior
+    """Reference signature (``utils/evaluate_models.py:26-28``) plus ``loader`` (path -> samples: int16 PCM or float32 in
+    [-1, 1); default :func:`read_wav_pcm`) and ``carry_over`` (False = reset the ring per file).  One GPU; the same
+    implementation as :func:`get_posterior_sharded` at world size 1 (one front-end launch over all files, one model launch
+    over all windows)."""
+    return get_posterior_sharded(models_dir, model_type, eval_type, list(test_files), frame_width, sample_rate, 0, 1,
+                                 loader=loader, carry_over=carry_over, device=device)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -375,21 +332,6 @@ def evaluate_reference_flow_sharded(engine: Engine, clips: Sequence[np.ndarray],
             "posterior_checksum": float(neg.sum(dtype=np.float64) + pos.sum(dtype=np.float64))}
 
 
-def _forward_rows(eng: Engine, rows: np.ndarray, win_row: np.ndarray) -> np.ndarray:
-    """encode+detect on the windows ``rows[r : r + T]`` for every r in ``win_row``: one upload, one launch."""
-    import torch  # only to hold the device buffers of the batched launch
-
-    dev = torch.device("cuda", eng.ctx.device)  # the engine's GPU, whatever torch's current device is
-    d_mel = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32)).to(dev)
-    d_row = torch.from_numpy(np.ascontiguousarray(win_row, dtype=np.int64)).to(dev)
-    d_valid = torch.full((len(win_row),), eng.window, dtype=torch.int32, device=dev)
-    d_out = torch.empty((len(win_row), eng.n_out), dtype=torch.float32, device=dev)
-    torch.cuda.synchronize(dev)
-    eng.forward_windows_dev(d_mel.data_ptr(), len(rows), d_row.data_ptr(), d_valid.data_ptr(), len(win_row), d_out.data_ptr())
-    eng.ctx.synchronize()
-    return d_out.cpu().numpy()
-
-
 def default_thresholds() -> np.ndarray:
     return np.arange(0.5, 0.99999, 0.005)  # evaluate_models.py:185
 
@@ -528,7 +470,11 @@ def clip_posteriors(engine: Engine, clips: Sequence[np.ndarray], hop: int = 2, f
     d_out = torch.empty((n + n_slide, engine.n_out), dtype=torch.float32, device=dev)
     torch.cuda.synchronize(dev)
     engine.logmel_dev(d_pcm.data_ptr(), d_so.data_ptr(), d_fo.data_ptr(), n, total_f, int(nf_pad.max()), d_mel.data_ptr(), fp)
-    engine.forward_windows_dev(d_mel.data_ptr(), total_f, d_row.data_ptr(), d_valid.data_ptr(), n, d_out.data_ptr())
+    # the n single windows on the one-kernel form whatever n is: a posterior must not depend on how many other clips share the
+    # launch (above crnn_split_at windows the library would take front + tail kernels, which sum in another order: ~1e-7),
+    # or the sharded evaluation would differ between world sizes
+    with engine.options(crnn_split_at=0):
+        engine.forward_windows_dev(d_mel.data_ptr(), total_f, d_row.data_ptr(), d_valid.data_ptr(), n, d_out.data_ptr())
     if n_slide:
         engine.forward_segments_dev(d_mel.data_ptr(), total_f, foffs[:-1], nw, hop, d_out[n:].data_ptr())
     engine.ctx.synchronize()
