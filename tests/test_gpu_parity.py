@@ -240,7 +240,10 @@ def test_crnn_split_bf16_mode(assets, oracles, golden, name):
         big = rng.uniform(0, 6.5, (1300, e.window, 40)).astype(np.float32)   # > 1,024 windows: front + tail kernels
         big[::7, 140:] = 0
         got_big = e.forward(big)
-        np.testing.assert_array_equal(got_big[:300], e.forward(big[:300]))   # same arithmetic in both forms
+        # the front kernel's projections are the fused kernel's bit for bit; gru_tail16_kernel sums the recurrent products in another order
+        assert np.abs(got_big[:300] - e.forward(big[:300])).max() < 2e-6
+        with e.options(crnn_tail_mfma=0):
+            np.testing.assert_array_equal(e.forward(big)[:300], e.forward(big[:300]))   # gru_tail_kernel: same arithmetic in both forms
         # ragged clips: windows with valid < T rows (zero padded in the kernel's staging) and sliding windows
         from wwhip.evaluate import clip_posteriors, synth_testset
         clips, _ = synth_testset(40, seed=5, min_s=0.6, max_s=2.4)
