@@ -130,10 +130,14 @@ int ww_model_set_precision(ww_model *model, int precision);
  *                          form crnn_rows_kernel + gru_tail_kernel from this many windows on (default 64; 0 = never)
  *   WW_OPT_CRNN_TAIL_MFMA  the recurrences of those two forms: 1 (default) = sixteen windows per workgroup, recurrent products
  *                          on v_mfma_f32_16x16x4_f32 (gru_tail16_kernel); 0 = one window per workgroup on the vector ALU
- *                          (gru_tail_kernel) */
+ *                          (gru_tail_kernel)
+ *   WW_OPT_WAVENET_ROWMAJOR 0 (default) = the fp32 Wavenet block loop in transposed form (channels x time: BatchNorm output and
+ *                          gate product feed the next MFMA straight from registers); 1 = rounds 1-2's row-major loop (both
+ *                          through LDS).  Same products, another summation order of the three taps and the bias. */
 #define WW_OPT_CRNN_SPLIT_AT 1
 #define WW_OPT_CRNN_SLIDE_MIN 2
 #define WW_OPT_CRNN_TAIL_MFMA 3
+#define WW_OPT_WAVENET_ROWMAJOR 4
 int ww_model_set_option(ww_model *model, int key, int64_t value);
 
 /* ---- front end: PCM -> log-mel ---------------------------------------------------------

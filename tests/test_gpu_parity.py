@@ -731,3 +731,28 @@ def test_two_host_threads_through_the_c_abi(assets, oracles):
                 np.testing.assert_array_equal(pa, pb)
         _, win, post, _, _ = got[name][-1]
         assert np.abs(post - oracles[name].forward(win)).max() < TOL_POST
+
+
+@pytest.mark.parametrize("name", ["Wavenet", "Wavenet_alt"])
+def test_wavenet_fp32_block_loop_forms(engines, oracles, name):
+    """The fp32 Wavenet's block loop in its two forms: transposed (default since round 3: channels x time, BatchNorm output and
+    gate product feed the next MFMA from registers) and row-major (option wavenet_rowmajor = 1, rounds 1-2).  Same products,
+    another summation order of the taps and the bias: both within tolerance of the oracle, within 2e-6 of each other, for
+    full, partially valid and all-zero windows, encoder output included."""
+    e = engines[name]
+    rng = np.random.default_rng(55)
+    wins = rng.uniform(0, 6.5, (70, e.window, 40)).astype(np.float32)
+    wins[1] = 0
+    wins[2, 100:] = 0
+    wins[3] = np.clip(rng.normal(3, 1.5, (e.window, 40)), 0, 8)
+    want, want_enc = oracles[name].forward(wins, want_enc=True)
+    got_t, enc_t = e.forward(wins, want_enc=True)
+    with e.options(wavenet_rowmajor=1):
+        got_r, enc_r = e.forward(wins, want_enc=True)
+    for got, enc in ((got_t, enc_t), (got_r, enc_r)):
+        assert np.abs(got - want).max() < TOL_POST
+        assert np.abs(enc.reshape(want_enc.shape) - want_enc).max() < 1e-4
+    assert np.abs(got_t - got_r).max() < 2e-6
+    assert np.abs(enc_t - enc_r).max() < 2e-5
+    mel = rng.uniform(0, 6.5, (e.window + 60, 40)).astype(np.float32)
+    assert np.abs(e.slide_forward(mel, 2) - oracles[name].slide_forward(mel, 2)).max() < TOL_POST

@@ -116,6 +116,7 @@ struct ww_model {
   int opt_split_at = 1024;  // WW_OPT_CRNN_SPLIT_AT
   int opt_slide_min = 64;   // WW_OPT_CRNN_SLIDE_MIN
   int opt_tail_mfma = 1;    // WW_OPT_CRNN_TAIL_MFMA
+  int opt_wave_rowmajor = 0;  // WW_OPT_WAVENET_ROWMAJOR
   std::vector<void *> allocs;
 };
 

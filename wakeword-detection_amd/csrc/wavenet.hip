@@ -205,16 +205,21 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define WV_SLOTS 14  // A-operand slots per block: gate (2 k-steps x {sig,tanh} x 2) = 8, res | skip (3 m-tiles x 2) = 6
 #define WV_PAGE_U4 (WV_SLOTS * 64)  // one block's parameter page in 16-byte units (the conv biases sit in padded k-slots)
 
-template <bool HEAD_ONLY, bool SPLIT_BF16, int WV_NW>
+// FP32T: the fp32 block loop in the TRANSPOSED form of the split-bf16 loop (channels x time; round 3) - see its comment below.
+template <bool HEAD_ONLY, bool SPLIT_BF16, int WV_NW, bool FP32T = false>
 __global__ __launch_bounds__(WV_NW * 64, WV_NW == 12 ? (SPLIT_BF16 ? WV_BF16_OCC : 3) : 2) void wavenet_kernel(wave_args a) {
   constexpr int WV_MPW = 12 / WV_NW, WV_THREADS = WV_NW * 64;
+  constexpr bool TRANSPOSED = SPLIT_BF16 || FP32T;  // state layout: lane = time column, four consecutive channels per register quad
+  static_assert(!(SPLIT_BF16 && FP32T) && (!FP32T || WV_NW == 12), "one arithmetic mode; the fp32 transposed loop is written for 12 x 1 tiles");
   static_assert(WV_MPW * WV_NW == 12, "12 row tiles");
   // LDS: region A = staged input [192][48] (prologue only), later u[2][208][16] + g[192][16]
   // split-bf16: u planes (same bytes as the fp32 u buffers) + two parameter pages (next to / under the head's tile)
   constexpr int LDS_FP32 = WV_T * WV_INLD > (2 * (WV_T + WV_PAD) * WV_C + WV_T * WV_S) ? WV_T * WV_INLD
                                                                                        : (2 * (WV_T + WV_PAD) * WV_C + WV_T * WV_S);
   constexpr int LDS_BF16 = 2 * (WV_T + WV_PAD) * WV_C + 3 * WV_PAGE_U4 * 4 + 32 * 8 * 4;  // u planes + 3 pages + BatchNorm table (NB <= 32)
-  __shared__ __align__(16) float lds[SPLIT_BF16 && LDS_BF16 > LDS_FP32 ? LDS_BF16 : LDS_FP32];
+  constexpr int LDS_F32T = 2 * (WV_T + WV_PAD) * WV_C + WV_T * WV_S + 32 * 7 * 16;        // u buffers + head tile + per-block vectors (NB <= 32)
+  constexpr int LDS_A = SPLIT_BF16 && LDS_BF16 > LDS_FP32 ? LDS_BF16 : LDS_FP32;
+  __shared__ __align__(16) float lds[FP32T && LDS_F32T > LDS_A ? LDS_F32T : LDS_A];
   __shared__ float red[WV_NW][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kk = lane >> 4;
@@ -281,21 +286,93 @@ __global__ __launch_bounds__(WV_NW * 64, WV_NW == 12 ? (SPLIT_BF16 ? WV_BF16_OCC
 #pragma unroll
       for (int kb = 0; kb < 3; ++kb) {
         const float4 av = *(const float4 *)(in_lds + (t0 + j) * WV_INLD + kb * 16 + kk * 4);
-        if (SPLIT_BF16) {  // operands swapped: the transposed tile (channels x time)
+        if (TRANSPOSED) {  // operands swapped: the transposed tile (channels x time)
           MFMA4(acc, bw[kb], av);
         } else {
           MFMA4(acc, av, bw[kb]);
         }
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) x[mi][r] = fmaxf(acc[r] + (SPLIT_BF16 ? a.b_in[kk * 4 + r] : bias), 0.f);
+      for (int r = 0; r < 4; ++r) x[mi][r] = fmaxf(acc[r] + (TRANSPOSED ? a.b_in[kk * 4 + r] : bias), 0.f);
       skip[mi][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
       skip[mi][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   }
   __syncthreads();  // in_lds is dead from here on
 
-  if (!SPLIT_BF16) {
+  if (FP32T) {
+    // ---- fp32 block loop, transposed (lane = time column t0 + j, registers = channels 4 kk + r), on v_mfma_f32_16x16x4_f32 with
+    //      the weights as the A operand.  The packed weights of the row-major loop serve as they are: k-step q of lane group
+    //      kk is input channel 4 kk + q in both forms.  What the transposition buys (as in the split-bf16 loop): the BatchNorm
+    //      output of a tile IS the undelayed tap's B operand and the gate product IS the res | skip conv's B operand - both
+    //      straight from registers.  LDS per block and wave: ONE 16-byte write (u, for the delayed taps of other rows) and
+    //      TWO 16-byte reads (rows t - 2d, t - d), against 8 four-byte writes, 4 sixteen-byte reads and two wave-private
+    //      round trips (u -> A operand, gate product -> A operand) in the row-major loop.  The conv biases are the
+    //      accumulators' initial values (per-lane float4 by channel group); all blocks' small vectors sit in one LDS table.
+    float *vtab = lds + 2 * (WV_T + WV_PAD) * WV_C + WV_T * WV_S;  // [NB][7][16]: bn_s, bn_t, b_sig, b_tanh, b_res, b_skip0, b_skip1
+    for (int i = tid; i < a.NB * 7 * 16; i += WV_THREADS) {
+      const int b = i / 112, v = (i / 16) % 7, c = i & 15;
+      vtab[i] = v == 0 ? a.bn_s[b * WV_C + c] : v == 1 ? a.bn_t[b * WV_C + c] : v < 4 ? a.b_gate[b * 32 + (v - 2) * 16 + c]
+                                                                                      : a.b_rs[b * 48 + (v - 4) * 16 + c];
+    }
+    for (int i = tid; i < 2 * WV_PAD * WV_C; i += WV_THREADS) {  // causal zero rows of both u buffers
+      int b = i / (WV_PAD * WV_C), o = i - b * (WV_PAD * WV_C);
+      ubuf[b * (WV_T + WV_PAD) * WV_C + o] = 0.f;
+    }
+    struct wblk_t { float4 wg[3][2], wrs[3]; };
+    auto wload = [&](int blk, wblk_t &p) {
+      const float *wg = a.w_gate4 + (size_t)blk * 3 * 4 * 32 * 4, *wrs = a.w_rs4 + (size_t)blk * 4 * 48 * 4;
+      const unsigned og = (unsigned)(kk * 32 + j) * 4, ors = (unsigned)(kk * 48 + j) * 4;
+#pragma unroll
+      for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) p.wg[kb][n] = *(const float4 *)(wg + og + kb * 4 * 32 * 4 + n * 16 * 4);
+#pragma unroll
+      for (int n = 0; n < 3; ++n) p.wrs[n] = *(const float4 *)(wrs + ors + n * 16 * 4);
+    };
+    wblk_t pw[2];
+    wload(0, pw[0]);
+    const int tl = wave * 16 + j;  // this lane's time column
+    __syncthreads();               // table + zero rows
+    auto f4 = [](const float4 &v) { return (f32x4){v.x, v.y, v.z, v.w}; };
+    auto run_block_t = [&](int blk, const wblk_t &P, wblk_t &Pnext) {
+      float *u = ubuf + (blk & 1) * (WV_T + WV_PAD) * WV_C + WV_PAD * WV_C;  // row 0 of u
+      const int d = (int)((a.dil4[blk >> 4] >> (4 * (blk & 15))) & 15);
+      const float4 *vt = (const float4 *)(vtab + blk * 112) + kk;            // vector v: vt[4 v]
+      const float4 bns = vt[0], bnt = vt[4];
+      const float4 uv = make_float4(x[0][0] * bns.x + bnt.x, x[0][1] * bns.y + bnt.y, x[0][2] * bns.z + bnt.z, x[0][3] * bns.w + bnt.w);
+      *(float4 *)(u + tl * WV_C + kk * 4) = uv;
+      wload(blk + 1 < a.NB ? blk + 1 : blk, Pnext);  // unconditional (clamped) prefetch, as the row-major loop
+      f32x4 as = f4(vt[8]), at = f4(vt[12]);
+      MFMA4(as, P.wg[2][0], uv);                     // tap 2 = this row: runs while the other waves arrive
+      MFMA4(at, P.wg[2][1], uv);
+      __syncthreads();  // u complete (all rows, all waves)
+      const float4 t0v = *(const float4 *)(u + (tl - 2 * d) * WV_C + kk * 4);  // rows < 0 hit the zero pad (d <= 8)
+      const float4 t1v = *(const float4 *)(u + (tl - d) * WV_C + kk * 4);
+      MFMA4(as, P.wg[0][0], t0v);
+      MFMA4(at, P.wg[0][1], t0v);
+      MFMA4(as, P.wg[1][0], t1v);
+      MFMA4(at, P.wg[1][1], t1v);
+      const float4 gv = make_float4(fast_tanh_w(at[0]) * fast_sigmoid_w(as[0]), fast_tanh_w(at[1]) * fast_sigmoid_w(as[1]),
+                                    fast_tanh_w(at[2]) * fast_sigmoid_w(as[2]), fast_tanh_w(at[3]) * fast_sigmoid_w(as[3]));
+      f32x4 ar = f4(vt[16]), s0 = f4(vt[20]), s1 = f4(vt[24]);
+      const int has_res = (a.has_res_mask >> blk) & 1;
+      if (has_res) { MFMA4(ar, P.wrs[0], gv); }
+      MFMA4(s0, P.wrs[1], gv);
+      MFMA4(s1, P.wrs[2], gv);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (has_res) x[0][r] = relu1(ar[r]) + x[0][r];
+        skip[0][0][r] = skip[0][0][r] + relu1(s0[r]);
+        skip[0][1][r] = skip[0][1][r] + relu1(s1[r]);
+      }
+    };
+    for (int blk = 0; blk < a.NB; blk += 2) {
+      run_block_t(blk, pw[0], pw[1]);
+      if (blk + 1 < a.NB) run_block_t(blk + 1, pw[1], pw[0]);
+    }
+    __syncthreads();
+  } else if (!SPLIT_BF16) {
   // causal zero rows of both u buffers
   for (int i = tid; i < 2 * WV_PAD * WV_C; i += WV_THREADS) {
     int b = i / (WV_PAD * WV_C), o = i - b * (WV_PAD * WV_C);
@@ -561,7 +638,7 @@ __global__ __launch_bounds__(WV_NW * 64, WV_NW == 12 ? (SPLIT_BF16 ? WV_BF16_OCC
     float *e = a.enc + (size_t)w * T * WV_S;
 #pragma unroll
     for (int mi = 0; mi < WV_MPW; ++mi) {
-      if (SPLIT_BF16) {  // transposed state: lane = time column, four consecutive channels per register quad
+      if (TRANSPOSED) {  // transposed state: lane = time column, four consecutive channels per register quad
         const int t = (wave * WV_MPW + mi) * 16 + j;
         if (t < T) {
           *(float4 *)(e + (size_t)t * WV_S + kk * 4) = make_float4(skip[mi][0][0], skip[mi][0][1], skip[mi][0][2], skip[mi][0][3]);
@@ -592,7 +669,7 @@ __global__ __launch_bounds__(WV_NW * 64, WV_NW == 12 ? (SPLIT_BF16 ? WV_BF16_OCC
   for (int mi = 0; mi < WV_MPW; ++mi) {
     const int t0 = (wave * WV_MPW + mi) * 16;
     float *ht = hbuf + t0 * WV_S;  // [16][32] tile, wave-private
-    if (SPLIT_BF16) {
+    if (TRANSPOSED) {
       *(float4 *)(ht + j * WV_S + kk * 4) = make_float4(fmaxf(skip[mi][0][0], 0.f), fmaxf(skip[mi][0][1], 0.f),
                                                         fmaxf(skip[mi][0][2], 0.f), fmaxf(skip[mi][0][3], 0.f));
       *(float4 *)(ht + j * WV_S + 16 + kk * 4) = make_float4(fmaxf(skip[mi][1][0], 0.f), fmaxf(skip[mi][1][1], 0.f),
@@ -705,8 +782,10 @@ int ww_k_wave_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
 #endif
   if (m->precision == WW_PRECISION_BF16X3)
     hipLaunchKernelGGL((wavenet_kernel<false, true, WV_BF16_NW>), dim3(nw), dim3(WV_BF16_NW * 64), 0, ctx->stream, a);
-  else
+  else if (m->opt_wave_rowmajor)
     hipLaunchKernelGGL((wavenet_kernel<false, false, 12>), dim3(nw), dim3(12 * 64), 0, ctx->stream, a);
+  else
+    hipLaunchKernelGGL((wavenet_kernel<false, false, 12, true>), dim3(nw), dim3(12 * 64), 0, ctx->stream, a);
   WW_HIP(ctx, hipGetLastError());
   return WW_OK;
 }

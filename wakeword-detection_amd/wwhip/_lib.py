@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("WWHIP_LIB") or os.path.join(_PKG, "libwwhip.so")
 WW_OK, WW_EINVAL, WW_EBLOB, WW_EHIP, WW_ENOMEM, WW_ESTATE, WW_ENODEVICE = 0, -1, -2, -3, -4, -5, -6
 KIND_CRNN, KIND_WAVENET = 1, 2
 PRECISION_FP32, PRECISION_BF16X3 = 0, 1
-OPT_CRNN_SPLIT_AT, OPT_CRNN_SLIDE_MIN, OPT_CRNN_TAIL_MFMA = 1, 2, 3
+OPT_CRNN_SPLIT_AT, OPT_CRNN_SLIDE_MIN, OPT_CRNN_TAIL_MFMA, OPT_WAVENET_ROWMAJOR = 1, 2, 3, 4
 STREAM_FULL_RECOMPUTE = 1
 
 

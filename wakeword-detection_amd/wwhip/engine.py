@@ -45,7 +45,7 @@ class Engine:
         self.enc_shape = (info.enc_rows, info.enc_width)
         self.model_dir = model_dir
         _lib.register("models", self)
-        self._options = {"crnn_split_at": 1024, "crnn_slide_min": 64, "crnn_tail_mfma": 1}  # the library's defaults
+        self._options = {"crnn_split_at": 1024, "crnn_slide_min": 64, "crnn_tail_mfma": 1, "wavenet_rowmajor": 0}  # the library's defaults
         self.precision = "fp32"
         if precision != "fp32":
             self.set_precision(precision)
@@ -64,9 +64,10 @@ class Engine:
         this many windows take front + tail kernels (0 = always one fused kernel); ``"crnn_slide_min"`` - regular
         sliding windows take the once-per-sequence form from this many windows on (0 = never); ``"crnn_tail_mfma"`` - 1 (default):
         the recurrences of those two forms for sixteen windows per workgroup on the matrix pipe, 0: one window per workgroup
-        on the vector ALU."""
+        on the vector ALU; ``"wavenet_rowmajor"`` - 1: the fp32 Wavenet's row-major block loop of rounds 1-2 instead of the
+        transposed one."""
         keys = {"crnn_split_at": _lib.OPT_CRNN_SPLIT_AT, "crnn_slide_min": _lib.OPT_CRNN_SLIDE_MIN,
-                "crnn_tail_mfma": _lib.OPT_CRNN_TAIL_MFMA}
+                "crnn_tail_mfma": _lib.OPT_CRNN_TAIL_MFMA, "wavenet_rowmajor": _lib.OPT_WAVENET_ROWMAJOR}
         if key not in keys:
             raise ValueError(f"option must be one of {sorted(keys)}")
         self._chk(self._lib.ww_model_set_option(self._model, keys[key], int(value)))
