@@ -55,6 +55,8 @@ PEAK_F32_MFMA = 157.3e12  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x
 PEAK_HBM = 8.0e12
 PEAK_BF16_MFMA = 2.5e15   # dense bf16, MI355X_MICROARCH.md
 PEAK_F64_VALU = 78.6e12   # fp64 vector FMA peak
+N_SIMD = 1024             # 256 CUs x 4
+VALU_CYCLES_PER_INST = 3.7  # measured: tools/pmc_calib.hip (v_fma_f32, >= 2 waves per SIMD); fp64 ops issue at the same rate (tools/valu_probe.hip)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -278,7 +280,7 @@ def throughput(world, K, clips, seconds):
     return world * K * clips * FRAMES_PER_CLIP / seconds
 
 
-def roofline_of(eng, prof, clips, fast_frontend):
+def roofline_of(eng, prof, clips, fast_frontend, step_s=None):
     kw = kernel_work(eng, clips)
     per_kernel = {}
     dom, dom_ms = None, -1.0
@@ -315,6 +317,28 @@ def roofline_of(eng, prof, clips, fast_frontend):
         roof["algorithmic_bytes"] = nbytes
     elif pmc is None:
         roof["traffic_note"] = "no PMC pass on these kernel sources (profiles/r03/pmc_counters.json absent or of another source_sha)"
+    # how busy the shared vector / matrix datapath is over a STEP (the fp32 MFMA and the vector ALU of a SIMD do not
+    # co-execute on gfx950: tools/pmc_calib.hip, profiles/r03/README.md): per kernel, busy cycles per SIMD =
+    # SQ_VALU_MFMA_BUSY_CYCLES / 1024 + 3.7 x (SQ_INSTS_VALU - SQ_INSTS_MFMA) / 1024 over the kernel's own SQ_BUSY_CYCLES / 32
+    # (all from one PMC pass, so the clock drops out), weighted with the kernels' live durations over the live step time
+    roof["step_datapath_busy"] = None
+    wl = (pmc or {}).get("workloads", {}).get(f"clips{clips}", {})
+    if step_s and all(k in wl and "SQ_BUSY_CYCLES" in wl[k] and "SQ_INSTS_VALU" in wl[k] for k in prof if k in kw):
+        parts, busy_s = {}, 0.0
+        for name, rec in prof.items():
+            if name not in kw:
+                continue
+            c = wl[name]
+            cyc = (c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) + VALU_CYCLES_PER_INST * (c["SQ_INSTS_VALU"] - c.get("SQ_INSTS_MFMA", 0.0))) / N_SIMD
+            b = cyc / (c["SQ_BUSY_CYCLES"] / 32.0)
+            t = rec["total_ms"] / max(rec["calls"], 1) * 1e-3
+            parts[name] = {"busy_frac_in_kernel": b, "matrix_frac_in_kernel": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / N_SIMD / (c["SQ_BUSY_CYCLES"] / 32.0),
+                           "kernel_us": t * 1e6}
+            busy_s += b * t
+        roof["step_datapath_busy"] = {"value": busy_s / step_s, "step_us": step_s * 1e6, "kernels": parts,
+                                      "method": "sum over the step's kernels of (matrix-busy + vector-issue cycles per SIMD, PMC) / (kernel cycles, "
+                                                "PMC) x live kernel duration, over the live pipelined step time; 3.7 cycles per vector "
+                                                "instruction and 32 per v_mfma_f32_16x16x4_f32 as calibrated by tools/pmc_calib.hip"}
     roof["kernel"] = dom
     roof["kernel_avg_us"] = round(dom_ms * 1e3, 3)
     roof["all_kernels_avg_us"] = per_kernel
@@ -651,8 +675,8 @@ def main():
                                          with_oracle=(world == 1 and not args.no_cpu_baseline))
 
     if rank == 0:
-        roof = roofline_of(eng, head["prof"], args.clips, args.fast_frontend)
         med = head["median_s"]
+        roof = roofline_of(eng, head["prof"], args.clips, args.fast_frontend, step_s=med / K)
         line = {
             "metric": "audio frames/sec (16 kHz, 40-mel, 10 ms hop) + FRR@0.5 FA/h",
             "value": throughput(world, K, args.clips, med),

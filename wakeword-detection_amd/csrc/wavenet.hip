@@ -307,7 +307,10 @@ __global__ __launch_bounds__(WV_NW * 64, WV_NW == 12 ? (SPLIT_BF16 ? WV_BF16_OCC
     //      output of a tile IS the undelayed tap's B operand and the gate product IS the res | skip conv's B operand - both
     //      straight from registers.  LDS per block and wave: ONE 16-byte write (u, for the delayed taps of other rows) and
     //      TWO 16-byte reads (rows t - 2d, t - d), against 8 four-byte writes, 4 sixteen-byte reads and two wave-private
-    //      round trips (u -> A operand, gate product -> A operand) in the row-major loop.  The conv biases are the
+    //      round trips (u -> A operand, gate product -> A operand) in the row-major loop.  u is stored channel-group-major,
+    //      [kk][row][4 floats] with the four planes a multiple of 256 bytes apart: consecutive lanes of a group touch
+    //      consecutive 16 bytes and the lane groups of ds_read_b128 / ds_write_b128 (MI355X_MICROARCH.md, LDS) cover all 64 banks
+    //      once (row-major [row][16] put the 8 lanes of a write group on 2 bank quads: 5.3 M conflict cycles per 256 windows).  The conv biases are the
     //      accumulators' initial values (per-lane float4 by channel group); all blocks' small vectors sit in one LDS table.
     float *vtab = lds + 2 * (WV_T + WV_PAD) * WV_C + WV_T * WV_S;  // [NB][7][16]: bn_s, bn_t, b_sig, b_tanh, b_res, b_skip0, b_skip1
     for (int i = tid; i < a.NB * 7 * 16; i += WV_THREADS) {
@@ -315,9 +318,11 @@ __global__ __launch_bounds__(WV_NW * 64, WV_NW == 12 ? (SPLIT_BF16 ? WV_BF16_OCC
       vtab[i] = v == 0 ? a.bn_s[b * WV_C + c] : v == 1 ? a.bn_t[b * WV_C + c] : v < 4 ? a.b_gate[b * 32 + (v - 2) * 16 + c]
                                                                                       : a.b_rs[b * 48 + (v - 4) * 16 + c];
     }
-    for (int i = tid; i < 2 * WV_PAD * WV_C; i += WV_THREADS) {  // causal zero rows of both u buffers
-      int b = i / (WV_PAD * WV_C), o = i - b * (WV_PAD * WV_C);
-      ubuf[b * (WV_T + WV_PAD) * WV_C + o] = 0.f;
+    constexpr int UPL = (WV_T + WV_PAD) * 4;  // floats per channel-group plane
+    static_assert(UPL % 64 == 0, "u planes must start on the same bank");
+    for (int i = tid; i < 2 * 4 * WV_PAD * 4; i += WV_THREADS) {  // causal zero rows of both u buffers, every plane
+      const int b = i / (4 * WV_PAD * 4), k = (i / (WV_PAD * 4)) & 3, o = i % (WV_PAD * 4);
+      ubuf[b * 4 * UPL + k * UPL + o] = 0.f;
     }
     struct wblk_t { float4 wg[3][2], wrs[3]; };
     auto wload = [&](int blk, wblk_t &p) {
@@ -336,19 +341,19 @@ __global__ __launch_bounds__(WV_NW * 64, WV_NW == 12 ? (SPLIT_BF16 ? WV_BF16_OCC
     __syncthreads();               // table + zero rows
     auto f4 = [](const float4 &v) { return (f32x4){v.x, v.y, v.z, v.w}; };
     auto run_block_t = [&](int blk, const wblk_t &P, wblk_t &Pnext) {
-      float *u = ubuf + (blk & 1) * (WV_T + WV_PAD) * WV_C + WV_PAD * WV_C;  // row 0 of u
+      float *u = ubuf + (blk & 1) * 4 * UPL + kk * UPL + WV_PAD * 4;          // row 0 of this lane's channel-group plane
       const int d = (int)((a.dil4[blk >> 4] >> (4 * (blk & 15))) & 15);
       const float4 *vt = (const float4 *)(vtab + blk * 112) + kk;            // vector v: vt[4 v]
       const float4 bns = vt[0], bnt = vt[4];
       const float4 uv = make_float4(x[0][0] * bns.x + bnt.x, x[0][1] * bns.y + bnt.y, x[0][2] * bns.z + bnt.z, x[0][3] * bns.w + bnt.w);
-      *(float4 *)(u + tl * WV_C + kk * 4) = uv;
+      *(float4 *)(u + tl * 4) = uv;
       wload(blk + 1 < a.NB ? blk + 1 : blk, Pnext);  // unconditional (clamped) prefetch, as the row-major loop
       f32x4 as = f4(vt[8]), at = f4(vt[12]);
       MFMA4(as, P.wg[2][0], uv);                     // tap 2 = this row: runs while the other waves arrive
       MFMA4(at, P.wg[2][1], uv);
       __syncthreads();  // u complete (all rows, all waves)
-      const float4 t0v = *(const float4 *)(u + (tl - 2 * d) * WV_C + kk * 4);  // rows < 0 hit the zero pad (d <= 8)
-      const float4 t1v = *(const float4 *)(u + (tl - d) * WV_C + kk * 4);
+      const float4 t0v = *(const float4 *)(u + (tl - 2 * d) * 4);  // rows < 0 hit the zero pad (d <= 8)
+      const float4 t1v = *(const float4 *)(u + (tl - d) * 4);
       MFMA4(as, P.wg[0][0], t0v);
       MFMA4(at, P.wg[0][1], t0v);
       MFMA4(as, P.wg[1][0], t1v);
