@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r03p
 mkdir -p $O
 STATS="--kernel-trace --stats --output-format csv"
-WHAT=${1:-all}   # kt | pmc | all  (two gpurun calls when one would run past the time limit)
+WHAT=${1:-all}   # kt | pmc1 | pmc2 | all  (separate gpurun calls when one would run past the time limit)
 if [ $WHAT = kt ] || [ $WHAT = all ]; then
 # 1. kernel-trace stats
 rocprofv3 $STATS -d $O/kt_bench_single -o run -- python3 $R/bench.py --pipeline 1 --no-cpu-baseline --no-extra > $O/bench_single_under_rocprof.json 2> $O/kt_bench_single.err
@@ -21,7 +21,7 @@ echo "kt slide done"
 rocprofv3 $STATS -d $O/kt_stream -o run -- python3 $R/tools/stream_prof.py > $O/stream_under_rocprof.txt 2> $O/kt_stream.err
 echo "kt stream done"
 fi
-if [ $WHAT = pmc ] || [ $WHAT = all ]; then
+if [ $WHAT = pmc1 ] || [ $WHAT = pmc2 ] || [ $WHAT = all ]; then
 # 2. PMC passes: one TCC counter per pass, SQ counters up to 8 per pass
 SQ1="SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY"
 SQ2="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD"
@@ -30,9 +30,12 @@ pmc() {  # name, counters, program...
   rocprofv3 --pmc $ctrs -d $O/pmc_$name -o run --output-format csv -- "$@" > $O/pmc_$name.log 2>&1 || echo "pmc pass $name failed"
   echo "pmc $name done"
 }
-for wl in "clips256 python3 $R/tools/kbench.py crnn 256 5" "wave256 python3 $R/tools/kbench.py wavenet 256 5 bf16x3" \
-          "wave256f python3 $R/tools/kbench.py wavenet 256 5" "slide10 python3 $R/tools/slide_throughput.py 2" \
-          "stream128 python3 $R/tools/stream_prof.py"; do
+WL1=("clips256 python3 $R/tools/kbench.py crnn 256 5" "wave256 python3 $R/tools/kbench.py wavenet 256 5 bf16x3" "wave256f python3 $R/tools/kbench.py wavenet 256 5")
+WL2=("slide10 python3 $R/tools/slide_throughput.py 10 models=crnn" "stream128 python3 $R/tools/stream_prof.py")
+WLS=()
+if [ $WHAT = pmc1 ] || [ $WHAT = all ]; then WLS+=("${WL1[@]}"); fi
+if [ $WHAT = pmc2 ] || [ $WHAT = all ]; then WLS+=("${WL2[@]}"); fi
+for wl in "${WLS[@]}"; do
   set -- $wl; name=$1; shift
   pmc ${name}_fetch FETCH_SIZE "$@"
   pmc ${name}_write WRITE_SIZE "$@"
@@ -40,8 +43,10 @@ for wl in "clips256 python3 $R/tools/kbench.py crnn 256 5" "wave256 python3 $R/t
   pmc ${name}_sq2 "$SQ2" "$@"
 done
 # 3. what the SQ counters count (known instruction streams)
+if [ $WHAT = pmc1 ] || [ $WHAT = all ]; then
 pmc calib "SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" $R/tools/build/pmc_calib
 $R/tools/build/pmc_calib > $O/pmc_calib_memtime.jsonl
+fi
 cd $R
 mkdir -p $O/summary
 python3 tools/pmc_collect.py $O/summary/pmc_counters.json clips256=$O/pmc_clips256_fetch clips256=$O/pmc_clips256_write clips256=$O/pmc_clips256_sq1 clips256=$O/pmc_clips256_sq2 \

@@ -7,12 +7,15 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "wakeword-detection_amd")]
 import numpy as np
 from wwhip.engine import Engine, frontend_params
 minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 10.0
-opts = dict(a.split("=", 1) for a in sys.argv[2:])  # e.g. crnn_tail_mfma=0 crnn_slide_min=0 (Engine.set_option)
+opts = dict(a.split("=", 1) for a in sys.argv[2:])  # e.g. crnn_tail_mfma=0 crnn_slide_min=0 (Engine.set_option); models=crnn
+only = opts.pop("models", "")
 rng = np.random.default_rng(0)
 n = int(minutes * 60 * 16000)
 pcm = np.clip(rng.normal(0, 2500, n), -32768, 32767).astype(np.int16)
 out = {}
 for name, prec in (("CRNN", "fp32"), ("CRNN", "bf16x3"), ("Wavenet", "fp32"), ("Wavenet", "bf16x3")):
+    if only and (name.lower() != only or prec != "fp32"):
+        continue
     eng = Engine(os.path.join(ROOT, "wakeword-detection_amd/assets/tf_lite_models", name), precision=prec)
     for k, v in opts.items():
         if eng.is_crnn:
