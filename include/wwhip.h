@@ -128,9 +128,10 @@ int ww_model_set_precision(ww_model *model, int precision);
  *                          instead of one crnn_fused_kernel (default 1024; 0 = always one fused kernel)
  *   WW_OPT_CRNN_SLIDE_MIN  regular sliding windows (ww_slide_forward, ww_forward_segments_dev) take the once-per-sequence
  *                          form crnn_rows_kernel + gru_tail_kernel from this many windows on (default 64; 0 = never)
- *   WW_OPT_CRNN_TAIL_MFMA  the recurrences of those two forms: 1 (default) = sixteen windows per workgroup, recurrent products
- *                          on v_mfma_f32_16x16x4_f32 (gru_tail16_kernel); 0 = one window per workgroup on the vector ALU
- *                          (gru_tail_kernel)
+ *   WW_OPT_CRNN_TAIL_MFMA  the recurrences of those two forms: sixteen windows per workgroup with the recurrent products and
+ *                          the layer-2 projection on v_mfma_f32_16x16x4_f32 (gru_tail16_kernel), or one window per workgroup
+ *                          on the vector ALU (gru_tail_kernel).  1 (default) = the matrix form from 9,216 windows per launch on
+ *                          (below that its 38-step serial chain on few workgroups loses); 2 = always; 0 = never
  *   WW_OPT_WAVENET_ROWMAJOR 0 (default) = the fp32 Wavenet block loop in transposed form (channels x time: BatchNorm output and
  *                          gate product feed the next MFMA straight from registers); 1 = rounds 1-2's row-major loop (both
  *                          through LDS).  Same products, another summation order of the three taps and the bias. */

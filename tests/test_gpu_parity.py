@@ -179,10 +179,10 @@ def test_wavenet_split_bf16_mode(assets, oracles, golden, name):
 @pytest.mark.parametrize("name", ["CRNN", "CRNN_softmax"])
 def test_crnn_large_batch_path(engines, oracles, name):
     """Above 1,024 windows per launch the CRNN runs as crnn_fused_kernel<front> + a tail kernel for the recurrences:
-    gru_tail16_kernel (default: sixteen windows per workgroup, recurrent products and the layer-2 projection on
-    v_mfma_f32_16x16x4_f32, a partial last workgroup: 1,500 = 93 x 16 + 12) within 2e-6 of the one-kernel path, and
-    gru_tail_kernel (option crnn_tail_mfma = 0: one window per workgroup on the vector ALU) bit for bit; the oracle's within
-    tolerance - windows with partial validity included, encoder output too."""
+    gru_tail16_kernel (option crnn_tail_mfma = 2 here; by default from 9,216 windows per launch on: sixteen windows per workgroup,
+    recurrent products and the layer-2 projection on v_mfma_f32_16x16x4_f32, a partial last workgroup: 1,500 = 93 x 16 + 12)
+    within 2e-6 of the one-kernel path, and gru_tail_kernel (one window per workgroup on the vector ALU; options 0 and, at
+    this size, 1) bit for bit; the oracle's within tolerance - windows with partial validity included, encoder output too."""
     rng = np.random.default_rng(31)
     e = engines[name]
     wins = rng.uniform(0, 6.5, (1500, e.window, 40)).astype(np.float32)
@@ -192,10 +192,10 @@ def test_crnn_large_batch_path(engines, oracles, name):
     idx = rng.choice(1500, 96, replace=False)
     want, want_enc = oracles[name].forward(wins[idx], want_enc=True)
     try:
-        for mfma in (1, 0):
+        for mfma in (2, 1, 0):
             e.set_option("crnn_tail_mfma", mfma)
             big, big_enc = e.forward(wins, want_enc=True)       # one launch of 1,500 windows: front + tail
-            if mfma:
+            if mfma == 2:
                 assert np.abs(big - small).max() < 2e-6, float(np.abs(big - small).max())
             else:
                 np.testing.assert_array_equal(big, small)
@@ -240,10 +240,9 @@ def test_crnn_split_bf16_mode(assets, oracles, golden, name):
         big = rng.uniform(0, 6.5, (1300, e.window, 40)).astype(np.float32)   # > 1,024 windows: front + tail kernels
         big[::7, 140:] = 0
         got_big = e.forward(big)
-        # the front kernel's projections are the fused kernel's bit for bit; gru_tail16_kernel sums the recurrent products in another order
-        assert np.abs(got_big[:300] - e.forward(big[:300])).max() < 2e-6
-        with e.options(crnn_tail_mfma=0):
-            np.testing.assert_array_equal(e.forward(big)[:300], e.forward(big[:300]))   # gru_tail_kernel: same arithmetic in both forms
+        np.testing.assert_array_equal(got_big[:300], e.forward(big[:300]))   # front + gru_tail_kernel: the fused kernel's arithmetic
+        with e.options(crnn_tail_mfma=2):  # gru_tail16_kernel sums the recurrent products in another order
+            assert np.abs(e.forward(big)[:300] - got_big[:300]).max() < 2e-6
         # ragged clips: windows with valid < T rows (zero padded in the kernel's staging) and sliding windows
         from wwhip.evaluate import clip_posteriors, synth_testset
         clips, _ = synth_testset(40, seed=5, min_s=0.6, max_s=2.4)
@@ -611,12 +610,11 @@ def test_crnn_sliding_rows_path_matches_per_window_kernels(engines, oracles, nam
         rows = (nw - 1) * hop + T + (0 if hop == 4 else 3)
         mel = rng.uniform(0, 6.5, (rows, 40)).astype(np.float32)
         mel[rng.integers(0, rows, 5)] = 0
-        got = e.slide_forward(mel, hop)                     # gathering gru_tail16_kernel (16 windows per workgroup, MFMA)
-        e.set_option("crnn_tail_mfma", 0)
-        try:
+        with e.options(crnn_tail_mfma=2):
+            got = e.slide_forward(mel, hop)                 # gathering gru_tail16_kernel (16 windows per workgroup, MFMA)
+        with e.options(crnn_tail_mfma=0):
             got_valu = e.slide_forward(mel, hop)            # gathering gru_tail_kernel (one window per workgroup, vector ALU)
-        finally:
-            e.set_option("crnn_tail_mfma", 1)
+        np.testing.assert_array_equal(e.slide_forward(mel, hop), got_valu)   # default: the matrix form only from 9,216 windows on
         assert got.shape[0] == (rows - T) // hop + 1 >= nw
         wins = np.stack([mel[i * hop:i * hop + T] for i in range(got.shape[0])])
         ref = np.concatenate([e.forward(wins[i:i + 512]) for i in range(0, len(wins), 512)])

@@ -751,7 +751,10 @@ int ww_model_set_option(ww_model *m, int key, int64_t value) {
   switch (key) {
     case WW_OPT_CRNN_SPLIT_AT: m->opt_split_at = (int)value; return WW_OK;
     case WW_OPT_CRNN_SLIDE_MIN: m->opt_slide_min = (int)value; return WW_OK;
-    case WW_OPT_CRNN_TAIL_MFMA: m->opt_tail_mfma = value != 0; return WW_OK;
+    case WW_OPT_CRNN_TAIL_MFMA:
+      if (value > 2) return ww_fail(m->ctx, WW_EINVAL, "WW_OPT_CRNN_TAIL_MFMA takes 0 (never), 1 (from 9,216 windows per launch) or 2 (always)");
+      m->opt_tail_mfma = (int)value;
+      return WW_OK;
     case WW_OPT_WAVENET_ROWMAJOR: m->opt_wave_rowmajor = value != 0; return WW_OK;
     default: return ww_fail(m->ctx, WW_EINVAL, "unknown model option %d", key);
   }

@@ -1870,11 +1870,15 @@ int ww_k_crnn_stream_forward(ww_ctx *ctx, const ww_model *m, const float *d_hist
 }
 
 // Everything behind the layer-1 projections: sixteen windows per workgroup with the recurrent products on the matrix pipe
-// (gru_tail16_kernel, default), or one window per workgroup on the vector ALU (gru_tail_kernel: WW_OPT_CRNN_TAIL_MFMA = 0).
+// (gru_tail16_kernel), or one window per workgroup on the vector ALU (gru_tail_kernel).  The matrix form is a 38-step serial
+// chain of ~4 k cycles per step on two waves: it needs >= ~600 workgroups to beat the vector form (tools/tail_sweep.py:
+// front + tail per launch 743 vs 745 us at 9,216 windows, 1,204 vs 1,309 at 16,384, but 226 vs 188 at 2,048), so
+// WW_OPT_CRNN_TAIL_MFMA = 1 (default) takes it from WW_TAIL16_MIN windows per launch on; 2 = always, 0 = never.
+#define WW_TAIL16_MIN 9216
 static size_t tail_seq_bytes(int nw) { return ww_bump::need((size_t)((nw + 15) / 16) * CV_OT * 16 * 2 * GR_H, 4); }
 static void launch_tail(ww_ctx *ctx, const ww_model *m, tail_args t, int nw, float *seq) {
   t.wx2 = m->crnn.wx2;
-  if (m->opt_tail_mfma) {
+  if (m->opt_tail_mfma == 2 || (m->opt_tail_mfma == 1 && nw >= WW_TAIL16_MIN)) {
     tail16_args a16 = {t, seq, nw};
     ww_launch_scope scope(ctx, "gru_tail16_kernel");
     hipLaunchKernelGGL(gru_tail16_kernel, dim3((unsigned)((nw + 15) / 16)), dim3(128), 0, ctx->stream, a16);

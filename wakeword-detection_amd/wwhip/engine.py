@@ -62,9 +62,9 @@ class Engine:
     def set_option(self, key: str, value: int) -> None:
         """Per-model dispatch options (``ww_model_set_option``): ``"crnn_split_at"`` - explicit-window launches above
         this many windows take front + tail kernels (0 = always one fused kernel); ``"crnn_slide_min"`` - regular
-        sliding windows take the once-per-sequence form from this many windows on (0 = never); ``"crnn_tail_mfma"`` - 1 (default):
-        the recurrences of those two forms for sixteen windows per workgroup on the matrix pipe, 0: one window per workgroup
-        on the vector ALU; ``"wavenet_rowmajor"`` - 1: the fp32 Wavenet's row-major block loop of rounds 1-2 instead of the
+        sliding windows take the once-per-sequence form from this many windows on (0 = never); ``"crnn_tail_mfma"`` - the recurrences
+        of those two forms for sixteen windows per workgroup on the matrix pipe: 1 (default) from 9,216 windows per launch on,
+        2 always, 0 never (one window per workgroup on the vector ALU); ``"wavenet_rowmajor"`` - 1: the fp32 Wavenet's row-major block loop of rounds 1-2 instead of the
         transposed one."""
         keys = {"crnn_split_at": _lib.OPT_CRNN_SPLIT_AT, "crnn_slide_min": _lib.OPT_CRNN_SLIDE_MIN,
                 "crnn_tail_mfma": _lib.OPT_CRNN_TAIL_MFMA, "wavenet_rowmajor": _lib.OPT_WAVENET_ROWMAJOR}

@@ -221,7 +221,10 @@ def _pieces_forward(eng: Engine, pieces: List[np.ndarray], n_win: List[int], hop
     n_tot = int(sum(n_win))
     d_out = torch.empty((n_tot, eng.n_out), dtype=torch.float32, device=dev)
     torch.cuda.synchronize(dev)
-    eng.forward_segments_dev(d_mel.data_ptr(), total_f, foffs[:-1], np.asarray(n_win, np.int32), hop, d_out.data_ptr())
+    # one tail kernel whatever the share's size: a rank's posteriors must not depend on how many windows its launch holds
+    # (the library would pick the tail by window count; the two tails sum in another order, ~1e-7)
+    with eng.options(crnn_tail_mfma=2):
+        eng.forward_segments_dev(d_mel.data_ptr(), total_f, foffs[:-1], np.asarray(n_win, np.int32), hop, d_out.data_ptr())
     eng.ctx.synchronize()
     return d_out.cpu().numpy()
 
@@ -476,7 +479,8 @@ def clip_posteriors(engine: Engine, clips: Sequence[np.ndarray], hop: int = 2, f
     with engine.options(crnn_split_at=0):
         engine.forward_windows_dev(d_mel.data_ptr(), total_f, d_row.data_ptr(), d_valid.data_ptr(), n, d_out.data_ptr())
     if n_slide:
-        engine.forward_segments_dev(d_mel.data_ptr(), total_f, foffs[:-1], nw, hop, d_out[n:].data_ptr())
+        with engine.options(crnn_tail_mfma=2):  # as above: the same tail kernel for every shard size
+            engine.forward_segments_dev(d_mel.data_ptr(), total_f, foffs[:-1], nw, hop, d_out[n:].data_ptr())
     engine.ctx.synchronize()
     post = d_out.cpu().numpy()[:, pidx]
     p_one, slide = post[:n], post[n:]
