@@ -339,29 +339,47 @@ __global__ __launch_bounds__(WV_NW * 64, WV_NW == 12 ? (SPLIT_BF16 ? WV_BF16_OCC
     wload(0, pw[0]);
     const int tl = wave * 16 + j;  // this lane's time column
     __syncthreads();               // table + zero rows
+    // a block's seven small vectors (this lane's channel group): read from the table one block AHEAD, behind the barrier, so
+    // that no LDS round trip sits in front of the u write, the accumulators' initial values or the res | skip products
+    // (the BatchNorm pair and the gate biases, which a block needs at once; the res | skip biases are requested at the top of their
+    // own block and used ~1,500 cycles later: prefetching all seven costs 56 registers and spills)
+    struct vblk_t { float4 bns, bnt, bsig, btanh; };
+    auto vload = [&](int blk, vblk_t &v) {
+      const float4 *vt = (const float4 *)(vtab + blk * 112) + kk;  // vector q: vt[4 q]
+      v.bns = vt[0]; v.bnt = vt[4]; v.bsig = vt[8]; v.btanh = vt[12];
+    };
+    vblk_t pv[2];
+    vload(0, pv[0]);
     auto f4 = [](const float4 &v) { return (f32x4){v.x, v.y, v.z, v.w}; };
-    auto run_block_t = [&](int blk, const wblk_t &P, wblk_t &Pnext) {
+    auto run_block_t = [&](int blk, const wblk_t &P, wblk_t &Pnext, const vblk_t &V, vblk_t &Vnext) {
       float *u = ubuf + (blk & 1) * 4 * UPL + kk * UPL + WV_PAD * 4;          // row 0 of this lane's channel-group plane
       const int d = (int)((a.dil4[blk >> 4] >> (4 * (blk & 15))) & 15);
-      const float4 *vt = (const float4 *)(vtab + blk * 112) + kk;            // vector v: vt[4 v]
-      const float4 bns = vt[0], bnt = vt[4];
-      const float4 uv = make_float4(x[0][0] * bns.x + bnt.x, x[0][1] * bns.y + bnt.y, x[0][2] * bns.z + bnt.z, x[0][3] * bns.w + bnt.w);
+      const float4 *vt = (const float4 *)(vtab + blk * 112) + kk;
+      const float4 bres = vt[16], bsk0 = vt[20], bsk1 = vt[24];
+      const float4 uv = make_float4(x[0][0] * V.bns.x + V.bnt.x, x[0][1] * V.bns.y + V.bnt.y, x[0][2] * V.bns.z + V.bnt.z,
+                                    x[0][3] * V.bns.w + V.bnt.w);
       *(float4 *)(u + tl * 4) = uv;
-      wload(blk + 1 < a.NB ? blk + 1 : blk, Pnext);  // unconditional (clamped) prefetch, as the row-major loop
-      f32x4 as = f4(vt[8]), at = f4(vt[12]);
+      const float *tap0 = u + (tl - 2 * d) * 4, *tap1 = u + (tl - d) * 4;     // rows < 0 hit the zero pad (d <= 8)
+      const int nb = blk + 1 < a.NB ? blk + 1 : blk;
+      wload(nb, Pnext);  // unconditional (clamped) prefetch, as the row-major loop
+      f32x4 as = f4(V.bsig), at = f4(V.btanh);
       MFMA4(as, P.wg[2][0], uv);                     // tap 2 = this row: runs while the other waves arrive
       MFMA4(at, P.wg[2][1], uv);
       __syncthreads();  // u complete (all rows, all waves)
-      const float4 t0v = *(const float4 *)(u + (tl - 2 * d) * 4);  // rows < 0 hit the zero pad (d <= 8)
-      const float4 t1v = *(const float4 *)(u + (tl - d) * 4);
+      const float4 t0v = *(const float4 *)tap0;
+      const float4 t1v = *(const float4 *)tap1;
+      vload(nb, Vnext);
+      __builtin_amdgcn_sched_barrier(0);  // both tap reads (and the table reads behind them) are in flight before the first wait
       MFMA4(as, P.wg[0][0], t0v);
       MFMA4(at, P.wg[0][1], t0v);
       MFMA4(as, P.wg[1][0], t1v);
       MFMA4(at, P.wg[1][1], t1v);
       const float4 gv = make_float4(fast_tanh_w(at[0]) * fast_sigmoid_w(as[0]), fast_tanh_w(at[1]) * fast_sigmoid_w(as[1]),
                                     fast_tanh_w(at[2]) * fast_sigmoid_w(as[2]), fast_tanh_w(at[3]) * fast_sigmoid_w(as[3]));
-      f32x4 ar = f4(vt[16]), s0 = f4(vt[20]), s1 = f4(vt[24]);
+      f32x4 ar = f4(bres), s0 = f4(bsk0), s1 = f4(bsk1);
       const int has_res = (a.has_res_mask >> blk) & 1;
+      // (hand-interleaving the k-steps of the accumulators - dependent MFMAs issue after 40 cycles, independent ones after 32 - was
+      //  1 % SLOWER: with three waves per SIMD the other waves fill those 8 cycles, and the compiler's own order keeps fewer values live)
       if (has_res) { MFMA4(ar, P.wrs[0], gv); }
       MFMA4(s0, P.wrs[1], gv);
       MFMA4(s1, P.wrs[2], gv);
@@ -373,8 +391,8 @@ __global__ __launch_bounds__(WV_NW * 64, WV_NW == 12 ? (SPLIT_BF16 ? WV_BF16_OCC
       }
     };
     for (int blk = 0; blk < a.NB; blk += 2) {
-      run_block_t(blk, pw[0], pw[1]);
-      if (blk + 1 < a.NB) run_block_t(blk + 1, pw[1], pw[0]);
+      run_block_t(blk, pw[0], pw[1], pv[0], pv[1]);
+      if (blk + 1 < a.NB) run_block_t(blk + 1, pw[1], pw[0], pv[1], pv[0]);
     }
     __syncthreads();
   } else if (!SPLIT_BF16) {
