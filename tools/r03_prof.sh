@@ -16,6 +16,8 @@ rocprofv3 $STATS -d $O/kt_bench_default -o run -- python3 $R/bench.py --no-cpu-b
 echo "kt bench default done"
 rocprofv3 $STATS -d $O/kt_bench_wavenet -o run -- python3 $R/bench.py --model wavenet --pipeline 1 --no-cpu-baseline --no-extra > $O/bench_wavenet_under_rocprof.json 2> $O/kt_bench_wavenet.err
 echo "kt bench wavenet done"
+rocprofv3 $STATS -d $O/kt_bench_wavenet_fp32 -o run -- python3 $R/bench.py --model wavenet --precision fp32 --pipeline 1 --no-cpu-baseline --no-extra > $O/bench_wavenet_fp32_under_rocprof.json 2> $O/kt_bench_wavenet_fp32.err
+echo "kt bench wavenet fp32 done"
 rocprofv3 $STATS -d $O/kt_slide -o run -- python3 $R/tools/slide_throughput.py 10 > $O/slide_under_rocprof.json 2> $O/kt_slide.err
 echo "kt slide done"
 rocprofv3 $STATS -d $O/kt_stream -o run -- python3 $R/tools/stream_prof.py > $O/stream_under_rocprof.txt 2> $O/kt_stream.err
@@ -58,7 +60,7 @@ python3 tools/pmc_collect.py $O/summary/pmc_counters.json clips256=$O/pmc_clips2
 fi
 cd $R
 mkdir -p $O/summary
-for d in kt_bench_single kt_bench_default kt_bench_wavenet kt_slide kt_stream; do
+for d in kt_bench_single kt_bench_default kt_bench_wavenet kt_bench_wavenet_fp32 kt_slide kt_stream; do
   f=$(ls $O/$d/*/*kernel_stats.csv $O/$d/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/summary/${d}_kernel_stats.csv
 done
 ls $O/summary
