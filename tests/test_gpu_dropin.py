@@ -646,3 +646,56 @@ def test_entry_points_leave_the_callers_device_alone(assets):
         torch.cuda.set_device(0)
     if n_dev < 2:
         pytest.skip("one GPU: only the no-op half of the check could run")
+
+
+def test_get_posterior_edge_cases(assets, tmp_path):
+    """get_posterior off the beaten path, against the C oracle over the same padded stream(s): a custom loader that returns
+    float32 samples (the front end's float entry point), `carry_over=False` (a fresh ring per file), a 25 ms `frame_width`
+    (400-sample chunks: not a multiple of the hop), a file too short for a window - skipped in the negative stream, `ValueError`
+    for a positive clip (the reference's `np.max` of an empty list) - and an empty file list."""
+    from wwhip.evaluate import get_posterior, read_wav, StreamPlan
+    from wwhip.models import engine_for
+    from oracle.cpu import CpuOracle
+    mdir = os.path.join(assets, "CRNN_softmax")
+    eng = engine_for(mdir)
+    ora = CpuOracle(eng.blob)
+    rng = np.random.default_rng(77)
+    pcms = [np.clip(rng.normal(0, 2500, n), -32768, 32767).astype(np.int16) for n in (30000, 3000, 41000)]
+    files = []
+    for i, p in enumerate(pcms):
+        files.append(str(tmp_path / f"e{i}.wav"))
+        _write_wav(files[-1], p)
+
+    def oracle_stream(lens_pcms, fl, carry):
+        plan = StreamPlan([len(p) for p in lens_pcms], eng.window, fl, carry_over=carry)
+        out = []
+        if carry:
+            whole = np.zeros(int(plan.padded.sum()), np.int16)
+            for k, p in enumerate(lens_pcms):
+                whole[plan.pos[k] + 8000: plan.pos[k] + 8000 + len(p)] = p
+            mel = ora.logmel(whole, 32768.0, False)
+            for k in range(len(lens_pcms)):
+                rows = mel[plan.F[k]: plan.F[k] + plan.n_frames[k]]
+                out.append(ora.slide_forward(rows, 2)[:plan.n_win[k], 1] if plan.n_win[k] else np.zeros(0, np.float32))
+        else:
+            for k, p in enumerate(lens_pcms):
+                one = np.zeros(int(plan.padded[k]), np.int16)
+                one[8000:8000 + len(p)] = p
+                out.append(ora.slide_forward(ora.logmel(one, 32768.0, False), 2)[:plan.n_win[k], 1])
+        return plan, out
+
+    for fw, carry, loader in ((20, True, None), (20, False, None), (25, True, None), (20, True, lambda p: read_wav(p))):
+        plan, want = oracle_stream(pcms, 16 * fw, carry)
+        assert plan.n_win[1] == 0 and plan.n_win[0] > 0
+        neg = np.array(get_posterior(mdir, "CRNN", "false_accepts", files, fw, 16000, loader=loader, carry_over=carry), np.float32)
+        flat = np.concatenate(want)
+        assert len(neg) == len(flat) == plan.total
+        assert np.abs(neg - flat).max() < TOL, (fw, carry, float(np.abs(neg - flat).max()))
+    pos = get_posterior(mdir, "CRNN", "false_negatives", [files[0], files[2]], 20, 16000)
+    plan, want = oracle_stream([pcms[0], pcms[2]], 320, True)
+    assert np.abs(np.array(pos) - np.array([w.max() for w in want])).max() < TOL
+    with pytest.raises(ValueError):
+        get_posterior(mdir, "CRNN", "false_negatives", files, 20, 16000)     # the 3,000-sample clip yields no window
+    assert get_posterior(mdir, "CRNN", "false_accepts", [], 20, 16000) == []
+    with pytest.raises(ValueError):
+        get_posterior(mdir, "LSTM", "false_accepts", files, 20, 16000)

@@ -245,6 +245,44 @@ def test_stream_plan_matches_reference_loop_over_files():
             assert max(sizes) - min(sizes) <= 1                     # contiguous ranges of equal size (dist.split_stream)
 
 
+@pytest.mark.parametrize("frame_width", [10, 20, 25, 40])
+def test_stream_plan_other_chunk_sizes_and_no_carry(frame_width):
+    """The same pin for other `frame_width`s of the evaluator's command line (10 ms: one mel frame per chunk, so the one-inference-
+    per-chunk rule lets the buffer grow; 25 ms = 400 samples: not a multiple of the hop, frames per chunk alternate 2, 3) and for
+    `carry_over=False` (a fresh ring per file)."""
+    rng = np.random.default_rng(5)
+    fl = 16 * frame_width
+    lens = [30000, 12345, 41000]
+    for carry in (True, False):
+        counter = [0]
+
+        def filter_model(mag):
+            counter[0] += 1
+            return np.full((1, 40), counter[0] - 1, np.float32)
+
+        filt = NR.RefFilter(filter_model)
+        filt.stft_mag = lambda: np.zeros(257, np.float32)
+        plan = E.StreamPlan(lens, 151, fl, carry_over=carry)
+        for k, n in enumerate(lens):
+            if not carry:                                           # a fresh Filter per file, frame ids restart at 0
+                counter[0] = 0
+                filt = NR.RefFilter(filter_model)
+                filt.stft_mag = lambda: np.zeros(257, np.float32)
+            wins = []
+            NR.sliding_posteriors(filt, rng.normal(0, 0.1, n).astype(np.float32), 151,
+                                  lambda w: wins.append((int(w[0, 0]), int(w[-1, 0]))) or 0.0, frame_length=fl)
+            assert plan.n_win[k] == len(wins), (frame_width, carry, k)
+            for i, (first, last) in enumerate(wins):
+                assert first == plan.F[k] + 2 * i and last == first + 150
+                s0, s1 = plan.sample_range(k, i, i + 1)
+                base = 0 if carry else 0
+                assert s0 == base + 160 * first and s1 == base + 160 * last + 512
+        if carry:
+            assert (plan.pos[1:] > 0).all()
+        else:
+            assert (plan.pos == 0).all() and (plan.F == 0).all()
+
+
 def test_join_negatives_is_concatenate_FA(tmp_path):
     """join_negatives (in memory) == concatenate_FA (wav files): first num_files clips, 100 ms of silence between."""
     import wave
