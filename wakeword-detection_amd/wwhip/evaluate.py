@@ -166,15 +166,14 @@ class StreamPlan:
         default: no sample before the first frame is needed)."""
         g0 = int(self.F[k]) + self.hop * i0
         g1 = int(self.F[k]) + self.hop * (i1 - 1) + self.T - 1
-        base = 0 if self.carry else int(self.pos[k])  # without carry every file has its own grid (F = 0, pos = 0)
-        return base + 160 * g0, base + 160 * g1 + WINDOW
+        return 160 * g0, 160 * g1 + WINDOW  # (without carry every file has its own stream: pos = 0, F = 0)
 
 
 def _stream_slice(plan: StreamPlan, load: Callable[[int], np.ndarray], cache: dict, s0: int, s1: int, k_hint: int) -> np.ndarray:
     """Samples ``[s0, s1)`` of the concatenated padded stream, touching only the files that overlap it."""
     pos = plan.pos if plan.carry else np.zeros_like(plan.pos)
     ks = [k_hint] if not plan.carry else [k for k in range(max(k_hint - 1, 0), len(pos)) if pos[k] < s1 and pos[k] + plan.padded[k] > s0]
-    parts, dt = [], np.int16
+    dt = np.int16
     for k in ks:
         if k not in cache:
             cache[k] = np.asarray(load(k))
