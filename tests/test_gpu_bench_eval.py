@@ -81,6 +81,26 @@ def test_bench_starts_its_own_ranks():
     assert d["eval_testset"]["world_size"] == 2 and d["streaming"]["crnn"]["p50_ms"] > 0
 
 
+def test_bench_under_torch_distributed_run():
+    """The driver's launch form for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` - the ranks come from the launcher (RANK / WORLD_SIZE in the environment),
+    bench.py must not start its own.  One-GPU box: gloo rehearsal.  The evaluation leg's numbers equal the one-rank line's."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29668", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12",
+                        "--warmup", "4", "--stream-ticks", "100", "--eval-clips", "256"], capture_output=True, text=True, timeout=900,
+                       env=dict(env, WW_BENCH_BACKEND="gloo", WW_BENCH_CPU_SECONDS="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 12 and d["eval_testset"]["world_size"] == 2 and d["cpu_baseline"] is None
+    one = _bench(["--steps", "12", "--warmup", "4", "--stream-ticks", "100", "--eval-clips", "256", "--no-cpu-baseline"])
+    for k in ("frr_at_0.5_fa_per_hour", "fa_count_at_threshold_0.5", "posterior_checksum", "windows", "negative_hours"):
+        assert d["eval_testset"][k] == one["eval_testset"][k], k
+    assert d["eval_testset"]["per_clip_variant"]["posterior_checksum"] == one["eval_testset"]["per_clip_variant"]["posterior_checksum"]
+
+
 @pytest.fixture(scope="module")
 def testset_one_rank(assets):
     from wwhip.evaluate import synth_testset, evaluate_testset_sharded
