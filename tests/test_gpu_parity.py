@@ -653,6 +653,12 @@ def test_forward_segments_dev_matches_explicit_windows(engines, oracles, name):
         wins = np.stack([mel[r0 + k * hop: r0 + k * hop + T] for r0, nw in zip(seg_row0, seg_nw) for k in range(nw)])
         ref = e.forward(wins)
         assert np.abs(got - ref).max() < 2e-6, (hop, float(np.abs(got - ref).max()))
+        if e.is_crnn:  # the matrix tail (what the evaluation flows pin) with per-window first rows across sequence boundaries
+            d_out.zero_()
+            with e.options(crnn_tail_mfma=2):
+                e.forward_segments_dev(d_mel.data_ptr(), len(mel), seg_row0, seg_nw, hop, d_out.data_ptr())
+            e.ctx.synchronize()
+            assert np.abs(d_out.cpu().numpy() - ref).max() < 2e-6
         idx = rng.choice(len(wins), 16, replace=False)  # and against the CPU oracle, not only the library's other kernels
         assert np.abs(got[idx] - oracles[name].forward(wins[idx])).max() < TOL_POST
     with pytest.raises(ValueError):
