@@ -303,6 +303,21 @@ def test_join_negatives_is_concatenate_FA(tmp_path):
     np.testing.assert_array_equal(E.join_negatives(clips, 3), np.concatenate([clips[0], z, clips[1], z, clips[2]]))
 
 
+def test_window_schedule_closed_form_equals_the_loop():
+    """window_schedule (cumulative-maximum closed form) against the literal loop on random chunk patterns: chunks of 0..5 frames,
+    windows of several lengths, hops 1..3 - including files that never fill a window and files that end mid-buffer."""
+    rng = np.random.default_rng(12)
+    for trial in range(300):
+        K = int(rng.integers(0, 400))
+        fpc = rng.integers(0, int(rng.integers(1, 6)) + 1, K)
+        T = int(rng.choice([1, 7, 151, 182]))
+        hop = int(rng.integers(1, 4))
+        got = E.window_schedule(fpc, T, hop)
+        want = E._window_schedule_loop(fpc, T, hop)
+        assert got.tolist() == want.tolist(), (trial, K, T, hop)
+    assert E.window_schedule(np.zeros(0, int), 151).size == 0
+
+
 def test_read_wav_roundtrip(tmp_path):
     import wave
     p = str(tmp_path / "a.wav")

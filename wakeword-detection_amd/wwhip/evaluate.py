@@ -67,7 +67,27 @@ def frame_schedule(n_padded_per_file: Sequence[int], hop: int = 160, chunk: int 
 def window_schedule(frames_per_chunk: np.ndarray, encoder_len: int, hop: int = 2) -> np.ndarray:
     """Start row (within the file's frame list) of every window the reference evaluates:
     at most one inference per chunk, taken when >= encoder_len frames are buffered, after which
-    ``hop`` frames are dropped (evaluate_models.py:66-73)."""
+    ``hop`` frames are dropped (evaluate_models.py:66-73).
+
+    Closed form of that loop: with c_j the frames emitted up to and including chunk j, window n needs c_j >= T + hop n and a
+    chunk of its own after window n - 1's, so it is taken at chunk j_n = max(m_n, j_{n-1} + 1) with m_n the first such j, i.e.
+    j_n = n + max_{i <= n} (m_i - i); windows exist while j_n is a chunk of the file.  (The literal loop is
+    ``_window_schedule_loop``; tests/test_host_logic.py holds the two together and against the reference's RingBuffer-driven loop.)"""
+    fpc = np.asarray(frames_per_chunk, np.int64)
+    if fpc.size == 0:
+        return np.zeros(0, np.int64)
+    c = np.cumsum(fpc)
+    n_max = int((c[-1] - encoder_len) // hop + 1) if c[-1] >= encoder_len else 0
+    if n_max <= 0:
+        return np.zeros(0, np.int64)
+    n = np.arange(n_max, dtype=np.int64)
+    m = np.searchsorted(c, encoder_len + hop * n, side="left")
+    j = n + np.maximum.accumulate(m - n)
+    return hop * n[: int(np.count_nonzero(j < fpc.size))]
+
+
+def _window_schedule_loop(frames_per_chunk: np.ndarray, encoder_len: int, hop: int = 2) -> np.ndarray:
+    """The reference's loop, statement for statement (what :func:`window_schedule` is the closed form of)."""
     starts = []
     have = 0  # frames buffered
     base = 0  # index of the first buffered frame
@@ -130,12 +150,8 @@ class StreamPlan:
         self.n_frames = np.array([int(f.sum()) for f in per_file], np.int64)
         # first global frame credited to the file: the ring emits frames in order, so it is the count emitted before it
         self.F = np.array([((p - WINDOW) // 160 + 1 if p >= WINDOW else 0) for p in self.pos], np.int64)
-        nw = []
-        for fpc in per_file:
-            ws = window_schedule(fpc, self.T, self.hop)
-            assert np.array_equal(ws, self.hop * np.arange(len(ws)))  # the schedule drops `hop` rows per inference
-            nw.append(len(ws))
-        self.n_win = np.asarray(nw, np.int64)
+        # (window i of a file starts at row hop * i of its frame list: the schedule drops `hop` rows per inference)
+        self.n_win = np.array([len(window_schedule(fpc, self.T, self.hop)) for fpc in per_file], np.int64)
         self.offs = np.concatenate(([0], np.cumsum(self.n_win)))
 
     @property
