@@ -250,6 +250,17 @@ def test_reference_flow_equals_get_posterior_and_oracle(reference_flow_one_rank,
     np.testing.assert_array_equal(one["fa_count"], wc)
     np.testing.assert_array_equal(one["frr"], wf)
     assert one["frr_at_0.5_fa_per_hour"] == frr_at_fa(wf, wa, 0.5)
+    # this stand-in's joined stream never crosses 0.5 after smoothing (FA counts all zero above), so the sweep over the stream
+    # is exercised at thresholds it does cross: the GPU sweep of the GPU posteriors against plot_FRR_FAR's restatement on the
+    # same numbers (identical counts: no tolerance involved), smoothing across the former rank cuts included
+    from wwhip.evaluate import far_frr
+    low = np.arange(0.02, 0.5, 0.01)
+    _, frr_l, fa_l, cnt_l = far_frr(one["positives"], one["negatives"], len(wake), one["hours"], thresholds=low, engine=eng)
+    rf, ra, rc, _ = NR.far_frr(one["positives"], one["negatives"], len(wake), one["hours"], thresholds=low)
+    assert rc.max() > 20 and rc[-1] == 0                         # rising edges are really counted
+    np.testing.assert_array_equal(cnt_l, rc)
+    np.testing.assert_array_equal(frr_l, rf)
+    np.testing.assert_allclose(fa_l, ra, rtol=1e-15)
 
 
 def test_fp32_fft_front_end_leaves_far_frr_untouched(testset_one_rank, reference_flow_one_rank):
