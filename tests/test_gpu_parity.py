@@ -85,6 +85,55 @@ def test_logmel_float_input_matches_int16(engines):
     np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("pre,hop,as_float", [(0.0, 160, False), (0.97, 160, False), (0.0, 100, True), (0.5, 512, False), (0.0, 7, False)])
+def test_logmel_rows_across_clip_boundaries(engines, oracles, pre, hop, as_float):
+    """logmel_rows_kernel numbers mel rows through the whole launch and gives a wave four consecutive rows, whatever clips
+    they belong to: a batch must give, bit for bit, what its clips give one at a time (where every wave holds rows of one
+    clip), including clips of 1-3 frames (several boundaries inside one wave), frame-less clips in between, odd sample
+    offsets (the unaligned staging) and the ragged end of the buffer."""
+    from wwhip.engine import frontend_params
+    rng = np.random.default_rng(77)
+    W = 512
+    lens = [W + 146 * hop, W, W + hop, 0, W + 2 * hop + 1, 37, W + 5 * hop + 3, W + 3 * hop, W - 1, W + 11 * hop + hop // 2, W + 4 * hop]
+    pcm = [np.clip(rng.normal(0, 4000, n), -32768, 32767).astype(np.int16) for n in lens]
+    if as_float:
+        pcm = [p.astype(np.float32) / np.float32(32768.0) for p in pcm]
+    fp = frontend_params(32768.0, False, pre, hop, True)
+    eng = engines["CRNN"]
+    batch = eng.logmel(pcm, fp)
+    for n, p, got in zip(lens, pcm, batch):
+        nf = (n - W) // hop + 1 if n >= W else 0
+        assert got.shape == (nf, 40)
+        alone = eng.logmel([p], fp)[0]
+        np.testing.assert_array_equal(got, alone)
+    if not as_float and hop == 160:
+        for p, got in zip(pcm, batch):
+            if len(got):
+                assert np.abs(got - oracles["CRNN"].logmel(p, 32768.0, False, pre)).max() < TOL_MEL
+
+
+def test_logmel_equal_clips_arithmetic_lookup_equals_offset_tables(engines):
+    """ww_clips_forward_dev tells the front end that its clips are equal and back to back (row -> clip by arithmetic);
+    ww_logmel on the same clips walks the offset tables: the same posteriors, bit for bit, for a clip length whose frame count
+    is not a multiple of four (every clip boundary falls inside a wave)."""
+    import torch
+    from wwhip.engine import frontend_params
+    rng = np.random.default_rng(78)
+    eng = engines["CRNN"]
+    for samples in (24000, 512 + 160 * 6, 700):
+        pcm = np.clip(rng.normal(0, 3000, (9, samples)), -32768, 32767).astype(np.int16)
+        fp = frontend_params(32767.0, True, 0.0, 160, True)
+        d = torch.from_numpy(pcm).cuda()
+        out = torch.empty((9, eng.n_out), dtype=torch.float32, device="cuda")
+        eng.clips_forward_dev(d.data_ptr(), 9, samples, out.data_ptr(), fp)
+        eng.ctx.synchronize()
+        mels = eng.logmel(list(pcm), fp)
+        wins = np.zeros((9, eng.window, 40), np.float32)
+        for i, m in enumerate(mels):
+            wins[i, :min(len(m), eng.window)] = m[:eng.window]
+        np.testing.assert_array_equal(out.cpu().numpy(), eng.forward(wins))
+
+
 # ---------------------------------------------------------------- models
 @pytest.mark.parametrize("name", MODELS)
 def test_forward_golden(engines, golden, name):

@@ -10,6 +10,7 @@ model = sys.argv[1] if len(sys.argv) > 1 else "crnn"
 clips = 256; steps = 400
 rng = np.random.default_rng(0)
 pcm = np.clip(rng.normal(0, 2000, (clips, 24000)), -32768, 32767).astype(np.int16)
+if "zeros" in sys.argv: pcm[:] = 0  # DVFS probe: same instruction stream, no toggling
 fp = frontend_params()
 for C in (1, 2, 3, 4, 6, 8):
     ctxs = [_lib.Context(0) for _ in range(C)]

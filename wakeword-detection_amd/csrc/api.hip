@@ -1164,7 +1164,7 @@ int ww_clips_forward_dev(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, i
     ww_bump bump(ctx->dev.ptr, ctx->dev.cap);
     float *d_mel = bump.take<float>((size_t)n_clips * (nf > 0 ? nf : 1) * F);
     void *ws = bump.take<char>(b_ws);
-    int r = ww_k_logmel(ctx, m, d_pcm, nullptr, d_so, d_fo, n_clips, (int64_t)n_clips * nf, nf, fp, d_mel);
+    int r = ww_k_logmel(ctx, m, d_pcm, nullptr, d_so, d_fo, n_clips, (int64_t)n_clips * nf, nf, fp, d_mel, samples);
     if (r) return r;
     // one window per clip: rows [c*nf, c*nf + min(nf, T)), zero padded to T
     return model_forward(ctx, m, d_mel, (int64_t)n_clips * nf, nullptr, nullptr, 0, (int)nf, (int)(nf < T ? nf : T),

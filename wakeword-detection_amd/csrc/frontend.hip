@@ -72,6 +72,10 @@ struct logmel_args {
   const float *frames;
   float *mag_out;
   int64_t n_frames_direct;
+  // logmel_rows_kernel: mel rows are numbered through the whole launch
+  int64_t total_frames;
+  int uniform_nf;      // > 0: every clip has this many frames and uniform_ns samples, clip u starts at sample u * uniform_ns
+  int64_t uniform_ns;
   long long *stamps;  // development (-DWW_FE_STAMPS=1): [workgroups][4 waves][12] s_memtime at the phase boundaries
 };
 
@@ -640,6 +644,465 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? 4 : 5) void logmel_kernel(log
   FE_STAMP(11)
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// logmel_rows_kernel (round 4): the fp64 front end with NOTHING shared between the waves of a workgroup.
+//
+// Why.  In the pipelined step the front end of batch i+1 runs in the shadow of batch i's crnn_fused_kernel, whose one
+// wave per SIMD keeps the shared fp32-MFMA / vector datapath about half busy; how much of the other half the front end
+// picks up is set by how many of its waves fit beside a CRNN workgroup.  logmel_kernel<f64> costs 10 KB of LDS and 128
+// registers per wave (40 KB per 4-wave workgroup: the 16-frame sample tile + Hann table + three transpose buffers), so two
+// workgroups = 8 waves fit.  This kernel costs 8.5 KB and 104 registers per wave and no workgroup barrier:
+//   * a wave owns the four consecutive GLOBAL frames 4 W .. 4 W + 3 of the launch (mel rows are numbered through all
+//     clips), so tiles run across clip boundaries: 37,632 frames = 9,408 full waves, none of the 256 three-frame tiles of
+//     the per-clip tiling, and ragged batches leave no partly filled workgroups behind;
+//   * it stages its own samples (<= 512 + 3 hop, two 16-byte loads per lane) into ITS transpose buffer, which is dead
+//     until the first DFT pass is over: LDS instructions of one wave execute in order, so neither the hand-over of the
+//     buffer from tile to transposes to magnitudes to the output tile nor the staging needs a barrier;
+//   * Hann pairs and twiddles come from the L1-resident tables (4 + 4 + 4 KB, shared by every wave of the chip);
+//   * 104 registers (amdgpu_num_vgpr counts in units of two on gfx90a+): the Hann products, the inter-pass twiddles and the
+//     untangling twiddles are software-pipelined by hand in chunks of 4 / 3 / 2 instead of all at once, and the mel
+//     weights are fetched group by group: three of these waves sit on a SIMD beside a 184-register CRNN wave, four alone.
+// A wave whose four frames do not lie in one clip within 3 hops of each other (a clip boundary) stages them frame by frame
+// (generic path, <= 1 wave in 37 for 1.5 s clips).  The arithmetic is logmel_kernel<f64>'s, instruction for instruction:
+// results are bit-identical.
+// ---------------------------------------------------------------------------------------------------------------------
+#ifndef LW_WPB
+#define LW_WPB 4  // waves per workgroup (they share nothing; 4 = fewest workgroups to dispatch)
+#endif
+#define LW_WBUF (4 * 16 * TR_LD * 8)  // 8,704 B per wave: 16x16 fp64 transposes of 4 frames; before that the sample tile
+#define LW_ROWF 528                   // generic path: floats per staged frame (512 + up to 7 of shift, 16-byte multiple)
+static_assert(4 * LW_ROWF * 4 <= LW_WBUF && (WIN + 3 * 512 + 16) * 4 <= LW_WBUF && 4 * MAG_LD * 4 <= LW_WBUF, "per-wave buffer too small");
+
+// dst[q * VEC + e] = normalised (and pre-emphasised) sample ga + q * VEC + e, q < n_vec; ga is a multiple of VEC
+template <bool F32IN>
+__device__ __forceinline__ void lw_stage_generic(const logmel_args &a, float *dst, int64_t ga, int n_vec, int64_t s_begin,
+                                                 int64_t total, int lane) {
+  constexpr int VEC = F32IN ? 4 : 8;
+  const float alpha = a.preemph;
+  for (int q = lane; q < n_vec; q += 64) {
+    const int64_t g = ga + (int64_t)q * VEC;
+    float v[VEC + 1];
+    // v[0] = sample g-1 (pre-emphasis carry; 0 at the start of the utterance)
+    v[0] = (alpha != 0.0f && g - 1 >= s_begin) ? norm_sample<F32IN>(a, g - 1) : 0.0f;
+    if (g + VEC <= total) {
+      if (F32IN) {
+        const float4 raw = *(const float4 *)(a.f32 + g);
+        v[1] = raw.x; v[2] = raw.y; v[3] = raw.z; v[4] = raw.w;
+      } else {
+        const uint4 raw = *(const uint4 *)(a.pcm + g);
+        const unsigned int w32[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int16_t s16 = (int16_t)((w32[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+          float f = pcm_quot((float)s16, a);
+          if (a.clip) f = fminf(fmaxf(f, -1.0f), 1.0f);
+          v[1 + e] = f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[1 + e] = (g + e < total) ? norm_sample<F32IN>(a, g + e) : 0.0f;
+    }
+    float o[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      // reference: frame -= pre_emphasis * previous  (separate fp32 multiply and subtract); sample s_begin sees a zero carry
+      const float prev = (g + e == s_begin) ? 0.0f : v[e];
+      o[e] = (alpha != 0.0f) ? __fsub_rn(v[1 + e], __fmul_rn(alpha, prev)) : v[1 + e];
+    }
+    float4 *d4 = (float4 *)(dst + (size_t)q * VEC);
+    d4[0] = make_float4(o[0], o[1], o[2], o[3]);
+    if (VEC == 8) d4[1] = make_float4(o[4], o[5], o[6], o[7]);
+  }
+}
+
+// The lane number, recomputed where it is needed (two instructions) instead of kept in a register across the transform:
+// volatile, so the compiler cannot merge it with an earlier copy and carry that one through the register-tight phases.
+__device__ __forceinline__ int lw_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
+__device__ __forceinline__ int64_t lw_readlane64(int64_t v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), src_lane);
+  const int hi = __builtin_amdgcn_readlane((int)(v >> 32), src_lane);
+  return ((int64_t)hi << 32) | (unsigned int)lo;
+}
+
+template <bool F32IN, bool SIMPLE>
+__global__ __launch_bounds__(64 * LW_WPB) __attribute__((amdgpu_num_vgpr(52))) void logmel_rows_kernel(logmel_args a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  typedef double R;
+  constexpr int VEC = F32IN ? 4 : 8;  // elements per 16-byte load
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform values in SGPRs
+  const int j = lane & 15, sub = lane >> 4;
+  // XCD-aware order: workgroup ids go round-robin to the 8 XCDs; ids of one residue get one contiguous eighth of the
+  // frames, so the 352 samples consecutive waves share are fetched through one L2
+  const int nper = gridDim.x >> 3;
+  const int64_t W = ((int64_t)(blockIdx.x & 7) * nper + (blockIdx.x >> 3)) * LW_WPB + wave;
+  const int64_t g0 = W * 4;
+  if (g0 >= a.total_frames) return;  // no barrier anywhere below: a wave may simply leave
+  unsigned char *wb = smem + (size_t)wave * LW_WBUF;
+  float *tile = (float *)wb;
+  FE_STAMP(0)
+
+  // ---- which clip does this 16-lane row's frame belong to, and where do its samples start
+  int64_t s_begin, b;
+  bool rv;
+  {
+    const int64_t g = g0 + sub;
+    rv = g < a.total_frames;
+    const int64_t gc = rv ? g : g0;
+    if (a.uniform_nf > 0) {  // equal-length clips back to back: arithmetic
+      const unsigned gu = (unsigned)gc, nfu = (unsigned)a.uniform_nf;
+      const unsigned u = gu / nfu, f = gu - u * nfu;
+      s_begin = (int64_t)u * a.uniform_ns;
+      b = s_begin + (int64_t)(f * (unsigned)a.hop);
+    } else {
+      int lo = 0, hi = a.n_utt;  // the last clip whose first mel row is <= g
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a.frame_offs[mid] <= gc) lo = mid; else hi = mid;
+      }
+      s_begin = a.sample_offs[lo];
+      const int64_t f = gc - a.frame_offs[lo];
+      b = s_begin + f * a.hop;
+      rv = rv && f >= 0 && b + WIN <= a.sample_offs[lo + 1];  // a row the offset tables do not cover is never stored
+    }
+  }
+  const unsigned long long vm = __ballot(rv);
+  if (vm == 0) return;
+  const int r_first = __builtin_ctzll(vm) >> 4, r_last = (63 - __builtin_clzll(vm)) >> 4;
+  const int64_t b0 = lw_readlane64(b, 16 * r_first), s0 = lw_readlane64(s_begin, 16 * r_first);
+  if (!rv) {  // surplus rows recompute the first valid frame (results unused)
+    b = b0;
+    s_begin = s0;
+  }
+  const int64_t total = a.sample_offs[a.n_utt];
+  // one contiguous tile serves the wave when every row starts within 3 hops of the first one, in the same clip
+  const bool contig = __all(s_begin == s0 && b >= b0 && b - b0 <= 3 * (int64_t)a.hop);
+  const float *src;
+  if (contig) {
+    const int64_t bmax = lw_readlane64(b, 16 * r_last);
+    const int shift = (int)(b0 % VEC);
+    const int64_t ga = b0 - shift;  // multiple of VEC, >= 0
+    const int n_vec = (shift + (int)(bmax - b0) + WIN + VEC - 1) / VEC;
+    if (SIMPLE) {
+      // No pre-emphasis, divisor 32767/32768, hop <= 168 (host checks): NV vectors per lane, straight-line: all loads in
+      // flight together
+      constexpr int NV = F32IN ? 4 : 2;
+      const int64_t last = (total - VEC) & ~(int64_t)(VEC - 1);  // last full aligned vector (total >= WIN here)
+      const int64_t tile_last = ga + (int64_t)(n_vec - 1) * VEC;
+      int64_t gq[NV];
+      uint4 raw[NV];
+#pragma unroll
+      for (int h = 0; h < NV; ++h) {
+        gq[h] = ga + (int64_t)(lane + 64 * h) * VEC;
+        int64_t gl = gq[h] < tile_last ? gq[h] : tile_last;  // never past this wave's last vector
+        gl = gl < last ? gl : last;
+        raw[h] = F32IN ? *(const uint4 *)(a.f32 + gl) : *(const uint4 *)(a.pcm + gl);
+      }
+      const float lim = a.clip ? 1.0f : __builtin_inff();
+#pragma unroll
+      for (int h = 0; h < NV; ++h) {
+        const int q = lane + 64 * h;
+        if (q < n_vec) {
+          float o[VEC];
+          if (gq[h] <= last) {
+            const unsigned int w32[4] = {raw[h].x, raw[h].y, raw[h].z, raw[h].w};
+            if (F32IN) {
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) o[e] = __uint_as_float(w32[e]);
+            } else {
+              // the exact quotient (see pcm_quot) on sample pairs: v_pk_mul_f32 / v_pk_fma_f32, two samples per issue
+              typedef float f32x2 __attribute__((ext_vector_type(2)));
+              const f32x2 r2 = {a.rdiv, a.rdiv}, nb2 = {-a.divisor, -a.divisor};
+#pragma unroll
+              for (int e = 0; e < VEC; e += 2) {
+                const f32x2 x = {(float)(int)(short)(w32[e >> 1] & 0xffffu), (float)((int)w32[e >> 1] >> 16)};
+                const f32x2 q0 = x * r2;
+                const f32x2 er = __builtin_elementwise_fma(nb2, q0, x);
+                const f32x2 qq = __builtin_elementwise_fma(er, r2, q0);
+                o[e] = __builtin_amdgcn_fmed3f(qq.x, -lim, lim);
+                o[e + 1] = __builtin_amdgcn_fmed3f(qq.y, -lim, lim);
+              }
+            }
+          } else {  // ragged end of the whole buffer: element-wise, zero beyond it
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = (gq[h] + e < total) ? norm_sample<F32IN>(a, gq[h] + e) : 0.0f;
+          }
+          float4 *d4 = (float4 *)(tile + (size_t)q * VEC);
+          d4[0] = make_float4(o[0], o[1], o[2], o[3]);
+          if (VEC == 8) d4[1] = make_float4(o[4], o[5], o[6], o[7]);
+        }
+      }
+    } else {
+      lw_stage_generic<F32IN>(a, tile, ga, n_vec, s0, total, lane);
+    }
+    src = tile + shift + (int)(b - b0);
+  } else {
+    // frames of two clips (or a very short one) in this wave: frame by frame
+    for (int r = 0; r < 4; ++r) {
+      if (!((vm >> (16 * r)) & 1)) continue;
+      const int64_t br = lw_readlane64(b, 16 * r), sr = lw_readlane64(s_begin, 16 * r);
+      const int sh = (int)(br % VEC);
+      lw_stage_generic<F32IN>(a, tile + r * LW_ROWF, br - sh, (sh + WIN + VEC - 1) / VEC, sr, total, lane);
+    }
+    src = tile + (rv ? sub : r_first) * LW_ROWF + (int)(b % VEC);
+  }
+  FE_STAMP(1)
+  lds_fence();
+  FE_STAMP(2)
+
+  // ---- FFT: every 16-lane row of the wave owns one frame
+  R *tr = (R *)wb;          // [4][16][TR_LD]
+  float *mg = (float *)wb;  // overlay: [4][MAG_LD]
+  cplx<R> v[16];
+  const double2 *twp = (const double2 *)a.tw16 + j;  // [k1][16 j] = W256^(j k1)
+  double2 tq[2][3];
+  {
+    // pass 1: lane j holds z[16 n1 + j], n1 = 0..15; Hann product in fp64 (tflite.py:175).  Hann pairs (h[2n], h[2n+1]),
+    // n = 16 n1 + j, from the half table of 128 pairs (h[m] = h[511 - m]) through the vector L1, four n1 at a time and one
+    // chunk ahead: 16 + 16 registers instead of the 64 of the whole set
+    const double2 *hb = (const double2 *)a.hann;
+    auto hload = [&](int n1) -> double2 {
+      if (n1 < 8) return hb[16 * n1 + j];
+      const double2 m = hb[16 * (15 - n1) + 15 - j];
+      return make_double2(m.y, m.x);
+    };
+    double2 h[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h[0][i] = hload(i);
+    const bool pairs = __all((((int)(src - tile)) & 1) == 0);
+    if (pairs) {
+      // 8-byte aligned pairs: ds_read_b64 (with hop = 160 the four frames of a wave sit 32 banks apart: conflict-free)
+      double xs[16];
+      lds_read16_b64_s128(src + 2 * j, xs);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (c + 1 < 4) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) h[(c + 1) & 1][i] = hload(4 * (c + 1) + i);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c == 0) lds_wait_all(xs);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int n1 = 4 * c + i;
+          v[n1].re = (R)__int_as_float(__double2loint(xs[n1])) * h[c & 1][i].x;
+          v[n1].im = (R)__int_as_float(__double2hiint(xs[n1])) * h[c & 1][i].y;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (c + 1 < 4) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) h[(c + 1) & 1][i] = hload(4 * (c + 1) + i);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int n = 16 * (4 * c + i) + j;
+          v[4 * c + i].re = (R)src[2 * n] * h[c & 1][i].x;
+          v[4 * c + i].im = (R)src[2 * n + 1] * h[c & 1][i].y;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  FE_STAMP(3)
+  FE_STAMP(4)
+  {
+    // the first three inter-pass twiddles are requested before the butterflies that precede their use
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tq[0][i] = twp[k_of(1 + i) * 16];
+    dft16<R>(v);
+    FE_STAMP(5)
+    // v[pos] *= W256^(j k_of(pos)): 15 sixteen-byte loads per lane from the L1-resident table, three at a time, one chunk ahead
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      if (c + 1 < 5) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) tq[(c + 1) & 1][i] = twp[k_of(1 + 3 * (c + 1) + i) * 16];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int pos = 1 + 3 * c + i;
+        v[pos] = cmul(v[pos], cplx<R>{tq[c & 1][i].x, tq[c & 1][i].y});
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    FE_STAMP(6)
+    // 16x16 transpose through LDS, real parts then imaginary parts (same buffer)
+    cplx<R> w[16];
+    const int l2 = lw_lane(), j = l2 & 15, sub = l2 >> 4;
+    R *trs = tr + sub * 16 * TR_LD;
+#pragma unroll
+    for (int pos = 0; pos < 16; ++pos) trs[k_of(pos) * TR_LD + j] = v[pos].re;
+    lds_fence();
+    {
+      double wre[16], wim[16];
+      lds_read16_b64((const double *)trs + j * TR_LD, wre);
+      lds_fence();
+#pragma unroll
+      for (int pos = 0; pos < 16; ++pos) trs[k_of(pos) * TR_LD + j] = v[pos].im;
+      lds_fence();
+      lds_read16_b64((const double *)trs + j * TR_LD, wim);
+      lds_wait_all(wre);
+      lds_wait_all(wim);
+#pragma unroll
+      for (int n2 = 0; n2 < 16; ++n2) {
+        w[n2].re = wre[n2];
+        w[n2].im = wim[n2];
+      }
+    }
+    FE_STAMP(7)
+    // pass 2: lane j = k1 holds Y[n2][k1]; output w[pos] = Z[k1 + 16 k_of(pos)]
+    dft16<R>(w);
+    FE_STAMP(8)
+    // untangle (see logmel_kernel): partners Z[256 - k] travel through the dead transpose buffer
+    const double2 *unp = (const double2 *)a.tw512 + j;  // W512^(j + 16 k2) at [16 k2]
+    double2 uq[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) uq[0][i] = unp[16 * i];
+    const int pj = (16 - j) & 15;
+    const R *prow0 = trs + (j == 0 ? 7 : 15) * TR_LD + pj;
+    const R *prow = trs + (j == 0 ? 16 : 15) * TR_LD + pj;
+    cplx<R> pz[8];
+    trs[7 * TR_LD + j] = w[pos_of(0)].re;
+#pragma unroll
+    for (int r = 8; r < 16; ++r) trs[r * TR_LD + j] = w[pos_of(r)].re;
+    lds_fence();
+    pz[0].re = prow0[0];
+#pragma unroll
+    for (int k2 = 1; k2 < 8; ++k2) pz[k2].re = prow[-k2 * TR_LD];
+    lds_fence();
+    trs[7 * TR_LD + j] = w[pos_of(0)].im;
+#pragma unroll
+    for (int r = 8; r < 16; ++r) trs[r * TR_LD + j] = w[pos_of(r)].im;
+    lds_fence();
+    pz[0].im = prow0[0];
+#pragma unroll
+    for (int k2 = 1; k2 < 8; ++k2) pz[k2].im = prow[-k2 * TR_LD];
+    lds_fence();
+    FE_STAMP(9)
+    float *mrow = mg + sub * MAG_LD;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c + 1 < 4) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) uq[(c + 1) & 1][i] = unp[16 * (2 * (c + 1) + i)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int k2 = 2 * c + i;
+        const cplx<R> own = w[pos_of(k2)];
+        const cplx<R> un = {uq[c & 1][i].x, uq[c & 1][i].y};
+        const R er = own.re + pz[k2].re, ei = own.im - pz[k2].im;
+        const R orr = own.im + pz[k2].im, oi = pz[k2].re - own.re;
+        const R tr_ = orr * un.re - oi * un.im, ti_ = orr * un.im + oi * un.re;
+        const R pr = er + tr_, pi = ei + ti_, qr = er - tr_, qi = ei - ti_;
+        const int k = j + 16 * k2;
+        mrow[k] = __builtin_amdgcn_sqrtf((float)(pr * pr + pi * pi));  // 2|X[k]|: the mel weights carry the 0.5
+        mrow[256 - k] = __builtin_amdgcn_sqrtf((float)(qr * qr + qi * qi));  // k = 0 -> bin 256
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {
+      // k = 128 pairs with itself: X[128] = conj(Z[128]) (lane 0, k2 = 8); bins 257..271 are zero padding
+      const cplx<R> z = w[pos_of(8)];
+      if (j == 0) mrow[128] = 2.0f * __builtin_amdgcn_sqrtf((float)(z.re * z.re + z.im * z.im));
+      else mrow[256 + j] = 0.0f;
+    }
+  }
+
+  // ---- mel filterbank on the vector ALU (see logmel_kernel): lane 4 s + q owns frame q and slot s of each band group;
+  //      every group's weight chunks are fetched when its turn comes
+  FE_STAMP(10)
+  lds_fence();
+  {
+    const int lane = lw_lane();
+    const int j = lane >> 2, sub = lane & 3;  // mel phase only: (slot, frame) of this lane
+    constexpr int CAPQ[3] = {9, 4, 3}, C0[3] = {0, 9, 13};
+    const float4 *wv = (const float4 *)a.melV + j;
+    const float *mrow = mg + sub * MAG_LD;
+    __builtin_amdgcn_sched_barrier(0);
+    int meta[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) meta[g] = a.melVmeta[g * 16 + j];
+    float4 wq[WW_MELV_CHUNKS];
+    int band[3];
+    float bias[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      band[g] = (int)((unsigned)meta[g] >> 16);  // 0xffff: empty slot
+      bias[g] = a.bias[band[g] < a.n_mel ? band[g] : 0];
+    }
+    float res[3];
+    if (a.melv_aligned) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        __builtin_amdgcn_sched_barrier(0);  // one group's magnitudes and weights in flight at a time
+#pragma unroll
+        for (int c = 0; c < CAPQ[g]; ++c) wq[C0[g] + c] = wv[(C0[g] + c) * 16];
+        lds_cfloat4 *mb = (lds_cfloat4 *)lds_opaque(mrow + (meta[g] & 0xffff));
+        float acc = 0.f, acc1 = 0.f;  // two chains: a dependent fp32 FMA does not issue back to back
+#pragma unroll
+        for (int c = 0; c < CAPQ[g]; ++c) {
+          const float4 w4 = wq[C0[g] + c];
+          const f32x4 m4 = mb[c];
+          acc = fmaf(m4[0], w4.x, acc);
+          acc1 = fmaf(m4[1], w4.y, acc1);
+          acc = fmaf(m4[2], w4.z, acc);
+          acc1 = fmaf(m4[3], w4.w, acc1);
+        }
+        acc += acc1;
+        res[g] = (logf(fmaxf(acc + bias[g], a.floor_v)) + a.log_off) * a.scale;
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < CAPQ[g]; ++c) wq[C0[g] + c] = wv[(C0[g] + c) * 16];
+        lds_cfloat *mb = lds_opaque(mrow + (meta[g] & 0xffff));
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < CAPQ[g]; ++c) {
+          const float4 w4 = wq[C0[g] + c];
+          acc = fmaf(mb[4 * c + 0], w4.x, acc);
+          acc = fmaf(mb[4 * c + 1], w4.y, acc);
+          acc = fmaf(mb[4 * c + 2], w4.z, acc);
+          acc = fmaf(mb[4 * c + 3], w4.w, acc);
+        }
+        res[g] = (logf(fmaxf(acc + bias[g], a.floor_v)) + a.log_off) * a.scale;
+      }
+    }
+    // park the wave's 4 x n_mel tile in LDS (its magnitudes are dead); empty slots write to a spare word each so that
+    // the code stays straight-line.  Mel rows are global frame numbers: the four rows leave as one contiguous store
+    // when all four are valid (16-byte aligned whenever n_mel is a multiple of 4: g0 is a multiple of 4)
+    lds_fence();
+    float *mt = mg;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) mt[band[g] < a.n_mel ? sub * a.n_mel + band[g] : 4 * a.n_mel + lane] = res[g];
+    lds_fence();
+    float *dstf = a.mel + g0 * (int64_t)a.n_mel;
+    const bool prefix = (vm & (vm + 1)) == 0;  // valid rows are 0 .. r_last
+    if (prefix && (((uintptr_t)dstf) & 15) == 0 && (a.n_mel & 3) == 0) {
+      const int nv = r_last + 1;
+      for (int i = lane; i < nv * a.n_mel / 4; i += 64) ((float4 *)dstf)[i] = ((const float4 *)mt)[i];
+    } else {
+      for (int i = lane; i < 4 * a.n_mel; i += 64)
+        if ((vm >> (16 * (i / a.n_mel))) & 1) dstf[i] = mt[i];
+    }
+  }
+  FE_STAMP(11)
+}
+
 // STFT magnitude of explicit frames [n][512] -> [n][257]; one wave per frame.
 template <typename R>
 __global__ __launch_bounds__(256) void stft_mag_kernel(logmel_args a) {
@@ -682,7 +1145,7 @@ static void fill_filter_args(logmel_args &a, const ww_model *m) {
 
 int ww_k_logmel(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, const float *d_f32, const int64_t *d_sample_offs,
                 const int64_t *d_frame_offs, int n_utt, int64_t total_frames, int64_t max_frames_per_utt,
-                const ww_frontend_params *fp, float *d_mel) {
+                const ww_frontend_params *fp, float *d_mel, int64_t uniform_samples) {
   if (n_utt <= 0 || total_frames <= 0 || max_frames_per_utt <= 0) return WW_OK;
   if (fp->hop <= 0 || fp->hop > 512) return ww_fail(ctx, WW_EINVAL, "hop %d out of range (1..512)", fp->hop);
   logmel_args a = {};
@@ -695,6 +1158,33 @@ int ww_k_logmel(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, const floa
   const bool f32in = d_f32 != nullptr;
   // straight-line staging (two vectors per thread) when nothing exotic is asked for
   const bool simple = fp->pre_emphasis == 0.0f && (f32in || a.fast_div) && WIN + (FPB - 1) * fp->hop + 16 <= 512 * (f32in ? 4 : 8);
+#ifndef WW_FE_OLD
+#define WW_FE_OLD 0  // development: 1 = logmel_kernel<f64> (rounds 1-3) for A/B runs
+#endif
+  if (fp->precise && !WW_FE_OLD) {
+    // fp64: waves own four consecutive global mel rows each (logmel_rows_kernel)
+    a.total_frames = total_frames;
+    if (uniform_samples > 0 && total_frames < 0x7fffffff && total_frames == (int64_t)n_utt * max_frames_per_utt) {
+      a.uniform_nf = (int)max_frames_per_utt;
+      a.uniform_ns = uniform_samples;
+    }
+    const bool simple_w = fp->pre_emphasis == 0.0f && (f32in || a.fast_div) && fp->hop <= 168;
+    const int64_t n_waves = (total_frames + 3) / 4;
+    const int64_t n_wg = 8 * ((((n_waves + LW_WPB - 1) / LW_WPB) + 7) / 8);
+    if (n_wg > 0x7fffffff) return ww_fail(ctx, WW_EINVAL, "front-end launch too large (%lld workgroups): split the batch", (long long)n_wg);
+    const dim3 grid_w((unsigned)n_wg), block_w(64 * LW_WPB);
+    const size_t sm = (size_t)LW_WPB * LW_WBUF;
+    ww_launch_scope scope(ctx, "logmel_kernel<f64>");
+    if (simple_w) {
+      if (f32in) hipLaunchKernelGGL((logmel_rows_kernel<true, true>), grid_w, block_w, sm, ctx->stream, a);
+      else hipLaunchKernelGGL((logmel_rows_kernel<false, true>), grid_w, block_w, sm, ctx->stream, a);
+    } else {
+      if (f32in) hipLaunchKernelGGL((logmel_rows_kernel<true, false>), grid_w, block_w, sm, ctx->stream, a);
+      else hipLaunchKernelGGL((logmel_rows_kernel<false, false>), grid_w, block_w, sm, ctx->stream, a);
+    }
+    WW_HIP(ctx, hipGetLastError());
+    return WW_OK;
+  }
   const int64_t tiles = (max_frames_per_utt + FPB - 1) / FPB;
   const int64_t n_ids = 8 * (((int64_t)n_utt + 7) / 8) * tiles;
   if (n_ids > 0x7fffffff) return ww_fail(ctx, WW_EINVAL, "front-end launch too large (%lld workgroups): split the batch", (long long)n_ids);
