@@ -230,8 +230,9 @@ def test_crnn_large_batch_path(engines, oracles, name):
     """Above 1,024 windows per launch the CRNN runs as crnn_fused_kernel<front> + a tail kernel for the recurrences:
     gru_tail16_kernel (option crnn_tail_mfma = 2 here; by default from 9,216 windows per launch on: sixteen windows per workgroup,
     recurrent products and the layer-2 projection on v_mfma_f32_16x16x4_f32, a partial last workgroup: 1,500 = 93 x 16 + 12)
-    within 2e-6 of the one-kernel path, and gru_tail_kernel (one window per workgroup on the vector ALU; options 0 and, at
-    this size, 1) bit for bit; the oracle's within tolerance - windows with partial validity included, encoder output too."""
+    and gru_tail_kernel (one window per workgroup on the vector ALU; options 0 and, at this size, 1).  Every form associates
+    its sums the same way (round 4), so all of them equal the one-kernel path BIT FOR BIT - a posterior does not depend on how
+    its window was dispatched; the oracle's within tolerance - windows with partial validity included, encoder output too."""
     rng = np.random.default_rng(31)
     e = engines[name]
     wins = rng.uniform(0, 6.5, (1500, e.window, 40)).astype(np.float32)
@@ -244,10 +245,7 @@ def test_crnn_large_batch_path(engines, oracles, name):
         for mfma in (2, 1, 0):
             e.set_option("crnn_tail_mfma", mfma)
             big, big_enc = e.forward(wins, want_enc=True)       # one launch of 1,500 windows: front + tail
-            if mfma == 2:
-                assert np.abs(big - small).max() < 2e-6, float(np.abs(big - small).max())
-            else:
-                np.testing.assert_array_equal(big, small)
+            np.testing.assert_array_equal(big, small)
             assert np.abs(big[idx] - want).max() < TOL_POST
             assert np.abs(big_enc[idx].reshape(want_enc.shape) - want_enc).max() < 1e-4
     finally:
@@ -663,6 +661,7 @@ def test_crnn_sliding_rows_path_matches_per_window_kernels(engines, oracles, nam
             got = e.slide_forward(mel, hop)                 # gathering gru_tail16_kernel (16 windows per workgroup, MFMA)
         with e.options(crnn_tail_mfma=0):
             got_valu = e.slide_forward(mel, hop)            # gathering gru_tail_kernel (one window per workgroup, vector ALU)
+        np.testing.assert_array_equal(got, got_valu)                         # one arithmetic, whichever tail (round 4)
         np.testing.assert_array_equal(e.slide_forward(mel, hop), got_valu)   # default: the matrix form only from 9,216 windows on
         assert got.shape[0] == (rows - T) // hop + 1 >= nw
         wins = np.stack([mel[i * hop:i * hop + T] for i in range(got.shape[0])])
@@ -671,6 +670,25 @@ def test_crnn_sliding_rows_path_matches_per_window_kernels(engines, oracles, nam
         assert np.abs(got_valu - ref).max() < 2e-6, (hop, nw, float(np.abs(got_valu - ref).max()))
         idx = rng.choice(len(wins), 24, replace=False)
         assert np.abs(got[idx] - oracles[name].forward(wins[idx])).max() < TOL_POST
+
+
+def test_crnn_default_dispatch_crossover_leaves_posteriors_alone(engines):
+    """With the library's default options the tail kernel changes at 9,216 windows per launch (gru_tail_kernel below,
+    gru_tail16_kernel from there on) and public calls chunk at 16,384: a posterior must not depend on the size of the call it
+    was part of, nor on its position in it.  20,000 sliding windows in one call (a 16,384-window chunk on the matrix tail + a
+    3,616-window chunk on the vector tail) against the same windows in calls of 5,000 (vector tail throughout) and with either
+    tail forced: bit for bit."""
+    e = engines["CRNN_softmax"]
+    rng = np.random.default_rng(99)
+    nw, hop, T = 20000, 2, e.window
+    mel = rng.uniform(0, 6.5, ((nw - 1) * hop + T, 40)).astype(np.float32)
+    whole = e.slide_forward(mel, hop)
+    assert whole.shape[0] == nw
+    parts = np.concatenate([e.slide_forward(mel[i * hop:(i + 5000 - 1) * hop + T], hop) for i in range(0, nw, 5000)])
+    np.testing.assert_array_equal(whole, parts)
+    for mfma in (0, 2):
+        with e.options(crnn_tail_mfma=mfma):
+            np.testing.assert_array_equal(e.slide_forward(mel, hop), whole)
 
 
 @pytest.mark.parametrize("name", ["CRNN", "Wavenet"])

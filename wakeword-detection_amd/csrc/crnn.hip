@@ -167,8 +167,12 @@ __device__ __forceinline__ float fast_sigmoid(float x) {
 }
 __device__ __forceinline__ float fast_tanh(float x) {
   const float e = __builtin_amdgcn_exp2f(2.8853900817779268f * x);  // exp(2x): inf -> 1, 0 -> -1
-  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+  return __fmaf_rn(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);  // spelled out: every kernel rounds it the same way
 }
+// The GRU cell's last two lines, spelled out (no contraction left to the compiler) so that the vector form (gru_step) and the
+// matrix form (gru_tail16_kernel) round identically:  c = tanh(xc + r * hc),  h' = z h + (1 - z) c
+__device__ __forceinline__ float gru_candidate(float r, float hc, float xc) { return fast_tanh(__fmaf_rn(r, hc, xc)); }
+__device__ __forceinline__ float gru_blend(float z, float h, float c) { return __fmaf_rn(z, h, __fmul_rn(__fsub_rn(1.0f, z), c)); }
 
 __device__ __forceinline__ float swap_pair(float v) {
   // value of the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2]
@@ -193,34 +197,60 @@ __device__ __forceinline__ void gru_load_w(gru_w &g, const float *wh, const floa
     g.r[2 * q] = (f32x2){r.x, r.y}; g.r[2 * q + 1] = (f32x2){r.z, r.w};
     g.c[2 * q] = (f32x2){c.x, c.y}; g.c[2 * q + 1] = (f32x2){c.z, c.w};
   }
-  g.bz = bh[dir * 3 * GR_H + unit];
-  g.br = bh[dir * 3 * GR_H + GR_H + unit];
-  g.bc = bh[dir * 3 * GR_H + 2 * GR_H + unit];
+  // the recurrent biases are the initial values of half 0's odd-k chains (gru_step); half 1's chains start from zero
+  g.bz = half ? 0.f : bh[dir * 3 * GR_H + unit];
+  g.br = half ? 0.f : bh[dir * 3 * GR_H + GR_H + unit];
+  g.bc = half ? 0.f : bh[dir * 3 * GR_H + 2 * GR_H + unit];
 }
 
 // One GRU step for lane (unit = lane >> 1, half = lane & 1).  hin: this direction's h in LDS.
 // Keras GRU v2 (reset_after): z = s(xz + hz), r = s(xr + hr), c = tanh(xc + r * hc), h' = z h + (1-z) c
-// The three 16-term dot products run as packed fp32 FMAs (v_pk_fma_f32: two terms per instruction,
-// even / odd partial sums), the halves of K meet through one DPP swap.
-__device__ __forceinline__ float gru_step(const gru_w &g, const float *hin, int half, float gz, float gr, float gc,
-                                          float h_own) {
+// ONE association for every kernel that evaluates the cell (this function: crnn_fused_kernel, gru_tail_kernel,
+// crnn_stream_kernel, the generic path; gru_tail16_kernel restates it on v_mfma_f32_16x16x4_f32, whose four products are an
+// fmaf chain onto the accumulator in k order - tools/mfma_order_probe.hip): a gate's pre-activation is
+//     (E0 + O0) + (E1 + O1)
+// with four fmaf chains over the units k of the state, eight terms each, k ascending:
+//     E0: k = 0, 2, .. 14 starting from the projected input x (z, r; 0 for c)      O0: k = 1, 3, .. 15 starting from b_h
+//     E1: k = 16, 18, .. 30 from 0                                                 O1: k = 17, 19, .. 31 from 0
+// Here E and O are the two halves of a packed fp32 FMA (v_pk_fma_f32) and the index 0 / 1 is the lane of the pair (half);
+// the halves meet through one DPP swap.  The result does not depend on which kernel a window was dispatched to.
+template <bool PREFETCH>
+__device__ __forceinline__ float gru_step(const gru_w &g, const float *hin, int half, float gz, float gr, float gc, float h_own,
+                                          const float *gx_next, float &nz, float &nr, float &nc) {
   const float4 *hp = (const float4 *)(hin + half * 16);
-  f32x2 az = {0.f, 0.f}, ar = {0.f, 0.f}, ac = {0.f, 0.f};
+  // all four reads in flight before the first product, in the order of their use (the LDS answers in issue order; left alone
+  // the scheduler issues the first-needed quad last)
+  float4 hv[4];
+  hv[0] = hp[0];
+  __builtin_amdgcn_sched_barrier(0);
+  hv[1] = hp[1];
+  hv[2] = hp[2];
+  hv[3] = hp[3];
+  __builtin_amdgcn_sched_barrier(0);
+  if (PREFETCH) {  // the next step's projected inputs (LDS): behind the h reads
+    nz = gx_next[0];
+    nr = gx_next[GR_H];
+    nc = gx_next[2 * GR_H];
+  }
+  f32x2 az = {half ? 0.f : gz, g.bz}, ar = {half ? 0.f : gr, g.br}, ac = {0.f, g.bc};
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const float4 hv = hp[q];
-    const f32x2 h0 = {hv.x, hv.y}, h1 = {hv.z, hv.w};
-    az = g.z[2 * q] * h0 + az; ar = g.r[2 * q] * h0 + ar; ac = g.c[2 * q] * h0 + ac;
-    az = g.z[2 * q + 1] * h1 + az; ar = g.r[2 * q + 1] * h1 + ar; ac = g.c[2 * q + 1] * h1 + ac;
+    const f32x2 h0 = {hv[q].x, hv[q].y}, h1 = {hv[q].z, hv[q].w};
+    // the three chains strictly round-robin (a dependent packed FMA does not issue back to back; left alone the scheduler
+    // runs one chain ahead of the others: +55 cycles per step)
+    az = __builtin_elementwise_fma(g.z[2 * q], h0, az); ar = __builtin_elementwise_fma(g.r[2 * q], h0, ar); ac = __builtin_elementwise_fma(g.c[2 * q], h0, ac);
+    __builtin_amdgcn_sched_barrier(0);
+    az = __builtin_elementwise_fma(g.z[2 * q + 1], h1, az); ar = __builtin_elementwise_fma(g.r[2 * q + 1], h1, ar); ac = __builtin_elementwise_fma(g.c[2 * q + 1], h1, ac);
+    __builtin_amdgcn_sched_barrier(0);
   }
   float sz = az.x + az.y, sr = ar.x + ar.y, sc = ac.x + ac.y;
   sz += swap_pair(sz);
   sr += swap_pair(sr);
   sc += swap_pair(sc);
-  const float z = fast_sigmoid(gz + (sz + g.bz));
-  const float r = fast_sigmoid(gr + (sr + g.br));
-  const float c = fast_tanh(gc + r * (sc + g.bc));
-  return z * h_own + (1.0f - z) * c;
+  const float z = fast_sigmoid(sz);
+  const float r = fast_sigmoid(sr);
+  return gru_blend(z, h_own, gru_candidate(r, sc, gc));
 }
 
 // Between the h write of one step and the h reads of the next: LDS instructions of ONE wave are
@@ -304,16 +334,21 @@ __device__ __forceinline__ float cf_recurrence(const gru_w &g, const float *gxs,
   const float *gxl = gxs + dir * 3 * H + unit;
   float h_own = 0.f;
   int t = dir ? OT - 1 : 0;
+  // a step's projected inputs start two of its chains, so they are fetched a step ahead (behind the h reads, which are the
+  // ones the step waits for)
+  float gz = gxl[t * GR_GX_LD], gr = gxl[t * GR_GX_LD + H], gc = gxl[t * GR_GX_LD + 2 * H];
   for (int s = 0; s < OT; ++s) {
     const int cur = s & 1;
-    const float gz = gxl[t * GR_GX_LD], gr = gxl[t * GR_GX_LD + H], gc = gxl[t * GR_GX_LD + 2 * H];
-    h_own = gru_step(g, hd + cur * H, half, gz, gr, gc, h_own);
+    const int tn = dir ? (t > 0 ? t - 1 : 0) : (t + 1 < OT ? t + 1 : OT - 1);
+    float nz, nr, nc;
+    h_own = gru_step<true>(g, hd + cur * H, half, gz, gr, gc, h_own, gxl + tn * GR_GX_LD, nz, nr, nc);
     if (half == 0) {
       hd[(cur ^ 1) * H + unit] = h_own;
       if (SEQ) seq1[t * GR_SEQ_LD + dir * H + unit] = h_own;
     }
     wsync_h();
-    t = dir ? t - 1 : t + 1;
+    gz = nz; gr = nr; gc = nc;
+    t = tn;
   }
   return h_own;
 }
@@ -327,6 +362,16 @@ __device__ __forceinline__ float cf_recurrence(const gru_w &g, const float *gxs,
   rem[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(rv_.e_, b_[0].e_, rem[0], 0, 0, 0);                       \
   rem[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(rv_.e_, b_[1].e_, rem[1], 0, 0, 0);                       \
   rem[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(rv_.e_, b_[2].e_, rem[2], 0, 0, 0);
+
+// the layer-2 projection's form of it: rows 16..18 on a second 16x16x4 tile (its other thirteen rows read zeros), so that ALL
+// nineteen rows are one fmaf chain in the same k order - the association gru_tail16_kernel reproduces step by step
+#define CF_ROUND_L2(av_, rv_, b_, e_)                                                                  \
+  acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_.e_, b_[0].e_, acc[0], 0, 0, 0);                     \
+  acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_.e_, b_[1].e_, acc[1], 0, 0, 0);                     \
+  acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_.e_, b_[2].e_, acc[2], 0, 0, 0);                     \
+  rem[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(rv_.e_, b_[0].e_, rem[0], 0, 0, 0);                     \
+  rem[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(rv_.e_, b_[1].e_, rem[1], 0, 0, 0);                     \
+  rem[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(rv_.e_, b_[2].e_, rem[2], 0, 0, 0);
 
 // development: s_memtime at the phase boundaries (fused_args::stamps; nullptr = off)
 #define CF_STAMP(i_)                                                                                          \
@@ -357,16 +402,17 @@ __device__ __forceinline__ void cf_phases_d_to_g(const fused_args &a, float *img
   CF_STAMP(6)
 
   // ---- E: layer-2 input projection gx2[t][n] = seq1[t][:] . Wx2[n][:] + bx2[n]  (19 rows, K = 64, N = 192): rows 0..15 as one
-  //      MFMA tile, rows 16..18 on the 4x4x1 form, 3 n-tiles per wave
+  //      MFMA tile, rows 16..18 as a second one (rows 19..31 of seq1 are zeros), 3 n-tiles per wave; every row is the same
+  //      fmaf chain from zero: k = 16 kb + 4 kk + e in the order kb, e, kk, the bias added last
   {
     f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     f32x4 rem[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       const float4 av = *(const float4 *)(&seq1[j * GR_SEQ_LD + kb * 16 + kk * 4]);
-      const float4 rv = *(const float4 *)(&seq1[(16 + (lane & 3)) * GR_SEQ_LD + kb * 16 + kk * 4]);  // row 19 is zero
+      const float4 rv = *(const float4 *)(&seq1[(16 + j) * GR_SEQ_LD + kb * 16 + kk * 4]);
       const float4 *b = bq2[kb];
-      CF_ROUND(av, rv, b, x) CF_ROUND(av, rv, b, y) CF_ROUND(av, rv, b, z) CF_ROUND(av, rv, b, w)
+      CF_ROUND_L2(av, rv, b, x) CF_ROUND_L2(av, rv, b, y) CF_ROUND_L2(av, rv, b, z) CF_ROUND_L2(av, rv, b, w)
     }
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
@@ -374,12 +420,9 @@ __device__ __forceinline__ void cf_phases_d_to_g(const fused_args &a, float *img
       const float bb = a.bx2[col];
 #pragma unroll
       for (int r = 0; r < 4; ++r) gxs[(kk * 4 + r) * GR_GX_LD + col] = acc[n][r] + bb;
+      if (kk == 0) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        float v = rem[n][i];
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        if (kk == 0) gxs[(16 + i) * GR_GX_LD + col] = v + bb;
+        for (int r = 0; r < 3; ++r) gxs[(16 + r) * GR_GX_LD + col] = rem[n][r] + bb;
       }
     }
   }
@@ -1337,9 +1380,9 @@ __global__ __launch_bounds__(128, 4) void gru_tail_kernel(tail_args a) {
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       const float4 av = *(const float4 *)(&seq1[j * GR_SEQ_LD + kb * 16 + kk * 4]);
-      const float4 rv = *(const float4 *)(&seq1[(16 + (lane & 3)) * GR_SEQ_LD + kb * 16 + kk * 4]);  // row 19 is zero
+      const float4 rv = *(const float4 *)(&seq1[(j < 3 ? 16 + j : 19) * GR_SEQ_LD + kb * 16 + kk * 4]);  // row 19 is zero
       const float4 *b = bq[kb];
-      CF_ROUND(av, rv, b, x) CF_ROUND(av, rv, b, y) CF_ROUND(av, rv, b, z) CF_ROUND(av, rv, b, w)
+      CF_ROUND_L2(av, rv, b, x) CF_ROUND_L2(av, rv, b, y) CF_ROUND_L2(av, rv, b, z) CF_ROUND_L2(av, rv, b, w)
     }
     __syncthreads();  // pass 0: both waves are done reading gx1 before anybody overwrites it (gx2 takes its place)
 #pragma unroll
@@ -1348,12 +1391,9 @@ __global__ __launch_bounds__(128, 4) void gru_tail_kernel(tail_args a) {
       const float bb = a.bx2[col];
 #pragma unroll
       for (int r = 0; r < 4; ++r) gxs[(kk * 4 + r) * GR_GX_LD + col] = acc[n][r] + bb;
+      if (kk == 0) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        float v = rem[n][i];
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        if (kk == 0) gxs[(16 + i) * GR_GX_LD + col] = v + bb;
+        for (int r = 0; r < 3; ++r) gxs[(16 + r) * GR_GX_LD + col] = rem[n][r] + bb;
       }
     }
   }
@@ -1410,8 +1450,9 @@ __global__ __launch_bounds__(128, 4) void gru_tail_kernel(tail_args a) {
 // Layer 2's input projection (as many MFMAs as all four recurrences together) is computed per step in the same
 // accumulators: A = seq1[t] of the sixteen windows (global workspace, written by layer 1), B = this direction's 96 rows of
 // W_x2 held in registers (6 tiles x 16 k-steps), issued for step t+1 between writing h(t) and reading it back.
-// The contraction index of every product is dealt to the lanes as k = (k-steps per lane group) * (lane >> 4) + k-step, so
-// that a lane's operands of consecutive k-steps are consecutive in memory (the order of an fp32 sum is free within 1e-7).
+// Every sum is associated exactly as the vector form associates it (gru_step's four chains per gate; phase E's one chain per
+// projected value, bias last) - v_mfma_f32_16x16x4_f32 is an fmaf chain in k order - so a window's posterior is the same bits
+// whichever tail it was given to (tests/test_gpu_parity.py::test_crnn_large_batch_path).
 // ------------------------------------------------------------------------------------------
 #define GT16_LD 36   // h exchange row: 32 units + 4
 #define GT16_ELD 68  // enc / hid row: 64 + 4
@@ -1424,11 +1465,16 @@ struct tail16_args {
 __global__ __launch_bounds__(128, 2) void gru_tail16_kernel(tail16_args aa) {
   constexpr int H = GR_H, OT = CV_OT;
   const tail_args &a = aa.t;
-  __shared__ __align__(16) float hs[2][2][16 * GT16_LD];
-  __shared__ __align__(16) float encs[16 * GT16_ELD];
-  __shared__ __align__(16) float hid[16 * GT16_ELD];
+  // LDS: the h exchange (9.2 KB) + each wave's recurrent weights as B-operand pages [tile 6][half 2][lane 64] x 16 bytes
+  // (24.6 KB: every lane reads back only what it wrote - 48 registers' worth that the four chains per tile need elsewhere);
+  // the head's enc / hid rows move into the dead pages at the end.  33.8 KB: four workgroups per CU, as the registers allow
+  __shared__ __align__(16) float sm16[2 * 2 * 16 * GT16_LD + 2 * 6 * 2 * 64 * 4];
+  float (*hs)[2][16 * GT16_LD] = (float (*)[2][16 * GT16_LD])sm16;
+  float *encs = sm16 + 2 * 2 * 16 * GT16_LD, *hid = encs + 16 * GT16_ELD;
+  static_assert(2 * 16 * GT16_ELD <= 2 * 6 * 2 * 64 * 4, "enc / hid rows do not fit the weight pages");
   const int tid = threadIdx.x, lane = tid & 63, dir = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
+  float4 *whl = (float4 *)(sm16 + 2 * 2 * 16 * GT16_LD) + (size_t)dir * 6 * 2 * 64 + lane;  // this lane's slot of page 0
   const int w0 = blockIdx.x * 16;
   float *seq = aa.seq + (size_t)blockIdx.x * OT * 16 * 2 * H;
 
@@ -1446,22 +1492,63 @@ __global__ __launch_bounds__(128, 2) void gru_tail16_kernel(tail16_args aa) {
     if (t == OT - 1) return a.gxR + (size_t)wi[r] * 6 * H;
     return a.gxI + (size_t)(i0[r] + (int64_t)(t - 1) * a.eight_g) * 6 * H;
   };
-  // recurrent weights as B operands: tile nt = gate * 2 + unit half; k-step ks, lane group g <-> unit 8 g + ks
-  float wh[6][8];
+  // recurrent weights as B operands: tile nt = gate * 2 + unit half.  The eight MFMAs of a tile and step are the four chains
+  // of gru_step, two MFMAs each: chain (hh, p) = units 16 hh + p, + 2, .. + 14; its MFMA q takes the k-lanes g = 0..3 <-> unit
+  // u = 16 hh + 8 q + 2 g + p.  Operand slot i = 4 hh + 2 q + p; in the LDS exchange row unit u sits at GT16_POS(u) =
+  // 8 g + i, so that a lane group reads its eight operands as two 16-byte words.
+#define GT16_POS(u_) (8 * (((u_) >> 1) & 3) + 4 * ((u_) >> 4) + 2 * (((u_) >> 3) & 1) + ((u_) & 1))
   float bh[6];
   auto load_wh = [&](const float *whp, const float *bhp) {
 #pragma unroll
     for (int nt = 0; nt < 6; ++nt) {
       const int row = (nt >> 1) * H + (nt & 1) * 16 + c;
-      const float4 *p = (const float4 *)(whp + ((size_t)dir * 3 * H + row) * H + 8 * g);
-      const float4 v0 = p[0], v1 = p[1];
-      wh[nt][0] = v0.x; wh[nt][1] = v0.y; wh[nt][2] = v0.z; wh[nt][3] = v0.w;
-      wh[nt][4] = v1.x; wh[nt][5] = v1.y; wh[nt][6] = v1.z; wh[nt][7] = v1.w;
+      const float *p = whp + ((size_t)dir * 3 * H + row) * H + 2 * g;
+      float wv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) wv[i] = p[16 * (i >> 2) + 8 * ((i >> 1) & 1) + (i & 1)];
+      whl[(2 * nt) * 64] = make_float4(wv[0], wv[1], wv[2], wv[3]);
+      whl[(2 * nt + 1) * 64] = make_float4(wv[4], wv[5], wv[6], wv[7]);
       bh[nt] = bhp[dir * 3 * H + row];
     }
   };
+  // pre[nt] = pre-activation of tile nt for the four windows of this lane: (E0 + O0) + (E1 + O1), E0 starting from X0_[nt] (the
+  // projected input of the z and r gates; zeros for c), O0 from b_h, the others from zero.  A tile's operands are read from
+  // its page while the previous tile's MFMAs run; one tile's chains at a time (all six at once would need 96 registers)
+#define GT16_PRE_ALL(X0_)                                                                          \
+  {                                                                                                \
+    float4 wb[2][2];                                                                               \
+    wb[0][0] = whl[0];                                                                             \
+    wb[0][1] = whl[64];                                                                            \
+    _Pragma("unroll") for (int nt = 0; nt < 6; ++nt) {                                             \
+      if (nt + 1 < 6) {                                                                            \
+        wb[(nt + 1) & 1][0] = whl[(2 * nt + 2) * 64];                                              \
+        wb[(nt + 1) & 1][1] = whl[(2 * nt + 3) * 64];                                              \
+      }                                                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                           \
+      const float4 b0 = wb[nt & 1][0], b1 = wb[nt & 1][1];                                         \
+      f32x4 e0 = nt < 4 ? X0_[nt < 4 ? nt : 0] : zero4, o0 = {bh[nt], bh[nt], bh[nt], bh[nt]};     \
+      e0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[0], b0.x, e0, 0, 0, 0);                         \
+      o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[1], b0.y, o0, 0, 0, 0);                         \
+      e0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[2], b0.z, e0, 0, 0, 0);                         \
+      o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[3], b0.w, o0, 0, 0, 0);                         \
+      f32x4 e1 = zero4, o1 = zero4;                                                                \
+      e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[4], b1.x, e1, 0, 0, 0);                         \
+      o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[5], b1.y, o1, 0, 0, 0);                         \
+      e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[6], b1.z, e1, 0, 0, 0);                         \
+      o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[7], b1.w, o1, 0, 0, 0);                         \
+      pre[nt] = (e0 + o0) + (e1 + o1);                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                                           \
+    }                                                                                              \
+  }
+  // the first step: h = 0, the chains are their initial values (0 * w adds nothing, so the products are skipped)
+#define GT16_PRE_FIRST(X0_)                                                                        \
+  _Pragma("unroll") for (int nt = 0; nt < 6; ++nt) {                                               \
+    const f32x4 o0 = {bh[nt], bh[nt], bh[nt], bh[nt]};                                             \
+    pre[nt] = ((nt < 4 ? X0_[nt < 4 ? nt : 0] : zero4) + o0) + (zero4 + zero4);                    \
+  }
   load_wh(a.wh1, a.bh1);
   for (int i = tid; i < 2 * 2 * 16 * GT16_LD; i += 128) (&hs[0][0][0])[i] = 0.f;
+  const int pos0 = GT16_POS(c), pos1 = GT16_POS(16 + c);  // where this lane's two units sit in an exchange row
 
   // ---- layer 1 ------------------------------------------------------------------------------
   float h_own[4][2];  // [row r][unit half]: h of (window 4 g + r, unit 16 uh + c)
@@ -1481,11 +1568,9 @@ __global__ __launch_bounds__(128, 2) void gru_tail16_kernel(tail16_args aa) {
 #pragma unroll 1
   for (int s = 0; s < OT; ++s) {
     const int t = dir ? OT - 1 - s : s, cur = s & 1;
-    f32x4 acc[6];
+    f32x4 x0[4];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) acc[nt] = (f32x4){gxn[0][nt] + bh[nt], gxn[1][nt] + bh[nt], gxn[2][nt] + bh[nt], gxn[3][nt] + bh[nt]};
-    acc[4] = (f32x4){bh[4], bh[4], bh[4], bh[4]};
-    acc[5] = (f32x4){bh[5], bh[5], bh[5], bh[5]};
+    for (int nt = 0; nt < 4; ++nt) x0[nt] = (f32x4){gxn[0][nt], gxn[1][nt], gxn[2][nt], gxn[3][nt]};
     float gxc[4][2];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { gxc[r][0] = gxn[r][4]; gxc[r][1] = gxn[r][5]; }
@@ -1498,42 +1583,45 @@ __global__ __launch_bounds__(128, 2) void gru_tail16_kernel(tail16_args aa) {
         for (int nt = 0; nt < 6; ++nt) gxn[r][nt] = row[(nt >> 1) * H + (nt & 1) * 16];
       }
     }
-    if (s > 0) {  // h = 0 at the first step
+    f32x4 pre[6];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    if (s > 0) {
       const float4 *hp = (const float4 *)(&hs[dir][cur][c * GT16_LD + 8 * g]);
       const float4 a0 = hp[0], a1 = hp[1];
       const float ha[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-        for (int nt = 0; nt < 6; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[ks], wh[nt][ks], acc[nt], 0, 0, 0);
+      GT16_PRE_ALL(x0)
+    } else {
+      GT16_PRE_FIRST(x0)
     }
 #pragma unroll
     for (int uh = 0; uh < 2; ++uh)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float z = fast_sigmoid(acc[uh][r]);
-        const float rr = fast_sigmoid(acc[2 + uh][r]);
-        const float cc = fast_tanh(gxc[r][uh] + rr * acc[4 + uh][r]);
-        const float hn = z * h_own[r][uh] + (1.0f - z) * cc;
+        const float z = fast_sigmoid(pre[uh][r]);
+        const float rr = fast_sigmoid(pre[2 + uh][r]);
+        const float hn = gru_blend(z, h_own[r][uh], gru_candidate(rr, pre[4 + uh][r], gxc[r][uh]));
         h_own[r][uh] = hn;
-        hs[dir][cur ^ 1][(4 * g + r) * GT16_LD + uh * 16 + c] = hn;
+        hs[dir][cur ^ 1][(4 * g + r) * GT16_LD + (uh ? pos1 : pos0)] = hn;
         seq[((size_t)t * 16 + 4 * g + r) * 2 * H + dir * H + uh * 16 + c] = hn;
       }
     wsync_h();
   }
   __syncthreads();  // seq1 of both directions is in memory (workgroup scope)
 
-  // ---- layer 2: input projection per step in the recurrence's accumulators --------------------
+  // ---- layer 2: the input projection of step t+1 is issued between writing h(t) and reading it back ---------------------
+  // gx2[t][window][n] as phase E of crnn_fused_kernel computes it: ONE fmaf chain from zero over k = 16 kb + 4 kk + e in the
+  // order kb, e, kk (kk = the k-lane), the bias added last.  A = seq1[t] of the sixteen windows (global workspace, written by
+  // layer 1), B = this direction's 96 rows of W_x2 in registers: slot 4 kb + e of lane group g <-> column 16 kb + 4 g + e
   load_wh(a.wh2, a.bh2);
-  float wx[6][16];  // W_x2 rows of this direction as B operands: k-step ks, lane group g <-> seq1 column 16 g + ks
+  float wx[6][16];
   float bx[6];
 #pragma unroll
   for (int nt = 0; nt < 6; ++nt) {
     const int row = dir * 3 * H + (nt >> 1) * H + (nt & 1) * 16 + c;
-    const float4 *p = (const float4 *)(a.wx2 + (size_t)row * 2 * H + 16 * g);
+    const float4 *p = (const float4 *)(a.wx2 + (size_t)row * 2 * H + 4 * g);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float4 v = p[q];
+      const float4 v = p[4 * q];
       wx[nt][4 * q] = v.x; wx[nt][4 * q + 1] = v.y; wx[nt][4 * q + 2] = v.z; wx[nt][4 * q + 3] = v.w;
     }
     bx[nt] = a.bx2[row];
@@ -1541,54 +1629,58 @@ __global__ __launch_bounds__(128, 2) void gru_tail16_kernel(tail16_args aa) {
   for (int i = tid; i < 2 * 2 * 16 * GT16_LD; i += 128) (&hs[0][0][0])[i] = 0.f;
 #pragma unroll
   for (int r = 0; r < 4; ++r) h_own[r][0] = h_own[r][1] = 0.f;
-  // acc2: tiles 0..3 = z, r (projection + recurrent part in one sum), 4..5 = projected c input, 6..7 = recurrent c part
-  f32x4 acc2[8];
+  f32x4 gx2[6];  // projected inputs of the step at hand: tiles 0..3 start the z and r chains, 4..5 are the candidate's x part
   auto project = [&](int t) {
-    const float4 *sp = (const float4 *)(seq + ((size_t)t * 16 + c) * 2 * H + 16 * g);
-    const float4 q0 = sp[0], q1 = sp[1], q2 = sp[2], q3 = sp[3];
-    const float sa[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+    const float4 *sp = (const float4 *)(seq + ((size_t)t * 16 + c) * 2 * H + 4 * g);
+    const float4 q0 = sp[0], q1 = sp[4], q2 = sp[8], q3 = sp[12];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) { const float b = bx[nt] + bh[nt]; acc2[nt] = (f32x4){b, b, b, b}; }
-    acc2[4] = (f32x4){bx[4], bx[4], bx[4], bx[4]};
-    acc2[5] = (f32x4){bx[5], bx[5], bx[5], bx[5]};
-    acc2[6] = (f32x4){bh[4], bh[4], bh[4], bh[4]};
-    acc2[7] = (f32x4){bh[5], bh[5], bh[5], bh[5]};
+    for (int nt = 0; nt < 6; ++nt) gx2[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#define GT16_PROJ(q_, kb_)                                                                           \
+  for (int nt = 0; nt < 6; ++nt) gx2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.x, wx[nt][4 * kb_ + 0], gx2[nt], 0, 0, 0); \
+  for (int nt = 0; nt < 6; ++nt) gx2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.y, wx[nt][4 * kb_ + 1], gx2[nt], 0, 0, 0); \
+  for (int nt = 0; nt < 6; ++nt) gx2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.z, wx[nt][4 * kb_ + 2], gx2[nt], 0, 0, 0); \
+  for (int nt = 0; nt < 6; ++nt) gx2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.w, wx[nt][4 * kb_ + 3], gx2[nt], 0, 0, 0);
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks)
+    GT16_PROJ(q0, 0)
 #pragma unroll
-      for (int nt = 0; nt < 6; ++nt) acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[ks], wx[nt][ks], acc2[nt], 0, 0, 0);
+    GT16_PROJ(q1, 1)
+#pragma unroll
+    GT16_PROJ(q2, 2)
+#pragma unroll
+    GT16_PROJ(q3, 3)
+#undef GT16_PROJ
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt) gx2[nt] += (f32x4){bx[nt], bx[nt], bx[nt], bx[nt]};
   };
   project(dir ? OT - 1 : 0);
   __syncthreads();
 #pragma unroll 1
   for (int s = 0; s < OT; ++s) {
     const int t = dir ? OT - 1 - s : s, cur = s & 1;
+    f32x4 pre[6];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
       const float4 *hp = (const float4 *)(&hs[dir][cur][c * GT16_LD + 8 * g]);
       const float4 a0 = hp[0], a1 = hp[1];
       const float ha[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[ks], wh[nt][ks], acc2[nt], 0, 0, 0);
-        acc2[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[ks], wh[4][ks], acc2[6], 0, 0, 0);
-        acc2[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[ks], wh[5][ks], acc2[7], 0, 0, 0);
-      }
+      GT16_PRE_ALL(gx2)
+    } else {
+      GT16_PRE_FIRST(gx2)
     }
 #pragma unroll
     for (int uh = 0; uh < 2; ++uh)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float z = fast_sigmoid(acc2[uh][r]);
-        const float rr = fast_sigmoid(acc2[2 + uh][r]);
-        const float cc = fast_tanh(acc2[4 + uh][r] + rr * acc2[6 + uh][r]);
-        const float hn = z * h_own[r][uh] + (1.0f - z) * cc;
+        const float z = fast_sigmoid(pre[uh][r]);
+        const float rr = fast_sigmoid(pre[2 + uh][r]);
+        const float hn = gru_blend(z, h_own[r][uh], gru_candidate(rr, pre[4 + uh][r], gx2[4 + uh][r]));
         h_own[r][uh] = hn;
-        hs[dir][cur ^ 1][(4 * g + r) * GT16_LD + uh * 16 + c] = hn;
+        hs[dir][cur ^ 1][(4 * g + r) * GT16_LD + (uh ? pos1 : pos0)] = hn;
       }
     if (s + 1 < OT) project(dir ? t - 1 : t + 1);  // between the h write and its read-back: covers the LDS round trip
     wsync_h();
   }
+  __syncthreads();  // both waves are done with their weight pages: enc / hid take their place
 #pragma unroll
   for (int uh = 0; uh < 2; ++uh)
 #pragma unroll
@@ -1640,6 +1732,10 @@ __global__ __launch_bounds__(128, 2) void gru_tail16_kernel(tail16_args aa) {
 }
 
 #undef CF_ROUND
+#undef CF_ROUND_L2
+#undef GT16_PRE_ALL
+#undef GT16_PRE_FIRST
+#undef GT16_POS
 
 // detect.tflite alone (reference detect_model(x), wakeword/tflite.py:228-229): one wave per row
 __global__ __launch_bounds__(64) void crnn_detect_kernel(const float *enc, const float *w1, const float *b1, const float *w2,
@@ -1756,7 +1852,8 @@ __global__ __launch_bounds__(128) void gru_generic_kernel(grug_args a) {
     if (s + 1 < OT) {
       nz = gxl[(size_t)tn * 6 * H]; nr = gxl[(size_t)tn * 6 * H + H]; nc = gxl[(size_t)tn * 6 * H + 2 * H];
     }
-    h_own = gru_step(g, &hbuf[dir][cur][0], half, gz, gr, gc, h_own);
+    float uz, ur, uc;
+    h_own = gru_step<false>(g, &hbuf[dir][cur][0], half, gz, gr, gc, h_own, nullptr, uz, ur, uc);
     if (half == 0) {
       hbuf[dir][cur ^ 1][unit] = h_own;
       if (a.seq) a.seq[((size_t)w * OT + t) * 2 * H + dir * H + unit] = h_own;

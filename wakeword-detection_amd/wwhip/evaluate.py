@@ -236,10 +236,9 @@ def _pieces_forward(eng: Engine, pieces: List[np.ndarray], n_win: List[int], hop
     n_tot = int(sum(n_win))
     d_out = torch.empty((n_tot, eng.n_out), dtype=torch.float32, device=dev)
     torch.cuda.synchronize(dev)
-    # one tail kernel whatever the share's size: a rank's posteriors must not depend on how many windows its launch holds
-    # (the library would pick the tail by window count; the two tails sum in another order, ~1e-7)
-    with eng.options(crnn_tail_mfma=2):
-        eng.forward_segments_dev(d_mel.data_ptr(), total_f, foffs[:-1], np.asarray(n_win, np.int32), hop, d_out.data_ptr())
+    # the library picks the tail kernel by the share's window count; every form of the CRNN associates its sums the same way
+    # (csrc/crnn.hip: gru_step), so a rank's posteriors do not depend on how many windows its launch holds
+    eng.forward_segments_dev(d_mel.data_ptr(), total_f, foffs[:-1], np.asarray(n_win, np.int32), hop, d_out.data_ptr())
     eng.ctx.synchronize()
     return d_out.cpu().numpy()
 
@@ -488,14 +487,11 @@ def clip_posteriors(engine: Engine, clips: Sequence[np.ndarray], hop: int = 2, f
     d_out = torch.empty((n + n_slide, engine.n_out), dtype=torch.float32, device=dev)
     torch.cuda.synchronize(dev)
     engine.logmel_dev(d_pcm.data_ptr(), d_so.data_ptr(), d_fo.data_ptr(), n, total_f, int(nf_pad.max()), d_mel.data_ptr(), fp)
-    # the n single windows on the one-kernel form whatever n is: a posterior must not depend on how many other clips share the
-    # launch (above crnn_split_at windows the library would take front + tail kernels, which sum in another order: ~1e-7),
-    # or the sharded evaluation would differ between world sizes
-    with engine.options(crnn_split_at=0):
-        engine.forward_windows_dev(d_mel.data_ptr(), total_f, d_row.data_ptr(), d_valid.data_ptr(), n, d_out.data_ptr())
+    # the n single windows: one fused kernel or front + tail kernels by n - the same bits either way (one association of every
+    # sum in all forms of the CRNN), so the sharded evaluation does not differ between world sizes
+    engine.forward_windows_dev(d_mel.data_ptr(), total_f, d_row.data_ptr(), d_valid.data_ptr(), n, d_out.data_ptr())
     if n_slide:
-        with engine.options(crnn_tail_mfma=2):  # as above: the same tail kernel for every shard size
-            engine.forward_segments_dev(d_mel.data_ptr(), total_f, foffs[:-1], nw, hop, d_out[n:].data_ptr())
+        engine.forward_segments_dev(d_mel.data_ptr(), total_f, foffs[:-1], nw, hop, d_out[n:].data_ptr())
     engine.ctx.synchronize()
     post = d_out.cpu().numpy()[:, pidx]
     p_one, slide = post[:n], post[n:]
