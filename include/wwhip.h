@@ -87,6 +87,16 @@ const char *ww_version(void);
  * The Python binding warns when the major versions differ (wwhip/_lib.py). */
 int ww_runtime_info(int32_t *built_hip_version, int32_t *runtime_version, int32_t *driver_version);
 
+/* Host-side staging for the sharded evaluators (wwhip/evaluate.py; replaces the per-sample ring writes and pydub joins of
+ * utils/evaluate_models.py:45-61,150-160 on the way to ONE upload): writes dst[0 .. total) once - run j copies count[j]
+ * samples from src[j] to dst + dst_off[j] (runs disjoint, dst_off ascending), everything between the runs is zeroed (the
+ * 0.5 s paddings and 100 ms gaps of the reference flow) - with `threads` host threads, each owning a contiguous slice of
+ * dst.  No GPU call; dst is normally page-locked.  WW_EINVAL on overlapping or descending runs.  Only dst[lo .. hi) is
+ * written (0 <= lo <= hi <= total): a caller stages a large buffer in a few slices and starts each slice's upload while the
+ * next one is being written. */
+int ww_host_stage_i16(int16_t *dst, int64_t total, int64_t n_runs, const int64_t *dst_off, const int16_t *const *src,
+                      const int64_t *count, int64_t lo, int64_t hi, int32_t threads);
+
 /* Per-kernel timing with HIP events on the ctx stream (bench.py roofline leg).  While
  * enabled every kernel launch is bracketed by two events; ww_profile_read synchronises and
  * writes a JSON object {"kernel": {"calls": n, "total_ms": t}, ...}. */

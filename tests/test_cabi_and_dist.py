@@ -162,3 +162,69 @@ def test_default_context_fails_fast_without_a_gpu(tmp_path):
             "try:\n    _lib.default_context(0)\nexcept RuntimeError as e:\n    print('raised', e)\n" % (ROOT, os.path.join(ROOT, "wakeword-detection_amd")))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=90)
     assert r.returncode == 0 and "raised" in r.stdout, r.stdout + r.stderr
+
+
+def test_host_staging_equals_the_padded_stream():
+    """ww_host_stage_i16 + wwhip.evaluate._piece_runs (what a rank uploads: the samples its windows are functions of, piece
+    after piece, written once by the library's host threads) against the literal construction - the padded files laid end to
+    end (never-reset ring) or each on its own - for positives and negative streams, several world sizes, a joined stream
+    (JoinedPCM: one run per clip) and the multi-threaded path; overlapping runs are refused.  Host code only: no GPU call."""
+    import ctypes as C
+    from wwhip import _lib
+    from wwhip import evaluate as E
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+
+    def stage(plan, runs, data, threads):
+        soffs, d, pp, c = E._piece_runs(plan, runs, data)
+        need = int(soffs[-1]) + 16
+        buf = np.full(need, -7, np.int16)
+        assert lib.ww_host_stage_i16(buf.ctypes.data, need, len(d), _lib.ptr(d), _lib.ptr(pp), _lib.ptr(c), 0, need, threads) == 0
+        return buf
+
+    for trial in range(12):
+        clips = [rng.integers(-3000, 3000, int(n)).astype(np.int16) for n in rng.integers(100, 60000, int(rng.integers(1, 9)))]
+        for carry in (True, False):
+            plan = E.StreamPlan([len(c) for c in clips], 151, 320, 16000, 2, carry)
+            whole = np.zeros(int(plan.padded.sum()), np.int16)
+            for k, x in enumerate(clips):
+                whole[plan.pos[k] + 8000: plan.pos[k] + 8000 + len(x)] = x
+            for et, world in (("false_negatives", 1), ("false_negatives", 3), ("false_accepts", 2)):
+                for rank in range(world):
+                    runs = plan.shares(et, world)[rank]
+                    if not runs:
+                        continue
+                    data = {f: clips[f] for k, _, _ in runs for f in ((k - 1, k) if carry and k > 0 else (k,))}
+                    want = []
+                    for k, i0, i1 in runs:
+                        s0, s1 = plan.sample_range(k, i0, i1)
+                        if carry:
+                            want.append(whole[s0:s1])
+                        else:
+                            one = np.zeros(int(plan.padded[k]), np.int16)
+                            one[8000:8000 + len(clips[k])] = clips[k]
+                            want.append(one[s0:s1])
+                    np.testing.assert_array_equal(stage(plan, runs, data, 3), np.concatenate(want + [np.zeros(16, np.int16)]))
+    clips = [rng.integers(-3000, 3000, int(n)).astype(np.int16) for n in rng.integers(100, 60000, 12)]
+    j, arr = E.join_negatives_lazy(clips, 9), E.join_negatives(clips, 9)
+    plan = E.StreamPlan([len(j)], 151)
+    whole = np.zeros(int(plan.padded[0]), np.int16)
+    whole[8000:8000 + len(arr)] = arr
+    for world in (1, 2, 5):
+        for rank in range(world):
+            runs = plan.shares("false_accepts", world)[rank]
+            s0, s1 = plan.sample_range(*runs[0])
+            np.testing.assert_array_equal(stage(plan, runs, {0: j}, 4)[:-16], whole[s0:s1])
+    big = rng.integers(-3000, 3000, 5_000_000).astype(np.int16)          # above the one-thread limit: 8 threads, 2 runs
+    d, c = np.array([100, 3_000_000], np.int64), np.array([2_000_000, 1_500_000], np.int64)
+    pp = np.array([big.ctypes.data, big.ctypes.data + 2 * 2_500_000], np.int64)
+    buf = np.full(6_000_000, -7, np.int16)
+    for lo, hi in ((0, 1_000_001), (1_000_001, 3_500_000), (3_500_000, 6_000_000)):   # in slices, as the uploader calls it
+        assert lib.ww_host_stage_i16(buf.ctypes.data, len(buf), 2, _lib.ptr(d), _lib.ptr(pp), _lib.ptr(c), lo, hi, 8) == 0
+    want = np.zeros(6_000_000, np.int16)
+    want[100:2_000_100] = big[:2_000_000]
+    want[3_000_000:4_500_000] = big[2_500_000:4_000_000]
+    np.testing.assert_array_equal(buf, want)
+    assert lib.ww_host_stage_i16(buf.ctypes.data, len(buf), 2, _lib.ptr(np.array([100, 50], np.int64)), _lib.ptr(pp), _lib.ptr(c),
+                                 0, len(buf), 8) != 0
+    assert lib.ww_host_stage_i16(buf.ctypes.data, len(buf), 2, _lib.ptr(d), _lib.ptr(pp), _lib.ptr(c), 10, 5, 8) != 0

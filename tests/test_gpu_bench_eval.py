@@ -69,7 +69,7 @@ def test_bench_starts_its_own_ranks():
     rank 0's line.  One-GPU box: gloo rehearsal, both ranks on GPU 0 - the line says so."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "4",
-                        "--stream-ticks", "100", "--eval-clips", "128"], capture_output=True, text=True, timeout=900,
+                        "--stream-ticks", "100", "--eval-clips", "128", "--eval-scale", "40"], capture_output=True, text=True, timeout=900,
                        env=dict(env, WW_BENCH_BACKEND="gloo", WW_BENCH_CPU_SECONDS="1"))
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -79,6 +79,10 @@ def test_bench_starts_its_own_ranks():
     assert abs(d["value"] - 2 * 12 * 256 * 150 / (d["ms_per_step"] * 12 * 1e-3)) / d["value"] < 1e-6
     assert "rehearsal" in d["config"] and "x2" in d["config"]["parallelism"]
     assert d["eval_testset"]["world_size"] == 2 and d["streaming"]["crnn"]["p50_ms"] > 0
+    assert d["streaming"]["crnn"]["p99.9_ms"] >= d["streaming"]["crnn"]["p99_ms"] >= d["streaming"]["crnn"]["p50_ms"]
+    tr = d["timed_regions"]     # the N > 1 line says what the collective costs and how far the ranks are apart
+    assert tr["collective_ms"] > 0 and 0 < tr["per_rank_median_ms"]["min"] <= tr["per_rank_median_ms"]["max"] <= tr["max_ms"] * 1.001
+    assert d["config"]["cpus_per_rank"] >= 1
 
 
 def test_bench_under_torch_distributed_run():
@@ -88,16 +92,23 @@ def test_bench_under_torch_distributed_run():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", "29668", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12",
-                        "--warmup", "4", "--stream-ticks", "100", "--eval-clips", "256"], capture_output=True, text=True, timeout=900,
+                        "--warmup", "4", "--stream-ticks", "100", "--eval-clips", "256", "--eval-scale", "60"], capture_output=True, text=True, timeout=900,
                        env=dict(env, WW_BENCH_BACKEND="gloo", WW_BENCH_CPU_SECONDS="1"))
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 12 and d["eval_testset"]["world_size"] == 2 and d["cpu_baseline"] is None
-    one = _bench(["--steps", "12", "--warmup", "4", "--stream-ticks", "100", "--eval-clips", "256", "--no-cpu-baseline"])
+    tr = d["timed_regions"]
+    assert tr["collective_ms"] > 0 and 0 < tr["per_rank_median_ms"]["min"] <= tr["per_rank_median_ms"]["max"]
+    one = _bench(["--steps", "12", "--warmup", "4", "--stream-ticks", "100", "--eval-clips", "256", "--eval-scale", "60", "--no-cpu-baseline"])
     for k in ("frr_at_0.5_fa_per_hour", "fa_count_at_threshold_0.5", "posterior_checksum", "windows", "negative_hours"):
         assert d["eval_testset"][k] == one["eval_testset"][k], k
+    a2, a1 = d["eval_testset"]["at_scale"], one["eval_testset"]["at_scale"]    # the at-scale leg (reduced here): 2 ranks = 1 rank
+    for k in ("frr_at_0.5_fa_per_hour", "fa_count_at_threshold_0.5", "posterior_checksum", "windows"):
+        assert a2[k] == a1[k], k
+    assert a2["world_size"] == 2 and 0.0 < a2["host_share"] < 1.0 and a2["device_ms"] > 0
+    assert {"plan", "slicing", "h2d", "device_wall", "gather", "sweep"} <= set(a2["host_phases_ms"])
     assert d["eval_testset"]["per_clip_variant"]["posterior_checksum"] == one["eval_testset"]["per_clip_variant"]["posterior_checksum"]
 
 

@@ -691,6 +691,15 @@ def test_get_posterior_edge_cases(assets, tmp_path):
         flat = np.concatenate(want)
         assert len(neg) == len(flat) == plan.total
         assert np.abs(neg - flat).max() < TOL, (fw, carry, float(np.abs(neg - flat).max()))
+    # a STEREO wav among mono ones (librosa averages the channels: float32 samples): every file is then brought to librosa's
+    # float scale - the mono files' int16 / 32768 - instead of mixing raw PCM with floats in one launch
+    st = str(tmp_path / "stereo.wav")
+    with wave.open(st, "wb") as w:
+        w.setnchannels(2); w.setsampwidth(2); w.setframerate(16000)
+        w.writeframes(np.stack([pcms[2], pcms[2]], axis=1).tobytes())      # both channels = clip 2: their mean is clip 2
+    neg_mixed = np.array(get_posterior(mdir, "CRNN", "false_accepts", [files[0], files[1], st], 20, 16000), np.float32)
+    neg_mono = np.array(get_posterior(mdir, "CRNN", "false_accepts", files, 20, 16000), np.float32)
+    assert len(neg_mixed) == len(neg_mono) and np.abs(neg_mixed - neg_mono).max() < 1e-5
     pos = get_posterior(mdir, "CRNN", "false_negatives", [files[0], files[2]], 20, 16000)
     plan, want = oracle_stream([pcms[0], pcms[2]], 320, True)
     assert np.abs(np.array(pos) - np.array([w.max() for w in want])).max() < TOL

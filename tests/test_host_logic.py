@@ -245,6 +245,49 @@ def test_stream_plan_matches_reference_loop_over_files():
             assert max(sizes) - min(sizes) <= 1                     # contiguous ranges of equal size (dist.split_stream)
 
 
+def test_stream_plan_closed_form_equals_the_per_file_schedules():
+    """StreamPlan computes the layout of a whole test split at once when a chunk is exactly `hop` mel hops (the reference's
+    320-sample chunks and hop 2): the same pos / F / n_frames / n_win as the per-file frame_schedule + window_schedule (which the
+    test above pins on the reference's loop), over random file lists incl. empty, sub-window and single-chunk files, both
+    carry modes, three window lengths."""
+    rng = np.random.default_rng(0)
+    for trial in range(200):
+        n = int(rng.integers(1, 12))
+        lens = rng.integers(0, 60000, n)
+        if trial % 5 == 0:
+            lens[rng.integers(0, n)] = 0
+        if trial % 7 == 0:
+            lens[:] = rng.integers(0, 700, n)
+        for T in (151, 182, 40):
+            for carry in (True, False):
+                fast = E.StreamPlan(lens, T, 320, 16000, 2, carry)
+                slow = E.StreamPlan(lens, T, 320, 16000, 2, carry)
+                slow._per_file()
+                for f in ("pos", "F", "n_frames", "n_win"):
+                    assert np.array_equal(getattr(fast, f), getattr(slow, f)), (trial, T, carry, f, lens.tolist())
+
+
+def test_joined_pcm_is_concatenate_fa_without_the_copy():
+    """JoinedPCM (the negative stream of evaluate_models.py:150-160 as a view on its clips) against join_negatives: length,
+    materialised array, and every (array, offset, count, position) run of arbitrary sample ranges."""
+    rng = np.random.default_rng(1)
+    clips = [rng.integers(-3000, 3000, int(n)).astype(np.int16) for n in rng.integers(1, 5000, 9)]
+    for num in (1, 4, 9, 20):
+        want = E.join_negatives(clips, num)
+        j = E.join_negatives_lazy(clips, num)
+        assert len(j) == len(want) and j.dtype == np.int16
+        np.testing.assert_array_equal(j.to_array(), want)
+        for _ in range(50):
+            a = int(rng.integers(0, len(want)))
+            n = int(rng.integers(1, len(want) - a + 1))
+            got = np.zeros(n, np.int16)
+            for arr, aa, nn, o in j.runs(a, n):
+                got[o:o + nn] = arr[aa:aa + nn]
+            np.testing.assert_array_equal(got, want[a:a + n])
+    with pytest.raises(TypeError):
+        E.JoinedPCM([np.zeros(4, np.float32)], 1600)
+
+
 @pytest.mark.parametrize("frame_width", [10, 20, 25, 40])
 def test_stream_plan_other_chunk_sizes_and_no_carry(frame_width):
     """The same pin for other `frame_width`s of the evaluator's command line (10 ms: one mel frame per chunk, so the one-inference-

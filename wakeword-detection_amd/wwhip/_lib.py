@@ -47,6 +47,7 @@ SYMBOLS: Dict[str, tuple] = {
     "ww_last_error": (C.c_char_p, [_vp]),
     "ww_version": (C.c_char_p, []),
     "ww_runtime_info": (C.c_int, [_P(_i32), _P(_i32), _P(_i32)]),
+    "ww_host_stage_i16": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i32]),
     "ww_profile_enable": (C.c_int, [_vp, C.c_int]),
     "ww_profile_read": (C.c_int, [_vp, C.c_char_p, _sz]),
     "ww_timer_start": (C.c_int, [_vp]),

@@ -28,6 +28,32 @@ WINDOW = 512
 CLIP_PAD = 8000  # 0.5 s of zeros each side of a clip (evaluate_models.py:52-53)
 CLIP_HOP = 2     # mel rows between windows (evaluate_models.py:42)
 _PIN = None  # page-locked staging buffer of clip_posteriors (torch tensor, grown on demand)
+_STAGE = None  # page-locked staging buffer of the sharded reference flow (torch tensor, grown on demand)
+_COPY_THREADS = 16  # host threads of ww_host_stage_i16 that assemble a rank's samples in the staging buffer
+
+
+class _Phases:
+    """Wall-clock seconds per host phase of an evaluation call (``timing`` dict of the sharded flows): ``with ph("name"):``
+    adds the block's duration to ``timing[name]``; a ``None`` dict makes it a no-op."""
+
+    def __init__(self, timing: Optional[dict]) -> None:
+        self.t = timing
+
+    def __call__(self, name: str):
+        import contextlib
+        import time
+
+        @contextlib.contextmanager
+        def scope():
+            if self.t is None:
+                yield
+                return
+            t0 = time.perf_counter()
+            try:
+                yield
+            finally:
+                self.t[name] = self.t.get(name, 0.0) + time.perf_counter() - t0
+        return scope()
 
 
 def read_wav(path: str, sample_rate: int = 16000) -> np.ndarray:
@@ -145,14 +171,43 @@ class StreamPlan:
         self.lengths = np.asarray(lengths, np.int64)
         padded = self.lengths + 2 * self.pad
         self.padded = padded + (-padded) % frame_length
-        per_file, starts = frame_schedule(self.padded.tolist(), 160, frame_length, carry_over)
+        if frame_length == 160 * self.hop:
+            self._closed_form()
+        else:
+            self._per_file()
+        self.offs = np.concatenate(([0], np.cumsum(self.n_win)))
+
+    def _per_file(self) -> None:
+        """The schedules file by file (:func:`frame_schedule`, :func:`window_schedule`): any chunk length."""
+        per_file, starts = frame_schedule(self.padded.tolist(), 160, self.frame_length, self.carry)
         self.pos = np.asarray(starts, np.int64)
         self.n_frames = np.array([int(f.sum()) for f in per_file], np.int64)
         # first global frame credited to the file: the ring emits frames in order, so it is the count emitted before it
         self.F = np.array([((p - WINDOW) // 160 + 1 if p >= WINDOW else 0) for p in self.pos], np.int64)
         # (window i of a file starts at row hop * i of its frame list: the schedule drops `hop` rows per inference)
         self.n_win = np.array([len(window_schedule(fpc, self.T, self.hop)) for fpc in per_file], np.int64)
-        self.offs = np.concatenate(([0], np.cumsum(self.n_win)))
+
+    def _closed_form(self) -> None:
+        """The same numbers for ALL files at once when a chunk is exactly ``hop`` mel hops (the reference: 320 samples, hop 2),
+        as arithmetic on the cumulative padded lengths - what a 2,500-file test split needs instead of 2,500 Python-level
+        schedules.  With tot(p) = frames the ring has emitted once p samples went in: a file at stream position pos has
+        F = tot(pos) frames before it and n_frames = tot(pos + padded) - F of its own; after its chunk j it holds
+        c_j = tot(pos + C (j + 1)) - F, so window n (needs c_j >= T + hop n) is ready at chunk
+        m_n = max(0, ceil(A / C) - 1 + n) with A = 512 + 160 (F + T - 1) - pos and C = 160 hop: m_n - n is constant, and
+        :func:`window_schedule`'s j_n = n + max_{i <= n} (m_i - i) = n + max(ceil(A / C) - 1, 0).  Windows exist while j_n is a
+        chunk of the file and n < n_max.  (tests/test_host_logic.py holds this against the per-file schedules and those
+        against the reference's loop.)"""
+        C = self.frame_length
+        ends = np.cumsum(self.padded)
+        self.pos = (ends - self.padded) if self.carry else np.zeros_like(self.padded)
+        tot = lambda p: np.where(p >= WINDOW, (p - WINDOW) // 160 + 1, 0)  # noqa: E731
+        self.F = tot(self.pos)
+        self.n_frames = tot(self.pos + self.padded) - self.F
+        J = self.padded // C
+        A = WINDOW + 160 * (self.F + self.T - 1) - self.pos
+        e0 = np.maximum(-((-A) // C) - 1, 0)
+        n_max = np.where(self.n_frames >= self.T, (self.n_frames - self.T) // self.hop + 1, 0)
+        self.n_win = np.clip(np.minimum(n_max, J - e0), 0, None).astype(np.int64)
 
     @property
     def total(self) -> int:
@@ -185,69 +240,189 @@ class StreamPlan:
         return 160 * g0, 160 * g1 + WINDOW  # (without carry every file has its own stream: pos = 0, F = 0)
 
 
-def _stream_slice(plan: StreamPlan, load: Callable[[int], np.ndarray], cache: dict, s0: int, s1: int, k_hint: int) -> np.ndarray:
-    """Samples ``[s0, s1)`` of the concatenated padded stream, touching only the files that overlap it."""
-    pos = plan.pos if plan.carry else np.zeros_like(plan.pos)
-    ks = [k_hint] if not plan.carry else [k for k in range(max(k_hint - 1, 0), len(pos)) if pos[k] < s1 and pos[k] + plan.padded[k] > s0]
-    dt = np.int16
-    for k in ks:
-        if k not in cache:
-            cache[k] = np.asarray(load(k))
-        if cache[k].dtype != np.int16:
-            dt = np.float32
-    out = np.zeros(s1 - s0, dt)
-    for k in ks:
-        x = cache[k].astype(dt, copy=False)
-        a = int(pos[k]) + plan.pad  # stream sample of x[0]
-        lo, hi = max(s0, a), min(s1, a + len(x))
-        if hi > lo:
-            out[lo - s0: hi - s0] = x[lo - a: hi - a]
-    return out
+class JoinedPCM:
+    """``concatenate_FA``'s one long wav (``evaluate_models.py:150-160``) WITHOUT materialising it: the clips stay where they
+    are and ``gap`` zero samples lie between them; the staging code copies each clip straight into the upload buffer (one
+    pass over two hours of audio instead of three).  ``len()``, ``dtype`` and ``to_array()`` are all a caller needs."""
+
+    dtype = np.dtype(np.int16)
+
+    def __init__(self, clips: Sequence[np.ndarray], gap: int) -> None:
+        self.parts = [np.asarray(c) for c in clips]
+        if any(c.dtype != np.int16 for c in self.parts):
+            raise TypeError("JoinedPCM holds int16 PCM")
+        n = np.array([len(c) for c in self.parts], np.int64)
+        self.starts = np.concatenate(([0], np.cumsum(n + gap)))[:-1] if len(n) else np.zeros(0, np.int64)
+        self.size = int(n.sum() + gap * max(len(n) - 1, 0))
+
+    def __len__(self) -> int:
+        return self.size
+
+    def runs(self, a: int, n: int):
+        """``(array, first element, count, offset inside [a, a + n))`` for every clip that overlaps ``[a, a + n)``."""
+        i = max(int(np.searchsorted(self.starts, a, side="right")) - 1, 0)
+        while i < len(self.parts) and self.starts[i] < a + n:
+            st = int(self.starts[i])
+            lo, hi = max(a, st), min(a + n, st + len(self.parts[i]))
+            if hi > lo:
+                yield self.parts[i], lo - st, hi - lo, lo - a
+            i += 1
+
+    def to_array(self) -> np.ndarray:
+        out = np.zeros(self.size, np.int16)
+        for c, st in zip(self.parts, self.starts):
+            out[st:st + len(c)] = c
+        return out
 
 
-def _pieces_forward(eng: Engine, pieces: List[np.ndarray], n_win: List[int], hop: int, precise: bool = True) -> np.ndarray:
-    """One front-end launch over ``pieces`` (each its own framing grid, frame j = samples [160 j, 160 j + 512)) and one
+def _piece_runs(plan: StreamPlan, runs, data: dict):
+    """For the window runs ``(file, i0, i1)``: the sample range ``[s0, s1)`` each is a function of (its piece), and the copy
+    runs that fill the pieces laid end to end: ``(dst_off, src address, count)`` arrays, ascending in ``dst_off``; whatever
+    they leave uncovered is zero padding.  A piece of file ``k`` reaches back at most 511 samples into file ``k - 1``.
+    Vectorised over the pieces (a test split has thousands); a :class:`JoinedPCM` file expands into one run per clip."""
+    ks = np.array([k for k, _, _ in runs], np.int64)
+    i0 = np.array([a for _, a, _ in runs], np.int64)
+    i1 = np.array([b for _, _, b in runs], np.int64)
+    F = plan.F[ks] if plan.carry else np.zeros_like(ks)
+    s0 = 160 * (F + plan.hop * i0)
+    s1 = 160 * (F + plan.hop * (i1 - 1) + plan.T - 1) + WINDOW
+    soffs = np.concatenate(([0], np.cumsum(s1 - s0))).astype(np.int64)
+    d_all, p_all, c_all = [], [], []
+    if any(isinstance(x, JoinedPCM) for x in data.values()):
+        (j,) = data.values()  # (_stage_pieces materialises joined streams that share a list with other files)
+        a = (int(plan.pos[0]) if plan.carry else 0) + plan.pad
+        st = j.starts
+        n = np.array([len(c) for c in j.parts], np.int64)
+        pa = np.array([c.__array_interface__["data"][0] for c in j.parts], np.int64)
+        for p in range(len(ks)):  # one piece per rank's range; one run per clip that overlaps it
+            lo, hi = max(int(s0[p]), a), min(int(s1[p]), a + len(j))
+            if hi > lo and len(n):
+                q0, q1 = np.maximum(st, lo - a), np.minimum(st + n, hi - a)
+                ok = q1 > q0
+                d_all.append((int(soffs[p]) + a - int(s0[p]) + q0)[ok])
+                p_all.append((pa + 2 * (q0 - st))[ok])
+                c_all.append((q1 - q0)[ok])
+    else:
+        n_files = len(plan.lengths)
+        addr = np.zeros(n_files, np.int64)
+        for f, x in data.items():
+            addr[f] = x.__array_interface__["data"][0]
+        for back in ((1, 0) if plan.carry else (0,)):
+            f = ks - back
+            ok = f >= 0
+            fo = np.where(ok, f, 0)
+            a = (plan.pos[fo] if plan.carry else 0) + plan.pad  # stream sample of the file's first sample
+            lo, hi = np.maximum(s0, a), np.minimum(s1, a + plan.lengths[fo])
+            ok &= hi > lo
+            d_all.append((soffs[:-1] + lo - s0)[ok])
+            p_all.append((addr[fo] + 2 * (lo - a))[ok])
+            c_all.append((hi - lo)[ok])
+    d, pp, c = (np.concatenate(x) if x else np.zeros(0, np.int64) for x in (d_all, p_all, c_all))
+    order = np.argsort(d, kind="stable")
+    return soffs, np.ascontiguousarray(d[order]), np.ascontiguousarray(pp[order]), np.ascontiguousarray(c[order])
+
+
+def _stage_pieces(plan: StreamPlan, runs, load: Callable[[int], np.ndarray], ph: _Phases, device: int):
+    """The samples the window runs ``(file, i0, i1)`` are functions of, piece after piece in ONE page-locked int16 buffer,
+    written exactly once by the library's host threads (``ww_host_stage_i16``: clip samples copied in, the paddings between
+    them zeroed), then uploaded asynchronously.  Returns ``(device tensor - upload in flight on torch's current
+    stream -, sample_offs [n + 1])``, or ``(None, list of float32 arrays)`` when a file is not int16 PCM (stereo wavs, custom
+    loaders: everything is then brought to float32 in [-1, 1), int16 / 32768, and staged through NumPy)."""
+    import torch
+    from . import _lib
+    global _STAGE
+    with ph("slicing"):
+        files = sorted({f for k, _, _ in runs for f in ((k - 1, k) if plan.carry and k > 0 else (k,))})
+        data = {}
+        for f in files:
+            x = load(f)
+            if isinstance(x, JoinedPCM) and len(plan.lengths) > 1:
+                x = x.to_array()  # a joined stream among other files: as an ordinary array
+            data[f] = x if isinstance(x, JoinedPCM) else np.ascontiguousarray(x)
+        if any(x.dtype != np.int16 for x in data.values()):
+            # not PCM16 everywhere: float32 samples (librosa's scale) for every file
+            data = {f: (x.to_array() if isinstance(x, JoinedPCM) else x) for f, x in data.items()}
+            data = {f: (x.astype(np.float32) / np.float32(32768.0) if x.dtype == np.int16 else x.astype(np.float32, copy=False))
+                    for f, x in data.items()}
+            pieces = []
+            for k, i0, i1 in runs:
+                s0, s1 = plan.sample_range(k, i0, i1)
+                out = np.zeros(s1 - s0, np.float32)
+                for f in ((k - 1, k) if plan.carry and k > 0 else (k,)):
+                    a = (int(plan.pos[f]) if plan.carry else 0) + plan.pad
+                    lo, hi = max(s0, a), min(s1, a + len(data[f]))
+                    if hi > lo:
+                        out[lo - s0:hi - s0] = data[f][lo - a:hi - a]
+                pieces.append(out)
+            return None, pieces
+        soffs, d, pp, c = _piece_runs(plan, runs, data)
+        need = int(soffs[-1]) + 16  # (the kernel's vector loads may run a few samples past the end: zeros there too)
+        if _STAGE is None or _STAGE.numel() < need:
+            _STAGE = None
+            _STAGE = torch.empty(need + need // 8, dtype=torch.int16, pin_memory=True)
+        # ONE staging call and ONE upload: starting each slice's upload while the next slice is written was measured and buys
+        # nothing (staging 7.2 -> 12 ms beside the DMA, upload wait 7.1 -> 2.5 ms: the host's memory system is the limit)
+        rc = _lib.load().ww_host_stage_i16(_STAGE.data_ptr(), need, len(d), _lib.ptr(d), _lib.ptr(pp), _lib.ptr(c), 0, need, _COPY_THREADS)
+        if rc != 0:
+            raise RuntimeError(f"ww_host_stage_i16 failed ({rc}): overlapping sample runs")
+        d_pcm = torch.empty(need, dtype=torch.int16, device=torch.device("cuda", device))
+        d_pcm.copy_(_STAGE[:need], non_blocking=True)
+        return d_pcm, soffs
+
+
+def _pieces_forward(eng: Engine, staged, soffs, n_win: List[int], hop: int, precise: bool, ph: _Phases,
+                    timing: Optional[dict]) -> np.ndarray:
+    """One front-end launch over the staged pieces (each its own framing grid, frame j = samples [160 j, 160 j + 512)) and one
     model launch over their windows (piece p: ``n_win[p]`` windows at rows ``hop i``): detect rows, piece by piece."""
     import torch  # only to hold the device buffers of the batched launch
 
-    n = len(pieces)
+    n = len(n_win)
     if n == 0 or sum(n_win) == 0:
         return np.zeros((0, eng.n_out), np.float32)
     dev = torch.device("cuda", eng.ctx.device)
-    nf = np.array([eng.num_frames(len(p)) for p in pieces], np.int64)
+    lens = np.diff(soffs) if staged is not None else np.array([len(p) for p in soffs], np.int64)
+    nf = np.where(lens >= WINDOW, (lens - WINDOW) // 160 + 1, 0).astype(np.int64)
     foffs = np.concatenate(([0], np.cumsum(nf)))
     total_f = int(foffs[-1])
-    for p, f, w in zip(pieces, nf, n_win):
-        assert w == 0 or (w - 1) * hop + eng.window <= f, "piece too short for its windows"
-    d_mel = torch.empty((max(total_f, 1), eng.n_mel), dtype=torch.float32, device=dev)
-    if all(p.dtype == np.int16 for p in pieces):
-        # librosa's floats are int16 / 32768 exactly: the device front end divides (correctly rounded) by the same 32768
-        soffs = np.concatenate(([0], np.cumsum([len(p) for p in pieces]))).astype(np.int64)
-        pcm = np.zeros(int(soffs[-1]) + 16, np.int16)  # (the kernel's vector loads may run a few samples past the end)
-        for i, p in enumerate(pieces):
-            pcm[soffs[i]: soffs[i + 1]] = p
-        d_pcm, d_so, d_fo = torch.from_numpy(pcm).to(dev), torch.from_numpy(soffs).to(dev), torch.from_numpy(foffs).to(dev)
-        torch.cuda.synchronize(dev)
-        eng.logmel_dev(d_pcm.data_ptr(), d_so.data_ptr(), d_fo.data_ptr(), n, total_f, int(nf.max()), d_mel.data_ptr(),
-                       frontend_params(32768.0, False, 0.0, 160, precise))
-    else:
-        mels = eng.logmel([np.asarray(p, np.float32) for p in pieces], frontend_params(1.0, False, 0.0, 160, precise))
-        d_mel[:total_f] = torch.from_numpy(np.concatenate(mels)).to(dev)
-    n_tot = int(sum(n_win))
-    d_out = torch.empty((n_tot, eng.n_out), dtype=torch.float32, device=dev)
-    torch.cuda.synchronize(dev)
-    # the library picks the tail kernel by the share's window count; every form of the CRNN associates its sums the same way
-    # (csrc/crnn.hip: gru_step), so a rank's posteriors do not depend on how many windows its launch holds
-    eng.forward_segments_dev(d_mel.data_ptr(), total_f, foffs[:-1], np.asarray(n_win, np.int32), hop, d_out.data_ptr())
-    eng.ctx.synchronize()
-    return d_out.cpu().numpy()
+    assert all(w == 0 or (w - 1) * hop + eng.window <= f for f, w in zip(nf, n_win)), "piece too short for its windows"
+    with ph("h2d"):
+        d_mel = torch.empty((max(total_f, 1), eng.n_mel), dtype=torch.float32, device=dev)
+        d_out = torch.empty((int(sum(n_win)), eng.n_out), dtype=torch.float32, device=dev)
+        if staged is not None:
+            # librosa's floats are int16 / 32768 exactly: the device front end divides (correctly rounded) by the same 32768
+            d_pcm = staged  # (the upload is in flight on torch's stream)
+            d_so, d_fo = torch.from_numpy(soffs).to(dev), torch.from_numpy(foffs).to(dev)
+        torch.cuda.current_stream(dev).synchronize()  # the library's stream is not torch's: the upload must have landed
+    if timing is not None:
+        eng.ctx.profile(True)
+    with ph("device_wall"):
+        if staged is not None:
+            eng.logmel_dev(d_pcm.data_ptr(), d_so.data_ptr(), d_fo.data_ptr(), n, total_f, int(nf.max()), d_mel.data_ptr(),
+                           frontend_params(32768.0, False, 0.0, 160, precise))
+        else:
+            mels = eng.logmel(soffs, frontend_params(1.0, False, 0.0, 160, precise))
+            d_mel[:total_f] = torch.from_numpy(np.concatenate(mels)).to(dev)
+            torch.cuda.current_stream(dev).synchronize()
+        # the library picks the tail kernel by the share's window count; every form of the CRNN associates its sums the same
+        # way (csrc/crnn.hip: gru_step), so a rank's posteriors do not depend on how many windows its launch holds
+        eng.forward_segments_dev(d_mel.data_ptr(), total_f, foffs[:-1], np.asarray(n_win, np.int32), hop, d_out.data_ptr())
+        eng.ctx.synchronize()
+    if timing is not None:
+        prof = eng.ctx.profile_read()
+        eng.ctx.profile(False)
+        timing["device_ms"] = timing.get("device_ms", 0.0) + sum(v["total_ms"] for v in prof.values())
+        for k, v in prof.items():
+            timing.setdefault("kernels_ms", {})[k] = timing.get("kernels_ms", {}).get(k, 0.0) + v["total_ms"]
+    with ph("d2h"):
+        return d_out.cpu().numpy()
 
 
 def get_posterior_sharded(models_dir, model_type, eval_type, test_files, frame_width, sample_rate, rank: int = 0,
                           world: int = 1, comm_device: Optional[str] = None,
                           loader: Optional[Callable[[str], np.ndarray]] = None, lengths: Optional[Sequence[int]] = None,
                           carry_over: bool = True, device: int = 0, engine: Optional[Engine] = None,
-                          precise: bool = True) -> list:
+                          precise: bool = True, timing: Optional[dict] = None, as_array: bool = False,
+                          info: Optional[dict] = None):
     """:func:`get_posterior` with its windows dealt to ``world`` ranks (one process per GPU; ``torch.distributed``
     initialised by the caller when ``world > 1``).  ``"false_negatives"``: whole files, longest first round-robin;
     ``"false_accepts"``: the window list - for the reference's evaluator ONE long wav (``evaluate_models.py:317-321``) -
@@ -258,46 +433,55 @@ def get_posterior_sharded(models_dir, model_type, eval_type, test_files, frame_w
 
     ``test_files``: paths (default loader :func:`read_wav_pcm`; ``lengths`` default = wav headers) or arrays already in
     memory (int16 PCM, or float32 samples in [-1, 1)).  ``precise=False``: the fp32-FFT front end (``ww_frontend_params.precise``
-    = 0) instead of the reference's float64 STFT."""
+    = 0) instead of the reference's float64 STFT.  ``timing``: a dict that receives this rank's wall-clock seconds per host
+    phase (``plan``, ``slicing``, ``h2d``, ``device_wall``, ``d2h``, ``gather``) and ``device_ms`` (HIP events around every
+    kernel of the call, ``ww_profile_read``); ``info`` receives ``windows`` (inferences of the whole call, all ranks).  ``as_array``: a float32 array instead of the reference's list (two hours of
+    negatives are 360,000 Python floats)."""
     if model_type not in ("CRNN", "Wavenet"):
         raise ValueError("model_type must be 'CRNN' or 'Wavenet'")
     if eval_type not in ("false_negatives", "false_accepts"):
         raise ValueError("eval_type must be 'false_negatives' or 'false_accepts'")
     eng: Engine = engine or engine_for(models_dir, device)
+    ph = _Phases(timing)
     frame_length = sample_rate // 1000 * frame_width
     in_memory = len(test_files) > 0 and not isinstance(test_files[0], (str, bytes)) and not hasattr(test_files[0], "__fspath__")
-    if in_memory:
-        load = lambda k: np.asarray(test_files[k])  # noqa: E731
-        lengths = [len(x) for x in test_files] if lengths is None else lengths
-    else:
-        rd = loader or (lambda p: read_wav_pcm(p, sample_rate))
-        load = lambda k: rd(str(test_files[k]))  # noqa: E731
-        if lengths is None:
-            lengths = [wav_length(str(f), sample_rate) for f in test_files] if loader is None else [len(rd(str(f))) for f in test_files]
-    if len(test_files) == 0:
-        return []
-    plan = StreamPlan(lengths, eng.window, frame_length, sample_rate, 2, carry_over)
-    mine = plan.shares(eval_type, world)[rank]
-    cache: dict = {}
-    pieces, n_win, slots = [], [], []
-    for k, i0, i1 in mine:
-        s0, s1 = plan.sample_range(k, i0, i1)
-        pieces.append(_stream_slice(plan, load, cache, s0, s1, k))
-        n_win.append(i1 - i0)
-        slots.append(np.arange(plan.offs[k] + i0, plan.offs[k] + i1))
-        for j in [j for j in cache if j < k - 1]:
-            del cache[j]
-    vals = _pieces_forward(eng, pieces, n_win, plan.hop, precise)[:, eng.posterior_index]
-    slots = np.concatenate(slots) if slots else np.zeros(0, np.int64)
-    if world > 1:
-        from . import dist as D
-        post = D.gather_posteriors(vals, slots, plan.total, device=comm_device)
-    else:
-        post = np.zeros(plan.total, np.float32)
-        post[slots] = vals
+    with ph("plan"):
+        if in_memory:
+            load = lambda k: test_files[k]  # noqa: E731
+            lengths = [len(x) for x in test_files] if lengths is None else lengths
+        else:
+            rd = loader or (lambda p: read_wav_pcm(p, sample_rate))
+            load = lambda k: rd(str(test_files[k]))  # noqa: E731
+            if lengths is None:
+                lengths = [wav_length(str(f), sample_rate) for f in test_files] if loader is None else [len(rd(str(f))) for f in test_files]
+        if len(test_files) == 0:
+            return []
+        plan = StreamPlan(lengths, eng.window, frame_length, sample_rate, 2, carry_over)
+        if info is not None:
+            info["windows"] = info.get("windows", 0) + plan.total  # inferences of the whole call, all ranks
+        mine = plan.shares(eval_type, world)[rank]
+        n_win = [i1 - i0 for _, i0, i1 in mine]
+        if mine:  # global slot of every window of my runs: offs[k] + i0 .. offs[k] + i1 - 1, run after run
+            nw = np.asarray(n_win, np.int64)
+            first = np.array([plan.offs[k] + i0 for k, i0, _ in mine], np.int64)
+            ends = np.cumsum(nw)
+            slots = np.arange(int(ends[-1]), dtype=np.int64) + np.repeat(first - (ends - nw), nw)
+        else:
+            slots = np.zeros(0, np.int64)
+    staged, soffs = _stage_pieces(plan, mine, load, ph, eng.ctx.device) if mine else (None, [])
+    vals = _pieces_forward(eng, staged, soffs, n_win, plan.hop, precise, ph, timing)[:, eng.posterior_index]
+    with ph("gather"):
+        if world > 1:
+            from . import dist as D
+            post = D.gather_posteriors(vals, slots, plan.total, device=comm_device)
+        else:
+            post = np.zeros(plan.total, np.float32)
+            post[slots] = vals
     if eval_type == "false_negatives":
-        return [np.max(post[plan.offs[k]:plan.offs[k + 1]]) for k in range(len(plan.n_win))]  # raises on an empty clip, like the reference
-    return post.tolist()
+        if (plan.n_win == 0).any():
+            raise ValueError("max() arg is an empty sequence")  # an empty clip: what np.max raises in the reference's loop
+        post = np.maximum.reduceat(post, plan.offs[:-1])
+    return post if as_array else post.tolist()
 
 
 def join_negatives(clips: Sequence[np.ndarray], num_files: int, sample_rate: int = 16000) -> np.ndarray:
@@ -310,42 +494,53 @@ def join_negatives(clips: Sequence[np.ndarray], num_files: int, sample_rate: int
     return np.concatenate(parts)
 
 
-def evaluate_negative_stream_sharded(engine: Engine, stream_pcm: np.ndarray, rank: int = 0, world: int = 1,
-                                     comm_device: Optional[str] = None, precise: bool = True) -> np.ndarray:
+def join_negatives_lazy(clips: Sequence[np.ndarray], num_files: int, sample_rate: int = 16000) -> JoinedPCM:
+    """:func:`join_negatives` as a :class:`JoinedPCM` (no copy of the clips)."""
+    return JoinedPCM([np.asarray(c, np.int16) for c in clips[:max(num_files, 1)]], sample_rate // 10)
+
+
+def evaluate_negative_stream_sharded(engine: Engine, stream_pcm, rank: int = 0, world: int = 1,
+                                     comm_device: Optional[str] = None, precise: bool = True,
+                                     timing: Optional[dict] = None, info: Optional[dict] = None) -> np.ndarray:
     """The reference's false-accept leg (``evaluate_models.py:317-321``: ``get_posterior(..., "false_accepts",
-    [FAR_path])``) on one long PCM stream, cut into ``world`` contiguous posterior ranges; full posterior array on
-    every rank (smoothing across the cuts happens after the gather, :func:`far_frr`)."""
-    return np.asarray(get_posterior_sharded(engine.model_dir, "CRNN" if engine.is_crnn else "Wavenet", "false_accepts",
-                                            [np.asarray(stream_pcm)], 20, 16000, rank, world, comm_device, engine=engine,
-                                            precise=precise), np.float32)
+    [FAR_path])``) on one long PCM stream (an int16 array or a :class:`JoinedPCM`), cut into ``world`` contiguous posterior
+    ranges; full posterior array on every rank (smoothing across the cuts happens after the gather, :func:`far_frr`)."""
+    stream = stream_pcm if isinstance(stream_pcm, JoinedPCM) else np.asarray(stream_pcm)
+    return get_posterior_sharded(engine.model_dir, "CRNN" if engine.is_crnn else "Wavenet", "false_accepts", [stream], 20, 16000,
+                                 rank, world, comm_device, engine=engine, precise=precise, timing=timing, as_array=True, info=info)
 
 
 def evaluate_reference_flow_sharded(engine: Engine, clips: Sequence[np.ndarray], labels: Sequence[int], rank: int = 0,
                                     world: int = 1, comm_device: Optional[str] = None, thresholds=None, windowsize: int = 30,
-                                    precise: bool = True):
+                                    precise: bool = True, timing: Optional[dict] = None):
     """``utils/evaluate_models.py`` ``main()`` (``:281-326``) on labelled int16 clips in memory, sharded over ``world``
     ranks: the wake-word clips go file by file through one never-reset ``Filter`` (quirk C2; utterance-sharded, a rank
     re-reads the <= 511-sample tail of a file's predecessor), the first ``num_wakewords`` other clips are joined by 100 ms
     of silence into ONE stream (``concatenate_FA``) that is evaluated continuously and cut into contiguous posterior ranges
     (:func:`evaluate_negative_stream_sharded`), hours = the joined stream's duration; rank 0 smooths and sweeps.
-    Returns the result dict on rank 0 and ``None`` elsewhere."""
+    Returns the result dict on rank 0 and ``None`` elsewhere.  ``timing``: see :func:`get_posterior_sharded`; the two legs
+    add up in it, and ``sweep`` is rank 0's smoothing + threshold sweep."""
     labels = np.asarray(labels).astype(bool)
     wake = [np.asarray(c, np.int16) for c, l in zip(clips, labels) if l]
     other = [np.asarray(c, np.int16) for c, l in zip(clips, labels) if not l]
     mtype = "CRNN" if engine.is_crnn else "Wavenet"
     num_wakewords = len(wake)
+    info: dict = {}
     pos = np.asarray(get_posterior_sharded(engine.model_dir, mtype, "false_negatives", wake, 20, 16000, rank, world,
-                                           comm_device, engine=engine, precise=precise), np.float32)
-    stream = join_negatives(other, num_wakewords) if other else np.zeros(0, np.int16)
-    neg = (evaluate_negative_stream_sharded(engine, stream, rank, world, comm_device, precise) if len(stream)
+                                           comm_device, engine=engine, precise=precise, timing=timing, as_array=True,
+                                           info=info), np.float32)
+    stream = join_negatives_lazy(other, num_wakewords) if other else None
+    neg = (evaluate_negative_stream_sharded(engine, stream, rank, world, comm_device, precise, timing, info) if stream is not None and len(stream)
            else np.zeros(0, np.float32))
     if rank != 0:
         return None
-    hours = len(stream) / 16000.0 / 3600.0
-    thr, frr, fa, cnt = far_frr(pos, neg, max(num_wakewords, 1), hours, thresholds, windowsize, engine=engine)
+    hours = (len(stream) if stream is not None else 0) / 16000.0 / 3600.0
+    with _Phases(timing)("sweep"):
+        thr, frr, fa, cnt = far_frr(pos, neg, max(num_wakewords, 1), hours, thresholds, windowsize, engine=engine)
     return {"thresholds": thr, "frr": frr, "fa_per_hour": fa, "fa_count": cnt, "frr_at_0.5_fa_per_hour": frr_at_fa(frr, fa, 0.5),
             "positives": pos, "negatives": neg, "hours": hours, "num_wakewords": num_wakewords,
-            "negative_clips_joined": min(len(other), max(num_wakewords, 1)), "windows": int(len(neg)) + int(num_wakewords),
+            "negative_clips_joined": min(len(other), max(num_wakewords, 1)), "windows": int(info.get("windows", 0)),
+            "negative_windows": int(len(neg)),
             "posterior_checksum": float(neg.sum(dtype=np.float64) + pos.sum(dtype=np.float64))}
 
 
@@ -429,6 +624,28 @@ def synth_testset(n_clips: int = 2048, seed: int = 1234, min_s: float = 0.8, max
     lens = rng.integers(int(min_s * 16000), int(max_s * 16000) + 1, n_clips)
     clips = [synth_clip(rng, int(n)) for n in lens]
     labels = (rng.random(n_clips) < 0.1).astype(np.uint8)
+    return clips, labels
+
+
+def synth_testset_scaled(n_wake: int = 2529, n_other: int = 2529, seed: int = 4321, min_s: float = 0.8, max_s: float = 2.5):
+    """A stand-in at the SIZE of the hey-snips test split as the reference's evaluator uses it (SURVEY 8d cfg 4): ``n_wake``
+    wake-word clips and the first ``n_other`` of the other clips (``utils/evaluate_models.py:299`` joins exactly
+    ``num_wakewords`` of them, whatever the split holds), the same signal model as :func:`synth_clip` generated in float32
+    (a two-hour set in seconds).  Returns ``(clips, labels)`` with the wake-word clips first."""
+    rng = np.random.default_rng(seed)
+    n = n_wake + n_other
+    lens = rng.integers(int(min_s * 16000), int(max_s * 16000) + 1, n)
+    clips = []
+    two_pi = np.float32(2 * np.pi)
+    for m in lens:
+        m = int(m)
+        t = np.arange(m, dtype=np.float32) * np.float32(1.0 / 16000.0)
+        dur = np.float32(max(m / 16000.0, 1e-3))
+        x = rng.standard_normal(m, dtype=np.float32) * np.float32(2000.0)
+        x += np.float32(8000.0) * np.sin(two_pi * (np.float32(200.0) * t + np.float32(0.5 * 3800.0) / dur * t * t))
+        clips.append(np.clip(np.rint(x), -32768, 32767).astype(np.int16))
+    labels = np.zeros(n, np.uint8)
+    labels[:n_wake] = 1
     return clips, labels
 
 
