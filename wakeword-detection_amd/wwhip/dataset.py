@@ -137,8 +137,9 @@ def write_h5(path: str, audio_clips: Sequence[dict]) -> None:
         import h5py  # type: ignore
     except ImportError:
         from . import h5min
-        # the built-in writer emits the same "earliest"-format structures h5py does; its output has only been read back
-        # by h5min itself in this image (tests/test_h5min.py cross-checks against h5py wherever h5py is installed)
+        # the built-in writer emits the same "earliest"-format structures h5py does: real libhdf5 reads its files back
+        # (tests/test_h5min.py::test_h5min_files_open_with_libhdf5, h5py 3.3.0 / libhdf5 1.10.6 of the image's conda python) and
+        # the built-in reader reads h5py-written ones bit for bit (::test_h5min_reads_a_file_written_by_h5py)
         _LOG.info("h5py is not installed: writing %s with the built-in HDF5 writer (wwhip.h5min)", path)
         h5min.write_datasets(path, {
             c["file_name"]: (np.asarray(c["features"], np.float32),
