@@ -108,11 +108,14 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
+PMC_FILE = os.path.join("profiles", "r04", "pmc_counters.json")
+
+
 def pmc_counters():
-    """profiles/r03/pmc_counters.json (tools/pmc_collect.py: rocprofv3 --pmc passes, mean per launch and kernel) if it
+    """profiles/r04/pmc_counters.json (tools/pmc_collect.py: rocprofv3 --pmc passes, mean per launch and kernel) if it
     was measured on THESE kernel sources, else None."""
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03", "pmc_counters.json")))
+        pmc = json.load(open(os.path.join(ROOT, PMC_FILE)))
     except (OSError, ValueError):
         return None
     return pmc if pmc.get("source_sha") == kernel_source_sha() else None
@@ -355,12 +358,12 @@ def roofline_of(eng, prof, clips, fast_frontend, step_s=None):
         roof["traffic"] = (2 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024
         roof["traffic_note"] = ("2 x FETCH_SIZE + WRITE_SIZE (KiB; gfx950 reports half of 16-byte-per-lane streaming reads: "
                                 "MI355X_MICROARCH.md), rocprofv3 --pmc in separate passes, mean bytes per launch "
-                                f"(profiles/r03/pmc_counters.json, kernel sources {pmc['source_sha']})")
+                                f"(profiles/r04/pmc_counters.json, kernel sources {pmc['source_sha']})")
         roof["algorithmic_bytes"] = nbytes
     elif pmc is None:
-        roof["traffic_note"] = "no PMC pass on these kernel sources (profiles/r03/pmc_counters.json absent or of another source_sha)"
+        roof["traffic_note"] = "no PMC pass on these kernel sources (profiles/r04/pmc_counters.json absent or of another source_sha)"
     # how busy the shared vector / matrix datapath is over a STEP (the fp32 MFMA and the vector ALU of a SIMD do not
-    # co-execute on gfx950: tools/pmc_calib.hip, profiles/r03/README.md): per kernel, busy cycles per SIMD =
+    # co-execute on gfx950: tools/pmc_calib.hip, profiles/r04/README.md): per kernel, busy cycles per SIMD =
     # SQ_VALU_MFMA_BUSY_CYCLES / 1024 + 3.7 x (SQ_INSTS_VALU - SQ_INSTS_MFMA) / 1024 over the kernel's own SQ_BUSY_CYCLES / 32
     # (all from one PMC pass, so the clock drops out), weighted with the kernels' live durations over the live step time
     roof["step_datapath_busy"] = None

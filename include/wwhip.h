@@ -79,6 +79,9 @@ int ww_ctx_synchronize(ww_ctx *ctx);
 void *ww_ctx_stream(ww_ctx *ctx);
 /* ctx may be NULL: the error of the calling THREAD's last failed ww_ctx_create (thread-local text). */
 const char *ww_last_error(const ww_ctx *ctx);
+/* "wwhip <major>.<minor> (...; ABI <n>: ...)".  The ABI number changes whenever an existing entry point changes its
+ * signature (ABI 4, round 4: ww_stream_create gained `flags` in round 3 - a host built against an older header must be
+ * rebuilt; check this string at load time, as wwhip/_lib.py does for the HIP runtime). */
 const char *ww_version(void);
 /* Which HIP runtime the library actually runs on.  libwwhip.so links libamdhip64 by soname; a host program that has
  * already loaded another copy (PyTorch-ROCm wheels bundle their own) decides which one that is.  built_hip_version =

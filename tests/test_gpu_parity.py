@@ -644,6 +644,36 @@ def test_stream_incremental_kernel_matches_full_recompute(assets, name):
         e.close()
 
 
+def test_full_recompute_bank_survives_an_option_change_after_its_creation(assets):
+    """A WW_STREAM_FULL_RECOMPUTE bank sizes its model scratch when it is created (1 KB while 2 S <= crnn_split_at: the fused
+    kernel keeps everything in LDS).  Options are per model and mutable: lowering the front/tail threshold afterwards sends
+    the bank's ticks to crnn_fused_kernel<front> + a tail, which want 2 S x 19 x 192 floats of scratch - the bank must grow
+    its buffer (round 3 wrote past the 1 KB one), and since every form rounds alike the posteriors must not change at all."""
+    from wwhip.engine import Engine, StreamBank
+    e = Engine(os.path.join(assets, "CRNN_softmax"))
+    S, ticks = 100, 24
+    rng = np.random.default_rng(5)
+    pcm = np.clip(rng.normal(0, 2500, (ticks, S, 320)), -32768, 32767).astype(np.int16)
+    speech = np.ones(S, np.uint8)
+    try:
+        ref_bank, bank = StreamBank(e, S, full_recompute=True), StreamBank(e, S, full_recompute=True)
+        want = [ref_bank.step(pcm[t], speech)[0].copy() for t in range(ticks)]
+        got = []
+        for t in range(ticks):
+            if t == 8:
+                e.set_option("crnn_split_at", 64)       # 200 windows per tick > 64: front + tail from here on
+            if t == 16:
+                e.set_option("crnn_tail_mfma", 2)       # ... and the sixteen-window tail, which wants its seq scratch too
+            got.append(bank.step(pcm[t], speech)[0].copy())
+        for t in range(ticks):
+            np.testing.assert_array_equal(got[t], want[t])
+        assert np.abs(np.array(want)).max() > 0
+        ref_bank.close()
+        bank.close()
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("name", ["CRNN", "CRNN_softmax"])
 def test_crnn_sliding_rows_path_matches_per_window_kernels(engines, oracles, name):
     """From 64 regular sliding windows on, the CRNN computes every projected row once per sequence (crnn_rows_kernel: one new
@@ -802,6 +832,43 @@ def test_two_host_threads_through_the_c_abi(assets, oracles):
                 np.testing.assert_array_equal(pa, pb)
         _, win, post, _, _ = got[name][-1]
         assert np.abs(post - oracles[name].forward(win)).max() < TOL_POST
+
+
+def test_short_lived_threads_release_their_contexts_and_engines(assets):
+    """The drop-in classes give every host thread its own ww_ctx and its own engines (wwhip/_lib.default_context,
+    wwhip/models.engine_for).  They live in thread-local storage: a thread-per-request host must get the stream, arenas and
+    uploaded weights of a finished thread back - six threads one after another leave no more live contexts / models than
+    there were, and each computed the same posteriors."""
+    import gc
+    import threading
+    from wwhip import _lib
+    from wwhip.models import engine_for
+    mdir = os.path.join(assets, "CRNN")
+    wins = np.random.default_rng(8).uniform(0, 6.5, (5, 151, 40)).astype(np.float32)
+    want = engine_for(mdir).forward(wins)
+    gc.collect()
+    base_ctx, base_models = len(_lib._live["contexts"]), len(_lib._live["models"])
+    outs, errs = [], []
+
+    def work():
+        try:
+            eng = engine_for(mdir)                       # this thread's engine on this thread's context
+            assert eng.ctx is _lib.default_context(0)
+            outs.append(eng.forward(wins))
+        except Exception as e:                           # pragma: no cover
+            errs.append(e)
+
+    for _ in range(6):
+        t = threading.Thread(target=work)
+        t.start()
+        t.join()
+        gc.collect()
+        assert len(_lib._live["contexts"]) <= base_ctx + 1 and len(_lib._live["models"]) <= base_models + 1
+    assert not errs and len(outs) == 6
+    for o in outs:
+        np.testing.assert_array_equal(o, want)
+    gc.collect()
+    assert len(_lib._live["contexts"]) == base_ctx and len(_lib._live["models"]) == base_models
 
 
 @pytest.mark.parametrize("name", ["Wavenet", "Wavenet_alt"])

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""rocprofv3 --pmc output directories -> profiles/r03/pmc_counters.json (what bench.py's roofline.traffic and
+"""rocprofv3 --pmc output directories -> profiles/r04/pmc_counters.json (what bench.py's roofline.traffic and
 step_datapath_busy read).  Usage:
 
     python tools/pmc_collect.py OUT.json workload=DIR [workload=DIR ...]
@@ -17,6 +17,8 @@ def short(name: str) -> str:
     n = name.replace("void ", "")
     m = re.match(r"(\w+)(<[^>]*>)?\(", n)
     base, targs = (m.group(1), m.group(2) or "") if m else (n, "")
+    if base == "logmel_rows_kernel":  # round 4: the fp64 front end (the library's own profile keeps the label)
+        return "logmel_kernel<f64>"
     if base == "logmel_kernel":
         return "logmel_kernel<f64>" if targs.startswith("<double") else "logmel_kernel<f32>"
     if base == "crnn_fused_kernel":
@@ -33,7 +35,7 @@ def short(name: str) -> str:
 def main():
     import bench
     out = {"source_sha": bench.kernel_source_sha(),
-           "note": "rocprofv3 --pmc passes (tools/r03_prof.sh), mean per launch.  FETCH_SIZE / WRITE_SIZE in KiB as reported "
+           "note": "rocprofv3 --pmc passes (tools/r04_prof.sh), mean per launch.  FETCH_SIZE / WRITE_SIZE in KiB as reported "
                    "(gfx950: FETCH_SIZE counts half of 16-byte-per-lane streaming reads -> traffic = 2 x FETCH + WRITE, "
                    "MI355X_MICROARCH.md); SQ_VALU_MFMA_BUSY_CYCLES in cycles summed over SIMDs; SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / "
                    "SQ_WAIT_* in quad-cycles summed over waves (same guide, s_memtime row).",

@@ -1,10 +1,10 @@
-# Round-3 profile set (development tool): rocprofv3 kernel-trace stats for every hot kernel (clip batch, sliding evaluation,
-# streaming), PMC passes (HBM traffic + SQ) of the same commands, counter calibration.  Everything goes to gpurun_out/r03p;
-# tools/pmc_collect.py turns the PMC directories into profiles/r03/pmc_counters.json.  Programs directly after `--`.
+# Round-4 profile set (development tool; round 3's with the new front-end kernel, the pipelined timeline and the at-scale evaluation): rocprofv3 kernel-trace stats for every hot kernel (clip batch, sliding evaluation,
+# streaming), PMC passes (HBM traffic + SQ) of the same commands, counter calibration.  Everything goes to gpurun_out/r04p;
+# tools/pmc_collect.py turns the PMC directories into profiles/r04/pmc_counters.json.  Programs directly after `--`.
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r03p
+O=$R/gpurun_out/r04p
 mkdir -p $O
 STATS="--kernel-trace --stats --output-format csv"
 WHAT=${1:-all}   # kt | pmc1 | pmc2 | all  (separate gpurun calls when one would run past the time limit)
@@ -22,6 +22,11 @@ rocprofv3 $STATS -d $O/kt_slide -o run -- python3 $R/tools/slide_throughput.py 1
 echo "kt slide done"
 rocprofv3 $STATS -d $O/kt_stream -o run -- python3 $R/tools/stream_prof.py > $O/stream_under_rocprof.txt 2> $O/kt_stream.err
 echo "kt stream done"
+rocprofv3 $STATS -d $O/kt_eval_scale -o run -- python3 $R/tools/eval_at_scale.py 2529 2 > $O/eval_at_scale_under_rocprof.txt 2> $O/kt_eval_scale.err
+echo "kt eval at scale done"
+rocprofv3 --kernel-trace -d $O/kt_pipe4 -o run --output-format csv -- python3 $R/tools/pipe_run.py 4 400 > $O/pipe4_under_rocprof.txt 2> $O/kt_pipe4.err
+python3 $R/tools/trace_timeline.py $(find $O/kt_pipe4 -name "*kernel_trace.csv" | head -1) 400 > $O/pipe4_timeline.txt
+echo "kt pipelined timeline done"
 fi
 if [ $WHAT = pmc1 ] || [ $WHAT = pmc2 ] || [ $WHAT = all ]; then
 # 2. PMC passes: one TCC counter per pass, SQ counters up to 8 per pass
@@ -46,8 +51,8 @@ for wl in "${WLS[@]}"; do
 done
 # 3. what the SQ counters count (known instruction streams)
 if [ $WHAT = pmc1 ] || [ $WHAT = all ]; then
-pmc calib "SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" $R/tools/build/pmc_calib
-$R/tools/build/pmc_calib > $O/pmc_calib_memtime.jsonl
+pmc calib "SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" $R/build_variants/pmc_calib
+$R/build_variants/pmc_calib > $O/pmc_calib_memtime.jsonl
 fi
 cd $R
 mkdir -p $O/summary
@@ -60,7 +65,8 @@ python3 tools/pmc_collect.py $O/summary/pmc_counters.json clips256=$O/pmc_clips2
 fi
 cd $R
 mkdir -p $O/summary
-for d in kt_bench_single kt_bench_default kt_bench_wavenet kt_bench_wavenet_fp32 kt_slide kt_stream; do
+for d in kt_bench_single kt_bench_default kt_bench_wavenet kt_bench_wavenet_fp32 kt_slide kt_stream kt_eval_scale; do
   f=$(ls $O/$d/*/*kernel_stats.csv $O/$d/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/summary/${d}_kernel_stats.csv
 done
+cp $O/pipe4_timeline.txt $O/summary/ 2>/dev/null || true
 ls $O/summary

@@ -69,7 +69,7 @@ struct ww_small_io {
 
 extern "C" {
 
-const char *ww_version(void) { return "wwhip 0.3 (gfx950)"; }
+const char *ww_version(void) { return "wwhip 0.4 (gfx950; ABI 4: ww_stream_create takes flags, ww_host_stage_i16)"; }
 
 int ww_runtime_info(int32_t *built_hip_version, int32_t *runtime_version, int32_t *driver_version) {
   if (built_hip_version) *built_hip_version = HIP_VERSION;  // headers the library was compiled against
@@ -1008,12 +1008,16 @@ static size_t model_ws(const ww_model *m, int nw) {
   return m->kind == WW_KIND_CRNN ? ww_crnn_workspace(m, nw) : ww_wave_workspace(m, nw);
 }
 
+// ws: model scratch inside the context's device arena (ww_ensure'd by the caller for model_ws(m, nw) or more): its capacity is
+// what is left of the arena behind it
 static int model_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *d_row,
                          const int32_t *d_valid, int64_t row0, int hop, int valid_const, int nw, void *ws, float *d_out,
                          float *d_enc) {
+  const char *lo = (const char *)ctx->dev.ptr, *p = (const char *)ws;
+  const size_t cap = (p >= lo && p <= lo + ctx->dev.cap) ? (size_t)(lo + ctx->dev.cap - p) : 0;
   return m->kind == WW_KIND_CRNN
-             ? ww_k_crnn_forward(ctx, m, d_mel, mel_rows, d_row, d_valid, row0, hop, valid_const, nw, ws, d_out, d_enc)
-             : ww_k_wave_forward(ctx, m, d_mel, mel_rows, d_row, d_valid, row0, hop, valid_const, nw, ws, d_out, d_enc);
+             ? ww_k_crnn_forward(ctx, m, d_mel, mel_rows, d_row, d_valid, row0, hop, valid_const, nw, ws, cap, d_out, d_enc)
+             : ww_k_wave_forward(ctx, m, d_mel, mel_rows, d_row, d_valid, row0, hop, valid_const, nw, ws, cap, d_out, d_enc);
 }
 
 // windows are processed in chunks so that the workspace stays bounded
@@ -1192,6 +1196,13 @@ int ww_clips_forward_dev(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, i
       d_fo = co.d_fo;
     }
   if (!d_so) {
+    // at most eight geometries stay cached (two small tables each); the oldest goes once nothing enqueued can still read it
+    if (ctx->clip_offs.size() >= 8) {
+      WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      hipFree(ctx->clip_offs.front().d_so);
+      hipFree(ctx->clip_offs.front().d_fo);
+      ctx->clip_offs.erase(ctx->clip_offs.begin());
+    }
     ww_ctx::clip_offs_t co;
     co.n_clips = n_clips; co.samples = samples; co.hop = fp->hop;
     WW_HIP(ctx, hipMalloc((void **)&co.d_so, sizeof(int64_t) * (n_clips + 1)));

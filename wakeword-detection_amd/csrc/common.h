@@ -205,8 +205,10 @@ int ww_k_viterbi2(ww_ctx *ctx, const float *d_in, int64_t n, int T, float stay_b
 // `sliding`: the caller may pass regular sliding windows (row0 + w*hop), for which the scratch of crnn_rows_kernel is reserved too
 size_t ww_crnn_workspace(const ww_model *m, int n_windows, bool sliding = true);
 int ww_k_crnn_init_device(ww_ctx *ctx);  // per-device kernel attributes (dynamic LDS above 64 KB)
+// ws_bytes: capacity of ws; a launch form that needs more (the model's options may have changed since ws was sized) fails with
+// WW_EINVAL instead of writing past it
 int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *d_win_row,
-                      const int32_t *d_win_valid, int64_t row0, int hop, int valid_const, int n_windows, void *ws,
+                      const int32_t *d_win_valid, int64_t row0, int hop, int valid_const, int n_windows, void *ws, size_t ws_bytes,
                       float *d_out, float *d_enc);
 bool ww_crnn_segments_capable(const ww_model *m, int hop);
 int ww_k_crnn_segments_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *seg_row0,
@@ -216,7 +218,7 @@ int ww_k_crnn_stream_forward(ww_ctx *ctx, const ww_model *m, const float *d_hist
                              const int32_t *d_win_valid, const int32_t *d_win_aux, float *d_gxc, int n_windows, float *d_out);
 size_t ww_wave_workspace(const ww_model *m, int n_windows);
 int ww_k_wave_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *d_win_row,
-                      const int32_t *d_win_valid, int64_t row0, int hop, int valid_const, int n_windows, void *ws,
+                      const int32_t *d_win_valid, int64_t row0, int hop, int valid_const, int n_windows, void *ws, size_t ws_bytes,
                       float *d_out, float *d_enc);
 int ww_k_far_frr(ww_ctx *ctx, const float *d_pos, int64_t n_pos, const float *d_neg, int64_t n_neg, int win,
                  const double *d_thr, int n_thr, double *d_smoothed, unsigned long long *d_pos_cnt,

@@ -2082,22 +2082,34 @@ size_t ww_crnn_workspace(const ww_model *m, int nw, bool sliding) {
 }
 
 int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *d_win_row,
-                      const int32_t *d_win_valid, int64_t row0, int hop, int valid_const, int nw, void *ws,
+                      const int32_t *d_win_valid, int64_t row0, int hop, int valid_const, int nw, void *ws, size_t ws_bytes,
                       float *d_out, float *d_enc) {
   if (nw <= 0) return WW_OK;
   const ww_crnn_dev &c = m->crnn;
   win_addr wa = {d_win_row, d_win_valid, row0, hop, valid_const, mel_rows};
+  // the scratch this launch takes under the model's CURRENT options (ww_model_set_option may have moved the thresholds
+  // since the caller sized ws): never past the end of what was handed in
+  const bool slide_form = !c.generic && !d_win_row && !d_win_valid && valid_const >= c.T && hop >= 1 && hop <= 8 && nw >= crnn_slide_min(m) &&
+                          row0 >= 0 && row0 + (int64_t)(nw - 1) * hop + c.T <= mel_rows;
+  {
+    size_t need = 0;
+    if (c.generic) need = crnn_generic_workspace(c, nw);
+    else if (slide_form) need = ww_bump::need(((size_t)9 * nw + 160) * 6 * c.H, 4) + tail_seq_bytes(nw) + 2048;
+    else if (crnn_split_threshold(m) > 0 && nw > crnn_split_threshold(m)) need = ww_bump::need((size_t)nw * c.OT * 6 * c.H, 4) + tail_seq_bytes(nw) + 2048;
+    if (need > ws_bytes)
+      return ww_fail(ctx, WW_EINVAL, "CRNN launch of %d windows needs %zu bytes of scratch, the caller reserved %zu (options changed "
+                     "after the buffer was sized?)", nw, need, ws_bytes);
+  }
   if (c.generic) return crnn_forward_generic(ctx, m, wa, d_mel, nw, ws, d_out, d_enc);
   fused_args a = {d_mel, wa, c.conv_w, c.conv_b, c.wx1s, c.bx1, c.wh1, c.bh1, c.wx2s, c.bx2, c.wh2, c.bh2,
                   c.w1, c.b1, c.w2, c.b2, d_enc, d_out, c.T, c.NOUT, c.HEAD, nullptr, nullptr, c.cwb, c.wx1b};
   const bool bf16 = m->precision == WW_PRECISION_BF16X3;
   // (also in split-bf16 mode: the mode permits bf16 products, and computing a seventh of them in fp32 is both faster and closer)
-  if (!d_win_row && !d_win_valid && valid_const >= c.T && hop >= 1 && hop <= 8 && nw >= crnn_slide_min(m) && row0 >= 0 &&
-      row0 + (int64_t)(nw - 1) * hop + c.T <= mel_rows) {
+  if (slide_form) {
     // windows sliding over one sequence: 1 + 2 positions per window instead of 19 (crnn_rows_kernel)
     const int g = gcd8(hop);
     const int64_t n_int = ((int64_t)(nw - 1) * hop + 128) / g + 1;
-    ww_bump b(ws, ~size_t(0));
+    ww_bump b(ws, ws_bytes);
     float *gI = b.take<float>((size_t)n_int * 6 * c.H), *gL = b.take<float>((size_t)nw * 6 * c.H), *gR = b.take<float>((size_t)nw * 6 * c.H);
     float *seq = (float *)b.take<char>(tail_seq_bytes(nw));
     rows_args r = {};
@@ -2121,7 +2133,7 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
   }
   const int thr = crnn_split_threshold(m);
   if (thr > 0 && nw > thr) {
-    ww_bump b(ws, ~size_t(0));
+    ww_bump b(ws, ws_bytes);
     a.gx_out = b.take<float>((size_t)nw * c.OT * 6 * c.H);
     float *seq = (float *)b.take<char>(tail_seq_bytes(nw));
     {

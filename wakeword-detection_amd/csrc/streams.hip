@@ -42,6 +42,7 @@ struct ww_streams {
   int64_t *d_win_row = nullptr;  // [2S]
   int32_t *d_win_valid = nullptr;
   void *ws = nullptr;
+  size_t ws_bytes = 0;           // capacity of ws (grown by ww_stream_step when the model's options ask for more)
   // host mirrors (pinned)
   int32_t *h_ctl = nullptr;
   int64_t *h_win_row = nullptr;
@@ -230,7 +231,7 @@ int ww_stream_create(ww_ctx *ctx, const ww_model *model, int32_t S, const ww_fro
   bool ok = hipMalloc((void **)&st->ring, (size_t)S * ST_RING * 4) == hipSuccess &&
             hipMalloc((void **)&st->hist, hist_elems * 4) == hipSuccess &&
             hipMalloc((void **)&st->prev, (size_t)S * 4) == hipSuccess &&
-            hipMalloc(&st->ws, ws_bytes) == hipSuccess &&
+            hipMalloc(&st->ws, ws_bytes) == hipSuccess && ((st->ws_bytes = ws_bytes), true) &&
             hipHostMalloc((void **)&st->h_out, (size_t)2 * S * st->NO * 4) == hipSuccess;
   {
     const size_t o_frames = 0, o_row = o_frames + (size_t)S * WW_CHUNK * 2, o_ctl = o_row + (size_t)2 * S * 8,
@@ -383,13 +384,27 @@ int ww_stream_step(ww_streams *st, const int16_t *frames, const uint8_t *is_spee
     }
   }
   WW_HIP(ctx, hipGetLastError());
+  if (nw && !st->incremental) {
+    // the per-window kernels' scratch under the model's options of THIS tick (ww_model_set_option may have lowered the
+    // front/tail threshold since the bank was created: the split form then wants nw x 19 x 192 floats)
+    const size_t need = m->kind == WW_KIND_CRNN ? ww_crnn_workspace(m, nw, false) : ww_wave_workspace(m, nw);
+    if (need > st->ws_bytes) {
+      WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      WW_HIP(ctx, hipFree(st->ws));
+      st->ws = nullptr;
+      st->ws_bytes = 0;
+      const size_t want = m->kind == WW_KIND_CRNN ? ww_crnn_workspace(m, 2 * S, false) : ww_wave_workspace(m, 2 * S);
+      if (hipMalloc(&st->ws, want > need ? want : need) != hipSuccess) return ww_fail(ctx, WW_ENOMEM, "cannot grow the model scratch of %d streams", S);
+      st->ws_bytes = want > need ? want : need;
+    }
+  }
   if (nw) {
     const float *d_hist = st->hist;
     int rc = st->incremental
                  ? ww_k_crnn_stream_forward(ctx, m, d_hist, (int64_t)S * st->HR, st->d_win_row, st->d_win_valid, st->d_win_aux, st->gxc, nw, st->h_out_dev)
              : m->kind == WW_KIND_CRNN
-                 ? ww_k_crnn_forward(ctx, m, d_hist, (int64_t)S * st->HR, st->d_win_row, st->d_win_valid, 0, 0, 0, nw, st->ws, st->h_out_dev, nullptr)
-                 : ww_k_wave_forward(ctx, m, d_hist, (int64_t)S * st->HR, st->d_win_row, st->d_win_valid, 0, 0, 0, nw, st->ws, st->h_out_dev, nullptr);
+                 ? ww_k_crnn_forward(ctx, m, d_hist, (int64_t)S * st->HR, st->d_win_row, st->d_win_valid, 0, 0, 0, nw, st->ws, st->ws_bytes, st->h_out_dev, nullptr)
+                 : ww_k_wave_forward(ctx, m, d_hist, (int64_t)S * st->HR, st->d_win_row, st->d_win_valid, 0, 0, 0, nw, st->ws, st->ws_bytes, st->h_out_dev, nullptr);
     if (rc) return rc;
     // the head kernels store the few posteriors of a tick straight into pinned host memory: no device-to-host copy
     // (a DMA operation of its own) between the last kernel and the host's wake-up

@@ -753,7 +753,7 @@ __global__ __launch_bounds__(WV_NW * 64, WV_NW == 12 ? (SPLIT_BF16 ? WV_BF16_OCC
 size_t ww_wave_workspace(const ww_model *, int) { return 256; }
 
 int ww_k_wave_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *d_win_row,
-                      const int32_t *d_win_valid, int64_t row0, int hop, int valid_const, int nw, void *, float *d_out,
+                      const int32_t *d_win_valid, int64_t row0, int hop, int valid_const, int nw, void *, size_t, float *d_out,
                       float *d_enc) {
   if (nw <= 0) return WW_OK;
   const ww_wave_dev &v = m->wave;

@@ -239,18 +239,18 @@ class Context:
             pass
 
 
-_default_ctx: Dict[tuple, Context] = {}
-_ctx_lock = threading.Lock()  # not _lock: Context() itself goes through load(), which takes that one
+_tls = threading.local()  # per host thread: {"ctx": {device: Context}}; dropped - and with it the contexts - when the thread ends
 
 
 def default_context(device: int = 0) -> Context:
     """The calling thread's context on ``device`` for the drop-in classes: include/wwhip.h asks for one ``ww_ctx`` per
     host thread (the reference itself is single-threaded: SURVEY 8b 'Threading / ownership'), so two threads that use
-    the drop-in classes never share a stream or a workspace."""
-    key = (device, threading.get_ident())
-    with _ctx_lock:
-        ctx = _default_ctx.get(key)
-        if ctx is None or ctx.handle is None:
-            ctx = Context(device)
-            _default_ctx[key] = ctx
+    the drop-in classes never share a stream or a workspace.  The context lives in thread-local storage: when a short-lived
+    thread ends, its context (stream, events, arenas) is released with it instead of staying on the GPU until the process
+    exits."""
+    per_thread = _tls.__dict__.setdefault("ctx", {})
+    ctx = per_thread.get(device)
+    if ctx is None or ctx.handle is None:
+        ctx = Context(device)
+        per_thread[device] = ctx
     return ctx

@@ -11,6 +11,7 @@ routed by which of the three graphs the path names.
 from __future__ import annotations
 
 import os
+import threading
 from typing import Any, Dict, List
 
 import numpy as np
@@ -19,18 +20,19 @@ from . import _lib
 from . import tflite_reader as R
 from .engine import Engine
 
-_ENGINES: Dict[str, Engine] = {}
+_TLS = threading.local()  # per host thread: {"engines": {(model dir, device): Engine}}
 
 
 def engine_for(model_dir: str, device: int = 0) -> Engine:
     """One resident :class:`Engine` per (model directory, device, host thread): an engine enqueues on its thread's own
-    context (``_lib.default_context``), which is never shared between threads."""
-    import threading
-    key = f"{os.path.abspath(model_dir)}@{device}@{threading.get_ident()}"
-    eng = _ENGINES.get(key)
+    context (``_lib.default_context``), which is never shared between threads.  Thread-local, like the context: a thread
+    that ends takes its engines (the uploaded weights) with it, and no lock is needed around the table."""
+    engines = _TLS.__dict__.setdefault("engines", {})
+    key = (os.path.abspath(model_dir), device)
+    eng = engines.get(key)
     if eng is None or eng.handle is None:
         eng = Engine(model_dir, device=device)
-        _ENGINES[key] = eng
+        engines[key] = eng
     return eng
 
 

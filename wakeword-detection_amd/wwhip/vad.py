@@ -47,35 +47,26 @@ def _default_classifier(mode: int) -> Callable[[bytes, int], bool]:
 
 
 class VoiceActivityDetector:
-    """``spokestack/vad/webrtc.py:22-86``: sets ``context.is_speech`` with rise / fall delays."""
+    """``spokestack/vad/webrtc.py:22-86`` - sets ``context.is_speech`` with rise / fall delays - as the one-stream case of
+    :class:`VadBank` (defined below): the stage classifies its frame, the bank runs the hysteresis, the stage writes the
+    context when the bank's output moved.  (``tests/test_host_logic.py`` replays a recorded trace of the reference class
+    through it; ``tests/test_gpu_dropin.py`` holds 128 of these against one 128-stream bank tick by tick.)"""
 
     def __init__(self, sample_rate: int = 16000, frame_width: int = 20, vad_rise_delay: int = 0, vad_fall_delay: int = 0,
                  mode: int = QUALITY, classifier: Optional[Callable[[bytes, int], bool]] = None, **kwargs) -> None:
         self._sample_rate = sample_rate
-        self._rise_length = vad_rise_delay // frame_width
-        self._fall_length = vad_fall_delay // frame_width
         self._classify = classifier if classifier is not None else _default_classifier(mode)
-        self._run_value = 0
-        self._run_length = 0
+        self._bank = VadBank(1, frame_width, vad_rise_delay, vad_fall_delay)
 
     def __call__(self, context: SpeechContext, frame: np.ndarray) -> None:
-        raw = self._classify(np.asarray(frame).tobytes(), self._sample_rate) > 0
-        if raw == self._run_value:
-            self._run_length += 1
-        else:
-            self._run_value = raw
-            self._run_length = 1
-        if self._run_value != context.is_speech:
-            if self._run_value and self._run_length >= self._rise_length:
-                context.is_speech = True
-                _LOG.info("vad: true")
-            if not self._run_value and self._run_length >= self._fall_length:
-                context.is_speech = False
-                _LOG.info("vad: false")
+        self._bank.is_speech[0] = bool(context.is_speech)  # the context is the state; other stages may have written it
+        now = bool(self._bank.step([self._classify(np.asarray(frame).tobytes(), self._sample_rate) > 0])[0])
+        if now != bool(context.is_speech):
+            context.is_speech = now
+            _LOG.info("vad: %s", "true" if now else "false")
 
     def reset(self) -> None:
-        self._run_value = 0
-        self._run_length = 0
+        self._bank.reset()
 
     def close(self) -> None:
         self.reset()
@@ -85,19 +76,19 @@ class VoiceActivityTrigger:
     """``spokestack/vad/webrtc.py:88-116``: activates the context on a rising speech edge."""
 
     def __init__(self) -> None:
-        self._is_speech = False
+        self._seen = False  # context.is_speech as of the previous frame
 
     def __call__(self, context: SpeechContext, frame: np.ndarray = None) -> None:
-        if context.is_speech != self._is_speech:
-            if context.is_speech:
-                context.is_active = True
-            self._is_speech = context.is_speech
+        rising = bool(context.is_speech) and not self._seen
+        self._seen = bool(context.is_speech)
+        if rising:
+            context.is_active = True
+
+    def reset(self) -> None:
+        self._seen = False
 
     def close(self) -> None:
         self.reset()
-
-    def reset(self) -> None:
-        self._is_speech = False
 
 
 class VadBank:
