@@ -702,6 +702,26 @@ def test_crnn_sliding_rows_path_matches_per_window_kernels(engines, oracles, nam
         assert np.abs(got[idx] - oracles[name].forward(wins[idx])).max() < TOL_POST
 
 
+def test_wavenet_split_bf16_launch_forms_agree(assets):
+    """Split-bf16 Wavenet: launches of up to 256 windows run twelve waves x one tile per window, larger ones four waves x
+    three tiles with two workgroups per CU (wavenet.hip, ww_k_wave_forward).  The per-tile arithmetic is the same: 700 windows
+    in one launch (wide form), in launches of 200 (one tile per wave) and of 300 (wide) give the same bits, encoder output
+    included; windows of partial validity among them."""
+    from wwhip.engine import Engine
+    e = Engine(os.path.join(assets, "Wavenet"), precision="bf16x3")
+    try:
+        rng = np.random.default_rng(41)
+        wins = rng.uniform(0, 6.5, (700, e.window, 40)).astype(np.float32)
+        wins[::9, 150:] = 0
+        whole, whole_enc = e.forward(wins, want_enc=True)
+        for step in (200, 300):
+            parts = [e.forward(wins[i:i + step], want_enc=True) for i in range(0, 700, step)]
+            np.testing.assert_array_equal(np.concatenate([p[0] for p in parts]), whole)
+            np.testing.assert_array_equal(np.concatenate([p[1] for p in parts]), whole_enc)
+    finally:
+        e.close()
+
+
 def test_crnn_default_dispatch_crossover_leaves_posteriors_alone(engines):
     """With the library's default options the tail kernel changes at 9,216 windows per launch (gru_tail_kernel below,
     gru_tail16_kernel from there on) and public calls chunk at 16,384: a posterior must not depend on the size of the call it

@@ -669,6 +669,15 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? 4 : 5) void logmel_kernel(log
 #ifndef LW_WPB
 #define LW_WPB 4  // waves per workgroup (they share nothing; 4 = fewest workgroups to dispatch)
 #endif
+#ifndef LW_HC
+#define LW_HC 4    // Hann pairs fetched per chunk (16 / LW_HC chunks, double-buffered)
+#endif
+#ifndef LW_TC
+#define LW_TC 3    // inter-pass twiddles fetched per chunk (15 / LW_TC chunks, double-buffered)
+#endif
+#ifndef LW_VGPR
+#define LW_VGPR 52  // amdgpu_num_vgpr counts in units of two on gfx90a+: 104 registers
+#endif
 #define LW_WBUF (4 * 16 * TR_LD * 8)  // 8,704 B per wave: 16x16 fp64 transposes of 4 frames; before that the sample tile
 #define LW_ROWF 528                   // generic path: floats per staged frame (512 + up to 7 of shift, 16-byte multiple)
 static_assert(4 * LW_ROWF * 4 <= LW_WBUF && (WIN + 3 * 512 + 16) * 4 <= LW_WBUF && 4 * MAG_LD * 4 <= LW_WBUF, "per-wave buffer too small");
@@ -731,7 +740,7 @@ __device__ __forceinline__ int64_t lw_readlane64(int64_t v, int src_lane) {
 }
 
 template <bool F32IN, bool SIMPLE>
-__global__ __launch_bounds__(64 * LW_WPB) __attribute__((amdgpu_num_vgpr(52))) void logmel_rows_kernel(logmel_args a) {
+__global__ __launch_bounds__(64 * LW_WPB) __attribute__((amdgpu_num_vgpr(LW_VGPR))) void logmel_rows_kernel(logmel_args a) {
   extern __shared__ __align__(16) unsigned char smem[];
   typedef double R;
   constexpr int VEC = F32IN ? 4 : 8;  // elements per 16-byte load
@@ -860,7 +869,7 @@ __global__ __launch_bounds__(64 * LW_WPB) __attribute__((amdgpu_num_vgpr(52))) v
   float *mg = (float *)wb;  // overlay: [4][MAG_LD]
   cplx<R> v[16];
   const double2 *twp = (const double2 *)a.tw16 + j;  // [k1][16 j] = W256^(j k1)
-  double2 tq[2][3];
+  double2 tq[2][LW_TC];
   {
     // pass 1: lane j holds z[16 n1 + j], n1 = 0..15; Hann product in fp64 (tflite.py:175).  Hann pairs (h[2n], h[2n+1]),
     // n = 16 n1 + j, from the half table of 128 pairs (h[m] = h[511 - m]) through the vector L1, four n1 at a time and one
@@ -871,25 +880,26 @@ __global__ __launch_bounds__(64 * LW_WPB) __attribute__((amdgpu_num_vgpr(52))) v
       const double2 m = hb[16 * (15 - n1) + 15 - j];
       return make_double2(m.y, m.x);
     };
-    double2 h[2][4];
+    constexpr int HC = LW_HC, NHC = 16 / HC;  // Hann pairs per chunk; one chunk in flight ahead of the one being used
+    double2 h[2][HC];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) h[0][i] = hload(i);
+    for (int i = 0; i < HC; ++i) h[0][i] = hload(i);
     const bool pairs = __all((((int)(src - tile)) & 1) == 0);
     if (pairs) {
       // 8-byte aligned pairs: ds_read_b64 (with hop = 160 the four frames of a wave sit 32 banks apart: conflict-free)
       double xs[16];
       lds_read16_b64_s128(src + 2 * j, xs);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if (c + 1 < 4) {
+      for (int c = 0; c < NHC; ++c) {
+        if (c + 1 < NHC) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) h[(c + 1) & 1][i] = hload(4 * (c + 1) + i);
+          for (int i = 0; i < HC; ++i) h[(c + 1) & 1][i] = hload(HC * (c + 1) + i);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (c == 0) lds_wait_all(xs);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int n1 = 4 * c + i;
+        for (int i = 0; i < HC; ++i) {
+          const int n1 = HC * c + i;
           v[n1].re = (R)__int_as_float(__double2loint(xs[n1])) * h[c & 1][i].x;
           v[n1].im = (R)__int_as_float(__double2hiint(xs[n1])) * h[c & 1][i].y;
         }
@@ -897,16 +907,16 @@ __global__ __launch_bounds__(64 * LW_WPB) __attribute__((amdgpu_num_vgpr(52))) v
       }
     } else {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if (c + 1 < 4) {
+      for (int c = 0; c < NHC; ++c) {
+        if (c + 1 < NHC) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) h[(c + 1) & 1][i] = hload(4 * (c + 1) + i);
+          for (int i = 0; i < HC; ++i) h[(c + 1) & 1][i] = hload(HC * (c + 1) + i);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int n = 16 * (4 * c + i) + j;
-          v[4 * c + i].re = (R)src[2 * n] * h[c & 1][i].x;
-          v[4 * c + i].im = (R)src[2 * n + 1] * h[c & 1][i].y;
+        for (int i = 0; i < HC; ++i) {
+          const int n = 16 * (HC * c + i) + j;
+          v[HC * c + i].re = (R)src[2 * n] * h[c & 1][i].x;
+          v[HC * c + i].im = (R)src[2 * n + 1] * h[c & 1][i].y;
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -915,22 +925,23 @@ __global__ __launch_bounds__(64 * LW_WPB) __attribute__((amdgpu_num_vgpr(52))) v
   FE_STAMP(3)
   FE_STAMP(4)
   {
-    // the first three inter-pass twiddles are requested before the butterflies that precede their use
+    // the first inter-pass twiddles are requested before the butterflies that precede their use
+    constexpr int TC = LW_TC, NTC = 15 / TC;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) tq[0][i] = twp[k_of(1 + i) * 16];
+    for (int i = 0; i < TC; ++i) tq[0][i] = twp[k_of(1 + i) * 16];
     dft16<R>(v);
     FE_STAMP(5)
-    // v[pos] *= W256^(j k_of(pos)): 15 sixteen-byte loads per lane from the L1-resident table, three at a time, one chunk ahead
+    // v[pos] *= W256^(j k_of(pos)): 15 sixteen-byte loads per lane from the L1-resident table, TC at a time, one chunk ahead
 #pragma unroll
-    for (int c = 0; c < 5; ++c) {
-      if (c + 1 < 5) {
+    for (int c = 0; c < NTC; ++c) {
+      if (c + 1 < NTC) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) tq[(c + 1) & 1][i] = twp[k_of(1 + 3 * (c + 1) + i) * 16];
+        for (int i = 0; i < TC; ++i) tq[(c + 1) & 1][i] = twp[k_of(1 + TC * (c + 1) + i) * 16];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int pos = 1 + 3 * c + i;
+      for (int i = 0; i < TC; ++i) {
+        const int pos = 1 + TC * c + i;
         v[pos] = cmul(v[pos], cplx<R>{tq[c & 1][i].x, tq[c & 1][i].y});
       }
       __builtin_amdgcn_sched_barrier(0);

@@ -46,6 +46,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef WV_BF16_NW
 #define WV_BF16_NW 12
 #endif
+#ifndef WV_BF16_WIDE_FROM
+#define WV_BF16_WIDE_FROM 256  // launches of more windows than this (= CUs of the chip) take the 4-wave x 3-tile form, two workgroups per CU
+#endif
 #ifndef WV_BF16_OCC
 #define WV_BF16_OCC 3   // waves per SIMD the split-bf16 kernel is compiled for (3 = one workgroup per CU)
 #endif
@@ -803,7 +806,15 @@ int ww_k_wave_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
     dump.d = a.stamps;
   }
 #endif
-  if (m->precision == WW_PRECISION_BF16X3)
+  // split-bf16: twelve waves x one 16-row tile while every window has a CU of its own (the 24 blocks of a window are a serial
+  // chain: more waves per window cover its latencies best, 39.1 vs 45.7 us per 256 windows); from the 257th window of a launch
+  // on FOUR waves x three tiles (173 registers, 74 KB: TWO workgroups per CU, each wave issuing three tiles' independent MFMAs
+  // and gate evaluations back to back): 1,656 vs 1,957 us per 16,384 windows, 69.8 vs 74.5 at 512.  Same arithmetic per
+  // tile in both forms: a posterior does not depend on the launch size (tests/test_gpu_parity.py).  (Six waves x two tiles -
+  // also two workgroups per CU - lose at every size: 2,393 us.)
+  if (m->precision == WW_PRECISION_BF16X3 && WV_BF16_NW == 12 && nw > WV_BF16_WIDE_FROM)
+    hipLaunchKernelGGL((wavenet_kernel<false, true, 4>), dim3(nw), dim3(4 * 64), 0, ctx->stream, a);
+  else if (m->precision == WW_PRECISION_BF16X3)
     hipLaunchKernelGGL((wavenet_kernel<false, true, WV_BF16_NW>), dim3(nw), dim3(WV_BF16_NW * 64), 0, ctx->stream, a);
   else if (m->opt_wave_rowmajor)
     hipLaunchKernelGGL((wavenet_kernel<false, false, 12>), dim3(nw), dim3(12 * 64), 0, ctx->stream, a);
