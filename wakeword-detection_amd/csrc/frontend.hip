@@ -667,8 +667,9 @@ __global__ __launch_bounds__(256, sizeof(R) == 8 ? 4 : 5) void logmel_kernel(log
 // results are bit-identical.
 // ---------------------------------------------------------------------------------------------------------------------
 #ifndef LW_WPB
-#define LW_WPB 4  // waves per workgroup (they share nothing; 4 = fewest workgroups to dispatch)
-#endif
+#define LW_WPB 2  // waves per workgroup (they share nothing).  Same box, rocprofv3, 256 / 4,096 clips: 4 waves 27.96 / 353.5 us,
+#endif            // 2 waves 27.2-27.5 / 350.5-352.0, 1 wave 27.6 / 350.9; logmel_kernel<f64> (rounds 1-3) 27.3-27.8 / 356.4-357.6
+
 #ifndef LW_HC
 #define LW_HC 4    // Hann pairs fetched per chunk (16 / LW_HC chunks, double-buffered)
 #endif
