@@ -857,7 +857,7 @@ static int logmel_host(ww_ctx *ctx, const ww_model *m, const void *samples, size
     for (int u = 0; u <= n_utt; ++u) h_so[u] = sample_offs[u] - base;
     memcpy(h_fo, frame_offs, sizeof(int64_t) * (n_utt + 1));
     rc = ww_k_logmel(ctx, m, elt == 2 ? (const int16_t *)io.dv(h_s) : nullptr, elt == 4 ? (const float *)io.dv(h_s) : nullptr,
-                     io.dv(h_so), io.dv(h_fo), n_utt, total_f, max_f, fp, io.dv(h_mel));
+                     io.dv(h_so), io.dv(h_fo), n_utt, total_f, max_f, fp, io.dv(h_mel), 0, total_s);
     if (rc) return rc;
     WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(mel, h_mel, (size_t)total_f * m->filt.n_mel * 4);
@@ -874,7 +874,7 @@ static int logmel_host(ww_ctx *ctx, const ww_model *m, const void *samples, size
   WW_HIP(ctx, hipMemcpyAsync(d_so, so.data(), sizeof(int64_t) * (n_utt + 1), hipMemcpyHostToDevice, ctx->stream));
   WW_HIP(ctx, hipMemcpyAsync(d_fo, frame_offs, sizeof(int64_t) * (n_utt + 1), hipMemcpyHostToDevice, ctx->stream));
   rc = ww_k_logmel(ctx, m, elt == 2 ? (const int16_t *)d_s : nullptr, elt == 4 ? (const float *)d_s : nullptr, d_so, d_fo,
-                   n_utt, total_f, max_f, fp, d_mel);
+                   n_utt, total_f, max_f, fp, d_mel, 0, total_s);
   if (rc) return rc;
   WW_HIP(ctx, hipMemcpyAsync(mel, d_mel, (size_t)total_f * m->filt.n_mel * 4, hipMemcpyDeviceToHost, ctx->stream));
   WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1222,7 +1222,7 @@ int ww_clips_forward_dev(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, i
     ww_bump bump(ctx->dev.ptr, ctx->dev.cap);
     float *d_mel = bump.take<float>((size_t)n_clips * (nf > 0 ? nf : 1) * F);
     void *ws = bump.take<char>(b_ws);
-    int r = ww_k_logmel(ctx, m, d_pcm, nullptr, d_so, d_fo, n_clips, (int64_t)n_clips * nf, nf, fp, d_mel, samples);
+    int r = ww_k_logmel(ctx, m, d_pcm, nullptr, d_so, d_fo, n_clips, (int64_t)n_clips * nf, nf, fp, d_mel, samples, (int64_t)n_clips * samples);
     if (r) return r;
     // one window per clip: rows [c*nf, c*nf + min(nf, T)), zero padded to T
     return model_forward(ctx, m, d_mel, (int64_t)n_clips * nf, nullptr, nullptr, 0, (int)nf, (int)(nf < T ? nf : T),

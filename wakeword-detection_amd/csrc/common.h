@@ -194,7 +194,8 @@ struct ww_bump {
 // ---- kernel-side entry points implemented in the .hip files ------------------------------
 int ww_k_logmel(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, const float *d_f32, const int64_t *d_sample_offs,
                 const int64_t *d_frame_offs, int n_utt, int64_t total_frames, int64_t max_frames_per_utt,
-                const ww_frontend_params *fp, float *d_mel, int64_t uniform_samples = 0);  // > 0: equal clips back to back from sample 0
+                const ww_frontend_params *fp, float *d_mel, int64_t uniform_samples = 0,  // > 0: equal clips back to back from sample 0
+                int64_t total_samples_hint = 0);  // > 0: sample_offs[n_utt], where the host knows it (device tables otherwise)
 int ww_k_stft_mag(ww_ctx *ctx, const ww_model *m, const float *d_frames, int64_t n, int precise, float *d_mag);
 int ww_k_mel_only(ww_ctx *ctx, const ww_model *m, const float *d_mag, int64_t n, float *d_mel);
 int ww_k_crnn_detect(ww_ctx *ctx, const ww_model *m, const float *d_enc, int nw, float *d_out);

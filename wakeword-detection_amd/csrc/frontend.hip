@@ -76,6 +76,8 @@ struct logmel_args {
   int64_t total_frames;
   int uniform_nf;      // > 0: every clip has this many frames and uniform_ns samples, clip u starts at sample u * uniform_ns
   int64_t uniform_ns;
+  unsigned uni_magic;  // uniform_nf >= 4: row / uniform_nf = __umulhi(row, uni_magic) >> uni_shift for every row < 2^31
+  int uni_shift;
   long long *stamps;  // development (-DWW_FE_STAMPS=1): [workgroups][4 waves][12] s_memtime at the phase boundaries
 };
 
@@ -740,7 +742,13 @@ __device__ __forceinline__ int64_t lw_readlane64(int64_t v, int src_lane) {
   return ((int64_t)hi << 32) | (unsigned int)lo;
 }
 
-template <bool F32IN, bool SIMPLE>
+__device__ __forceinline__ int lw_readlane64(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
+template <bool SMALL> struct lw_idx { typedef int64_t type; };
+template <> struct lw_idx<true> { typedef int type; };  // every sample index of the launch fits 31 bits (the host checked)
+
+// SMALL: sample indices in 32 bits and (equal clips) the row -> clip division as one multiply: the index arithmetic of a wave
+// is vector instructions like everything else, ~100 of the ~960 it issues in 64-bit form.
+template <bool F32IN, bool SIMPLE, bool SMALL = false>
 __global__ __launch_bounds__(64 * LW_WPB) __attribute__((amdgpu_num_vgpr(LW_VGPR))) void logmel_rows_kernel(logmel_args a) {
   extern __shared__ __align__(16) unsigned char smem[];
   typedef double R;
@@ -758,58 +766,71 @@ __global__ __launch_bounds__(64 * LW_WPB) __attribute__((amdgpu_num_vgpr(LW_VGPR
   FE_STAMP(0)
 
   // ---- which clip does this 16-lane row's frame belong to, and where do its samples start
-  int64_t s_begin, b;
+  typedef typename lw_idx<SMALL>::type idx_t;
+  idx_t s_begin, b;
   bool rv;
   {
     const int64_t g = g0 + sub;
     rv = g < a.total_frames;
     const int64_t gc = rv ? g : g0;
-    if (a.uniform_nf > 0) {  // equal-length clips back to back: arithmetic
+    if (SMALL && a.uni_magic) {
+      // equal clips of >= 4 frames back to back: the wave's first row is a scalar, its clip comes out of one multiply, and a
+      // row of the wave is in that clip or the next one
+      const unsigned g0u = (unsigned)g0, nfu = (unsigned)a.uniform_nf;
+      const unsigned u0 = __umulhi(g0u, a.uni_magic) >> a.uni_shift;
+      unsigned f = g0u - u0 * nfu + (unsigned)sub;
+      const bool next = f >= nfu;
+      f -= next ? nfu : 0u;
+      s_begin = (idx_t)((u0 + (next ? 1u : 0u)) * (unsigned)a.uniform_ns);
+      b = s_begin + (idx_t)(f * (unsigned)a.hop);  // (rows past the launch's last one get the first row's values below)
+    } else if (a.uniform_nf > 0) {  // equal-length clips back to back: arithmetic
       const unsigned gu = (unsigned)gc, nfu = (unsigned)a.uniform_nf;
       const unsigned u = gu / nfu, f = gu - u * nfu;
-      s_begin = (int64_t)u * a.uniform_ns;
-      b = s_begin + (int64_t)(f * (unsigned)a.hop);
+      s_begin = (idx_t)((int64_t)u * a.uniform_ns);
+      b = s_begin + (idx_t)(f * (unsigned)a.hop);
     } else {
       int lo = 0, hi = a.n_utt;  // the last clip whose first mel row is <= g
       while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if (a.frame_offs[mid] <= gc) lo = mid; else hi = mid;
       }
-      s_begin = a.sample_offs[lo];
+      const int64_t sb = a.sample_offs[lo];
       const int64_t f = gc - a.frame_offs[lo];
-      b = s_begin + f * a.hop;
-      rv = rv && f >= 0 && b + WIN <= a.sample_offs[lo + 1];  // a row the offset tables do not cover is never stored
+      const int64_t bb = sb + f * a.hop;
+      rv = rv && f >= 0 && bb + WIN <= a.sample_offs[lo + 1];  // a row the offset tables do not cover is never stored
+      s_begin = (idx_t)sb;
+      b = (idx_t)bb;
     }
   }
   const unsigned long long vm = __ballot(rv);
   if (vm == 0) return;
   const int r_first = __builtin_ctzll(vm) >> 4, r_last = (63 - __builtin_clzll(vm)) >> 4;
-  const int64_t b0 = lw_readlane64(b, 16 * r_first), s0 = lw_readlane64(s_begin, 16 * r_first);
+  const idx_t b0 = lw_readlane64(b, 16 * r_first), s0 = lw_readlane64(s_begin, 16 * r_first);
   if (!rv) {  // surplus rows recompute the first valid frame (results unused)
     b = b0;
     s_begin = s0;
   }
-  const int64_t total = a.sample_offs[a.n_utt];
+  const idx_t total = (idx_t)a.sample_offs[a.n_utt];
   // one contiguous tile serves the wave when every row starts within 3 hops of the first one, in the same clip
-  const bool contig = __all(s_begin == s0 && b >= b0 && b - b0 <= 3 * (int64_t)a.hop);
+  const bool contig = __all(s_begin == s0 && b >= b0 && b - b0 <= 3 * (idx_t)a.hop);
   const float *src;
   if (contig) {
-    const int64_t bmax = lw_readlane64(b, 16 * r_last);
+    const idx_t bmax = lw_readlane64(b, 16 * r_last);
     const int shift = (int)(b0 % VEC);
-    const int64_t ga = b0 - shift;  // multiple of VEC, >= 0
+    const idx_t ga = b0 - shift;  // multiple of VEC, >= 0
     const int n_vec = (shift + (int)(bmax - b0) + WIN + VEC - 1) / VEC;
     if (SIMPLE) {
       // No pre-emphasis, divisor 32767/32768, hop <= 168 (host checks): NV vectors per lane, straight-line: all loads in
       // flight together
       constexpr int NV = F32IN ? 4 : 2;
-      const int64_t last = (total - VEC) & ~(int64_t)(VEC - 1);  // last full aligned vector (total >= WIN here)
-      const int64_t tile_last = ga + (int64_t)(n_vec - 1) * VEC;
-      int64_t gq[NV];
+      const idx_t last = (total - VEC) & ~(idx_t)(VEC - 1);  // last full aligned vector (total >= WIN here)
+      const idx_t tile_last = ga + (idx_t)(n_vec - 1) * VEC;
+      idx_t gq[NV];
       uint4 raw[NV];
 #pragma unroll
       for (int h = 0; h < NV; ++h) {
-        gq[h] = ga + (int64_t)(lane + 64 * h) * VEC;
-        int64_t gl = gq[h] < tile_last ? gq[h] : tile_last;  // never past this wave's last vector
+        gq[h] = ga + (idx_t)(lane + 64 * h) * VEC;
+        idx_t gl = gq[h] < tile_last ? gq[h] : tile_last;  // never past this wave's last vector
         gl = gl < last ? gl : last;
         raw[h] = F32IN ? *(const uint4 *)(a.f32 + gl) : *(const uint4 *)(a.pcm + gl);
       }
@@ -840,7 +861,7 @@ __global__ __launch_bounds__(64 * LW_WPB) __attribute__((amdgpu_num_vgpr(LW_VGPR
             }
           } else {  // ragged end of the whole buffer: element-wise, zero beyond it
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) o[e] = (gq[h] + e < total) ? norm_sample<F32IN>(a, gq[h] + e) : 0.0f;
+            for (int e = 0; e < VEC; ++e) o[e] = (gq[h] + e < total) ? norm_sample<F32IN>(a, (int64_t)gq[h] + e) : 0.0f;
           }
           float4 *d4 = (float4 *)(tile + (size_t)q * VEC);
           d4[0] = make_float4(o[0], o[1], o[2], o[3]);
@@ -848,7 +869,7 @@ __global__ __launch_bounds__(64 * LW_WPB) __attribute__((amdgpu_num_vgpr(LW_VGPR
         }
       }
     } else {
-      lw_stage_generic<F32IN>(a, tile, ga, n_vec, s0, total, lane);
+      lw_stage_generic<F32IN>(a, tile, (int64_t)ga, n_vec, (int64_t)s0, (int64_t)total, lane);
     }
     src = tile + shift + (int)(b - b0);
   } else {
@@ -857,7 +878,7 @@ __global__ __launch_bounds__(64 * LW_WPB) __attribute__((amdgpu_num_vgpr(LW_VGPR
       if (!((vm >> (16 * r)) & 1)) continue;
       const int64_t br = lw_readlane64(b, 16 * r), sr = lw_readlane64(s_begin, 16 * r);
       const int sh = (int)(br % VEC);
-      lw_stage_generic<F32IN>(a, tile + r * LW_ROWF, br - sh, (sh + WIN + VEC - 1) / VEC, sr, total, lane);
+      lw_stage_generic<F32IN>(a, tile + r * LW_ROWF, br - sh, (sh + WIN + VEC - 1) / VEC, sr, (int64_t)total, lane);
     }
     src = tile + (rv ? sub : r_first) * LW_ROWF + (int)(b % VEC);
   }
@@ -1157,7 +1178,7 @@ static void fill_filter_args(logmel_args &a, const ww_model *m) {
 
 int ww_k_logmel(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, const float *d_f32, const int64_t *d_sample_offs,
                 const int64_t *d_frame_offs, int n_utt, int64_t total_frames, int64_t max_frames_per_utt,
-                const ww_frontend_params *fp, float *d_mel, int64_t uniform_samples) {
+                const ww_frontend_params *fp, float *d_mel, int64_t uniform_samples, int64_t total_samples_hint) {
   if (n_utt <= 0 || total_frames <= 0 || max_frames_per_utt <= 0) return WW_OK;
   if (fp->hop <= 0 || fp->hop > 512) return ww_fail(ctx, WW_EINVAL, "hop %d out of range (1..512)", fp->hop);
   logmel_args a = {};
@@ -1181,13 +1202,26 @@ int ww_k_logmel(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, const floa
       a.uniform_ns = uniform_samples;
     }
     const bool simple_w = fp->pre_emphasis == 0.0f && (f32in || a.fast_div) && fp->hop <= 168;
+    // 32-bit sample indices when the caller could tell that every index of the launch fits 31 bits; with equal clips of >= 4
+    // frames the row -> clip division becomes one multiply: M = ceil(2^(31 + l) / nf), l = ceil(log2 nf), is exact for
+    // every row < 2^31 (M nf - 2^(31 + l) < nf <= 2^l)
+    const bool small_w = simple_w && total_samples_hint > 0 && total_samples_hint < 0x7fff0000ll;
+    if (small_w && a.uniform_nf >= 4) {
+      int l = 0;
+      while ((1ll << l) < a.uniform_nf) ++l;
+      a.uni_magic = (unsigned)(((1ull << (31 + l)) + (unsigned)a.uniform_nf - 1) / (unsigned)a.uniform_nf);
+      a.uni_shift = l - 1;
+    }
     const int64_t n_waves = (total_frames + 3) / 4;
     const int64_t n_wg = 8 * ((((n_waves + LW_WPB - 1) / LW_WPB) + 7) / 8);
     if (n_wg > 0x7fffffff) return ww_fail(ctx, WW_EINVAL, "front-end launch too large (%lld workgroups): split the batch", (long long)n_wg);
     const dim3 grid_w((unsigned)n_wg), block_w(64 * LW_WPB);
     const size_t sm = (size_t)LW_WPB * LW_WBUF;
     ww_launch_scope scope(ctx, "logmel_kernel<f64>");
-    if (simple_w) {
+    if (small_w) {
+      if (f32in) hipLaunchKernelGGL((logmel_rows_kernel<true, true, true>), grid_w, block_w, sm, ctx->stream, a);
+      else hipLaunchKernelGGL((logmel_rows_kernel<false, true, true>), grid_w, block_w, sm, ctx->stream, a);
+    } else if (simple_w) {
       if (f32in) hipLaunchKernelGGL((logmel_rows_kernel<true, true>), grid_w, block_w, sm, ctx->stream, a);
       else hipLaunchKernelGGL((logmel_rows_kernel<false, true>), grid_w, block_w, sm, ctx->stream, a);
     } else {
