@@ -57,3 +57,23 @@ def gather_posteriors(local: np.ndarray, index: Sequence[int], n_total: int, gro
             b = b[:k].cpu().numpy()
             out[b[:, 0].astype(np.int64)] = b[:, 1].astype(np.float32)
     return out
+
+
+def gather_values(local: np.ndarray, counts: Sequence[int], group=None, device=None) -> List[np.ndarray]:
+    """Every rank contributes ``local`` (float32, ``counts[rank]`` values - every rank knows every rank's count, e.g. from a
+    plan all ranks compute alike) and receives the list of all ranks' arrays: ONE all_gather of float32 payloads padded to
+    the largest count, no index traffic (the sharded reference flow: each rank can work out which global slots any rank's
+    values belong to)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    assert len(counts) == world and len(local) == counts[dist.get_rank(group)]
+    dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
+    mx = int(max(counts)) if len(counts) else 0
+    payload = torch.zeros(max(mx, 1), dtype=torch.float32, device=dev)
+    if len(local):
+        payload[: len(local)] = torch.as_tensor(np.ascontiguousarray(local, dtype=np.float32), device=dev)
+    bufs = [torch.empty_like(payload) for _ in range(world)]
+    dist.all_gather(bufs, payload, group=group)
+    return [b[:int(c)].cpu().numpy() for b, c in zip(bufs, counts)]

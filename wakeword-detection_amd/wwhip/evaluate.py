@@ -459,24 +459,30 @@ def get_posterior_sharded(models_dir, model_type, eval_type, test_files, frame_w
         plan = StreamPlan(lengths, eng.window, frame_length, sample_rate, 2, carry_over)
         if info is not None:
             info["windows"] = info.get("windows", 0) + plan.total  # inferences of the whole call, all ranks
-        mine = plan.shares(eval_type, world)[rank]
+        shares = plan.shares(eval_type, world)
+        mine = shares[rank]
         n_win = [i1 - i0 for _, i0, i1 in mine]
-        if mine:  # global slot of every window of my runs: offs[k] + i0 .. offs[k] + i1 - 1, run after run
-            nw = np.asarray(n_win, np.int64)
-            first = np.array([plan.offs[k] + i0 for k, i0, _ in mine], np.int64)
+
+        def slots_of(runs):  # global slot of every window of the runs: offs[k] + i0 .. offs[k] + i1 - 1, run after run
+            if not runs:
+                return np.zeros(0, np.int64)
+            nw = np.array([i1 - i0 for _, i0, i1 in runs], np.int64)
+            first = np.array([plan.offs[k] + i0 for k, i0, _ in runs], np.int64)
             ends = np.cumsum(nw)
-            slots = np.arange(int(ends[-1]), dtype=np.int64) + np.repeat(first - (ends - nw), nw)
-        else:
-            slots = np.zeros(0, np.int64)
+            return np.arange(int(ends[-1]), dtype=np.int64) + np.repeat(first - (ends - nw), nw)
     staged, soffs = _stage_pieces(plan, mine, load, ph, eng.ctx.device) if mine else (None, [])
     vals = _pieces_forward(eng, staged, soffs, n_win, plan.hop, precise, ph, timing)[:, eng.posterior_index]
     with ph("gather"):
+        post = np.zeros(plan.total, np.float32)
         if world > 1:
+            # the plan is the same arithmetic on every rank, so every rank knows which slots any rank's values fill: the
+            # exchange is the values alone (float32, padded to the largest share)
             from . import dist as D
-            post = D.gather_posteriors(vals, slots, plan.total, device=comm_device)
+            every = D.gather_values(vals, [sum(i1 - i0 for _, i0, i1 in sh) for sh in shares], device=comm_device)
+            for sh, v in zip(shares, every):
+                post[slots_of(sh)] = v
         else:
-            post = np.zeros(plan.total, np.float32)
-            post[slots] = vals
+            post[slots_of(mine)] = vals
     if eval_type == "false_negatives":
         if (plan.n_win == 0).any():
             raise ValueError("max() arg is an empty sequence")  # an empty clip: what np.max raises in the reference's loop
