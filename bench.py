@@ -360,6 +360,12 @@ def roofline_of(eng, prof, clips, fast_frontend, step_s=None):
                                 "MI355X_MICROARCH.md), rocprofv3 --pmc in separate passes, mean bytes per launch "
                                 f"(profiles/r04/pmc_counters.json, kernel sources {pmc['source_sha']})")
         roof["algorithmic_bytes"] = nbytes
+        if dom.startswith("crnn_fused_kernel"):
+            # SURVEY 8(d) counts the 622,724 B of weights ONCE; each of the 8 XCDs has an L2 of its own and fetches them once,
+            # which is what HBM-side traffic can reach at best - both figures, so that the ratio to `traffic` is unambiguous
+            roof["algorithmic_bytes_weights_once"] = nbytes - 7 * 622724
+            roof["algorithmic_bytes_note"] = ("algorithmic_bytes = windows in + posteriors out + the weights once PER XCD L2 (8 x 622,724 B); "
+                                              "algorithmic_bytes_weights_once = SURVEY 8(d)'s definition (weights once per launch)")
     elif pmc is None:
         roof["traffic_note"] = "no PMC pass on these kernel sources (profiles/r04/pmc_counters.json absent or of another source_sha)"
     # how busy the shared vector / matrix datapath is over a STEP (the fp32 MFMA and the vector ALU of a SIMD do not
