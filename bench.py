@@ -461,7 +461,7 @@ def eval_at_scale(torch, np, dist, comm_dev, rank, world, eng, n_wake, with_orac
     """BASELINE configs[3] at the SIZE it names: the reference evaluator's flow (utils/evaluate_models.py:281-326) over a
     stand-in as large as the hey-snips test split - 2,529 wake-word clips through the never-reset Filter + the first 2,529
     other clips joined into ONE ~1.2 h stream (concatenate_FA joins exactly num_wakewords of them, :299) - sharded over the
-    ranks, with where the time goes: host phases (plan, slicing = staging the samples, upload, gather, sweep) against the
+    ranks, with where the time goes: host phases (plan, slicing = staging the samples, upload, gather, sweep; staging runs beside the kernels) against the
     kernels' own time (HIP events, ww_profile_read).  Next to it the C oracle on a bounded sample of the same flow."""
     from wwhip.evaluate import synth_testset_scaled, evaluate_reference_flow_sharded
     clips, labels = synth_testset_scaled(n_wake, n_wake)
@@ -486,10 +486,13 @@ def eval_at_scale(torch, np, dist, comm_dev, rank, world, eng, n_wake, with_orac
            "audio_frames_per_s": audio_s * 100.0 / el, "realtime_factor": audio_s / el, "windows": r["windows"],
            "device_ms": tm["device_ms"], "kernels_ms": tm.get("kernels_ms"),
            "host_phases_ms": {k: v * 1e3 for k, v in tm.items() if isinstance(v, float) and k != "device_ms"},
+           "chunks": tm.get("chunks"),
            "host_share": 1.0 - tm["device_ms"] * 1e-3 / el,
            "note": "rank 0's clock and phases (every rank stages, uploads and runs only its share); host_share = 1 - device_ms / "
-                   "seconds; slicing = ww_host_stage_i16 writing the padded pieces into page-locked memory once (16 host threads), "
-                   "h2d = waiting for the upload, device_wall = the launches incl. their host-side descriptors",
+                   "seconds; the share goes to the GPU in chunks of up to ~26 min of audio: this thread plans a chunk (prepare / plan / slicing: "
+                   "which samples of which clips), submits it to the library's uploader (ww_uploader: its threads write the chunk "
+                   "into page-locked memory once and start the upload) and enqueues the kernels over the chunk before, behind its "
+                   "upload (upload_wait = waiting for the uploader, device_wall = launches + the final wait for the GPU)",
            "frr_at_0.5_fa_per_hour": r["frr_at_0.5_fa_per_hour"], "fa_count_at_threshold_0.5": int(r["fa_count"][0]),
            "posterior_checksum": r["posterior_checksum"]}
     if with_oracle:

@@ -100,6 +100,26 @@ int ww_runtime_info(int32_t *built_hip_version, int32_t *runtime_version, int32_
 int ww_host_stage_i16(int16_t *dst, int64_t total, int64_t n_runs, const int64_t *dst_off, const int16_t *const *src,
                       const int64_t *count, int64_t lo, int64_t hi, int32_t threads);
 
+/* The same staging on a thread of the library's own, followed by the upload: an uploader owns `slots` page-locked buffers
+ * (grown on demand), `copy_threads` copy threads and a copy stream on the context's device.  One submit = one chunk of a
+ * rank's share of a test split: dst[0 .. total) assembled from the runs as ww_host_stage_i16 does, then copied to d_pcm, and
+ * n_meta int64 words (the chunk's sample / frame offset tables) copied to d_meta.  The call copies the run arrays and `meta`
+ * and returns at once with a ticket (1, 2, ...; chunks are processed in ticket order); the CLIP samples src[j] point to must
+ * stay where they are until ww_uploader_wait(ticket) has returned.  ww_uploader_poll: 1 once the ticket's copies are enqueued,
+ * 0 before.  ww_uploader_wait blocks the calling host thread until they are, then makes the context's stream wait for them
+ * on the device (no host wait for the transfer itself) - the caller launches its kernels over d_pcm right behind it - and
+ * reports what went wrong with the chunk if anything did (WW_EINVAL: overlapping runs; WW_ENOMEM; WW_EHIP).  Each ticket is
+ * waited for at most once.  The reference has no counterpart: its evaluator feeds one wav at a time, 20 ms per step
+ * (utils/evaluate_models.py:52-88); this is the transport that keeps two hours of audio per GPU moving while the interpreter
+ * plans the next chunk.  One host thread drives an uploader; ww_uploader_destroy finishes what was submitted. */
+typedef struct ww_uploader ww_uploader;
+int ww_uploader_create(ww_ctx *ctx, int32_t slots, int32_t copy_threads, ww_uploader **out);
+int ww_uploader_destroy(ww_uploader *up);
+int ww_uploader_submit(ww_uploader *up, int64_t total, int64_t n_runs, const int64_t *dst_off, const int16_t *const *src,
+                       const int64_t *count, int16_t *d_pcm, int64_t n_meta, const int64_t *meta, int64_t *d_meta, int64_t *ticket);
+int ww_uploader_poll(ww_uploader *up, int64_t ticket);
+int ww_uploader_wait(ww_uploader *up, int64_t ticket, ww_ctx *ctx);
+
 /* Per-kernel timing with HIP events on the ctx stream (bench.py roofline leg).  While
  * enabled every kernel launch is bracketed by two events; ww_profile_read synchronises and
  * writes a JSON object {"kernel": {"calls": n, "total_ms": t}, ...}. */
@@ -214,7 +234,9 @@ int ww_forward_windows_dev(ww_ctx *ctx, const ww_model *model, const float *d_me
  * sequence s has seg_nw[s] complete windows, window k of it covers rows [seg_row0[s] + k*hop, + window).
  * seg_row0 / seg_nw are HOST arrays; d_out receives the detect rows sequence by sequence.  This is the window loop of
  * utils/evaluate_models.py:66-88 over many files at once; for the CRNN the conv and the layer-1 projection of a time
- * position are computed once per sequence instead of once per window that contains it. */
+ * position are computed once per sequence instead of once per window that contains it.  The host arrays are consumed before
+ * the call returns; the kernels are enqueued like every _dev entry point's (the CRNN's launch descriptors travel through two
+ * page-locked buffers of the context, so a caller can stage its next batch while this one computes). */
 int ww_forward_segments_dev(ww_ctx *ctx, const ww_model *model, const float *d_mel, int64_t mel_rows, const int64_t *seg_row0,
                             const int32_t *seg_nw, int32_t n_seg, int32_t hop, float *d_out);
 

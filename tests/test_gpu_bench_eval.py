@@ -108,7 +108,7 @@ def test_bench_under_torch_distributed_run():
     for k in ("frr_at_0.5_fa_per_hour", "fa_count_at_threshold_0.5", "posterior_checksum", "windows"):
         assert a2[k] == a1[k], k
     assert a2["world_size"] == 2 and 0.0 < a2["host_share"] < 1.0 and a2["device_ms"] > 0
-    assert {"plan", "slicing", "h2d", "device_wall", "gather", "sweep"} <= set(a2["host_phases_ms"])
+    assert {"plan", "slicing", "submit", "upload_wait", "device_wall", "gather", "sweep"} <= set(a2["host_phases_ms"])
     assert d["eval_testset"]["per_clip_variant"]["posterior_checksum"] == one["eval_testset"]["per_clip_variant"]["posterior_checksum"]
 
 
@@ -208,6 +208,51 @@ def test_reference_flow_sharded_identical_for_any_rank_count(reference_flow_one_
     np.testing.assert_array_equal(got["frr"], one["frr"])
     assert float(got["checksum"]) == one["posterior_checksum"] == line["posterior_checksum"]
     assert line["frr_at_0.5_fa_per_hour"] == one["frr_at_0.5_fa_per_hour"]
+
+
+@pytest.mark.timeout(600)
+def test_reference_flow_does_not_depend_on_the_staging_chunks(reference_flow_one_rank, monkeypatch):
+    """The sharded flow sends a rank's share to the GPU in chunks through a staging pipeline (wwhip.evaluate._run_jobs: a
+    host thread stages and uploads chunk i + 1 while chunk i computes).  Where the cuts fall must not show: with chunks of
+    about 20 s of audio (dozens of chunks per leg, the three page-locked slots reused many times, negative-stream cuts inside
+    clips and inside gaps, tail kernels of every size class) every posterior, FA count and FRR value equals the default
+    run's, bit for bit; and a clip that is not int16 sends its chunk through the float32 path without upsetting the rest."""
+    from wwhip import evaluate as E
+    eng, clips, labels, one = reference_flow_one_rank
+    for chunk in (320_000, 1_000_000):
+        monkeypatch.setattr(E, "_CHUNK_SAMPLES", chunk)
+        tm = {}
+        got = E.evaluate_reference_flow_sharded(eng, clips, labels, timing=tm)
+        assert tm["chunks"] > (10 if chunk > 500_000 else 40) and tm["device_ms"] > 0
+        for key in ("negatives", "positives", "fa_count", "frr"):
+            np.testing.assert_array_equal(got[key], one[key])
+        assert got["posterior_checksum"] == one["posterior_checksum"] and got["windows"] == one["windows"]
+    # get_posterior_sharded over arrays in memory, one of them float32 (librosa's scale): the chunk that holds it (and only
+    # that one) takes the float path; int16 / 32768 is exact, so nothing changes
+    monkeypatch.setattr(E, "_CHUNK_SAMPLES", 200_000)
+    wake = [c for c, l in zip(clips, labels) if l][:24]
+    want = E.get_posterior_sharded(eng.model_dir, "CRNN", "false_negatives", wake, 20, 16000, engine=eng, as_array=True)
+    np.testing.assert_array_equal(want, one["positives"][:24])
+    mixed = list(wake)
+    mixed[7] = wake[7].astype(np.float32) / np.float32(32768.0)
+    got = E.get_posterior_sharded(eng.model_dir, "CRNN", "false_negatives", mixed, 20, 16000, engine=eng, as_array=True)
+    np.testing.assert_array_equal(got, want)
+    # a failure while launching (here: made up, at the third chunk, with later chunks already submitted to the uploader)
+    # comes out as itself, and the next call finds the pipeline in order
+    calls, real = [], E._chunk_forward
+
+    def failing(e, ch, precise, ph):
+        calls.append(ch)
+        if len(calls) == 3:
+            raise RuntimeError("made-up launch failure")
+        return real(e, ch, precise, ph)
+
+    monkeypatch.setattr(E, "_chunk_forward", failing)
+    with pytest.raises(RuntimeError, match="made-up launch failure"):
+        E.get_posterior_sharded(eng.model_dir, "CRNN", "false_negatives", wake, 20, 16000, engine=eng, as_array=True)
+    monkeypatch.setattr(E, "_chunk_forward", real)
+    np.testing.assert_array_equal(E.get_posterior_sharded(eng.model_dir, "CRNN", "false_negatives", wake, 20, 16000, engine=eng,
+                                                          as_array=True), want)
 
 
 def test_reference_flow_equals_get_posterior_and_oracle(reference_flow_one_rank, tmp_path):

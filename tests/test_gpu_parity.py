@@ -914,3 +914,81 @@ def test_wavenet_fp32_block_loop_forms(engines, oracles, name):
     assert np.abs(enc_t - enc_r).max() < 2e-5
     mel = rng.uniform(0, 6.5, (e.window + 60, 40)).astype(np.float32)
     assert np.abs(e.slide_forward(mel, 2) - oracles[name].slide_forward(mel, 2)).max() < TOL_POST
+
+
+@pytest.mark.timeout(300)
+def test_uploader_delivers_what_host_staging_writes(assets):
+    """ww_uploader_* (include/wwhip.h): the library thread that assembles a chunk of sample runs in a page-locked slot and
+    sends it to the device, against ww_host_stage_i16 into ordinary memory on the same runs - twelve chunks through three
+    slots (every slot reused four times, sizes growing and shrinking so the slots are re-allocated on the way), runs that
+    start at odd sample offsets, gaps of every size, a chunk with no runs at all (all zeros) and an empty table; tickets count
+    1, 2, ...; poll turns 1; a chunk whose runs overlap is refused at its wait (ValueError) without upsetting its
+    neighbours; a ticket is waited for once; an uploader serves only contexts of its device; destroy finishes what was
+    submitted."""
+    import torch
+    from wwhip import _lib
+    lib = _lib.load()
+    ctx = _lib.default_context(0)
+    up = _lib.Uploader(ctx, slots=3, copy_threads=4)
+    rng = np.random.default_rng(11)
+    clips = [rng.integers(-30000, 30000, int(n)).astype(np.int16) for n in rng.integers(50, 90000, 40)]
+    jobs = []
+    for k in range(12):
+        total = int(rng.integers(1, 5_000_000)) if k not in (3, 7) else (2_500_000 if k == 3 else 300)
+        n_runs = 0 if k == 5 else int(rng.integers(1, 30))
+        # ascending disjoint runs inside [0, total)
+        cuts = np.sort(rng.choice(total + 1, 2 * n_runs, replace=total + 1 < 2 * n_runs)) if n_runs else np.zeros(0, np.int64)
+        d, p, c, keep = [], [], [], []
+        for j in range(n_runs):
+            lo, hi = int(cuts[2 * j]), int(cuts[2 * j + 1])
+            src = clips[int(rng.integers(len(clips)))]
+            cnt = min(hi - lo, len(src))
+            first = int(rng.integers(0, len(src) - cnt + 1))
+            d.append(lo); c.append(cnt); p.append(src.ctypes.data + 2 * first); keep.append(src)
+        d, p, c = (np.asarray(x, np.int64) for x in (d, p, c))
+        want = np.full(total, 99, np.int16)
+        assert lib.ww_host_stage_i16(want.ctypes.data, total, len(d), _lib.ptr(d), _lib.ptr(p), _lib.ptr(c), 0, total, 3) == 0
+        meta = rng.integers(0, 1 << 40, 0 if k == 9 else int(rng.integers(1, 4000))).astype(np.int64)
+        d_pcm = torch.full((total,), 77, dtype=torch.int16, device="cuda:0")
+        d_meta = torch.full((max(len(meta), 1),), -5, dtype=torch.int64, device="cuda:0")
+        torch.cuda.synchronize()
+        t = up.submit(total, d, p, c, d_pcm.data_ptr(), meta, d_meta.data_ptr())
+        assert t == k + 1
+        jobs.append((t, want, meta, d_pcm, d_meta, keep))
+    # an overlapping chunk in between
+    bad = up.submit(1000, np.array([0, 10], np.int64), np.array([clips[0].ctypes.data] * 2, np.int64), np.array([20, 5], np.int64),
+                    jobs[0][3].data_ptr(), np.zeros(0, np.int64), 0)
+    last = up.submit(10, np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.int64), jobs[7][3].data_ptr(), np.zeros(0, np.int64), 0)
+    for t, want, meta, d_pcm, d_meta, _ in jobs:
+        up.wait(t, ctx)
+        assert up.done(t)
+        ctx.synchronize()                     # the context's stream waited for the copies on the device
+        if t != 8:                            # (chunk 8's first ten samples are overwritten by `last` below)
+            np.testing.assert_array_equal(d_pcm.cpu().numpy(), want)
+        if len(meta):
+            np.testing.assert_array_equal(d_meta.cpu().numpy(), meta)
+    with pytest.raises(ValueError, match="overlap"):
+        up.wait(bad, ctx)
+    with pytest.raises(ValueError, match="waited for before"):
+        up.wait(jobs[0][0], ctx)
+    with pytest.raises(ValueError, match="no such ticket"):
+        up.wait(last + 5, ctx)
+    up.wait(last, ctx)
+    ctx.synchronize()
+    got = jobs[7][3].cpu().numpy()
+    np.testing.assert_array_equal(got[:10], 0)
+    np.testing.assert_array_equal(got[10:], jobs[7][1][10:])
+    with pytest.raises(ValueError):
+        _lib.Uploader(ctx, slots=1)
+    # destroy with work still queued: the copies land before the call returns
+    d_pcm = torch.zeros(200_000, dtype=torch.int16, device="cuda:0")
+    src = clips[int(np.argmax([len(x) for x in clips]))]
+    n = min(len(src), 150_000)
+    torch.cuda.synchronize()
+    up.submit(200_000, np.array([100], np.int64), np.array([src.ctypes.data], np.int64), np.array([n], np.int64), d_pcm.data_ptr(),
+              np.zeros(0, np.int64), 0)
+    up.close()
+    torch.cuda.synchronize()
+    got = d_pcm.cpu().numpy()
+    np.testing.assert_array_equal(got[100:100 + n], src[:n])
+    assert not got[:100].any() and not got[100 + n:].any()

@@ -454,3 +454,32 @@ def test_vad_hysteresis_and_trigger():
     except ImportError:
         with pytest.raises(RuntimeError):
             VoiceActivityDetector()                      # no webrtcvad: the classifier must be given
+
+
+@pytest.mark.timeout(120)
+def test_staging_pipeline_hands_a_planning_failure_to_the_caller():
+    """wwhip.evaluate._run_jobs: a failure while a chunk is being planned (the loader fails inside the first chunk; a job
+    constructor raises) reaches the caller as itself and nothing was submitted or launched - the part of the pipeline's
+    failure handling that needs no GPU (tests/test_gpu_bench_eval.py has a failing launch with uploads in flight)."""
+    from wwhip import evaluate as E
+
+    class Ctx:
+        device = 0
+
+        def synchronize(self):
+            raise AssertionError("nothing was launched: nothing to wait for")
+
+    class Eng:
+        window, ctx = 151, Ctx()
+
+    def loader(path):
+        if int(path) >= 2:
+            raise OSError(f"cannot read {path}")
+        return np.zeros(20000, np.int16)
+
+    ph = E._Phases(None)
+    with pytest.raises(OSError, match="cannot read 2"):
+        E._run_jobs(Eng, [lambda: E._PosteriorJob(Eng, "false_negatives", [str(i) for i in range(8)], 20, 16000, 0, 1, loader,
+                                                   [20000] * 8, True, ph, None, first_chunk=1 << 30)], True, ph, None)
+    with pytest.raises(ZeroDivisionError):
+        E._run_jobs(Eng, [lambda: 1 // 0], True, ph, None)

@@ -5,10 +5,10 @@
 set -e
 cd "$(dirname "$0")/.."
 name=$1; defs=$2; shift 2 || true
-only=${@:-api.hip frontend.hip crnn.hip wavenet.hip posterior.hip streams.hip}
+only=${@:-api.hip frontend.hip crnn.hip wavenet.hip posterior.hip streams.hip uploader.hip}
 mkdir -p build_variants/obj_$name
 objs=""
-for f in api.hip frontend.hip crnn.hip wavenet.hip posterior.hip streams.hip; do
+for f in api.hip frontend.hip crnn.hip wavenet.hip posterior.hip streams.hip uploader.hip; do
   o=build_variants/obj_$name/${f%.hip}.o
   if echo " $only " | grep -q " $f "; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-unused-result $defs -c wakeword-detection_amd/csrc/$f -o $o &

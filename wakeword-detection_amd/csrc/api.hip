@@ -1,7 +1,6 @@
 // C ABI of libwwhip.so: context, model upload, host/device entry points (see include/wwhip.h).
 #include "common.h"
 
-#include <thread>
 
 #include <algorithm>
 #include <cmath>
@@ -69,7 +68,7 @@ struct ww_small_io {
 
 extern "C" {
 
-const char *ww_version(void) { return "wwhip 0.4 (gfx950; ABI 4: ww_stream_create takes flags, ww_host_stage_i16)"; }
+const char *ww_version(void) { return "wwhip 0.4 (gfx950; ABI 4: ww_stream_create takes flags, ww_host_stage_i16, ww_uploader_*)"; }
 
 int ww_runtime_info(int32_t *built_hip_version, int32_t *runtime_version, int32_t *driver_version) {
   if (built_hip_version) *built_hip_version = HIP_VERSION;  // headers the library was compiled against
@@ -133,6 +132,10 @@ int ww_ctx_destroy(ww_ctx *ctx) {
     }
   if (ctx->dev.ptr) hipFree(ctx->dev.ptr);
   if (ctx->pinned.ptr) hipHostFree(ctx->pinned.ptr);
+  for (int k = 0; k < 2; ++k) {
+    if (ctx->desc_pin[k].ptr) hipHostFree(ctx->desc_pin[k].ptr);
+    if (ctx->desc_ev[k]) hipEventDestroy(ctx->desc_ev[k]);
+  }
   hipEventDestroy(ctx->t0);
   hipEventDestroy(ctx->t1);
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
@@ -760,51 +763,6 @@ int ww_model_set_option(ww_model *m, int key, int64_t value) {
     case WW_OPT_WAVENET_ROWMAJOR: m->opt_wave_rowmajor = value != 0; return WW_OK;
     default: return ww_fail(m->ctx, WW_EINVAL, "unknown model option %d", key);
   }
-}
-
-int ww_host_stage_i16(int16_t *dst, int64_t total, int64_t n_runs, const int64_t *dst_off, const int16_t *const *src,
-                      const int64_t *count, int64_t lo_all, int64_t hi_all, int32_t threads) {
-  if (total < 0 || n_runs < 0 || (total > 0 && !dst) || (n_runs > 0 && (!dst_off || !src || !count))) return WW_EINVAL;
-  if (lo_all < 0 || lo_all > hi_all || hi_all > total) return WW_EINVAL;
-  int64_t end = 0;
-  for (int64_t j = 0; j < n_runs; ++j) {
-    if (count[j] < 0 || dst_off[j] < end || dst_off[j] + count[j] > total || (count[j] > 0 && !src[j])) return WW_EINVAL;
-    end = dst_off[j] + count[j];
-  }
-  const int64_t span = hi_all - lo_all;
-  if (span == 0) return WW_OK;
-  int nt = threads < 1 ? 1 : threads > 64 ? 64 : threads;
-  if (span < (int64_t)(1 << 20)) nt = 1;  // a thread costs more than half a megasample of memcpy
-  // thread t writes dst[lo, hi): the parts of the runs inside it, zeros elsewhere
-  auto work = [&](int64_t lo, int64_t hi) {
-    // first run that ends after lo
-    int64_t a = 0, b = n_runs;
-    while (a < b) {
-      const int64_t m = (a + b) >> 1;
-      if (dst_off[m] + count[m] <= lo) a = m + 1; else b = m;
-    }
-    int64_t cur = lo;
-    for (int64_t j = a; j < n_runs && dst_off[j] < hi; ++j) {
-      const int64_t s = dst_off[j] > cur ? dst_off[j] : cur, e = dst_off[j] + count[j] < hi ? dst_off[j] + count[j] : hi;
-      if (s > cur) memset(dst + cur, 0, (size_t)(s - cur) * 2);
-      if (e > s) memcpy(dst + s, src[j] + (s - dst_off[j]), (size_t)(e - s) * 2);
-      cur = e > cur ? e : cur;
-    }
-    if (hi > cur) memset(dst + cur, 0, (size_t)(hi - cur) * 2);
-  };
-  if (nt == 1) {
-    work(lo_all, hi_all);
-    return WW_OK;
-  }
-  std::vector<std::thread> pool;
-  const int64_t step = ((span + nt - 1) / nt + 63) & ~(int64_t)63;
-  for (int t = 0; t < nt; ++t) {
-    const int64_t lo = lo_all + (int64_t)t * step, hi = lo + step < hi_all ? lo + step : hi_all;
-    if (lo >= hi) break;
-    pool.emplace_back(work, lo, hi);
-  }
-  for (auto &th : pool) th.join();
-  return WW_OK;
 }
 
 int64_t ww_num_frames(int64_t n, int32_t hop) {

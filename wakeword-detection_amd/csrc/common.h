@@ -43,6 +43,12 @@ struct ww_ctx {
     int64_t *d_so = nullptr, *d_fo = nullptr;
   };
   std::vector<clip_offs_t> clip_offs;
+  // host-built launch descriptors on their way to the device (ww_k_crnn_segments_forward): two page-locked buffers used
+  // alternately, each free again once the event behind its copies has passed - the call never waits for its kernels
+  ww_arena desc_pin[2];
+  hipEvent_t desc_ev[2] = {nullptr, nullptr};
+  bool desc_busy[2] = {false, false};
+  unsigned desc_k = 0;
 };
 
 // Device-resident mel filterbank in banded form: band m covers bins [start[m], start[m]+len[m])

@@ -2041,8 +2041,23 @@ int ww_k_crnn_segments_forward(ww_ctx *ctx, const ww_model *m, const float *d_me
       int64_t *d_i0 = b.take<int64_t>(i0.size());
       float *gI = b.take<float>((size_t)nI * 6 * c.H), *gL = b.take<float>((size_t)nW * 6 * c.H), *gR = b.take<float>((size_t)nW * 6 * c.H);
       float *seq = (float *)b.take<char>(tail_seq_bytes((int)nW));
-      WW_HIP(ctx, hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(rows_tile), hipMemcpyHostToDevice, ctx->stream));
-      WW_HIP(ctx, hipMemcpyAsync(d_i0, i0.data(), i0.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+      // the descriptors leave through one of the context's two page-locked buffers: the copies are asynchronous and the call
+      // goes on to build the next group (or returns) while this group's kernels run
+      const int slot = (int)(ctx->desc_k++ & 1);
+      if (!ctx->desc_ev[slot]) WW_HIP(ctx, hipEventCreateWithFlags(&ctx->desc_ev[slot], hipEventDisableTiming));
+      if (ctx->desc_busy[slot]) {
+        WW_HIP(ctx, hipEventSynchronize(ctx->desc_ev[slot]));
+        ctx->desc_busy[slot] = false;
+      }
+      const size_t n_t = tiles.size() * sizeof(rows_tile), n_i = i0.size() * 8, o_i = (n_t + 63) & ~(size_t)63;
+      if ((rc = ww_ensure(ctx, ctx->desc_pin[slot], o_i + n_i, true))) return rc;
+      char *hp = (char *)ctx->desc_pin[slot].ptr;
+      memcpy(hp, tiles.data(), n_t);
+      memcpy(hp + o_i, i0.data(), n_i);
+      WW_HIP(ctx, hipMemcpyAsync(d_tiles, hp, n_t, hipMemcpyHostToDevice, ctx->stream));
+      WW_HIP(ctx, hipMemcpyAsync(d_i0, hp + o_i, n_i, hipMemcpyHostToDevice, ctx->stream));
+      WW_HIP(ctx, hipEventRecord(ctx->desc_ev[slot], ctx->stream));
+      ctx->desc_busy[slot] = true;
       rows_args r = {};
       r.mel = d_mel; r.mel_rows = mel_rows;
       r.w4[0] = c.conv_w; r.w4[1] = c.conv_wL; r.w4[2] = c.conv_wR;
@@ -2057,8 +2072,6 @@ int ww_k_crnn_segments_forward(ww_ctx *ctx, const ww_model *m, const float *d_me
                      d_out + (size_t)w_done * c.NOUT, c.NOUT, c.HEAD, gI, gL, gR, hop / g, 8 / g, d_i0, nullptr};
       launch_tail(ctx, m, t, (int)nW, seq);
       WW_HIP(ctx, hipGetLastError());
-      // the host vectors are reused by the next group: the copies out of them must have been taken
-      WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
       w_done += nW;
     }
     s0 = s1;

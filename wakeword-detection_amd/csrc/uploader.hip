@@ -1,0 +1,388 @@
+// uploader.hip - the host end of the evaluation flows' input path (no kernels in this file).
+//
+// The reference's evaluator reads one wav after the other and feeds it 20 ms at a time (utils/evaluate_models.py:52-88); here a
+// rank's share of a test split travels to the GPU in chunks of minutes of audio.  A chunk is "these sample runs of these clips
+// at these offsets, zeros in between" (the 0.5 s paddings around every clip, the 100 ms gaps of the joined negative stream):
+//   * ww_host_stage_i16 writes such a chunk into a caller's page-locked buffer with a handful of host threads, once;
+//   * ww_uploader does the same on a thread of its own and sends the chunk on through a copy stream - the caller (one Python
+//     thread: wwhip/evaluate.py) plans the next chunk and launches the previous one meanwhile, and never holds a lock the
+//     copy needs.
+#include "common.h"
+
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <thread>
+
+namespace {
+
+// The destination is a page-locked upload buffer the CPU never reads back, so whole 16-byte lines go out as streaming
+// (non-temporal) stores - no read-for-ownership of the destination (a third of the staging traffic) and the clips' cache lines
+// stay in the cache for nobody.  Heads and tails up to the next 16-byte boundary are ordinary stores.
+#ifndef WW_STAGE_NT_MIN
+#define WW_STAGE_NT_MIN 256  // bytes from which a run goes out as streaming stores
+#endif
+typedef long long stage_v2 __attribute__((vector_size(16), aligned(16)));
+typedef long long stage_v2u __attribute__((vector_size(16), aligned(1)));
+inline void stage_copy(char *d, const char *s, size_t n) {
+  if (n < WW_STAGE_NT_MIN) { memcpy(d, s, n); return; }
+  const size_t head = (16 - ((uintptr_t)d & 15)) & 15;
+  memcpy(d, s, head);
+  d += head; s += head; n -= head;
+  size_t i = 0;
+  for (; i + 64 <= n; i += 64) {
+    const stage_v2 a = *(const stage_v2u *)(s + i), b = *(const stage_v2u *)(s + i + 16), c = *(const stage_v2u *)(s + i + 32),
+                   e = *(const stage_v2u *)(s + i + 48);
+    __builtin_nontemporal_store(a, (stage_v2 *)(d + i));
+    __builtin_nontemporal_store(b, (stage_v2 *)(d + i + 16));
+    __builtin_nontemporal_store(c, (stage_v2 *)(d + i + 32));
+    __builtin_nontemporal_store(e, (stage_v2 *)(d + i + 48));
+  }
+  memcpy(d + i, s + i, n - i);
+}
+inline void stage_fill0(char *d, size_t n) {
+  if (n < WW_STAGE_NT_MIN) { memset(d, 0, n); return; }
+  const size_t head = (16 - ((uintptr_t)d & 15)) & 15;
+  memset(d, 0, head);
+  d += head; n -= head;
+  const stage_v2 z = {0, 0};
+  size_t i = 0;
+  for (; i + 16 <= n; i += 16) __builtin_nontemporal_store(z, (stage_v2 *)(d + i));
+  memset(d + i, 0, n - i);
+}
+
+struct stage_runs {
+  int64_t n = 0;
+  const int64_t *dst_off = nullptr;
+  const int16_t *const *src = nullptr;
+  const int64_t *count = nullptr;
+};
+
+// ascending, disjoint, inside [0, total)
+bool runs_valid(const stage_runs &r, int64_t total) {
+  int64_t end = 0;
+  for (int64_t j = 0; j < r.n; ++j) {
+    if (r.count[j] < 0 || r.dst_off[j] < end || r.dst_off[j] + r.count[j] > total || (r.count[j] > 0 && !r.src[j])) return false;
+    end = r.dst_off[j] + r.count[j];
+  }
+  return true;
+}
+
+// dst[lo, hi) := the parts of the runs inside it, zeros elsewhere
+void stage_range(int16_t *dst, const stage_runs &r, int64_t lo, int64_t hi) {
+  int64_t a = 0, b = r.n;  // first run that ends after lo
+  while (a < b) {
+    const int64_t m = (a + b) >> 1;
+    if (r.dst_off[m] + r.count[m] <= lo) a = m + 1; else b = m;
+  }
+  int64_t cur = lo;
+  for (int64_t j = a; j < r.n && r.dst_off[j] < hi; ++j) {
+    const int64_t s = r.dst_off[j] > cur ? r.dst_off[j] : cur, e = r.dst_off[j] + r.count[j] < hi ? r.dst_off[j] + r.count[j] : hi;
+    if (s > cur) stage_fill0((char *)(dst + cur), (size_t)(s - cur) * 2);
+    if (e > s) stage_copy((char *)(dst + s), (const char *)(r.src[j] + (s - r.dst_off[j])), (size_t)(e - s) * 2);
+    cur = e > cur ? e : cur;
+  }
+  if (hi > cur) stage_fill0((char *)(dst + cur), (size_t)(hi - cur) * 2);
+  std::atomic_thread_fence(std::memory_order_seq_cst);  // the streaming stores are globally visible before the thread reports back
+}
+
+int clamp_threads(int threads, int64_t span) {
+  const int nt = threads < 1 ? 1 : threads > 64 ? 64 : threads;
+  return span < (int64_t)(1 << 20) ? 1 : nt;  // a thread costs more than half a megasample of memcpy
+}
+
+// slice t of nt over [lo, hi), 64-sample aligned
+inline void slice_of(int64_t lo_all, int64_t hi_all, int nt, int t, int64_t *lo, int64_t *hi) {
+  const int64_t step = (((hi_all - lo_all) + nt - 1) / nt + 63) & ~(int64_t)63;
+  *lo = lo_all + (int64_t)t * step;
+  *hi = *lo + step < hi_all ? *lo + step : hi_all;
+}
+
+// The uploader's copy threads: started once, woken per chunk (a std::thread per slice and chunk costs as much as a small chunk).
+class copy_pool {
+  std::vector<std::thread> th_;
+  std::mutex m_;
+  std::condition_variable go_, done_;
+  std::function<void(int)> job_;
+  uint64_t gen_ = 0;
+  int left_ = 0;
+  bool quit_ = false;
+
+  void loop(int t) {
+    uint64_t seen = 0;
+    for (;;) {
+      std::function<void(int)> job;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        go_.wait(lk, [&] { return quit_ || gen_ != seen; });
+        if (quit_) return;
+        seen = gen_;
+        job = job_;
+      }
+      job(t);
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        if (--left_ == 0) done_.notify_all();
+      }
+    }
+  }
+
+ public:
+  explicit copy_pool(int n) {
+    for (int t = 0; t < n; ++t) th_.emplace_back([this, t] { loop(t); });
+  }
+  int size() const { return (int)th_.size(); }
+  // f(t) for t = 0 .. size() - 1, one per thread; returns when all have finished
+  void run(const std::function<void(int)> &f) {
+    std::unique_lock<std::mutex> lk(m_);
+    job_ = f;
+    left_ = (int)th_.size();
+    ++gen_;
+    go_.notify_all();
+    done_.wait(lk, [&] { return left_ == 0; });
+  }
+  ~copy_pool() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      quit_ = true;
+    }
+    go_.notify_all();
+    for (auto &t : th_) t.join();
+  }
+};
+
+}  // namespace
+
+struct ww_uploader {
+  int device = 0;
+  hipStream_t copy_stream = nullptr;
+  struct slot_t {
+    void *pin = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+    bool busy = false;  // an upload out of the slot has been enqueued and not yet waited for
+  };
+  std::vector<slot_t> slots;
+  unsigned next_slot = 0;
+  struct job_t {
+    int64_t ticket = 0, total = 0;
+    std::vector<int64_t> dst_off, count, meta;
+    std::vector<const int16_t *> src;
+    int16_t *d_pcm = nullptr;
+    int64_t *d_meta = nullptr;
+  };
+  struct result_t {
+    int rc = WW_OK;
+    int slot = -1;
+    std::string what;
+  };
+  std::deque<job_t> queue;
+  std::map<int64_t, result_t> results;  // finished tickets nobody has waited for yet
+  std::mutex m;
+  std::condition_variable cv_work, cv_done;
+  int64_t next_ticket = 1, done_ticket = 0;
+  bool quit = false;
+  std::thread worker;
+  copy_pool *pool = nullptr;
+
+  result_t process(job_t &j) {
+    result_t r;
+    auto fail = [&](int rc, const char *what, hipError_t e) {
+      r.rc = rc;
+      r.what = std::string(what) + (e != hipSuccess ? std::string(": ") + hipGetErrorString(e) : std::string());
+      return r;
+    };
+    const stage_runs runs = {(int64_t)j.dst_off.size(), j.dst_off.data(), j.src.data(), j.count.data()};
+    if (!runs_valid(runs, j.total)) return fail(WW_EINVAL, "ww_uploader: sample runs overlap, are out of order or leave the chunk", hipSuccess);
+    const int si = (int)(next_slot++ % slots.size());
+    slot_t &s = slots[si];
+    hipError_t e;
+    if (s.busy) {  // the upload that last used the slot must have left it
+      if ((e = hipEventSynchronize(s.ev)) != hipSuccess) return fail(WW_EHIP, "ww_uploader: hipEventSynchronize", e);
+      s.busy = false;
+    }
+    const size_t b_pcm = ((size_t)j.total * 2 + 63) & ~(size_t)63, b_meta = j.meta.size() * 8;
+    if (b_pcm + b_meta + 64 > s.cap) {
+      if (s.pin) hipHostFree(s.pin);
+      s.pin = nullptr;
+      s.cap = 0;
+      const size_t want = b_pcm + b_meta + 64 + (b_pcm + b_meta) / 8;
+      if ((e = hipHostMalloc(&s.pin, want, hipHostMallocDefault)) != hipSuccess) {
+        s.pin = nullptr;
+        return fail(WW_ENOMEM, "ww_uploader: cannot allocate a page-locked slot", e);
+      }
+      s.cap = want;
+    }
+    int16_t *dst = (int16_t *)s.pin;
+    const int nt = clamp_threads(pool->size(), j.total);
+    if (nt == 1) {
+      stage_range(dst, runs, 0, j.total);
+    } else {
+      const int64_t total = j.total;
+      pool->run([&, dst, total, nt](int t) {
+        if (t >= nt) return;
+        int64_t lo, hi;
+        slice_of(0, total, nt, t, &lo, &hi);
+        if (lo < hi) stage_range(dst, runs, lo, hi);
+      });
+    }
+    if (b_meta) memcpy((char *)s.pin + b_pcm, j.meta.data(), b_meta);
+    if (j.total > 0 && (e = hipMemcpyAsync(j.d_pcm, s.pin, (size_t)j.total * 2, hipMemcpyHostToDevice, copy_stream)) != hipSuccess)
+      return fail(WW_EHIP, "ww_uploader: hipMemcpyAsync (samples)", e);
+    if (b_meta && (e = hipMemcpyAsync(j.d_meta, (char *)s.pin + b_pcm, b_meta, hipMemcpyHostToDevice, copy_stream)) != hipSuccess)
+      return fail(WW_EHIP, "ww_uploader: hipMemcpyAsync (tables)", e);
+    if ((e = hipEventRecord(s.ev, copy_stream)) != hipSuccess) return fail(WW_EHIP, "ww_uploader: hipEventRecord", e);
+    s.busy = true;
+    r.slot = si;
+    return r;
+  }
+
+  void loop() {
+    (void)hipSetDevice(device);
+    for (;;) {
+      job_t j;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv_work.wait(lk, [&] { return quit || !queue.empty(); });
+        if (queue.empty()) return;  // (quit: the queue is drained first)
+        j = std::move(queue.front());
+        queue.pop_front();
+      }
+      result_t r = process(j);
+      {
+        std::lock_guard<std::mutex> lk(m);
+        results[j.ticket] = std::move(r);
+        done_ticket = j.ticket;
+      }
+      cv_done.notify_all();
+    }
+  }
+};
+
+extern "C" {
+
+int ww_host_stage_i16(int16_t *dst, int64_t total, int64_t n_runs, const int64_t *dst_off, const int16_t *const *src,
+                      const int64_t *count, int64_t lo_all, int64_t hi_all, int32_t threads) {
+  if (total < 0 || n_runs < 0 || (total > 0 && !dst) || (n_runs > 0 && (!dst_off || !src || !count))) return WW_EINVAL;
+  if (lo_all < 0 || lo_all > hi_all || hi_all > total) return WW_EINVAL;
+  const stage_runs runs = {n_runs, dst_off, src, count};
+  if (!runs_valid(runs, total)) return WW_EINVAL;
+  if (hi_all == lo_all) return WW_OK;
+  const int nt = clamp_threads(threads, hi_all - lo_all);
+  if (nt == 1) {
+    stage_range(dst, runs, lo_all, hi_all);
+    return WW_OK;
+  }
+  std::vector<std::thread> pool;
+  for (int t = 0; t < nt; ++t) {
+    int64_t lo, hi;
+    slice_of(lo_all, hi_all, nt, t, &lo, &hi);
+    if (lo >= hi) break;
+    pool.emplace_back([=, &runs] { stage_range(dst, runs, lo, hi); });
+  }
+  for (auto &th : pool) th.join();
+  return WW_OK;
+}
+
+int ww_uploader_create(ww_ctx *ctx, int32_t slots, int32_t copy_threads, ww_uploader **out) {
+  if (!ctx || !out) return ww_fail(ctx, WW_EINVAL, "NULL argument");
+  *out = nullptr;
+  if (slots < 2 || slots > 16) return ww_fail(ctx, WW_EINVAL, "ww_uploader_create: 2 .. 16 slots (got %d)", slots);
+  if (copy_threads < 1 || copy_threads > 64) return ww_fail(ctx, WW_EINVAL, "ww_uploader_create: 1 .. 64 copy threads (got %d)", copy_threads);
+  WW_ON_DEVICE(ctx, dev_scope);
+  ww_uploader *up = new ww_uploader();
+  up->device = ctx->device;
+  hipError_t e = hipStreamCreateWithFlags(&up->copy_stream, hipStreamNonBlocking);
+  up->slots.resize((size_t)slots);
+  for (auto &s : up->slots)
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev, hipEventDisableTiming);
+  if (e != hipSuccess) {
+    for (auto &s : up->slots)
+      if (s.ev) hipEventDestroy(s.ev);
+    if (up->copy_stream) hipStreamDestroy(up->copy_stream);
+    delete up;
+    return ww_fail(ctx, WW_EHIP, "ww_uploader_create: %s", hipGetErrorString(e));
+  }
+  up->pool = new copy_pool(copy_threads);
+  up->worker = std::thread([up] { up->loop(); });
+  *out = up;
+  return WW_OK;
+}
+
+int ww_uploader_destroy(ww_uploader *up) {
+  if (!up) return WW_OK;
+  {
+    std::lock_guard<std::mutex> lk(up->m);
+    up->quit = true;
+  }
+  up->cv_work.notify_all();
+  if (up->worker.joinable()) up->worker.join();
+  delete up->pool;
+  ww_device_scope dev_scope(up->device);
+  hipStreamSynchronize(up->copy_stream);
+  for (auto &s : up->slots) {
+    if (s.pin) hipHostFree(s.pin);
+    if (s.ev) hipEventDestroy(s.ev);
+  }
+  hipStreamDestroy(up->copy_stream);
+  delete up;
+  return WW_OK;
+}
+
+int ww_uploader_submit(ww_uploader *up, int64_t total, int64_t n_runs, const int64_t *dst_off, const int16_t *const *src,
+                       const int64_t *count, int16_t *d_pcm, int64_t n_meta, const int64_t *meta, int64_t *d_meta, int64_t *ticket) {
+  if (!up || !ticket) return WW_EINVAL;
+  *ticket = 0;
+  if (total < 0 || n_runs < 0 || n_meta < 0 || (total > 0 && !d_pcm) || (n_meta > 0 && (!meta || !d_meta)) ||
+      (n_runs > 0 && (!dst_off || !src || !count)))
+    return WW_EINVAL;
+  ww_uploader::job_t j;
+  j.total = total;
+  j.dst_off.assign(dst_off, dst_off + n_runs);
+  j.count.assign(count, count + n_runs);
+  j.src.assign(src, src + n_runs);
+  j.meta.assign(meta, meta + n_meta);
+  j.d_pcm = d_pcm;
+  j.d_meta = d_meta;
+  {
+    std::lock_guard<std::mutex> lk(up->m);
+    if (up->quit) return WW_EINVAL;
+    j.ticket = *ticket = up->next_ticket++;
+    up->queue.push_back(std::move(j));
+  }
+  up->cv_work.notify_one();
+  return WW_OK;
+}
+
+int ww_uploader_poll(ww_uploader *up, int64_t ticket) {
+  if (!up || ticket < 1) return WW_EINVAL;
+  std::lock_guard<std::mutex> lk(up->m);
+  if (ticket >= up->next_ticket) return WW_EINVAL;
+  return up->done_ticket >= ticket ? 1 : 0;
+}
+
+int ww_uploader_wait(ww_uploader *up, int64_t ticket, ww_ctx *ctx) {
+  if (!up || !ctx) return ww_fail(ctx, WW_EINVAL, "NULL argument");
+  if (ctx->device != up->device) return ww_fail(ctx, WW_EINVAL, "ww_uploader_wait: the uploader works for device %d, the context for %d", up->device, ctx->device);
+  ww_uploader::result_t r;
+  {
+    std::unique_lock<std::mutex> lk(up->m);
+    if (ticket < 1 || ticket >= up->next_ticket) return ww_fail(ctx, WW_EINVAL, "ww_uploader_wait: no such ticket (%lld)", (long long)ticket);
+    up->cv_done.wait(lk, [&] { return up->done_ticket >= ticket; });
+    auto it = up->results.find(ticket);
+    if (it == up->results.end()) return ww_fail(ctx, WW_EINVAL, "ww_uploader_wait: ticket %lld was waited for before", (long long)ticket);
+    r = std::move(it->second);
+    up->results.erase(it);
+  }
+  if (r.rc != WW_OK) return ww_fail(ctx, r.rc, "%s", r.what.c_str());
+  WW_ON_DEVICE(ctx, dev_scope);
+  // the slot's event: recorded behind this ticket's copies - or, if the slot has gone round since, behind later copies on the
+  // same in-order stream (the uploader itself waited for this ticket's before it reused the slot)
+  WW_HIP(ctx, hipStreamWaitEvent(ctx->stream, up->slots[(size_t)r.slot].ev, 0));
+  return WW_OK;
+}
+
+}  // extern "C"

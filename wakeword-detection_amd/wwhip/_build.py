@@ -17,7 +17,7 @@ CSRC = os.path.join(ROOT, "csrc")
 OBJ_DIR = os.path.join(CSRC, "build")
 LIB_PATH = os.path.join(PKG_DIR, "libwwhip.so")
 
-SOURCES = ["api.hip", "frontend.hip", "crnn.hip", "wavenet.hip", "posterior.hip", "streams.hip"]
+SOURCES = ["api.hip", "frontend.hip", "crnn.hip", "wavenet.hip", "posterior.hip", "streams.hip", "uploader.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
 FLAGS += os.environ.get("WWHIP_DEFS", "").split()  # development only: e.g. WWHIP_DEFS="-DFPB=32"
 

@@ -48,6 +48,11 @@ SYMBOLS: Dict[str, tuple] = {
     "ww_version": (C.c_char_p, []),
     "ww_runtime_info": (C.c_int, [_P(_i32), _P(_i32), _P(_i32)]),
     "ww_host_stage_i16": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i32]),
+    "ww_uploader_create": (C.c_int, [_vp, _i32, _i32, _P(_vp)]),
+    "ww_uploader_destroy": (C.c_int, [_vp]),
+    "ww_uploader_submit": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _P(_i64)]),
+    "ww_uploader_poll": (C.c_int, [_vp, _i64]),
+    "ww_uploader_wait": (C.c_int, [_vp, _i64, _vp]),
     "ww_profile_enable": (C.c_int, [_vp, C.c_int]),
     "ww_profile_read": (C.c_int, [_vp, C.c_char_p, _sz]),
     "ww_timer_start": (C.c_int, [_vp]),
@@ -82,12 +87,12 @@ _lib: Optional[C.CDLL] = None
 _lock = threading.Lock()
 
 # Native objects must be released before the interpreter (and with it the HIP runtime) is torn
-# down, and in dependency order: stream banks, then models, then contexts.  Objects register
+# down, and in dependency order: uploaders and stream banks, then models, then contexts.  Objects register
 # here; an atexit hook closes them; after that close() / __del__ are no-ops.
 import atexit
 import weakref
 
-_live = {"streams": weakref.WeakSet(), "models": weakref.WeakSet(), "contexts": weakref.WeakSet()}
+_live = {"uploaders": weakref.WeakSet(), "streams": weakref.WeakSet(), "models": weakref.WeakSet(), "contexts": weakref.WeakSet()}
 _shutdown = False
 
 
@@ -101,7 +106,7 @@ def is_shutdown() -> bool:
 
 def _close_all() -> None:
     global _shutdown
-    for kind in ("streams", "models", "contexts"):
+    for kind in ("uploaders", "streams", "models", "contexts"):
         for obj in list(_live[kind]):
             try:
                 obj.close()
@@ -230,6 +235,50 @@ class Context:
     def close(self) -> None:
         if self._h and not _shutdown:
             load().ww_ctx_destroy(self._h)
+        self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Uploader:
+    """One ``ww_uploader``: a library thread that assembles chunks of int16 samples in page-locked slots and sends them to the
+    context's device on a copy stream of its own (``include/wwhip.h``)."""
+
+    def __init__(self, ctx: Context, slots: int = 3, copy_threads: int = 8) -> None:
+        h = C.c_void_p()
+        raise_for(load().ww_uploader_create(ctx.handle, int(slots), int(copy_threads), C.byref(h)), ctx.handle)
+        self._h, self.device = h, ctx.device
+        register("uploaders", self)
+
+    def submit(self, total: int, dst_off: np.ndarray, src: np.ndarray, count: np.ndarray, d_pcm_ptr: int, meta: np.ndarray,
+               d_meta_ptr: int) -> int:
+        """Queue one chunk (arrays int64, contiguous; ``src`` = addresses of the runs' first samples); returns the ticket."""
+        t = C.c_int64(0)
+        for a in (dst_off, src, count, meta):
+            if a.dtype != np.int64 or not a.flags.c_contiguous:
+                raise ValueError("Uploader.submit takes contiguous int64 arrays")
+        if not (len(dst_off) == len(src) == len(count)):
+            raise ValueError("dst_off, src and count must have one entry per run")
+        rc = load().ww_uploader_submit(self._h, int(total), len(dst_off), ptr(dst_off), ptr(src), ptr(count), C.c_void_p(d_pcm_ptr),
+                                       len(meta), ptr(meta), C.c_void_p(d_meta_ptr), C.byref(t))
+        if rc != WW_OK:
+            raise ValueError(f"ww_uploader_submit refused the chunk ({rc})")
+        return int(t.value)
+
+    def done(self, ticket: int) -> bool:
+        return load().ww_uploader_poll(self._h, int(ticket)) == 1
+
+    def wait(self, ticket: int, ctx: Context) -> None:
+        """Block until the ticket's copies are enqueued; ``ctx``'s stream then waits for them on the device."""
+        raise_for(load().ww_uploader_wait(self._h, int(ticket), ctx.handle), ctx.handle)
+
+    def close(self) -> None:
+        if self._h and not _shutdown:
+            load().ww_uploader_destroy(self._h)
         self._h = None
 
     def __del__(self):  # pragma: no cover

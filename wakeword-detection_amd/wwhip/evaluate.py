@@ -28,8 +28,7 @@ WINDOW = 512
 CLIP_PAD = 8000  # 0.5 s of zeros each side of a clip (evaluate_models.py:52-53)
 CLIP_HOP = 2     # mel rows between windows (evaluate_models.py:42)
 _PIN = None  # page-locked staging buffer of clip_posteriors (torch tensor, grown on demand)
-_STAGE = None  # page-locked staging buffer of the sharded reference flow (torch tensor, grown on demand)
-_COPY_THREADS = 16  # host threads of ww_host_stage_i16 that assemble a rank's samples in the staging buffer
+_COPY_THREADS = 8  # copy threads of the uploader that assembles a rank's samples in page-locked memory
 
 
 class _Phases:
@@ -248,12 +247,21 @@ class JoinedPCM:
     dtype = np.dtype(np.int16)
 
     def __init__(self, clips: Sequence[np.ndarray], gap: int) -> None:
-        self.parts = [np.asarray(c) for c in clips]
+        self.parts = [c if type(c) is np.ndarray and c.flags.c_contiguous else np.ascontiguousarray(c) for c in clips]
         if any(c.dtype != np.int16 for c in self.parts):
             raise TypeError("JoinedPCM holds int16 PCM")
-        n = np.array([len(c) for c in self.parts], np.int64)
+        n = np.fromiter(map(len, self.parts), np.int64, len(self.parts))
+        self.lens = n
+        self._addrs = np.zeros(len(n), np.int64)  # filled range by range (addresses): a dict lookup per clip, paid where it is used
         self.starts = np.concatenate(([0], np.cumsum(n + gap)))[:-1] if len(n) else np.zeros(0, np.int64)
         self.size = int(n.sum() + gap * max(len(n) - 1, 0))
+
+    def addresses(self, c0: int, c1: int) -> np.ndarray:
+        """Addresses of the first samples of clips ``c0 .. c1 - 1`` (the staging copies read from there)."""
+        a = self._addrs[c0:c1]
+        for i in np.flatnonzero(a == 0):
+            a[i] = self.parts[c0 + i].__array_interface__["data"][0]
+        return a
 
     def __len__(self) -> int:
         return self.size
@@ -280,27 +288,26 @@ def _piece_runs(plan: StreamPlan, runs, data: dict):
     runs that fill the pieces laid end to end: ``(dst_off, src address, count)`` arrays, ascending in ``dst_off``; whatever
     they leave uncovered is zero padding.  A piece of file ``k`` reaches back at most 511 samples into file ``k - 1``.
     Vectorised over the pieces (a test split has thousands); a :class:`JoinedPCM` file expands into one run per clip."""
-    ks = np.array([k for k, _, _ in runs], np.int64)
-    i0 = np.array([a for _, a, _ in runs], np.int64)
-    i1 = np.array([b for _, _, b in runs], np.int64)
+    ra = np.asarray(runs, np.int64).reshape(-1, 3)
+    ks, i0, i1 = ra[:, 0], ra[:, 1], ra[:, 2]
     F = plan.F[ks] if plan.carry else np.zeros_like(ks)
     s0 = 160 * (F + plan.hop * i0)
     s1 = 160 * (F + plan.hop * (i1 - 1) + plan.T - 1) + WINDOW
     soffs = np.concatenate(([0], np.cumsum(s1 - s0))).astype(np.int64)
     d_all, p_all, c_all = [], [], []
     if any(isinstance(x, JoinedPCM) for x in data.values()):
-        (j,) = data.values()  # (_stage_pieces materialises joined streams that share a list with other files)
+        (j,) = data.values()  # (_stage_chunk materialises joined streams that share a list with other files)
         a = (int(plan.pos[0]) if plan.carry else 0) + plan.pad
-        st = j.starts
-        n = np.array([len(c) for c in j.parts], np.int64)
-        pa = np.array([c.__array_interface__["data"][0] for c in j.parts], np.int64)
-        for p in range(len(ks)):  # one piece per rank's range; one run per clip that overlaps it
+        st, n = j.starts, j.lens
+        for p in range(len(ks)):  # one piece per range of the stream; one run per clip that overlaps it
             lo, hi = max(int(s0[p]), a), min(int(s1[p]), a + len(j))
             if hi > lo and len(n):
-                q0, q1 = np.maximum(st, lo - a), np.minimum(st + n, hi - a)
+                c0 = max(int(np.searchsorted(st, lo - a, side="right")) - 1, 0)
+                c1 = int(np.searchsorted(st, hi - a, side="left"))
+                q0, q1 = np.maximum(st[c0:c1], lo - a), np.minimum(st[c0:c1] + n[c0:c1], hi - a)
                 ok = q1 > q0
                 d_all.append((int(soffs[p]) + a - int(s0[p]) + q0)[ok])
-                p_all.append((pa + 2 * (q0 - st))[ok])
+                p_all.append((j.addresses(c0, c1) + 2 * (q0 - st[c0:c1]))[ok])
                 c_all.append((q1 - q0)[ok])
     else:
         n_files = len(plan.lengths)
@@ -322,15 +329,38 @@ def _piece_runs(plan: StreamPlan, runs, data: dict):
     return soffs, np.ascontiguousarray(d[order]), np.ascontiguousarray(pp[order]), np.ascontiguousarray(c[order])
 
 
-def _stage_pieces(plan: StreamPlan, runs, load: Callable[[int], np.ndarray], ph: _Phases, device: int):
-    """The samples the window runs ``(file, i0, i1)`` are functions of, piece after piece in ONE page-locked int16 buffer,
-    written exactly once by the library's host threads (``ww_host_stage_i16``: clip samples copied in, the paddings between
-    them zeroed), then uploaded asynchronously.  Returns ``(device tensor - upload in flight on torch's current
-    stream -, sample_offs [n + 1])``, or ``(None, list of float32 arrays)`` when a file is not int16 PCM (stereo wavs, custom
-    loaders: everything is then brought to float32 in [-1, 1), int16 / 32768, and staged through NumPy)."""
-    import torch
+_TLS = None  # per host thread (threading.local): {device: the library's uploader - page-locked slots, copy threads, copy stream}
+_UPLOAD_SLOTS = 3     # chunks in flight between the interpreter and the kernels: one being written, one uploading, one waiting
+_CHUNK_SAMPLES = 24 << 20  # samples staged, uploaded and evaluated per step of the pipeline (48 MB of PCM, ~26 min of audio)
+
+
+def _uploader(eng: Engine):
+    """The calling thread's uploader on the engine's device (one host thread drives an uploader, include/wwhip.h); it goes
+    when the thread does."""
+    import threading
     from . import _lib
-    global _STAGE
+    global _TLS
+    if _TLS is None:
+        _TLS = threading.local()
+    per_thread = _TLS.__dict__.setdefault("uploaders", {})
+    up = per_thread.get(eng.ctx.device)
+    if up is None or up._h is None:
+        up = per_thread[eng.ctx.device] = _lib.Uploader(eng.ctx, _UPLOAD_SLOTS, _COPY_THREADS)
+    return up
+
+
+class _Chunk:
+    """One step of a rank's share on its way to the GPU: ``runs`` (file, i0, i1) -> samples in a page-locked slot -> device."""
+    __slots__ = ("job", "runs", "n_win", "copy", "keep", "soffs", "foffs", "nf_max", "total_f", "d_pcm", "d_so", "d_fo", "ticket",
+                 "host_pieces", "d_mel", "d_out")
+
+
+def _prep_chunk(ch: "_Chunk", ph: _Phases) -> None:
+    """Host arithmetic of one chunk: which samples of which clips its pieces hold (``ch.copy``: the runs
+    ``ww_host_stage_i16`` takes) and the sample / frame offset tables of the pieces.  When a file is not int16 PCM (stereo
+    wavs, custom loaders) everything is brought to float32 in [-1, 1) instead (int16 / 32768) and staged through NumPy
+    (``ch.host_pieces``)."""
+    plan, runs, load = ch.job.plan, ch.runs, ch.job.load
     with ph("slicing"):
         files = sorted({f for k, _, _ in runs for f in ((k - 1, k) if plan.carry and k > 0 else (k,))})
         data = {}
@@ -354,67 +384,244 @@ def _stage_pieces(plan: StreamPlan, runs, load: Callable[[int], np.ndarray], ph:
                     if hi > lo:
                         out[lo - s0:hi - s0] = data[f][lo - a:hi - a]
                 pieces.append(out)
-            return None, pieces
+            ch.host_pieces = pieces
+            return
         soffs, d, pp, c = _piece_runs(plan, runs, data)
-        need = int(soffs[-1]) + 16  # (the kernel's vector loads may run a few samples past the end: zeros there too)
-        if _STAGE is None or _STAGE.numel() < need:
-            _STAGE = None
-            _STAGE = torch.empty(need + need // 8, dtype=torch.int16, pin_memory=True)
-        # ONE staging call and ONE upload: starting each slice's upload while the next slice is written was measured and buys
-        # nothing (staging 7.2 -> 12 ms beside the DMA, upload wait 7.1 -> 2.5 ms: the host's memory system is the limit)
-        rc = _lib.load().ww_host_stage_i16(_STAGE.data_ptr(), need, len(d), _lib.ptr(d), _lib.ptr(pp), _lib.ptr(c), 0, need, _COPY_THREADS)
-        if rc != 0:
-            raise RuntimeError(f"ww_host_stage_i16 failed ({rc}): overlapping sample runs")
-        d_pcm = torch.empty(need, dtype=torch.int16, device=torch.device("cuda", device))
-        d_pcm.copy_(_STAGE[:need], non_blocking=True)
-        return d_pcm, soffs
+        lens = np.diff(soffs)
+        nf = np.where(lens >= WINDOW, (lens - WINDOW) // 160 + 1, 0).astype(np.int64)
+        ch.keep = data  # (the clips must stay where they are until the copy threads have read them)
+        ch.copy = (d, pp, c)
+        ch.soffs, ch.foffs = soffs, np.concatenate(([0], np.cumsum(nf)))
+        ch.nf_max, ch.total_f = int(nf.max()) if len(nf) else 0, int(ch.foffs[-1])
+        assert all(w == 0 or (w - 1) * plan.hop + plan.T <= f for f, w in zip(nf, ch.n_win)), "piece too short for its windows"
 
 
-def _pieces_forward(eng: Engine, staged, soffs, n_win: List[int], hop: int, precise: bool, ph: _Phases,
-                    timing: Optional[dict]) -> np.ndarray:
-    """One front-end launch over the staged pieces (each its own framing grid, frame j = samples [160 j, 160 j + 512)) and one
-    model launch over their windows (piece p: ``n_win[p]`` windows at rows ``hop i``): detect rows, piece by piece."""
+def _submit_chunk(eng: Engine, ch: "_Chunk", ph: _Phases) -> None:
+    """Hands the chunk to the library's uploader (``ww_uploader_submit``): its thread lays the pieces end to end in a
+    page-locked slot - clip samples copied in with streaming stores, the paddings between them zeroed, each sample written
+    exactly once - and sends them and the two offset tables to the device on its copy stream.  Returns at once."""
+    import torch
+    if ch.host_pieces is not None:
+        return
+    with ph("submit"):
+        d, pp, c = ch.copy
+        n = len(ch.runs)
+        need = int(ch.soffs[-1]) + 16  # (the kernel's vector loads may run a few samples past the end: zeros there too)
+        dev = torch.device("cuda", eng.ctx.device)
+        ch.d_pcm = torch.empty(need, dtype=torch.int16, device=dev)
+        d_meta = torch.empty(2 * (n + 1), dtype=torch.int64, device=dev)
+        ch.d_so, ch.d_fo = d_meta[:n + 1], d_meta[n + 1:]
+        ch.ticket = _uploader(eng).submit(need, d, pp, c, ch.d_pcm.data_ptr(), np.concatenate((ch.soffs, ch.foffs)), d_meta.data_ptr())
+        ch.copy = None  # (ch.keep: the clips stay where they are until the uploader has read them)
+
+
+def _chunk_forward(eng: Engine, ch: "_Chunk", precise: bool, ph: _Phases) -> None:
+    """One front-end launch over the chunk's pieces (each its own framing grid, frame j = samples [160 j, 160 j + 512)) and
+    one model launch over their windows (piece p: ``n_win[p]`` windows at rows ``hop i``); the detect rows stay on the device
+    (``ch.d_out``) until the job collects them."""
     import torch  # only to hold the device buffers of the batched launch
 
-    n = len(n_win)
-    if n == 0 or sum(n_win) == 0:
-        return np.zeros((0, eng.n_out), np.float32)
     dev = torch.device("cuda", eng.ctx.device)
-    lens = np.diff(soffs) if staged is not None else np.array([len(p) for p in soffs], np.int64)
-    nf = np.where(lens >= WINDOW, (lens - WINDOW) // 160 + 1, 0).astype(np.int64)
-    foffs = np.concatenate(([0], np.cumsum(nf)))
-    total_f = int(foffs[-1])
-    assert all(w == 0 or (w - 1) * hop + eng.window <= f for f, w in zip(nf, n_win)), "piece too short for its windows"
-    with ph("h2d"):
-        d_mel = torch.empty((max(total_f, 1), eng.n_mel), dtype=torch.float32, device=dev)
-        d_out = torch.empty((int(sum(n_win)), eng.n_out), dtype=torch.float32, device=dev)
-        if staged is not None:
-            # librosa's floats are int16 / 32768 exactly: the device front end divides (correctly rounded) by the same 32768
-            d_pcm = staged  # (the upload is in flight on torch's stream)
-            d_so, d_fo = torch.from_numpy(soffs).to(dev), torch.from_numpy(foffs).to(dev)
-        torch.cuda.current_stream(dev).synchronize()  # the library's stream is not torch's: the upload must have landed
+    hop = ch.job.plan.hop
+    n = len(ch.n_win)
+    ch.d_out = torch.empty((int(sum(ch.n_win)), eng.n_out), dtype=torch.float32, device=dev)
+    if ch.host_pieces is None:
+        # librosa's floats are int16 / 32768 exactly: the device front end divides (correctly rounded) by the same 32768
+        with ph("upload_wait"):
+            # returns when the chunk's samples are on their way; the library's stream waits for them on the device
+            _uploader(eng).wait(ch.ticket, eng.ctx)
+            ch.keep = None
+        with ph("device_wall"):
+            ch.d_mel = torch.empty((max(ch.total_f, 1), eng.n_mel), dtype=torch.float32, device=dev)
+            eng.logmel_dev(ch.d_pcm.data_ptr(), ch.d_so.data_ptr(), ch.d_fo.data_ptr(), n, ch.total_f, ch.nf_max, ch.d_mel.data_ptr(),
+                           frontend_params(32768.0, False, 0.0, 160, precise))
+            foffs, total_f = ch.foffs, ch.total_f
+    else:
+        with ph("device_wall"):
+            mels = eng.logmel(ch.host_pieces, frontend_params(1.0, False, 0.0, 160, precise))
+            nf = np.array([len(m) for m in mels], np.int64)
+            foffs = np.concatenate(([0], np.cumsum(nf)))
+            total_f = int(foffs[-1])
+            assert all(w == 0 or (w - 1) * hop + eng.window <= f for f, w in zip(nf, ch.n_win)), "piece too short for its windows"
+            ch.d_mel = torch.empty((max(total_f, 1), eng.n_mel), dtype=torch.float32, device=dev)
+            ch.d_mel[:total_f] = torch.from_numpy(np.concatenate(mels)).to(dev)
+            torch.cuda.current_stream(dev).synchronize()
+    with ph("device_wall"):
+        # the library picks the tail kernel by the launch's window count; every form of the CRNN associates its sums the same
+        # way (csrc/crnn.hip: gru_step), so a posterior does not depend on how many windows its launch holds - nor on how a
+        # share is cut into chunks
+        eng.forward_segments_dev(ch.d_mel.data_ptr(), total_f, foffs[:-1], np.asarray(ch.n_win, np.int32), hop, ch.d_out.data_ptr())
+    # (nothing here waits for the GPU: ch.d_pcm / ch.d_mel / ch.d_out stay alive until _run_jobs has synchronised)
+
+
+class _PosteriorJob:
+    """One ``get_posterior`` call on this rank: the plan (the same arithmetic on every rank), this rank's share of it cut into
+    chunks of about ``_CHUNK_SAMPLES`` samples, and - after :func:`_run_jobs` - the posteriors of the share."""
+
+    def __init__(self, eng: Engine, eval_type: str, test_files, frame_width: int, sample_rate: int, rank: int, world: int,
+                 loader, lengths, carry_over: bool, ph: _Phases, info: Optional[dict], first_chunk: int = 1 << 21) -> None:
+        self.eng, self.eval_type, self.rank, self.world = eng, eval_type, rank, world
+        frame_length = sample_rate // 1000 * frame_width
+        in_memory = len(test_files) > 0 and not isinstance(test_files[0], (str, bytes)) and not hasattr(test_files[0], "__fspath__")
+        with ph("plan"):
+            if in_memory:
+                self.load = lambda k: test_files[k]  # noqa: E731
+                lengths = [len(x) for x in test_files] if lengths is None else lengths
+            else:
+                rd = loader or (lambda p: read_wav_pcm(p, sample_rate))
+                self.load = lambda k: rd(str(test_files[k]))  # noqa: E731
+                if lengths is None:
+                    lengths = [wav_length(str(f), sample_rate) for f in test_files] if loader is None else [len(rd(str(f))) for f in test_files]
+            self.plan = plan = StreamPlan(lengths, eng.window, frame_length, sample_rate, 2, carry_over)
+            if info is not None:
+                info["windows"] = info.get("windows", 0) + plan.total  # inferences of the whole call, all ranks
+            self.shares = plan.shares(eval_type, world)
+            self.mine = self.shares[rank]
+            self.chunks: List[_Chunk] = []
+            for runs in self._cut(self.mine, first_chunk):
+                ch = _Chunk()
+                ch.job, ch.runs, ch.n_win = self, runs, [i1 - i0 for _, i0, i1 in runs]
+                ch.host_pieces = ch.d_pcm = ch.d_mel = ch.d_out = ch.ticket = ch.copy = ch.keep = None
+                self.chunks.append(ch)
+        self.vals: Optional[np.ndarray] = None
+
+    def _cut(self, runs, first: int):
+        """The share as consecutive groups of runs; a run longer than a chunk (the negative stream is ONE file) is cut into
+        window ranges - each re-reads the ``T - hop`` frames it shares with its neighbour.  Chunk sizes (samples) grow from
+        ``first`` by doubling up to ``_CHUNK_SAMPLES``: a small first chunk is on the GPU early, large later ones keep the
+        launches efficient."""
+        plan = self.plan
+        per_win = 160 * plan.hop
+        out, cur, cur_n = [], [], 0
+        size = max(min(first, _CHUNK_SAMPLES), per_win)
+
+        def close():
+            nonlocal cur, cur_n, size
+            if cur:
+                out.append(cur)
+                cur, cur_n = [], 0
+                size = min(2 * size, _CHUNK_SAMPLES)
+
+        for k, i0, i1 in runs:
+            while i1 - i0 > (size + size // 2) // per_win:  # (a remainder below half a chunk stays with the last cut)
+                close()
+                w = max(size // per_win, 1)
+                cur, cur_n = [(k, i0, i0 + w)], size
+                i0 += w
+                close()
+            n = 160 * (plan.hop * (i1 - i0 - 1) + plan.T - 1) + WINDOW
+            if cur and cur_n + n > size:
+                close()
+            cur.append((k, i0, i1))
+            cur_n += n
+        close()
+        return out
+
+    def slots_of(self, runs) -> np.ndarray:
+        """Global slot of every window of the runs: offs[k] + i0 .. offs[k] + i1 - 1, run after run."""
+        if not runs:
+            return np.zeros(0, np.int64)
+        plan = self.plan
+        nw = np.array([i1 - i0 for _, i0, i1 in runs], np.int64)
+        first = np.array([plan.offs[k] + i0 for k, i0, _ in runs], np.int64)
+        ends = np.cumsum(nw)
+        if (first[1:] == first[:-1] + nw[:-1]).all():
+            return slice(int(first[0]), int(first[0] + ends[-1]))  # consecutive slots (one rank; a contiguous range of the stream)
+        return np.arange(int(ends[-1]), dtype=np.int64) + np.repeat(first - (ends - nw), nw)
+
+    def collect(self, ph: _Phases) -> None:
+        """Detect rows of the share from the device (after :func:`_run_jobs`: every kernel has finished)."""
+        import torch
+        with ph("d2h"):
+            outs = [ch.d_out for ch in self.chunks if ch.d_out is not None and ch.d_out.shape[0]]
+            if outs:
+                self.vals = (outs[0] if len(outs) == 1 else torch.cat(outs))[:, self.eng.posterior_index].cpu().numpy()
+            else:
+                self.vals = np.zeros(0, np.float32)
+            for ch in self.chunks:
+                ch.d_out = None
+
+    def finish(self, comm_device: Optional[str], ph: _Phases, as_array: bool):
+        """The gather (the one exchange) and what ``get_posterior`` returns, on every rank."""
+        plan = self.plan
+        with ph("gather"):
+            post = np.zeros(plan.total, np.float32)
+            if self.world > 1:
+                # the plan is the same arithmetic on every rank, so every rank knows which slots any rank's values fill: the
+                # exchange is the values alone (float32, padded to the largest share)
+                from . import dist as D
+                every = D.gather_values(self.vals, [sum(i1 - i0 for _, i0, i1 in sh) for sh in self.shares], device=comm_device)
+                for sh, v in zip(self.shares, every):
+                    post[self.slots_of(sh)] = v
+            else:
+                post[self.slots_of(self.mine)] = self.vals
+        if self.eval_type == "false_negatives":
+            if (plan.n_win == 0).any():
+                raise ValueError("max() arg is an empty sequence")  # an empty clip: what np.max raises in the reference's loop
+            post = np.maximum.reduceat(post, plan.offs[:-1])
+        return post if as_array else post.tolist()
+
+
+def _run_jobs(eng: Engine, jobs: Sequence, precise: bool, ph: _Phases, timing: Optional[dict]) -> List[_PosteriorJob]:
+    """The chunks of the jobs, in order, through a pipeline of three workers that never wait for one another's locks: THIS
+    thread works out which samples a chunk's pieces hold (:func:`_prep_chunk`, Python arithmetic) and hands them to the
+    library's uploader (:func:`_submit_chunk`); the uploader's threads write the chunk into page-locked memory and start its
+    upload; and as soon as a chunk is on its way this thread enqueues the front end and the model over it behind the upload
+    (:func:`_chunk_forward`: a device-side wait, no call waits for the GPU) - the interpreter, the copy threads, the DMA
+    engine and the kernels work on consecutive chunks at the same time.  ``jobs``: :class:`_PosteriorJob` objects or callables
+    that build one (or ``None``); a callable runs when the pipeline gets there, so a second job is joined and planned while
+    the first one's chunks upload and compute.  Returns the jobs, their shares' posteriors collected."""
+    from collections import deque
+
+    made: List[_PosteriorJob] = []
+    pending: "deque[_Chunk]" = deque()   # submitted, not yet launched
+    done: List[_Chunk] = []
     if timing is not None:
         eng.ctx.profile(True)
-    with ph("device_wall"):
-        if staged is not None:
-            eng.logmel_dev(d_pcm.data_ptr(), d_so.data_ptr(), d_fo.data_ptr(), n, total_f, int(nf.max()), d_mel.data_ptr(),
-                           frontend_params(32768.0, False, 0.0, 160, precise))
-        else:
-            mels = eng.logmel(soffs, frontend_params(1.0, False, 0.0, 160, precise))
-            d_mel[:total_f] = torch.from_numpy(np.concatenate(mels)).to(dev)
-            torch.cuda.current_stream(dev).synchronize()
-        # the library picks the tail kernel by the share's window count; every form of the CRNN associates its sums the same
-        # way (csrc/crnn.hip: gru_step), so a rank's posteriors do not depend on how many windows its launch holds
-        eng.forward_segments_dev(d_mel.data_ptr(), total_f, foffs[:-1], np.asarray(n_win, np.int32), hop, d_out.data_ptr())
-        eng.ctx.synchronize()
+    try:
+        for j in jobs:
+            job = j() if callable(j) else j
+            if job is None:
+                continue
+            made.append(job)
+            for ch in job.chunks:
+                _prep_chunk(ch, ph)
+                _submit_chunk(eng, ch, ph)
+                pending.append(ch)
+                # launch what is ready; never run more than the uploader's slots ahead of the launches
+                while pending and (len(pending) >= _UPLOAD_SLOTS or pending[0].ticket is None or _uploader(eng).done(pending[0].ticket)):
+                    ch0 = pending.popleft()
+                    done.append(ch0)
+                    _chunk_forward(eng, ch0, precise, ph)
+        while pending:
+            ch0 = pending.popleft()
+            done.append(ch0)
+            _chunk_forward(eng, ch0, precise, ph)
+        with ph("device_wall"):
+            eng.ctx.synchronize()
+    finally:
+        # on the way out of an error too: nothing enqueued or submitted may outlive its buffers or the clips it reads
+        for ch in pending:
+            if ch.ticket is not None:
+                try:
+                    _uploader(eng).wait(ch.ticket, eng.ctx)
+                except Exception:  # noqa: BLE001 - the first error is the one that is reported
+                    pass
+        if done or pending:
+            eng.ctx.synchronize()
+        for ch in list(done) + list(pending):
+            ch.d_pcm = ch.d_mel = ch.d_so = ch.d_fo = ch.keep = None
     if timing is not None:
-        prof = eng.ctx.profile_read()
-        eng.ctx.profile(False)
+        with ph("profile_read"):
+            prof = eng.ctx.profile_read()
+            eng.ctx.profile(False)
         timing["device_ms"] = timing.get("device_ms", 0.0) + sum(v["total_ms"] for v in prof.values())
         for k, v in prof.items():
             timing.setdefault("kernels_ms", {})[k] = timing.get("kernels_ms", {}).get(k, 0.0) + v["total_ms"]
-    with ph("d2h"):
-        return d_out.cpu().numpy()
+        timing["chunks"] = timing.get("chunks", 0) + len(done)
+    for job in made:
+        job.collect(ph)
+    return made
 
 
 def get_posterior_sharded(models_dir, model_type, eval_type, test_files, frame_width, sample_rate, rank: int = 0,
@@ -428,66 +635,28 @@ def get_posterior_sharded(models_dir, model_type, eval_type, test_files, frame_w
     ``"false_accepts"``: the window list - for the reference's evaluator ONE long wav (``evaluate_models.py:317-321``) -
     cut into ``world`` contiguous posterior ranges (``dist.split_stream``).  A rank loads and front-ends only the samples
     its windows are functions of: posterior ``i`` of a file needs the global frames ``[F + 2 i, F + 2 i + T)``, i.e. each
-    range re-reads a ``T - 2``-frame overlap and the results are exact.  The one exchange is the posterior gather.  Every
-    rank returns the full list :func:`get_posterior` returns.
+    range re-reads a ``T - 2``-frame overlap and the results are exact.  The share goes to the GPU in chunks of ~13 minutes
+    of audio through a staging pipeline (:func:`_run_jobs`).  The one exchange is the posterior gather.  Every rank returns
+    the full list :func:`get_posterior` returns.
 
     ``test_files``: paths (default loader :func:`read_wav_pcm`; ``lengths`` default = wav headers) or arrays already in
     memory (int16 PCM, or float32 samples in [-1, 1)).  ``precise=False``: the fp32-FFT front end (``ww_frontend_params.precise``
     = 0) instead of the reference's float64 STFT.  ``timing``: a dict that receives this rank's wall-clock seconds per host
-    phase (``plan``, ``slicing``, ``h2d``, ``device_wall``, ``d2h``, ``gather``) and ``device_ms`` (HIP events around every
-    kernel of the call, ``ww_profile_read``); ``info`` receives ``windows`` (inferences of the whole call, all ranks).  ``as_array``: a float32 array instead of the reference's list (two hours of
-    negatives are 360,000 Python floats)."""
+    phase (``plan``; ``slicing`` and ``upload_enqueue`` on the staging thread, i.e. beside the others; ``stage_wait`` = this thread waiting
+    for a staged chunk, ``device_wall`` = launches + the final wait for the GPU, ``d2h``, ``gather``), ``device_ms`` (HIP events around every kernel of the call, ``ww_profile_read``) and
+    ``chunks``; ``info`` receives ``windows`` (inferences of the whole call, all ranks).  ``as_array``: a float32 array
+    instead of the reference's list (two hours of negatives are 360,000 Python floats)."""
     if model_type not in ("CRNN", "Wavenet"):
         raise ValueError("model_type must be 'CRNN' or 'Wavenet'")
     if eval_type not in ("false_negatives", "false_accepts"):
         raise ValueError("eval_type must be 'false_negatives' or 'false_accepts'")
+    if len(test_files) == 0:
+        return []
     eng: Engine = engine or engine_for(models_dir, device)
     ph = _Phases(timing)
-    frame_length = sample_rate // 1000 * frame_width
-    in_memory = len(test_files) > 0 and not isinstance(test_files[0], (str, bytes)) and not hasattr(test_files[0], "__fspath__")
-    with ph("plan"):
-        if in_memory:
-            load = lambda k: test_files[k]  # noqa: E731
-            lengths = [len(x) for x in test_files] if lengths is None else lengths
-        else:
-            rd = loader or (lambda p: read_wav_pcm(p, sample_rate))
-            load = lambda k: rd(str(test_files[k]))  # noqa: E731
-            if lengths is None:
-                lengths = [wav_length(str(f), sample_rate) for f in test_files] if loader is None else [len(rd(str(f))) for f in test_files]
-        if len(test_files) == 0:
-            return []
-        plan = StreamPlan(lengths, eng.window, frame_length, sample_rate, 2, carry_over)
-        if info is not None:
-            info["windows"] = info.get("windows", 0) + plan.total  # inferences of the whole call, all ranks
-        shares = plan.shares(eval_type, world)
-        mine = shares[rank]
-        n_win = [i1 - i0 for _, i0, i1 in mine]
-
-        def slots_of(runs):  # global slot of every window of the runs: offs[k] + i0 .. offs[k] + i1 - 1, run after run
-            if not runs:
-                return np.zeros(0, np.int64)
-            nw = np.array([i1 - i0 for _, i0, i1 in runs], np.int64)
-            first = np.array([plan.offs[k] + i0 for k, i0, _ in runs], np.int64)
-            ends = np.cumsum(nw)
-            return np.arange(int(ends[-1]), dtype=np.int64) + np.repeat(first - (ends - nw), nw)
-    staged, soffs = _stage_pieces(plan, mine, load, ph, eng.ctx.device) if mine else (None, [])
-    vals = _pieces_forward(eng, staged, soffs, n_win, plan.hop, precise, ph, timing)[:, eng.posterior_index]
-    with ph("gather"):
-        post = np.zeros(plan.total, np.float32)
-        if world > 1:
-            # the plan is the same arithmetic on every rank, so every rank knows which slots any rank's values fill: the
-            # exchange is the values alone (float32, padded to the largest share)
-            from . import dist as D
-            every = D.gather_values(vals, [sum(i1 - i0 for _, i0, i1 in sh) for sh in shares], device=comm_device)
-            for sh, v in zip(shares, every):
-                post[slots_of(sh)] = v
-        else:
-            post[slots_of(mine)] = vals
-    if eval_type == "false_negatives":
-        if (plan.n_win == 0).any():
-            raise ValueError("max() arg is an empty sequence")  # an empty clip: what np.max raises in the reference's loop
-        post = np.maximum.reduceat(post, plan.offs[:-1])
-    return post if as_array else post.tolist()
+    (job,) = _run_jobs(eng, [lambda: _PosteriorJob(eng, eval_type, test_files, frame_width, sample_rate, rank, world, loader,
+                                                   lengths, carry_over, ph, info)], precise, ph, timing)
+    return job.finish(comm_device, ph, as_array)
 
 
 def join_negatives(clips: Sequence[np.ndarray], num_files: int, sample_rate: int = 16000) -> np.ndarray:
@@ -502,7 +671,8 @@ def join_negatives(clips: Sequence[np.ndarray], num_files: int, sample_rate: int
 
 def join_negatives_lazy(clips: Sequence[np.ndarray], num_files: int, sample_rate: int = 16000) -> JoinedPCM:
     """:func:`join_negatives` as a :class:`JoinedPCM` (no copy of the clips)."""
-    return JoinedPCM([np.asarray(c, np.int16) for c in clips[:max(num_files, 1)]], sample_rate // 10)
+    return JoinedPCM([c if type(c) is np.ndarray and c.dtype == np.int16 else np.asarray(c, np.int16) for c in clips[:max(num_files, 1)]],
+                     sample_rate // 10)
 
 
 def evaluate_negative_stream_sharded(engine: Engine, stream_pcm, rank: int = 0, world: int = 1,
@@ -526,18 +696,38 @@ def evaluate_reference_flow_sharded(engine: Engine, clips: Sequence[np.ndarray],
     (:func:`evaluate_negative_stream_sharded`), hours = the joined stream's duration; rank 0 smooths and sweeps.
     Returns the result dict on rank 0 and ``None`` elsewhere.  ``timing``: see :func:`get_posterior_sharded`; the two legs
     add up in it, and ``sweep`` is rank 0's smoothing + threshold sweep."""
+    ph = _Phases(timing)
     labels = np.asarray(labels).astype(bool)
-    wake = [np.asarray(c, np.int16) for c, l in zip(clips, labels) if l]
-    other = [np.asarray(c, np.int16) for c, l in zip(clips, labels) if not l]
-    mtype = "CRNN" if engine.is_crnn else "Wavenet"
-    num_wakewords = len(wake)
+    num_wakewords = int(labels.sum())
     info: dict = {}
-    pos = np.asarray(get_posterior_sharded(engine.model_dir, mtype, "false_negatives", wake, 20, 16000, rank, world,
-                                           comm_device, engine=engine, precise=precise, timing=timing, as_array=True,
-                                           info=info), np.float32)
-    stream = join_negatives_lazy(other, num_wakewords) if other else None
-    neg = (evaluate_negative_stream_sharded(engine, stream, rank, world, comm_device, precise, timing, info) if stream is not None and len(stream)
-           else np.zeros(0, np.float32))
+    made: dict = {}
+
+    # both legs as ONE pipeline (:func:`_run_jobs`), the negative stream FIRST: it holds more windows per uploaded byte (no
+    # half seconds of padding around every clip), so the GPU has work for the time the wake-word clips take to stage
+    def negative_job():
+        with ph("prepare"):
+            idx = np.flatnonzero(~labels)[:max(num_wakewords, 1)]
+            other = [clips[i] for i in idx]
+            made["n_joined"] = len(other)
+            stream = made["stream"] = join_negatives_lazy(other, num_wakewords) if other else None
+        if stream is None or len(stream) == 0:
+            return None
+        made["neg"] = _PosteriorJob(engine, "false_accepts", [stream], 20, 16000, rank, world, None, None, True, ph, info)
+        return made["neg"]
+
+    def wake_job():
+        if num_wakewords == 0:
+            return None
+        with ph("prepare"):
+            wake = [c if type(c) is np.ndarray and c.dtype == np.int16 else np.asarray(c, np.int16) for c in (clips[i] for i in np.flatnonzero(labels))]
+        made["wake"] = _PosteriorJob(engine, "false_negatives", wake, 20, 16000, rank, world, None, None, True, ph, info,
+                                     first_chunk=_CHUNK_SAMPLES if "neg" in made else 1 << 21)  # (the pipeline is full by then)
+        return made["wake"]
+
+    _run_jobs(engine, [negative_job, wake_job], precise, ph, timing)
+    pos = made["wake"].finish(comm_device, ph, True) if "wake" in made else np.zeros(0, np.float32)
+    neg = made["neg"].finish(comm_device, ph, True) if "neg" in made else np.zeros(0, np.float32)
+    stream = made.get("stream")
     if rank != 0:
         return None
     hours = (len(stream) if stream is not None else 0) / 16000.0 / 3600.0
@@ -545,7 +735,7 @@ def evaluate_reference_flow_sharded(engine: Engine, clips: Sequence[np.ndarray],
         thr, frr, fa, cnt = far_frr(pos, neg, max(num_wakewords, 1), hours, thresholds, windowsize, engine=engine)
     return {"thresholds": thr, "frr": frr, "fa_per_hour": fa, "fa_count": cnt, "frr_at_0.5_fa_per_hour": frr_at_fa(frr, fa, 0.5),
             "positives": pos, "negatives": neg, "hours": hours, "num_wakewords": num_wakewords,
-            "negative_clips_joined": min(len(other), max(num_wakewords, 1)), "windows": int(info.get("windows", 0)),
+            "negative_clips_joined": made.get("n_joined", 0), "windows": int(info.get("windows", 0)),
             "negative_windows": int(len(neg)),
             "posterior_checksum": float(neg.sum(dtype=np.float64) + pos.sum(dtype=np.float64))}
 
