@@ -14,6 +14,7 @@
 // Round 1's three-kernel chain (conv5x20_kernel -> gemm_nt_kernel -> gru_head_kernel, 52 us per 256 windows against
 // 34 us fused) and its bf16x6 projection GEMM are gone; their measurements are in DESIGN.md 7.1.
 #include "common.h"
+#include <type_traits>
 
 #include <cstdlib>
 
@@ -29,14 +30,47 @@ struct win_addr {
 };
 
 __device__ __forceinline__ void window_span(const win_addr &wa, int w, int T, int64_t &row, int &valid) {
-  row = wa.row ? wa.row[w] : wa.row0 + (int64_t)w * wa.hop;
-  valid = wa.valid ? wa.valid[w] : wa.valid_const;
+  if (wa.row && wa.valid) {  // (both tables: the two loads go out together, one round trip at the head of the kernel)
+    const int64_t r = wa.row[w];
+    const int v = wa.valid[w];
+    row = r;
+    valid = v;
+  } else {
+    row = wa.row ? wa.row[w] : wa.row0 + (int64_t)w * wa.hop;
+    valid = wa.valid ? wa.valid[w] : wa.valid_const;
+  }
   if (valid > T) valid = T;
   if (row + valid > wa.mel_rows) valid = (int)(wa.mel_rows - row);
   if (valid < 0) valid = 0;
 }
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Four mel features at p (zeros unless `in`).  Whether the window's first row is 16-byte aligned is uniform over a workgroup,
+// so the staging loops branch on it ONCE, outside (stage_loads below): with the 16-byte and the 4 x 4-byte form behind one
+// per-element condition the compiler drained the memory counter after every element's loads - six round trips to L2 in a
+// row at the head of crnn_fused_kernel (6.4 k of its 72 k cycles) instead of six loads in flight.
+template <bool AL16>
+__device__ __forceinline__ float4 ld_mel4(const float *p, bool in) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (in) {
+    if (AL16) v = *(const float4 *)p;
+    else v = make_float4(p[0], p[1], p[2], p[3]);
+  }
+  return v;
+}
+// The same from an address that is readable whatever `in` says (the caller clamps it into the buffer): the load is
+// unconditional - no exec masking, nothing the next load has to wait for - and `in` only selects between it and zeros.
+template <bool AL16>
+__device__ __forceinline__ float4 ld_mel4_sel(const float *p_safe, bool in) {
+  const float4 v = ld_mel4<AL16>(p_safe, true);
+  return make_float4(in ? v.x : 0.f, in ? v.y : 0.f, in ? v.z : 0.f, in ? v.w : 0.f);
+}
+template <typename F>
+__device__ __forceinline__ void stage_loads(bool al16, F &&body) {
+  if (al16) body(std::true_type{});
+  else body(std::false_type{});
+}
 
 // ------------------------------------------------------------------------------------------
 // conv
@@ -374,8 +408,16 @@ __device__ __forceinline__ float cf_recurrence(const gru_w &g, const float *gxs,
   rem[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(rv_.e_, b_[2].e_, rem[2], 0, 0, 0);
 
 // development: s_memtime at the phase boundaries (fused_args::stamps; nullptr = off)
+#ifdef CF_STAMP_PHASE_A  // development build: slots 6..9 hold the inside of phase A instead of phases D..G
+#define CF_STAMP(i_)                                                                                          \
+  if ((i_) < 6 && a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wave) * 10 + (i_)] = __builtin_amdgcn_s_memtime();
+#define CF_STAMP_A(i_)                                                                                        \
+  if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wave) * 10 + (i_)] = __builtin_amdgcn_s_memtime();
+#else
 #define CF_STAMP(i_)                                                                                          \
   if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 4 + wave) * 10 + (i_)] = __builtin_amdgcn_s_memtime();
+#define CF_STAMP_A(i_)
+#endif
 
 // Phases D..G of the fused kernels (fp32 and split-bf16 front halves share them): gx1 is in LDS, g holds this wave's
 // recurrent weights (waves 0, 1: layer 1; waves 2, 3: layer 2).
@@ -501,19 +543,20 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
     const int n = valid * CV_NMEL;
     const bool al16 = ((((uintptr_t)src) & 15) == 0);
     float4 stage[MAXV];
+    // n is a multiple of 4: a float4 is inside the window or outside it.  Outside ones are never scattered, so they load the
+    // window's last float4 again instead of being masked: six unconditional loads, all in flight at once
+    if (n > 0)
+      stage_loads(al16, [&](auto al) {
+        constexpr bool AL = decltype(al)::value;
 #pragma unroll
-    for (int q = 0; q < MAXV; ++q) {
-      const int i = (q * CF_THREADS + tid) * 4;
-      if (al16 && i + 3 < n) {
-        stage[q] = *(const float4 *)(src + i);
-      } else {
-        stage[q].x = i < n ? src[i] : 0.f;
-        stage[q].y = i + 1 < n ? src[i + 1] : 0.f;
-        stage[q].z = i + 2 < n ? src[i + 2] : 0.f;
-        stage[q].w = i + 3 < n ? src[i + 3] : 0.f;
-      }
-    }
+        for (int q = 0; q < MAXV; ++q) {
+          const int i = (q * CF_THREADS + tid) * 4;
+          stage[q] = ld_mel4<AL>(src + (i < n ? i : n - 4), true);
+        }
+      });
+    CF_STAMP_A(6)
     for (int i = tid; i < CF_IMG_FLOATS / 4; i += CF_THREADS) ((float4 *)img)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    CF_STAMP_A(7)
     // while the window is on its way: LDS offsets of this lane's conv operands and results for its six m-tiles
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -531,20 +574,21 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
       }
     }
     __syncthreads();
+    CF_STAMP_A(8)
 #pragma unroll
     for (int q = 0; q < MAXV; ++q) {
       const int i = (q * CF_THREADS + tid) * 4;
-      const float e[4] = {stage[q].x, stage[q].y, stage[q].z, stage[q].w};
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int ii = i + c;
-        if (ii < n) {
-          const int it = ii / CV_NMEL, im = ii - it * CV_NMEL;
-          img[(im + CV_PF) * CV_LDT + it + CV_PT] = e[c];
-        }
+      if (i < n) {  // the four features are four consecutive mel bins of ONE frame (40 = 10 x 4): one division, four rows of the image
+        const int it = i / CV_NMEL, im = i - it * CV_NMEL;
+        float *d = img + (im + CV_PF) * CV_LDT + it + CV_PT;
+        d[0] = stage[q].x;
+        d[CV_LDT] = stage[q].y;
+        d[2 * CV_LDT] = stage[q].z;
+        d[3 * CV_LDT] = stage[q].w;
       }
     }
   }
+  CF_STAMP_A(9)
   __syncthreads();
   CF_STAMP(1)
   // ---- B: conv -> feat (LDS).  Six m-tiles per wave, software-pipelined by hand: the next tile's A operands are read while
@@ -945,17 +989,15 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_rows_kernel(rows_args a) {
     const int ncols = 15 * stride + CV_KT;
     const bool al16 = ((((uintptr_t)a.mel) & 15) == 0);
     float4 stage[MAXV];
+    stage_loads(al16, [&](auto al) {
+      constexpr bool AL = decltype(al)::value;
 #pragma unroll
-    for (int q = 0; q < MAXV; ++q) {
-      const int f4 = q * CF_THREADS + tid, it = f4 / 10;
-      const int64_t r = field0 + it;
-      if (it < ncols && r >= 0 && r < a.mel_rows) {
-        const float *src = a.mel + r * CV_NMEL + (f4 - it * 10) * 4;
-        stage[q] = al16 ? *(const float4 *)src : make_float4(src[0], src[1], src[2], src[3]);
-      } else {
-        stage[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int q = 0; q < MAXV; ++q) {
+        const int f4 = q * CF_THREADS + tid, it = f4 / 10;
+        const int64_t r = field0 + it, rc = r < 0 ? 0 : r < a.mel_rows ? r : a.mel_rows - 1;  // (the host checked: mel_rows >= T)
+        stage[q] = ld_mel4_sel<AL>(a.mel + rc * CV_NMEL + (f4 - it * 10) * 4, it < ncols && r >= 0 && r < a.mel_rows);
       }
-    }
+    });
     for (int i = tid; i < CF_IMG_FLOATS / 4; i += CF_THREADS) ((float4 *)img)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
@@ -1142,21 +1184,17 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_bf16_kernel(fused_ar
     const bool al16 = ((((uintptr_t)src) & 15) == 0);
     float4 lo4[NIT], hi4[NIT];
 #pragma unroll
-    for (int q = 0; q < NIT; ++q) {
-      const int item = q * CF_THREADS + tid, fp = item / 10, mq = item - fp * 10;
-      const int f0 = 2 * fp, f1 = 2 * fp + 1;
-      auto ld = [&](int fr) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (fr < valid) {
-          const float *p = src + fr * CV_NMEL + mq * 4;
-          if (al16) v = *(const float4 *)p;
-          else v = make_float4(p[0], p[1], p[2], p[3]);
-        }
-        return v;
-      };
-      lo4[q] = ld(f0);
-      hi4[q] = ld(f1);
-    }
+    for (int q = 0; q < NIT; ++q) lo4[q] = hi4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid > 0) stage_loads(al16, [&](auto al) {
+      constexpr bool AL = decltype(al)::value;
+#pragma unroll
+      for (int q = 0; q < NIT; ++q) {
+        const int item = q * CF_THREADS + tid, fp = item / 10, mq = item - fp * 10;
+        const int f0 = 2 * fp, f1 = 2 * fp + 1;
+        lo4[q] = ld_mel4_sel<AL>(src + (f0 < valid ? f0 : valid - 1) * CV_NMEL + mq * 4, f0 < valid);
+        hi4[q] = ld_mel4_sel<AL>(src + (f1 < valid ? f1 : valid - 1) * CV_NMEL + mq * 4, f1 < valid);
+      }
+    });
     for (int i = tid; i < CFB_IMG_FLOATS / 4; i += CF_THREADS) ((float4 *)img)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
