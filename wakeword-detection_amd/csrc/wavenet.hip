@@ -246,27 +246,95 @@ __global__ __launch_bounds__(WV_NW * 64, WV_NW == 12 ? (SPLIT_BF16 ? WV_BF16_OCC
       }
     (void)x; (void)ubuf;
   } else {
-  int64_t row = a.wa.row ? a.wa.row[w] : a.wa.row0 + (int64_t)w * a.wa.hop;
-  int valid = a.wa.valid ? a.wa.valid[w] : a.wa.valid_const;
+  int64_t row;
+  int valid;
+  if (a.wa.row && a.wa.valid) {  // (both tables: the two loads go out together)
+    const int64_t r_ = a.wa.row[w];
+    const int v_ = a.wa.valid[w];
+    row = r_;
+    valid = v_;
+  } else {  // (plain ifs: as `p ? p[w] : constant` the compiler parked the constant in scratch memory to select between two addresses)
+    row = a.wa.row0 + (int64_t)w * a.wa.hop;
+    valid = a.wa.valid_const;
+    if (a.wa.row) row = a.wa.row[w];
+    if (a.wa.valid) valid = a.wa.valid[w];
+  }
   if (valid > T) valid = T;
   if (row + valid > a.wa.mel_rows) valid = (int)(a.wa.mel_rows - row);
   if (valid < 0) valid = 0;
 
+  // the input conv's operands: requested now, used behind the staging
+  float4 bw[3];
+#pragma unroll
+  for (int kb = 0; kb < 3; ++kb) bw[kb] = *(const float4 *)(a.w_in4 + ((size_t)(kb * 4 + kk) * 16 + j) * 4);
+  const float bias = a.b_in[j];
+  // ... and what the block loop's LDS tables are filled from (split-bf16: parameter pages 0 and 1 and the BatchNorm table; fp32
+  // transposed: the per-block vector table): requested here, parked in LDS once the staged input is dead - as loops of
+  // "load, store" behind the input conv they were three to four round trips to L2 in a row on every window's critical path
+  constexpr int NPL = (WV_PAGE_U4 + WV_THREADS - 1) / WV_THREADS;                 // page pieces per thread (the last one partial)
+  static_assert(NPL >= 2 && NPL <= 4, "page pieces per thread");
+  constexpr int NVT = (32 * 7 * 16 + WV_THREADS - 1) / WV_THREADS;                // fp32 vector-table entries per thread (NB <= 32)
+  // (clang ext-vector elements: arrays of HIP's struct vector types stayed in scratch memory)
+  u32x4 pg0[NPL], pg1[NPL];
+  f32x4 bnv = {0.f, 0.f, 0.f, 0.f};
+  float vte[NVT];
+  if (SPLIT_BF16) {
+    const int second = a.NB > 1 ? 1 : 0;
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+      const int i = tid + q * WV_THREADS < WV_PAGE_U4 ? tid + q * WV_THREADS : WV_PAGE_U4 - 1;
+      pg0[q] = *(const u32x4 *)(a.wpk + i);
+      pg1[q] = *(const u32x4 *)(a.wpk + (size_t)second * WV_PAGE_U4 + i);
+    }
+    const int bi = tid < a.NB * 8 ? tid : 0;                                    // [NB][2][4] float4 = scale, shift (NB <= 32 <= threads / 8)
+    bnv = *(const f32x4 *)(((bi >> 2) & 1 ? a.bn_t : a.bn_s) + (bi >> 3) * WV_C + 4 * (bi & 3));
+  }
+  if (FP32T) {
+#pragma unroll
+    for (int q = 0; q < NVT; ++q) {
+      int i = tid + q * WV_THREADS;
+      i = i < a.NB * 7 * 16 ? i : 0;
+      const int b = i / 112, v = (i / 16) % 7, c = i & 15;
+      const float *p = v == 0 ? a.bn_s + b * WV_C + c : v == 1 ? a.bn_t + b * WV_C + c : v < 4 ? a.b_gate + b * 32 + (v - 2) * 16 + c
+                                                                                             : a.b_rs + b * 48 + (v - 4) * 16 + c;
+      vte[q] = *p;
+    }
+  }
+
   // ---- stage the window: in_lds[t][0..47], zero outside [0,valid) x [0,n_mel)
   float *in_lds = lds;
-  for (int i = tid; i < WV_T * WV_INLD / 4; i += WV_THREADS) ((float4 *)in_lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  __syncthreads();
   {
     const float *src = a.mel + row * a.n_mel;
     const int n = valid * a.n_mel;
     if ((a.n_mel & 3) == 0 && ((((uintptr_t)src) & 15) == 0)) {
-      // the window is one contiguous [valid][n_mel] block and a row is a whole number of float4s:
-      // 16-byte loads (issued back to back), 16-byte LDS stores
-      for (int i = tid; i < n / 4; i += WV_THREADS) {
-        const int e = i * 4, t = e / a.n_mel, c = e - t * a.n_mel;
-        *(float4 *)(in_lds + t * WV_INLD + c) = *(const float4 *)(src + e);
+      // the window is one contiguous [valid][n_mel] block and a row is a whole number of float4s.  All of a thread's
+      // 16-byte loads are issued first (unconditional, from clamped addresses: nothing for the next load to wait for), the
+      // zero fill runs while they are in flight, then the 16-byte LDS stores
+      constexpr int SQ = (WV_T * WV_INLD / 4 + WV_THREADS - 1) / WV_THREADS;
+      const int n4 = n >> 2;
+      f32x4 st[SQ];
+#pragma unroll
+      for (int q = 0; q < SQ; ++q) st[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (n4 > 0) {
+#pragma unroll
+        for (int q = 0; q < SQ; ++q) {
+          const int i = tid + q * WV_THREADS;
+          st[q] = *(const f32x4 *)(src + 4 * (i < n4 ? i : n4 - 1));
+        }
+      }
+      for (int i = tid; i < WV_T * WV_INLD / 4; i += WV_THREADS) ((float4 *)in_lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < SQ; ++q) {
+        const int i = tid + q * WV_THREADS;
+        if (i < n4) {
+          const int e = i * 4, t = e / a.n_mel, c = e - t * a.n_mel;
+          *(f32x4 *)(in_lds + t * WV_INLD + c) = st[q];
+        }
       }
     } else {
+      for (int i = tid; i < WV_T * WV_INLD / 4; i += WV_THREADS) ((float4 *)in_lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      __syncthreads();
       for (int i = tid; i < n; i += WV_THREADS) {
         int t = i / a.n_mel, c = i - t * a.n_mel;
         in_lds[t * WV_INLD + c] = src[i];
@@ -278,10 +346,6 @@ __global__ __launch_bounds__(WV_NW * 64, WV_NW == 12 ? (SPLIT_BF16 ? WV_BF16_OCC
   // ---- input 1x1 conv + ReLU -> x in accumulator layout.  m-tile mi of this wave covers rows
   // (wave*3 + mi)*16 .. +15; lane holds rows kk*4 + r, column j.
   {
-    float4 bw[3];
-#pragma unroll
-    for (int kb = 0; kb < 3; ++kb) bw[kb] = *(const float4 *)(a.w_in4 + ((size_t)(kb * 4 + kk) * 16 + j) * 4);
-    const float bias = a.b_in[j];
 #pragma unroll
     for (int mi = 0; mi < WV_MPW; ++mi) {
       const int t0 = (wave * WV_MPW + mi) * 16;
@@ -316,10 +380,10 @@ __global__ __launch_bounds__(WV_NW * 64, WV_NW == 12 ? (SPLIT_BF16 ? WV_BF16_OCC
     //      once (row-major [row][16] put the 8 lanes of a write group on 2 bank quads: 5.3 M conflict cycles per 256 windows).  The conv biases are the
     //      accumulators' initial values (per-lane float4 by channel group); all blocks' small vectors sit in one LDS table.
     float *vtab = lds + 2 * (WV_T + WV_PAD) * WV_C + WV_T * WV_S;  // [NB][7][16]: bn_s, bn_t, b_sig, b_tanh, b_res, b_skip0, b_skip1
-    for (int i = tid; i < a.NB * 7 * 16; i += WV_THREADS) {
-      const int b = i / 112, v = (i / 16) % 7, c = i & 15;
-      vtab[i] = v == 0 ? a.bn_s[b * WV_C + c] : v == 1 ? a.bn_t[b * WV_C + c] : v < 4 ? a.b_gate[b * 32 + (v - 2) * 16 + c]
-                                                                                      : a.b_rs[b * 48 + (v - 4) * 16 + c];
+#pragma unroll
+    for (int q = 0; q < NVT; ++q) {
+      const int i = tid + q * WV_THREADS;
+      if (i < a.NB * 7 * 16) vtab[i] = vte[q];
     }
     constexpr int UPL = (WV_T + WV_PAD) * 4;  // floats per channel-group plane
     static_assert(UPL % 64 == 0, "u planes must start on the same bank");
@@ -497,24 +561,20 @@ __global__ __launch_bounds__(WV_NW * 64, WV_NW == 12 ? (SPLIT_BF16 ? WV_BF16_OCC
     // double-buffered pages read after the barrier left ~1000 cycles of operand reads on the critical path.)
     uint4 *pages = (uint4 *)(lds + 2 * (WV_T + WV_PAD) * WV_C);                  // [3][WV_PAGE_U4]
     const uint4 *gpage = a.wpk;
-    constexpr int NPL = (WV_PAGE_U4 + WV_THREADS - 1) / WV_THREADS;               // page pieces per thread (the last one partial)
-    static_assert(NPL >= 2 && NPL <= 4, "page pieces per thread");
     auto pclamp = [&](int q) { return tid + q * WV_THREADS < WV_PAGE_U4 ? tid + q * WV_THREADS : WV_PAGE_U4 - 1; };
     const int pidx0 = pclamp(0), pidx1 = pclamp(1), pidx2 = pclamp(2), pidx3 = pclamp(3);
-    {
-      const int second = a.NB > 1 ? 1 : 0;
-      for (int i = tid; i < WV_PAGE_U4; i += WV_THREADS) {
-        pages[i] = gpage[i];
-        pages[WV_PAGE_U4 + i] = gpage[(size_t)second * WV_PAGE_U4 + i];
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {  // pages 0 and 1: on their way since the top of the kernel
+      const int i = tid + q * WV_THREADS;
+      if (i < WV_PAGE_U4) {
+        *(u32x4 *)(pages + i) = pg0[q];
+        *(u32x4 *)(pages + WV_PAGE_U4 + i) = pg1[q];
       }
     }
     // The BatchNorm vectors are needed BEFORE a block's barrier (they produce u), i.e. before that block's
     // page is published: all blocks' copies live in their own small table, filled once.
     float4 *bnall = (float4 *)(pages + 3 * WV_PAGE_U4);                           // [NB][2][4] float4 = scale, shift
-    for (int i = tid; i < a.NB * 8; i += WV_THREADS) {
-      const int b = i >> 3, v = (i >> 2) & 1, q = i & 3;
-      bnall[i] = *(const float4 *)((v ? a.bn_t : a.bn_s) + b * WV_C + 4 * q);
-    }
+    if (tid < a.NB * 8) *(f32x4 *)(bnall + tid) = bnv;
     __syncthreads();
     const unsigned long long dil_lo = a.dil4[0], dil_hi = a.dil4[1];             // kernel-argument SGPRs: no load inside the loop
     const short one = (short)(kk == 0 ? 0x3F80 : 0);
