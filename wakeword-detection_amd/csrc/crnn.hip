@@ -449,6 +449,12 @@ __device__ __forceinline__ void cf_phases_d_to_g(const fused_args &a, float *img
   {
     f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     f32x4 rem[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    // the biases: requested in front of the products they are added to (asked for where they are used, each of the three
+    // was a round trip to L2 of its own at the end of the phase)
+    float bb2[3];
+#pragma unroll
+    for (int n = 0; n < 3; ++n) bb2[n] = a.bx2[(wave * 3 + n) * 16 + j];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       const float4 av = *(const float4 *)(&seq1[j * GR_SEQ_LD + kb * 16 + kk * 4]);
@@ -459,7 +465,7 @@ __device__ __forceinline__ void cf_phases_d_to_g(const fused_args &a, float *img
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
       const int col = (wave * 3 + n) * 16 + j;
-      const float bb = a.bx2[col];
+      const float bb = bb2[n];
 #pragma unroll
       for (int r = 0; r < 4; ++r) gxs[(kk * 4 + r) * GR_GX_LD + col] = acc[n][r] + bb;
       if (kk == 0) {
@@ -490,15 +496,17 @@ __device__ __forceinline__ void cf_phases_d_to_g(const fused_args &a, float *img
 
   // ---- G: detect head: Dense(64, relu) -> Dense(NOUT) -> sigmoid | softmax   (wave 0)
   if (wave == 0) {
+    const float b1v = a.b1[lane], b2v = a.b2[lane < a.NOUT ? lane : 0];  // on their way during the dot products
+    __builtin_amdgcn_sched_barrier(0);
     float acc = 0.f;
 #pragma unroll 16
     for (int k = 0; k < 2 * H; ++k) acc = fmaf(w1s[lane * GR_W1_LD + k], encs[k], acc);
-    hid[lane] = fmaxf(acc + a.b1[lane], 0.f);
+    hid[lane] = fmaxf(acc + b1v, 0.f);
     wsync_g();
     float y = 0.f;
     if (lane < a.NOUT) {
       for (int k = 0; k < 2 * H; ++k) y = fmaf(w2s[lane * 64 + k], hid[k], y);
-      y += a.b2[lane];
+      y += b2v;
     }
     if (a.HEAD == 0) {
       if (lane < a.NOUT) a.out[(size_t)w * a.NOUT + lane] = sigmoid_f(y);
@@ -673,6 +681,12 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
     float4 avq[2], rvq[2];
     avq[0] = *(const float4 *)(a0p);
     rvq[0] = *(const float4 *)(a1p);
+    float bv1[3];  // the biases of this lane's three columns: requested now, added 40 k-steps later
+#pragma unroll
+    for (int n = 0; n < 3; ++n) bv1[n] = a.bx1[wave * 48 + n * 16 + j];
+    // recurrent weights: requested here too (48 registers the projection does not need), used a barrier (waves 0, 1) or a whole
+    // recurrence (waves 2, 3) later - requested behind the projection they arrived in the first ~800 cycles of phase D
+    if (!FRONT_ONLY) gru_load_w(g, wave < 2 ? a.wh1 : a.wh2, wave < 2 ? a.bh1 : a.bh2, dir, unit, half);
 #pragma unroll
     for (int ks = 0; ks < 40; ++ks) {
       if (ks + 3 < 40) {
@@ -689,13 +703,11 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
       CF_ROUND(av, rv, b, x) CF_ROUND(av, rv, b, y) CF_ROUND(av, rv, b, z) CF_ROUND(av, rv, b, w)
       __builtin_amdgcn_sched_barrier(0);
     }
-    // recurrent weights: requested here, needed a barrier (waves 0, 1) or a whole recurrence (waves 2, 3) later
-    if (!FRONT_ONLY) gru_load_w(g, wave < 2 ? a.wh1 : a.wh2, wave < 2 ? a.bh1 : a.bh2, dir, unit, half);
     // the four k sub-steps of a column sit in lanes col, col+16, col+32, col+48
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
       const int col = wave * 48 + n * 16 + j;
-      const float bv = a.bx1[col];
+      const float bv = bv1[n];
 #pragma unroll
       for (int r = 0; r < 4; ++r) gxs[(kk * 4 + r) * GR_GX_LD + col] = acc[n][r] + bv;
 #pragma unroll
@@ -881,6 +893,10 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_stream_kernel(stream_args 
     f32x4 rem[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     float4 rvq[2];
     rvq[0] = *(const float4 *)(a1p);
+    float bv1[3];  // the biases of this lane's three columns: requested now, added when the products are complete
+#pragma unroll
+    for (int n = 0; n < 3; ++n) bv1[n] = a.bx1[wave * 48 + n * 16 + j];
+    gru_load_w(g, wave < 2 ? a.wh1 : a.wh2, wave < 2 ? a.bh1 : a.bh2, dir, unit, half);  // (as crnn_fused_kernel: in front of the projection)
 #pragma unroll
     for (int ks = 0; ks < 40; ++ks) {
       if (ks + CS_DEPTH - 1 < 40) {
@@ -899,14 +915,13 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_stream_kernel(stream_args 
 #undef CS_ROUND
       __builtin_amdgcn_sched_barrier(0);
     }
-    gru_load_w(g, wave < 2 ? a.wh1 : a.wh2, wave < 2 ? a.bh1 : a.bh2, dir, unit, half);
     int nslot = q0 + 128;
     nslot = nslot >= RA ? nslot - RA : nslot;
     float *crow_new = cache + (size_t)nslot * (6 * H);
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
       const int col = wave * 48 + n * 16 + j;
-      const float bv = a.bx1[col];
+      const float bv = bv1[n];
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         float v = rem[n][i];
@@ -1083,6 +1098,9 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_rows_kernel(rows_args a) {
     f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     float4 avq[2];
     avq[0] = *(const float4 *)(a0p);
+    float bv1[3];  // the biases of this lane's three columns: requested now, added when the products are complete
+#pragma unroll
+    for (int n = 0; n < 3; ++n) bv1[n] = a.bx1[wave * 48 + n * 16 + j];
 #pragma unroll
     for (int ks = 0; ks < 40; ++ks) {
       if (ks + 3 < 40) {
@@ -1105,7 +1123,7 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_rows_kernel(rows_args a) {
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
       const int col = wave * 48 + n * 16 + j;
-      const float bv = a.bx1[col];
+      const float bv = bv1[n];
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (kk * 4 + r < np) out[(size_t)(kk * 4 + r) * 192 + col] = acc[n][r] + bv;
@@ -1299,6 +1317,10 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_bf16_kernel(fused_ar
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int n = 0; n < 3; ++n) acc[mt][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bv1[3];  // the biases of this lane's three columns: requested now, added when the products are complete
+#pragma unroll
+    for (int n = 0; n < 3; ++n) bv1[n] = a.bx1[wave * 48 + n * 16 + j];
+    if (!FRONT_ONLY) gru_load_w(g, wave < 2 ? a.wh1 : a.wh2, wave < 2 ? a.bh1 : a.bh2, dir, unit, half);  // (in front of the projection)
 #pragma unroll
     for (int ks = 0; ks < 20; ++ks) {
       if (ks + 2 < 20) {
@@ -1320,11 +1342,10 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_bf16_kernel(fused_ar
         }
       }
     }
-    if (!FRONT_ONLY) gru_load_w(g, wave < 2 ? a.wh1 : a.wh2, wave < 2 ? a.bh1 : a.bh2, dir, unit, half);
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
       const int col = wave * 48 + n * 16 + j;
-      const float bv = a.bx1[col];
+      const float bv = bv1[n];
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -1415,6 +1436,9 @@ __global__ __launch_bounds__(128, 4) void gru_tail_kernel(tail_args a) {
     for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
       for (int n = 0; n < 3; ++n) bq[kb][n] = *(const float4 *)(a.wx2s + ((size_t)(kb * 4 + kk) * 192 + (nt0 + n) * 16 + j) * 4);
+    float bb2[3];  // the biases with the weights (asked for where they are added, each was a round trip of its own)
+#pragma unroll
+    for (int n = 0; n < 3; ++n) bb2[n] = a.bx2[(nt0 + n) * 16 + j];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       const float4 av = *(const float4 *)(&seq1[j * GR_SEQ_LD + kb * 16 + kk * 4]);
@@ -1426,7 +1450,7 @@ __global__ __launch_bounds__(128, 4) void gru_tail_kernel(tail_args a) {
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
       const int col = (nt0 + n) * 16 + j;
-      const float bb = a.bx2[col];
+      const float bb = bb2[n];
 #pragma unroll
       for (int r = 0; r < 4; ++r) gxs[(kk * 4 + r) * GR_GX_LD + col] = acc[n][r] + bb;
       if (kk == 0) {
@@ -1447,6 +1471,7 @@ __global__ __launch_bounds__(128, 4) void gru_tail_kernel(tail_args a) {
   }
   __syncthreads();
   if (dir == 0) {  // detect head, w1 row `lane` straight from L2 (16 KB, shared by every workgroup)
+    const float b1v = a.b1[lane], b2v = a.b2[lane < a.NOUT ? lane : 0];
     float acc = 0.f;  // one chain in k order: bit-identical to crnn_fused_kernel's head
     const float4 *wr = (const float4 *)(a.w1 + (size_t)lane * 2 * H);
 #pragma unroll
@@ -1456,12 +1481,12 @@ __global__ __launch_bounds__(128, 4) void gru_tail_kernel(tail_args a) {
       acc = fmaf(wv.x, ev.x, acc); acc = fmaf(wv.y, ev.y, acc);
       acc = fmaf(wv.z, ev.z, acc); acc = fmaf(wv.w, ev.w, acc);
     }
-    hid[lane] = fmaxf(acc + a.b1[lane], 0.f);
+    hid[lane] = fmaxf(acc + b1v, 0.f);
     wsync_g();
     float y = 0.f;
     if (lane < a.NOUT) {
       for (int k = 0; k < 2 * H; ++k) y = fmaf(a.w2[lane * 64 + k], hid[k], y);
-      y += a.b2[lane];
+      y += b2v;
     }
     if (a.HEAD == 0) {
       if (lane < a.NOUT) a.out[(size_t)w * a.NOUT + lane] = sigmoid_f(y);
