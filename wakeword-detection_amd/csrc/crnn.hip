@@ -1405,19 +1405,26 @@ __global__ __launch_bounds__(128, 4) void gru_tail_kernel(tail_args a) {
   const int w = blockIdx.x;
   gru_w g;
   gru_load_w(g, a.wh1, a.bh1, dir, unit, half);
-  if (a.gx1) {
-    const float4 *src = (const float4 *)(a.gx1 + (size_t)w * OT * 6 * H);
-    for (int q = tid; q < OT * 6 * H / 4; q += 128) {
-      const int e = q * 4, t = e / (6 * H), c = e - t * 6 * H;
-      *(float4 *)(&gxs[t * GR_GX_LD + c]) = src[q];
-    }
-  } else {
-    for (int q = tid; q < OT * 6 * H / 4; q += 128) {
-      const int t = q / 48, c4 = q - t * 48;
-      const float *row = t == 0 ? a.gxL + (size_t)w * 6 * H
+  {
+    // the window's 19 projected rows -> LDS: all of a thread's 16-byte loads first (unconditional, the last ones clamped), then
+    // the stores - as a loop of "load, store" every element was a round trip to L2 of its own, eight in a row per window
+    constexpr int NQ = OT * 6 * H / 4, NS = (NQ + 127) / 128;
+    int64_t i0w = (int64_t)w * a.hop_g;
+    if (!a.gx1 && a.iI0) i0w = a.iI0[w];
+    f32x4 st[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int q = min(tid + 128 * s, NQ - 1), t = q / 48, c4 = q - t * 48;
+      const float *row = a.gx1 ? a.gx1 + ((size_t)w * OT + t) * 6 * H
+                       : t == 0 ? a.gxL + (size_t)w * 6 * H
                        : t == OT - 1 ? a.gxR + (size_t)w * 6 * H
-                                     : a.gxI + ((size_t)(a.iI0 ? a.iI0[w] : (int64_t)w * a.hop_g) + (size_t)(t - 1) * a.eight_g) * 6 * H;
-      *(float4 *)(&gxs[t * GR_GX_LD + c4 * 4]) = ((const float4 *)row)[c4];
+                                     : a.gxI + ((size_t)i0w + (size_t)(t - 1) * a.eight_g) * 6 * H;
+      st[s] = *(const f32x4 *)(row + c4 * 4);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int q = tid + 128 * s, t = q / 48, c4 = q - t * 48;
+      if (q < NQ) *(f32x4 *)(&gxs[t * GR_GX_LD + c4 * 4]) = st[s];
     }
   }
   for (int i = tid; i < 20 * GR_SEQ_LD; i += 128) seq1[i] = 0.f;
@@ -1545,9 +1552,13 @@ __global__ __launch_bounds__(128, 2) void gru_tail16_kernel(tail16_args aa) {
   int wi[4];
   int64_t i0[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    wi[r] = min(w0 + 4 * g + r, aa.nw - 1);
-    i0[r] = a.gx1 ? 0 : (a.iI0 ? a.iI0[wi[r]] : (int64_t)wi[r] * a.hop_g);
+  for (int r = 0; r < 4; ++r) wi[r] = min(w0 + 4 * g + r, aa.nw - 1);
+  if (!a.gx1 && a.iI0) {  // (one uniform branch around four loads in flight; as a per-row ternary they were four round trips in a row)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) i0[r] = a.iI0[wi[r]];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) i0[r] = a.gx1 ? 0 : (int64_t)wi[r] * a.hop_g;
   }
   auto gx_row = [&](int r, int t) -> const float * {
     if (a.gx1) return a.gx1 + ((size_t)wi[r] * OT + t) * 6 * H;
