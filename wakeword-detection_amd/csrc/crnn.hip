@@ -768,10 +768,18 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_stream_kernel(stream_args 
   const int j = lane & 15, kk = lane >> 4;
   const int w = blockIdx.x;
   CF_STAMP(0)
-  int64_t row;
-  int valid;
-  window_span(a.wa, w, a.T, row, valid);
-  const int aux = sa.aux[w];
+  // the window's three descriptor words (first mel row, valid rows, cache slot) in ONE load: lanes 0..3 read the two halves of
+  // row[w], valid[w] and aux[w] (three arrays, one instruction), the values come back as scalars - read one after the other they
+  // were three round trips in a row at the head of every tick's kernel (the streaming path always passes both tables)
+  const int *dp = lane == 0 ? (const int *)(a.wa.row + w) : lane == 1 ? (const int *)(a.wa.row + w) + 1
+                : lane == 2 ? (const int *)(a.wa.valid + w) : (const int *)(sa.aux + w);
+  const int dv = *dp;
+  int64_t row = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dv, 1) << 32) | (unsigned)__builtin_amdgcn_readlane(dv, 0));
+  int valid = __builtin_amdgcn_readlane(dv, 2);
+  const int aux = __builtin_amdgcn_readlane(dv, 3);
+  if (valid > a.T) valid = a.T;  // (as window_span)
+  if (row + valid > a.wa.mel_rows) valid = (int)(a.wa.mel_rows - row);
+  if (valid < 0) valid = 0;
   const int q0 = aux % RA;
   float *cache = sa.gxc + (size_t)(aux - q0) * (6 * H);
 

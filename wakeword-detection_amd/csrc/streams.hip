@@ -25,6 +25,7 @@
 #include "fft_device.h"
 
 #define ST_RING 832  // 511 + 320 rounded up
+#define ST_WL_BYTES (((WW_MEL_TAPS * 64 * 4 + 2047) / 2048) * 2048)  // the mel weights in LDS, padded to whole rounds of 128 x 16 bytes
 
 struct ww_streams {
   ww_ctx *ctx = nullptr;
@@ -105,36 +106,51 @@ __global__ __launch_bounds__(128) void stream_frontend_kernel(stream_fe_args a) 
   size_t off = 0;
   cplx<R> *fbuf = (cplx<R> *)(smem + off); off += 2 * FFT_LD * sizeof(cplx<R>);
   float *mag = (float *)(smem + off); off += 2 * 260 * sizeof(float);
-  float *wl = (float *)(smem + off); off += WW_MEL_TAPS * 64 * sizeof(float);
+  float *wl = (float *)(smem + off); off += ST_WL_BYTES;  // (rounded up to whole 128-thread store rounds)
   float *x = (float *)(smem + off); off += ST_RING * sizeof(float);  // [ST_RING]
   short *xs = (short *)(smem + off);  // [WW_CHUNK] raw samples of the tick
 
-  // ---- this tick's window descriptors: host-pinned -> device arrays (read by the model kernels that follow)
-  for (int i = s * 128 + tid; i < a.nw; i += a.S * 128) {
-    a.d_row[i] = a.h_row[i];
-    a.d_valid[i] = a.h_valid[i];
-    a.d_aux[i] = a.h_aux[i];
-  }
+  // ---- this tick's window descriptors: host-pinned -> device arrays (read by the model kernels that follow).  A tick has at
+  // most two windows per stream, i.e. one descriptor per thread of the first workgroups: requested here with everything else
+  // that crosses the bus (unconditionally, from a clamped index), stored below once the loads behind them are out as well -
+  // copied in place, the first workgroups waited for the bus before they asked for anything else
+  const int di = s * 128 + tid, dic = di < a.nw ? di : 0;
+  const int64_t h_row0 = a.h_row[dic];
+  const int h_valid0 = a.h_valid[dic], h_aux0 = a.h_aux[dic];
   // device-side inputs that do not depend on the control words are requested before the branch on them, i.e. while
   // the control words and samples are still crossing the bus: mel weights, the whole sample ring (fill <= 511 of its
   // 832 slots are meaningful; the rest is never read), the pre-emphasis carry, the transform's constants
-  constexpr int WLQ = (WW_MEL_TAPS * 64 / 4 + 127) / 128;
-  float4 wlq[WLQ];
+  constexpr int WLQ = ST_WL_BYTES / 16 / 128;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 wlq[WLQ];
 #pragma unroll
   for (int q = 0; q < WLQ; ++q) {
     const int i = tid + q * 128;
-    wlq[q] = ((const float4 *)a.wpad)[i < WW_MEL_TAPS * 64 / 4 ? i : 0];
+    wlq[q] = ((const f32x4 *)a.wpad)[i < WW_MEL_TAPS * 64 / 4 ? i : 0];
   }
+  const int mel_st = lane < a.n_mel ? a.start[lane] : 0;      // (the mel stage's two per-band scalars: asked for here, not
+  const float mel_bias = lane < a.n_mel ? a.bias[lane] : 0.0f;  // behind the transform where they are used)
   float *ring = a.ring + (size_t)s * ST_RING;
   const float4 ringq = ((const float4 *)ring)[tid];  // samples 4 tid .. 4 tid + 3 (128 threads x 4 = 512 >= fill)
   const float carry = a.prev[s];
   fft_consts<R> fc;
   fft_load_consts<R>(fc, lane, a.hann, a.tw256, a.tw512);
+  // parked in LDS unconditionally and BEFORE the branch on the control words: behind it, and under a per-piece condition, the
+  // compiler moved each load down to its store - five round trips to L2 in a row (the wl region is padded to whole rounds)
+#pragma unroll
+  for (int q = 0; q < WLQ; ++q) ((f32x4 *)wl)[tid + q * 128] = wlq[q];
+  if (di < a.nw) {
+    a.d_row[di] = h_row0;
+    a.d_valid[di] = h_valid0;
+    a.d_aux[di] = h_aux0;
+  }
+  for (int i = di + a.S * 128; i < a.nw; i += a.S * 128) {  // (more than 128 windows per stream and tick: not a shape the host produces)
+    a.d_row[i] = a.h_row[i];
+    a.d_valid[i] = a.h_valid[i];
+    a.d_aux[i] = a.h_aux[i];
+  }
   if (skip) return;  // context.is_active: the frame is not sampled at all (tflite.py:139-140)
 
-#pragma unroll
-  for (int q = 0; q < WLQ; ++q)
-    if (tid + q * 128 < WW_MEL_TAPS * 64 / 4) ((float4 *)wl)[tid + q * 128] = wlq[q];
   // ---- [ring | new samples] in LDS
   ((float4 *)x)[tid] = ringq;
   if (tid < 40) ((uint4 *)xs)[tid] = raw;
@@ -163,9 +179,7 @@ __global__ __launch_bounds__(128) void stream_frontend_kernel(stream_fe_args a) 
     auto x2 = [&](int n) -> float2 { return make_float2(src[2 * n], src[2 * n + 1]); };
     float *mg = mag + wave * 260;
     frame_fft_mag<R>(x2, fc, fbuf + wave * FFT_LD, mg, lane);
-    const int st = lane < a.n_mel ? a.start[lane] : 0;
-    const float bias = lane < a.n_mel ? a.bias[lane] : 0.0f;
-    const float mv = mel_band(mg, wl, st, bias, a.floor_v, a.log_off, a.scale, lane);
+    const float mv = mel_band(mg, wl, mel_st, mel_bias, a.floor_v, a.log_off, a.scale, lane);
     if (lane < a.n_mel) {
       const int slots = a.T + 1;
       int p = pos + wave;  // mirrored ring: the row goes to p % slots and p % slots + slots
@@ -376,10 +390,10 @@ int ww_stream_step(ww_streams *st, const int16_t *frames, const uint8_t *is_spee
   {
     ww_launch_scope scope(ctx, "stream_frontend_kernel");
     if (st->fp.precise) {
-      size_t sm = 2 * FFT_LD * 16 + 2 * 260 * 4 + WW_MEL_TAPS * 64 * 4 + ST_RING * 4 + WW_CHUNK * 2;
+      size_t sm = 2 * FFT_LD * 16 + 2 * 260 * 4 + ST_WL_BYTES + ST_RING * 4 + WW_CHUNK * 2;
       hipLaunchKernelGGL((stream_frontend_kernel<double>), dim3(S), dim3(128), sm, ctx->stream, a);
     } else {
-      size_t sm = 2 * FFT_LD * 8 + 2 * 260 * 4 + WW_MEL_TAPS * 64 * 4 + ST_RING * 4 + WW_CHUNK * 2;
+      size_t sm = 2 * FFT_LD * 8 + 2 * 260 * 4 + ST_WL_BYTES + ST_RING * 4 + WW_CHUNK * 2;
       hipLaunchKernelGGL((stream_frontend_kernel<float>), dim3(S), dim3(128), sm, ctx->stream, a);
     }
   }
