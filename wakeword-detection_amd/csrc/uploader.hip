@@ -167,6 +167,7 @@ struct ww_uploader {
   };
   std::vector<slot_t> slots;
   unsigned next_slot = 0;
+  size_t largest = 0;  // bytes of the largest chunk so far
   struct job_t {
     int64_t ticket = 0, total = 0;
     std::vector<int64_t> dst_off, count, meta;
@@ -205,11 +206,14 @@ struct ww_uploader {
       s.busy = false;
     }
     const size_t b_pcm = ((size_t)j.total * 2 + 63) & ~(size_t)63, b_meta = j.meta.size() * 8;
+    // a slot that has to grow grows to the largest chunk ANY slot has seen: chunk sizes differ and the slots go round, so
+    // sizing each slot for its own history alone re-allocated page-locked memory (milliseconds) in call after call
+    if (b_pcm + b_meta + 64 > largest) largest = b_pcm + b_meta + 64;
     if (b_pcm + b_meta + 64 > s.cap) {
       if (s.pin) hipHostFree(s.pin);
       s.pin = nullptr;
       s.cap = 0;
-      const size_t want = b_pcm + b_meta + 64 + (b_pcm + b_meta) / 8;
+      const size_t want = largest + largest / 8;
       if ((e = hipHostMalloc(&s.pin, want, hipHostMallocDefault)) != hipSuccess) {
         s.pin = nullptr;
         return fail(WW_ENOMEM, "ww_uploader: cannot allocate a page-locked slot", e);
