@@ -15,6 +15,7 @@
 #include <functional>
 #include <map>
 #include <mutex>
+#include <new>
 #include <thread>
 
 namespace {
@@ -260,6 +261,8 @@ struct ww_uploader {
         std::lock_guard<std::mutex> lk(m);
         results[j.ticket] = std::move(r);
         done_ticket = j.ticket;
+        // results nobody came for (a caller that gave up on its chunks): only the most recent ones are kept
+        while (!results.empty() && results.begin()->first + 4096 < j.ticket) results.erase(results.begin());
       }
       cv_done.notify_all();
     }
@@ -343,19 +346,24 @@ int ww_uploader_submit(ww_uploader *up, int64_t total, int64_t n_runs, const int
   if (total < 0 || n_runs < 0 || n_meta < 0 || (total > 0 && !d_pcm) || (n_meta > 0 && (!meta || !d_meta)) ||
       (n_runs > 0 && (!dst_off || !src || !count)))
     return WW_EINVAL;
-  ww_uploader::job_t j;
-  j.total = total;
-  j.dst_off.assign(dst_off, dst_off + n_runs);
-  j.count.assign(count, count + n_runs);
-  j.src.assign(src, src + n_runs);
-  j.meta.assign(meta, meta + n_meta);
-  j.d_pcm = d_pcm;
-  j.d_meta = d_meta;
-  {
-    std::lock_guard<std::mutex> lk(up->m);
-    if (up->quit) return WW_EINVAL;
-    j.ticket = *ticket = up->next_ticket++;
-    up->queue.push_back(std::move(j));
+  try {  // (the copies of the caller's arrays allocate: no exception may cross the C boundary)
+    ww_uploader::job_t j;
+    j.total = total;
+    j.dst_off.assign(dst_off, dst_off + n_runs);
+    j.count.assign(count, count + n_runs);
+    j.src.assign(src, src + n_runs);
+    j.meta.assign(meta, meta + n_meta);
+    j.d_pcm = d_pcm;
+    j.d_meta = d_meta;
+    {
+      std::lock_guard<std::mutex> lk(up->m);
+      if (up->quit) return WW_EINVAL;
+      j.ticket = up->next_ticket;
+      up->queue.push_back(std::move(j));
+      *ticket = up->next_ticket++;
+    }
+  } catch (const std::bad_alloc &) {
+    return WW_ENOMEM;
   }
   up->cv_work.notify_one();
   return WW_OK;
@@ -377,7 +385,7 @@ int ww_uploader_wait(ww_uploader *up, int64_t ticket, ww_ctx *ctx) {
     if (ticket < 1 || ticket >= up->next_ticket) return ww_fail(ctx, WW_EINVAL, "ww_uploader_wait: no such ticket (%lld)", (long long)ticket);
     up->cv_done.wait(lk, [&] { return up->done_ticket >= ticket; });
     auto it = up->results.find(ticket);
-    if (it == up->results.end()) return ww_fail(ctx, WW_EINVAL, "ww_uploader_wait: ticket %lld was waited for before", (long long)ticket);
+    if (it == up->results.end()) return ww_fail(ctx, WW_EINVAL, "ww_uploader_wait: ticket %lld was waited for before (or left unclaimed for 4,096 chunks)", (long long)ticket);
     r = std::move(it->second);
     up->results.erase(it);
   }

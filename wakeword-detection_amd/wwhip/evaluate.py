@@ -219,8 +219,9 @@ class StreamPlan:
         from . import dist as D
         out: List[List[Tuple[int, int, int]]] = [[] for _ in range(world)]
         if eval_type == "false_negatives":
+            nw = self.n_win.tolist()  # (Python ints once: indexing the array per file costs more than the rest of the plan)
             for r, files in enumerate(D.shard_by_length(self.lengths.tolist(), world)):
-                out[r] = [(k, 0, int(self.n_win[k])) for k in sorted(files) if self.n_win[k] > 0]
+                out[r] = [(k, 0, nw[k]) for k in sorted(files) if nw[k] > 0]
         else:
             for r, (lo, hi) in enumerate(D.split_stream(self.total, world)):
                 k = int(np.searchsorted(self.offs, lo, side="right")) - 1
