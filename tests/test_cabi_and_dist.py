@@ -150,6 +150,22 @@ for eval_type in ("false_negatives", "false_accepts"):
     full = D.gather_posteriors(vals.astype(np.float32), slots, plan.total)
     want = np.concatenate([(plan.F[k] + 2 * np.arange(plan.n_win[k])) * 0.25 for k in range(5)]).astype(np.float32)
     assert np.array_equal(full, want), eval_type
+    # the product's own exchange (wwhip.evaluate._PosteriorJob.finish: values only, every rank derives the slots from the plan)
+    from wwhip import evaluate as E
+    class Eng: window = 151
+    lens = [30000, 41000, 14000, 24000, 51234, 9000, 33000]
+    job = E._PosteriorJob(Eng, eval_type, [np.zeros(n, np.int16) for n in lens], 20, 16000, rank, world, None, None, True,
+                          E._Phases(None), None)
+    p2 = job.plan
+    assert (p2.n_win > 0).all()
+    assert [tuple(r) for r in job.mine] == [tuple(r) for r in p2.shares(eval_type, world)[rank]]
+    assert [r for ch in job.chunks for r in ch.runs] == list(job.mine)          # the share, cut into chunks, nothing lost
+    name = lambda k, i0, i1: (p2.F[k] + 2 * np.arange(i0, i1)) * 0.25           # a "posterior" that names its first global frame
+    job.vals = np.concatenate([name(k, i0, i1) for k, i0, i1 in job.mine]).astype(np.float32) if job.mine else np.zeros(0, np.float32)
+    got = job.finish(None, E._Phases(None), True)
+    every = [name(k, 0, p2.n_win[k]).astype(np.float32) for k in range(len(lens))]
+    want2 = np.array([v.max() for v in every], np.float32) if eval_type == "false_negatives" else np.concatenate(every)
+    assert np.array_equal(got, want2), (eval_type, got[:8], want2[:8])
 dist.barrier(); dist.destroy_process_group()
 open(os.path.join({out!r}, f"plan{{rank}}.ok"), "w").write("ok")
 """
