@@ -294,6 +294,12 @@ __device__ __forceinline__ void wsync_h() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// Workgroup barrier between LDS producers and consumers only: waits for this wave's LDS traffic, not for its outstanding
+// global loads (__syncthreads() drains the memory counter too - a prefetch issued just before it is then waited for in full)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ void wsync_g() {
   // LDS traffic of one wave is processed in order; wait for it only (not for outstanding
   // global loads, which an acq_rel fence would also drain) and stop compiler reordering
@@ -332,6 +338,17 @@ __device__ __forceinline__ void wsync_g() {
 #define CF_IMG_FLOATS (CV_ROWS * CV_LDT)
 #define CF_FEAT_FLOATS (CV_OT * CF_FLD)
 #define CF_SMEM_BYTES ((CF_IMG_FLOATS + CF_FEAT_FLOATS) * 4)
+// crnn_fused_kernel keeps only rows 0..15 of feat in the feat region: rows 16..18 (the projection's 3-row remainder tile) are
+// written into the image once every wave has read its last image operand - as a [20][2 k-steps x 3 rows x 16] block with the
+// image's row pitch (image rows 0..19: under gx, which is written last; clear of seq1 / h, which are zeroed first), so that
+// the remainder operand's address advances by compile-time offsets like the main tile's.
+// 78.1 -> 70.3 KB per workgroup: two of them leave a front-end workgroup's 17 KB free on the CU (timing probes with fewer
+// feat rows, same instruction stream: pipelined step 44.7 -> 43.6 us at 16 rows, 43.2 at 13, 42.9 at 8: DESIGN.md 7.1).
+#define CF_FUSED_FEAT_ROWS 16
+#define CF_FUSED_SMEM_BYTES ((CF_IMG_FLOATS + CF_FUSED_FEAT_ROWS * CF_FLD) * 4)
+#define CF_REM_COL0 0  // first image column of the aliased block (columns CF_REM_COL0 .. + 95 of image rows 0 .. 19)
+static_assert(CV_OT - CF_FUSED_FEAT_ROWS == 3 && CF_REM_COL0 + 96 <= CV_LDT && 20 * CV_LDT <= 20 * GR_GX_LD /* = CF_SEQ */,
+              "the aliased remainder block is [20][2 x 3 x 16] inside the image, below seq1");
 // offsets (floats) inside the image region once the conv is done
 #define CF_GX 0
 #define CF_SEQ (20 * GR_GX_LD)
@@ -341,6 +358,7 @@ __device__ __forceinline__ void wsync_g() {
 #define CF_W2S (CF_HID + 2 * GR_H)
 static_assert(CF_W2S + 8 * 64 <= CF_IMG_FLOATS, "post-conv LDS layout exceeds the image region");
 static_assert(64 * GR_W1_LD <= CF_FEAT_FLOATS && 16 * 192 * 4 <= CF_FEAT_FLOATS, "feat region too small for its later tenants");
+static_assert(64 * GR_W1_LD <= CF_FUSED_FEAT_ROWS * CF_FLD, "fused kernel's feat region too small for the head's first layer");
 
 struct fused_args {
   const float *mel;
@@ -578,7 +596,9 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
       for (int r = 0; r < 4; ++r) {
         const int mo = mt * 16 + kk * 4 + r;
         const int to = mo / CV_OF, fo = mo - to * CV_OF;
-        o_off[i][r] = mo < M ? to * CF_FLD + fo * 32 + j : -1;
+        // tile 5 of every wave (rows m >= 320) is positions 16..18: into the image (k = 32 fo + 16 n + j: k-step 2 fo + n ->
+        // image row fo, column CF_REM_COL0 + 48 n + 16 (t - 16) + j)
+        o_off[i][r] = mo >= M ? -1 : i < 5 ? to * CF_FLD + fo * 32 + j : fo * CV_LDT + CF_REM_COL0 + 16 * (to - 16) + j;
       }
     }
     __syncthreads();
@@ -599,6 +619,12 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
   CF_STAMP_A(9)
   __syncthreads();
   CF_STAMP(1)
+  // (raw buffer loads with a scalar k-step offset would take the 64-bit pointer adds off the vector ALU, but this compiler
+  //  lowers __builtin_amdgcn_raw_buffer_load_b128 to a one-dword load on gfx950: not used)
+  const float *wb = a.wx1s + ((size_t)kk * 192 + wave * 48 + j) * 4;
+  constexpr size_t KS_STRIDE = (size_t)4 * 192 * 4;
+  auto w_ld = [&](int ks, int n) { return *(const float4 *)(wb + ks * KS_STRIDE + n * 64); };
+  float4 bq[4][3];
   // ---- B: conv -> feat (LDS).  Six m-tiles per wave, software-pipelined by hand: the next tile's A operands are read while
   //      this tile's MFMAs run, and the previous tile's ReLU + store sit in the middle of them.  Vector instructions between
   //      fp32 MFMAs cost matrix time, so the loop holds none it can avoid: operand and store offsets were computed during the
@@ -616,9 +642,12 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
     auto store_tile = [&](int i, const f32x4 &r0, const f32x4 &r1) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (i < 5 || o_off[i][r] >= 0) {  // only the last tile of wave 3 has rows past M
+        if (i < 5) {
           feat[o_off[i][r]] = relu1(r0[r]);
           feat[o_off[i][r] + 16] = relu1(r1[r]);
+        } else if (o_off[i][r] >= 0) {  // (only the last tile of wave 3 has rows past M); the two channel halves are 48 columns apart
+          img[o_off[i][r]] = relu1(r0[r]);
+          img[o_off[i][r] + 48] = relu1(r1[r]);
         }
       }
     };
@@ -647,24 +676,21 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
       prev0 = acc0;
       prev1 = acc1;
     }
+    // the projection's first W operands: requested here, in front of the two barriers (they do not wait for global loads)
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int n = 0; n < 3; ++n) bq[s][n] = w_ld(s, n);
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();  // every wave has read its last image operand: rows 16..18 of feat may take the image's place
     store_tile(5, prev0, prev1);
 #undef CF_CONV_KB
   }
-  // (raw buffer loads with a scalar k-step offset would take the 64-bit pointer adds off the vector ALU, but this compiler
-  //  lowers __builtin_amdgcn_raw_buffer_load_b128 to a one-dword load on gfx950: not used)
-  const float *wb = a.wx1s + ((size_t)kk * 192 + wave * 48 + j) * 4;
-  constexpr size_t KS_STRIDE = (size_t)4 * 192 * 4;
-  auto w_ld = [&](int ks, int n) { return *(const float4 *)(wb + ks * KS_STRIDE + n * 64); };
-  float4 bq[4][3];
-#pragma unroll
-  for (int s = 0; s < 3; ++s)
-#pragma unroll
-    for (int n = 0; n < 3; ++n) bq[s][n] = w_ld(s, n);
   CF_STAMP(2)
-  __syncthreads();  // feat complete; the image is dead from here on
+  lds_barrier();  // feat complete (rows 0..15 in the feat region, rows 16..18 in the image, which holds nothing else any more)
   CF_STAMP(3)
   float *gxs = img + CF_GX, *seq1 = img + CF_SEQ, *hb = img + CF_HB;
-  for (int i = tid; i < 32 * GR_SEQ_LD; i += CF_THREADS) seq1[i] = 0.f;
+  for (int i = tid; i < 32 * GR_SEQ_LD; i += CF_THREADS) seq1[i] = 0.f;  // (image rows 24 ..: clear of the aliased block)
   if (tid < 2 * 2 * 2 * H) hb[tid] = 0.f;
 
   // ---- C: layer-1 input projection
@@ -672,8 +698,8 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
   gru_w g;  // waves 0, 1: layer 1; waves 2, 3: layer 2
   {
     const float *a0p = feat + j * CF_FLD + kk * 4;
-    const int r1 = 16 + (lane & 3);
-    const float *a1p = feat + (r1 < OT ? r1 : OT - 1) * CF_FLD + kk * 4;  // lane%4 == 3: row 19 does not exist, its sums are never stored
+    const int r1 = (lane & 3) < 3 ? (lane & 3) : 2;  // rows 16 + r1; lane % 4 == 3: row 19 does not exist, its sums are never stored
+    const float *a1p = img + CF_REM_COL0 + 16 * r1 + kk * 4;  // the aliased block: k-step ks is image row ks / 2, columns 48 (ks % 2) ..
     f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     f32x4 rem[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     // operand ring, fully unrolled so that the slots are plain registers (a rotating copy would have to wait for the
@@ -695,7 +721,7 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
       }
       if (ks + 1 < 40) {
         avq[(ks + 1) & 1] = *(const float4 *)(a0p + (ks + 1) * 16);
-        rvq[(ks + 1) & 1] = *(const float4 *)(a1p + (ks + 1) * 16);
+        rvq[(ks + 1) & 1] = *(const float4 *)(a1p + ((ks + 1) >> 1) * CV_LDT + ((ks + 1) & 1) * 48);
       }
       __builtin_amdgcn_sched_barrier(0);  // the prefetches stay HERE: sunk to just before their use, the LDS reads cost ~130 cycles per k-step
       const float4 av = avq[ks & 1], rv = rvq[ks & 1];
@@ -703,6 +729,7 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
       CF_ROUND(av, rv, b, x) CF_ROUND(av, rv, b, y) CF_ROUND(av, rv, b, z) CF_ROUND(av, rv, b, w)
       __builtin_amdgcn_sched_barrier(0);
     }
+    lds_barrier();  // gx takes the aliased block's place: every wave must have read its last remainder operand out of it
     // the four k sub-steps of a column sit in lanes col, col+16, col+32, col+48
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
@@ -2003,8 +2030,8 @@ static int crnn_split_threshold(const ww_model *m) { return m->opt_split_at; }
 int ww_k_crnn_init_device(ww_ctx *ctx) {
   WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
   WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
-  WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
-  WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
+  WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, CF_FUSED_SMEM_BYTES));
+  WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, CF_FUSED_SMEM_BYTES));
   WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, CFB_SMEM_BYTES));
   WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, CFB_SMEM_BYTES));
   return WW_OK;
@@ -2234,7 +2261,7 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
     {
       ww_launch_scope scope(ctx, bf16 ? "crnn_fused_kernel<front,bf16x3>" : "crnn_fused_kernel<front>");
       if (bf16) hipLaunchKernelGGL(crnn_fused_bf16_kernel<true>, dim3(nw), dim3(CF_THREADS), CFB_SMEM_BYTES, ctx->stream, a);
-      else hipLaunchKernelGGL(crnn_fused_kernel<true>, dim3(nw), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, a);
+      else hipLaunchKernelGGL(crnn_fused_kernel<true>, dim3(nw), dim3(CF_THREADS), CF_FUSED_SMEM_BYTES, ctx->stream, a);
     }
     tail_args t = {a.gx_out, c.wh1, c.bh1, c.wx2s, c.bx2, c.wh2, c.bh2, c.w1, c.b1, c.w2, c.b2, d_enc, d_out, c.NOUT, c.HEAD, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr};
     launch_tail(ctx, m, t, nw, seq);
@@ -2250,7 +2277,7 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
   {
     ww_launch_scope scope(ctx, bf16 ? "crnn_fused_kernel<bf16x3>" : "crnn_fused_kernel");
     if (bf16) hipLaunchKernelGGL(crnn_fused_bf16_kernel<false>, dim3(nw), dim3(CF_THREADS), CFB_SMEM_BYTES, ctx->stream, a);
-    else hipLaunchKernelGGL(crnn_fused_kernel<false>, dim3(nw), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, a);
+    else hipLaunchKernelGGL(crnn_fused_kernel<false>, dim3(nw), dim3(CF_THREADS), CF_FUSED_SMEM_BYTES, ctx->stream, a);
   }
   WW_HIP(ctx, hipGetLastError());
   if (want_stamps) {
