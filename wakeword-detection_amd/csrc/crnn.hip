@@ -338,17 +338,22 @@ __device__ __forceinline__ void wsync_g() {
 #define CF_IMG_FLOATS (CV_ROWS * CV_LDT)
 #define CF_FEAT_FLOATS (CV_OT * CF_FLD)
 #define CF_SMEM_BYTES ((CF_IMG_FLOATS + CF_FEAT_FLOATS) * 4)
-// crnn_fused_kernel keeps only rows 0..15 of feat in the feat region: rows 16..18 (the projection's 3-row remainder tile) are
-// written into the image once every wave has read its last image operand - as a [20][2 k-steps x 3 rows x 16] block with the
-// image's row pitch (image rows 0..19: under gx, which is written last; clear of seq1 / h, which are zeroed first), so that
-// the remainder operand's address advances by compile-time offsets like the main tile's.
-// 78.1 -> 70.3 KB per workgroup: two of them leave a front-end workgroup's 17 KB free on the CU (timing probes with fewer
-// feat rows, same instruction stream: pipelined step 44.7 -> 43.6 us at 16 rows, 43.2 at 13, 42.9 at 8: DESIGN.md 7.1).
-#define CF_FUSED_FEAT_ROWS 16
+// crnn_fused_kernel keeps only rows 0..12 of feat in the feat region.  Once every wave has read its last image operand the image
+// is dead, and the rows the conv produces last go into it as a flat array UNDER gx (which is written last) and clear of seq1 / h
+// (which are zeroed first): rows 13..15 as three ordinary feat rows (pitch CF_FLD: the projection's main-tile operand pointer
+// advances by the same 16 floats per k-step in every lane, only its base differs), rows 16..18 - the 3-row remainder tile, read
+// through a pointer of its own - as a [20][2 k-steps x 3 rows x 16] block behind them (compile-time offsets).
+// 78.1 -> 62.6 KB per workgroup: two of them leave two front-end workgroups' 2 x 17 KB free on the CU (timing probes with fewer
+// feat rows, same instruction stream: pipelined step 44.7 us at 19 rows, 43.6 at 16, 43.2 at 13, 42.9 at 8: DESIGN.md 7.1).
+#define CF_NO_ROW (-0x40000000)                // store offset of a conv row past the window's last one
+#define CF_FUSED_FEAT_ROWS 13
 #define CF_FUSED_SMEM_BYTES ((CF_IMG_FLOATS + CF_FUSED_FEAT_ROWS * CF_FLD) * 4)
-#define CF_REM_COL0 0  // first image column of the aliased block (columns CF_REM_COL0 .. + 95 of image rows 0 .. 19)
-static_assert(CV_OT - CF_FUSED_FEAT_ROWS == 3 && CF_REM_COL0 + 96 <= CV_LDT && 20 * CV_LDT <= 20 * GR_GX_LD /* = CF_SEQ */,
-              "the aliased remainder block is [20][2 x 3 x 16] inside the image, below seq1");
+#define CF_ALIAS_ROWS0 24                      // image offset (floats) of feat rows 13..15: (24 - CF_IMG_FLOATS) / 4 = 10 - 2 * 13 (mod 16), i.e. row j
+                                               // sits on the 16-byte slot 2 j (mod 16) of the bank cycle like the rows in the feat region
+#define CF_ALIAS_REM (CF_ALIAS_ROWS0 + 3 * CF_FLD)  // ... of the remainder block [20][96]
+static_assert((((CF_ALIAS_ROWS0 - CF_IMG_FLOATS) / 4 - 2 * 13) % 16 + 16) % 16 == 0 && CF_IMG_FLOATS % 4 == 0, "aliased rows off their bank slots");
+static_assert(CV_OT - 16 == 3 && 16 - CF_FUSED_FEAT_ROWS == 3 && CF_ALIAS_REM + 20 * 96 <= 20 * GR_GX_LD /* = CF_SEQ */,
+              "the aliased rows must lie under gx");
 // offsets (floats) inside the image region once the conv is done
 #define CF_GX 0
 #define CF_SEQ (20 * GR_GX_LD)
@@ -596,9 +601,12 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
       for (int r = 0; r < 4; ++r) {
         const int mo = mt * 16 + kk * 4 + r;
         const int to = mo / CV_OF, fo = mo - to * CV_OF;
-        // tile 5 of every wave (rows m >= 320) is positions 16..18: into the image (k = 32 fo + 16 n + j: k-step 2 fo + n ->
-        // image row fo, column CF_REM_COL0 + 48 n + 16 (t - 16) + j)
-        o_off[i][r] = mo >= M ? -1 : i < 5 ? to * CF_FLD + fo * 32 + j : fo * CV_LDT + CF_REM_COL0 + 16 * (to - 16) + j;
+        // offsets from `feat`; rows 13..15 (in tiles 4) and 16..18 (tiles 5) go into the image, below feat: negative offsets.
+        // remainder block: k = 32 fo + 16 n + j is k-step 2 fo + n -> row fo of the block, column 48 n + 16 (t - 16) + j
+        // (i is a compile-time constant: tiles 0..3 hold rows t <= 12, tile 4 rows 12..15, tile 5 rows 16..18 and, in wave 3, rows past M)
+        if (i < 4) o_off[i][r] = to * CF_FLD + fo * 32 + j;
+        else if (i == 4) o_off[i][r] = (to < 13 ? to * CF_FLD : CF_ALIAS_ROWS0 - CF_IMG_FLOATS + (to - 13) * CF_FLD) + fo * 32 + j;
+        else o_off[i][r] = mo >= M ? CF_NO_ROW : CF_ALIAS_REM - CF_IMG_FLOATS + fo * 96 + 16 * (to - 16) + j;
       }
     }
     __syncthreads();
@@ -645,9 +653,9 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
         if (i < 5) {
           feat[o_off[i][r]] = relu1(r0[r]);
           feat[o_off[i][r] + 16] = relu1(r1[r]);
-        } else if (o_off[i][r] >= 0) {  // (only the last tile of wave 3 has rows past M); the two channel halves are 48 columns apart
-          img[o_off[i][r]] = relu1(r0[r]);
-          img[o_off[i][r] + 48] = relu1(r1[r]);
+        } else if (o_off[i][r] != CF_NO_ROW) {  // (only the last tile of wave 3 has rows past M); the remainder block's channel halves are 48 apart
+          feat[o_off[i][r]] = relu1(r0[r]);
+          feat[o_off[i][r] + 48] = relu1(r1[r]);
         }
       }
     };
@@ -661,7 +669,7 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
   acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i & 1][kb_].w, wreg[kb_][0].w, acc0, 0, 0, 0);       \
   acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i & 1][kb_].w, wreg[kb_][1].w, acc1, 0, 0, 0);
     float4 av[2][CV_KB];
-    f32x4 prev0 = {0.f, 0.f, 0.f, 0.f}, prev1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 prev0 = {0.f, 0.f, 0.f, 0.f}, prev1 = {0.f, 0.f, 0.f, 0.f}, t4_0 = prev0, t4_1 = prev0;
     load_a(av[0], 0);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -670,7 +678,8 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
       f32x4 acc0 = {cb0, cb0, cb0, cb0}, acc1 = {cb1, cb1, cb1, cb1};
       CF_CONV_KB(0) CF_CONV_KB(1) CF_CONV_KB(2)
       __builtin_amdgcn_sched_barrier(0);
-      if (i > 0) store_tile(i - 1, prev0, prev1);
+      if (i > 0 && i < 5) store_tile(i - 1, prev0, prev1);  // tiles 4 and 5 hold the rows that go into the image: kept until it is dead
+      if (i == 5) { t4_0 = prev0; t4_1 = prev1; }
       __builtin_amdgcn_sched_barrier(0);
       CF_CONV_KB(3) CF_CONV_KB(4) CF_CONV_KB(5) CF_CONV_KB(6)
       prev0 = acc0;
@@ -682,24 +691,25 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
 #pragma unroll
       for (int n = 0; n < 3; ++n) bq[s][n] = w_ld(s, n);
     __builtin_amdgcn_sched_barrier(0);
-    lds_barrier();  // every wave has read its last image operand: rows 16..18 of feat may take the image's place
+    lds_barrier();  // every wave has read its last image operand: rows 13..18 of feat may take the image's place
+    store_tile(4, t4_0, t4_1);
     store_tile(5, prev0, prev1);
 #undef CF_CONV_KB
   }
   CF_STAMP(2)
-  lds_barrier();  // feat complete (rows 0..15 in the feat region, rows 16..18 in the image, which holds nothing else any more)
+  lds_barrier();  // feat complete (rows 0..12 in the feat region, rows 13..18 in the image, which holds nothing else any more)
   CF_STAMP(3)
   float *gxs = img + CF_GX, *seq1 = img + CF_SEQ, *hb = img + CF_HB;
-  for (int i = tid; i < 32 * GR_SEQ_LD; i += CF_THREADS) seq1[i] = 0.f;  // (image rows 24 ..: clear of the aliased block)
+  for (int i = tid; i < 32 * GR_SEQ_LD; i += CF_THREADS) seq1[i] = 0.f;  // (behind gx: clear of the aliased rows)
   if (tid < 2 * 2 * 2 * H) hb[tid] = 0.f;
 
   // ---- C: layer-1 input projection
   const int unit = lane >> 1, half = lane & 1, dir = wave & 1;
   gru_w g;  // waves 0, 1: layer 1; waves 2, 3: layer 2
   {
-    const float *a0p = feat + j * CF_FLD + kk * 4;
+    const float *a0p = (j < 13 ? feat + j * CF_FLD : img + CF_ALIAS_ROWS0 + (j - 13) * CF_FLD) + kk * 4;  // rows 13..15: in the image
     const int r1 = (lane & 3) < 3 ? (lane & 3) : 2;  // rows 16 + r1; lane % 4 == 3: row 19 does not exist, its sums are never stored
-    const float *a1p = img + CF_REM_COL0 + 16 * r1 + kk * 4;  // the aliased block: k-step ks is image row ks / 2, columns 48 (ks % 2) ..
+    const float *a1p = img + CF_ALIAS_REM + 16 * r1 + kk * 4;  // the remainder block: k-step ks is its row ks / 2, columns 48 (ks % 2) ..
     f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     f32x4 rem[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     // operand ring, fully unrolled so that the slots are plain registers (a rotating copy would have to wait for the
@@ -721,7 +731,7 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_fused_kernel(fused_args a)
       }
       if (ks + 1 < 40) {
         avq[(ks + 1) & 1] = *(const float4 *)(a0p + (ks + 1) * 16);
-        rvq[(ks + 1) & 1] = *(const float4 *)(a1p + ((ks + 1) >> 1) * CV_LDT + ((ks + 1) & 1) * 48);
+        rvq[(ks + 1) & 1] = *(const float4 *)(a1p + ((ks + 1) >> 1) * 96 + ((ks + 1) & 1) * 48);
       }
       __builtin_amdgcn_sched_barrier(0);  // the prefetches stay HERE: sunk to just before their use, the LDS reads cost ~130 cycles per k-step
       const float4 av = avq[ks & 1], rv = rvq[ks & 1];
