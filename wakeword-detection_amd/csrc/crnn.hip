@@ -329,9 +329,10 @@ __device__ __forceinline__ void wsync_g() {
 // One wave per SIMD: v_mfma_f32_16x16x4_f32 reaches its issue rate from a single wave with independent accumulators,
 // while two such waves on a SIMD got in each other's way (8-wave form of this kernel: the older wave of a SIMD took
 // 14.8k cycles over 9.6k cycles of MFMAs and its partner advanced only once it was alone).
-// LDS: the window image (28.9 KB; after B it holds gx, seq1, h, the head's small vectors) + feat (49.2 KB; after C
-// the head's first layer) = 78.1 KB, two workgroups per CU: one's recurrences and staging run beside
-// the other's MFMA phases.
+// LDS: the window image (28.9 KB; after B it holds the last six feat rows, then gx, seq1, h, the head's small vectors) + feat
+// rows 0..12 (33.7 KB; after C the head's first layer) = 62.6 KB (78.1 KB until the end of round 4: CF_FUSED_SMEM_BYTES below),
+// two workgroups per CU - one's recurrences and staging run beside the other's MFMA phases - with room for two front-end
+// workgroups beside them.
 // ------------------------------------------------------------------------------------------
 #define CF_THREADS 256
 #define CF_FLD 648  // feat row: 640 + 8; FLD/4 = 162 = 2 (mod 16): the 16-lane groups of the A-operand ds_read_b128 hit 16 distinct slots
