@@ -81,7 +81,8 @@ void *ww_ctx_stream(ww_ctx *ctx);
 const char *ww_last_error(const ww_ctx *ctx);
 /* "wwhip <major>.<minor> (...; ABI <n>: ...)".  The ABI number changes whenever an existing entry point changes its
  * signature (ABI 4, round 4: ww_stream_create gained `flags` in round 3 - a host built against an older header must be
- * rebuilt; check this string at load time, as wwhip/_lib.py does for the HIP runtime). */
+ * rebuilt); wwhip/_lib.py parses the number at load time and refuses a library of another ABI. */
+#define WW_ABI 4
 const char *ww_version(void);
 /* Which HIP runtime the library actually runs on.  libwwhip.so links libamdhip64 by soname; a host program that has
  * already loaded another copy (PyTorch-ROCm wheels bundle their own) decides which one that is.  built_hip_version =
@@ -259,12 +260,27 @@ int ww_clips_forward_dev(ww_ctx *ctx, const ww_model *model, const int16_t *d_pc
 /* flags: WW_STREAM_FULL_RECOMPUTE = every streaming CRNN window recomputed from its mel rows by the batch kernels instead of
  * the incremental crnn_stream_kernel (3 new time positions per window); results agree to 2e-6.  0 = default. */
 #define WW_STREAM_FULL_RECOMPUTE 1u
+/* Round 5: a tick of the incremental CRNN bank is ONE kernel launch - the front end of a stream's new frames runs inside the
+ * workgroups of that stream's new windows - and ww_stream_step waits for a tick's posteriors by polling {value, tick number}
+ * pairs the kernels store into page-locked memory instead of the runtime's completion signal (every bank whose context owns
+ * its stream; on a borrowed stream the call still returns only when the stream has drained).  Same bits either way.
+ * WW_STREAM_TWO_LAUNCH keeps the front-end kernel + model kernel form, WW_STREAM_SYNC_WAIT the hipStreamSynchronize wait:
+ * the forms the tests compare against. */
+#define WW_STREAM_TWO_LAUNCH 2u
+#define WW_STREAM_SYNC_WAIT 4u
 int ww_stream_create(ww_ctx *ctx, const ww_model *model, int32_t n_streams, const ww_frontend_params *fp, uint32_t flags,
                      ww_streams **out);
 int ww_stream_destroy(ww_streams *st);
 int ww_stream_step(ww_streams *st, const int16_t *frames, const uint8_t *is_speech, float *post, int32_t *n_post);
 /* WakewordTrigger.reset (tflite.py:241-246) for the listed streams (ids NULL -> all). */
 int ww_stream_reset(ww_streams *st, const int32_t *ids, int32_t n);
+/* Where a tick's time goes on the HOST side of ww_stream_step (the loop of spokestack/pipeline.py:25-28 is host-paced, so
+ * BASELINE config 5's per-tick latency is this call): mean nanoseconds per phase over the ticks since the last reset -
+ * [0] plan (control words and window descriptors of the tick), [1] the caller's frames into the page-locked block,
+ * [2] first kernel launch, [3] second kernel launch (0 where a tick is one launch), [4] waiting for the posteriors,
+ * [5] copy-out into post / n_post.  A monotonic-clock read per phase: always on. */
+#define WW_STREAM_TL_PHASES 6
+int ww_stream_timeline(ww_streams *st, double *mean_ns, int64_t *ticks, int32_t reset);
 
 /* ---- posterior smoothing + threshold sweep -----------------------------------------------
  * Replaces plot_FRR_FAR's numeric core (utils/evaluate_models.py:185-218):

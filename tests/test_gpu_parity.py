@@ -644,6 +644,83 @@ def test_stream_incremental_kernel_matches_full_recompute(assets, name):
         e.close()
 
 
+@pytest.mark.parametrize("name,precise", [("CRNN", True), ("CRNN_softmax", True), ("CRNN", False)])
+def test_one_launch_tick_equals_the_two_launch_form(assets, name, precise):
+    """Round 5: a tick of the incremental CRNN bank is ONE launch - the front end of a stream's new frames runs inside the
+    workgroups of that stream's new windows, the workgroup of the newest window alone writes the stream's state (sample ring
+    and carry ping-pong by the stream's parity so that its sibling still reads last tick's) - and the host polls the
+    posteriors' {value, tick number} pairs.  Against the front-end kernel + model kernel form waited for with
+    hipStreamSynchronize: 320 ticks with the VAD bit going on and off per stream (a silent stream's ring still advances; a
+    whole tick without a window), streams that are active for a while (not sampled at all: tflite.py:139-140), resets of
+    single streams and of the whole bank, pre-emphasis on - bit for bit, every tick."""
+    from wwhip.engine import Engine, StreamBank, frontend_params
+    e = Engine(os.path.join(assets, name))
+    S, ticks = 9, 320
+    rng = np.random.default_rng(505)
+    pcm = np.clip(rng.normal(0, 2500, (ticks, S, 320)), -32768, 32767).astype(np.int16)
+    speech = (rng.uniform(size=(ticks, S)) < 0.85).astype(np.uint8)
+    speech[:, 0] = 1
+    speech[60:64] = 0                       # whole ticks without a window (the host then waits for the stream instead)
+    speech[150:190, 3] = 0                  # a long silence: the ring advances, the mel history stands still
+    active = np.zeros((ticks, S), np.uint8)
+    active[90:140, 4] = 1                   # an activated stream is not sampled until the flag is cleared
+    active[:, 7] = rng.uniform(size=ticks) < 0.2
+    fp = frontend_params(pre_emphasis=0.97, precise=precise)
+
+    def run(**kw):
+        bank = StreamBank(e, S, fp=fp, **kw)
+        out = []
+        for t in range(ticks):
+            if t == 120:
+                bank.reset([2, 5])
+            if t == 200:
+                bank.reset()
+            out.append(bank.step(pcm[t], speech[t], active[t]))
+        bank.close()
+        return out
+
+    try:
+        one = run()
+        two = run(two_launch=True, sync_wait=True)
+        for t, ((p0, n0), (p1, n1)) in enumerate(zip(one, two)):
+            np.testing.assert_array_equal(n0, n1, err_msg=f"tick {t}")
+            np.testing.assert_array_equal(p0, p1, err_msg=f"tick {t}")
+        assert sum(int(n.sum()) for _, n in one) > 3500
+        assert any(int(n.sum()) == 0 for _, n in one[10:])
+        for kw in ({"two_launch": True}, {"sync_wait": True}):   # the other two combinations: polled two-launch, waited one-launch
+            other = run(**kw)
+            for t, ((p0, n0), (p1, n1)) in enumerate(zip(one, other)):
+                np.testing.assert_array_equal(p0, p1, err_msg=f"{kw} tick {t}")
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("name,prec", [("Wavenet", "fp32"), ("Wavenet", "bf16x3"), ("CRNN", "bf16x3")])
+def test_polled_tick_equals_the_waited_one(assets, name, prec):
+    """Every bank whose context owns its stream waits for a tick by polling the {value, tick number} pairs the heads store into
+    page-locked memory (wavenet_kernel, the one-kernel CRNN forms); WW_STREAM_SYNC_WAIT keeps hipStreamSynchronize and rows of
+    h_out.  Same posteriors."""
+    from wwhip.engine import Engine, StreamBank
+    e = Engine(os.path.join(assets, name), precision=prec)
+    S, ticks = 6, 40
+    rng = np.random.default_rng(11)
+    pcm = np.clip(rng.normal(0, 2500, (ticks, S, 320)), -32768, 32767).astype(np.int16)
+    speech = (rng.uniform(size=(ticks, S)) < 0.8).astype(np.uint8)
+    try:
+        outs = []
+        for kw in ({}, {"sync_wait": True}, {"full_recompute": True}, {"full_recompute": True, "sync_wait": True}):
+            bank = StreamBank(e, S, **kw)
+            outs.append([bank.step(pcm[t], speech[t]) for t in range(ticks)])
+            bank.close()
+        for a, b in ((0, 1), (2, 3)):
+            for (p0, n0), (p1, n1) in zip(outs[a], outs[b]):
+                np.testing.assert_array_equal(n0, n1)
+                np.testing.assert_array_equal(p0, p1)
+        assert sum(int(n.sum()) for _, n in outs[0]) > 250
+    finally:
+        e.close()
+
+
 def test_full_recompute_bank_survives_an_option_change_after_its_creation(assets):
     """A WW_STREAM_FULL_RECOMPUTE bank sizes its model scratch when it is created (1 KB while 2 S <= crnn_split_at: the fused
     kernel keeps everything in LDS).  Options are per model and mutable: lowering the front/tail threshold afterwards sends

@@ -68,7 +68,8 @@ struct ww_small_io {
 
 extern "C" {
 
-const char *ww_version(void) { return "wwhip 0.4 (gfx950; ABI 4: ww_stream_create takes flags, ww_host_stage_i16, ww_uploader_*)"; }
+static_assert(WW_ABI == 4, "ww_version's text carries the ABI number");
+const char *ww_version(void) { return "wwhip 0.5 (gfx950; ABI 4: ww_stream_create takes flags, ww_host_stage_i16, ww_uploader_*, ww_stream_timeline)"; }
 
 int ww_runtime_info(int32_t *built_hip_version, int32_t *runtime_version, int32_t *driver_version) {
   if (built_hip_version) *built_hip_version = HIP_VERSION;  // headers the library was compiled against

@@ -197,6 +197,31 @@ struct ww_bump {
   static size_t need(size_t n, size_t elem) { return (n * elem + 255) & ~size_t(255); }
 };
 
+// A tick's posteriors as {value, tick number} pairs in page-locked host memory, each written with ONE 8-byte store by the head
+// of the model kernels (crnn.hip: cf_phases_d_to_g; wavenet.hip): the host polls them instead of waiting for the runtime's
+// completion signal (streams.hip: ww_stream_step; 5.6 us of wake-up on this box, tools/launch_probe.hip).  slots == nullptr: off.
+struct ww_tick_tag {
+  unsigned long long *slots;  // [windows of the launch]: value bits | (uint64) seq << 32
+  unsigned seq;
+  int pidx;                   // the head's output element that is the posterior
+};
+
+// The streaming front end's side of crnn_stream_kernel<FE != 0> - ONE launch per tick (crnn.hip).  Workgroup 2 s + k is window k of
+// stream s's tick; it reads the stream's control words and samples over the bus itself.
+#define WW_ST_RING 832  // 511 + 320 rounded up
+struct ww_tick_fe {
+  const int16_t *frames;  // page-locked host memory [S][WW_CHUNK]
+  const int32_t *ctl;     // page-locked host memory [S][4]: fill, n_frames, flags (1 speech, 2 active, 4 state parity), pos | rowq << 16
+  float *ring;            // [2][S][WW_ST_RING]: a stream's sample ring, ping-pong by its state parity (read [par], written [par ^ 1])
+  float *prev;            // [2][S] pre-emphasis carry, likewise
+  float *hist;            // [S][HR][F] mirrored mel rings (the model's `mel`)
+  int S, HR;
+  float divisor;
+  int clip;
+  float preemph;
+  int hop;
+};
+
 // ---- kernel-side entry points implemented in the .hip files ------------------------------
 int ww_k_logmel(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, const float *d_f32, const int64_t *d_sample_offs,
                 const int64_t *d_frame_offs, int n_utt, int64_t total_frames, int64_t max_frames_per_utt,
@@ -216,17 +241,22 @@ int ww_k_crnn_init_device(ww_ctx *ctx);  // per-device kernel attributes (dynami
 // WW_EINVAL instead of writing past it
 int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *d_win_row,
                       const int32_t *d_win_valid, int64_t row0, int hop, int valid_const, int n_windows, void *ws, size_t ws_bytes,
-                      float *d_out, float *d_enc);
+                      float *d_out, float *d_enc, const ww_tick_tag *tag = nullptr);
 bool ww_crnn_segments_capable(const ww_model *m, int hop);
 int ww_k_crnn_segments_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *seg_row0,
                                const int32_t *seg_nw, int n_seg, int hop, float *d_out);
 bool ww_crnn_stream_capable(const ww_model *m);
 int ww_k_crnn_stream_forward(ww_ctx *ctx, const ww_model *m, const float *d_hist, int64_t hist_rows, const int64_t *d_win_row,
-                             const int32_t *d_win_valid, const int32_t *d_win_aux, float *d_gxc, int n_windows, float *d_out);
+                             const int32_t *d_win_valid, const int32_t *d_win_aux, float *d_gxc, int n_windows, float *d_out,
+                             const ww_tick_tag *tag = nullptr);
+// one launch per tick: front end + incremental CRNN of all S streams (2 S workgroups); posteriors as tags only
+int ww_k_crnn_tick(ww_ctx *ctx, const ww_model *m, const ww_tick_fe &fe, int precise, float *d_gxc, const ww_tick_tag &tag);
+// does a ww_k_crnn_forward launch of n explicit windows write the tags (the one-kernel forms do)?
+bool ww_crnn_forward_tags(const ww_model *m, int n_windows);
 size_t ww_wave_workspace(const ww_model *m, int n_windows);
 int ww_k_wave_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *d_win_row,
                       const int32_t *d_win_valid, int64_t row0, int hop, int valid_const, int n_windows, void *ws, size_t ws_bytes,
-                      float *d_out, float *d_enc);
+                      float *d_out, float *d_enc, const ww_tick_tag *tag = nullptr);
 int ww_k_far_frr(ww_ctx *ctx, const float *d_pos, int64_t n_pos, const float *d_neg, int64_t n_neg, int win,
                  const double *d_thr, int n_thr, double *d_smoothed, unsigned long long *d_pos_cnt,
                  unsigned long long *d_fa_cnt);

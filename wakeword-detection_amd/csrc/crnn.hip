@@ -14,6 +14,7 @@
 // Round 1's three-kernel chain (conv5x20_kernel -> gemm_nt_kernel -> gru_head_kernel, 52 us per 256 windows against
 // 34 us fused) and its bf16x6 projection GEMM are gone; their measurements are in DESIGN.md 7.1.
 #include "common.h"
+#include "fft_device.h"
 #include <type_traits>
 
 #include <cstdlib>
@@ -383,7 +384,15 @@ struct fused_args {
   float *gx_out;      // FRONT_ONLY: [Nw][OT][192] layer-1 input projections incl. b_x
   const unsigned short *cwb;   // bf16x3: conv weights, A-operand order [plane 2][k-step 4][m-tile 2][lane 64][8]
   const unsigned short *wx1b;  // bf16x3: W_x1, B-operand order [plane 2][k-step 20][n-tile 12][lane 64][8]
+  ww_tick_tag tag;             // streaming ticks: the posterior as a {value, tick number} pair instead of the row of `out` (common.h)
 };
+
+// One 8-byte store straight to page-locked host memory (system scope: not parked in L2): the host sees value and tick number
+// together or not at all.
+__device__ __forceinline__ void tick_tag_store(const ww_tick_tag &t, int w, float v) {
+  const unsigned long long word = (unsigned long long)__float_as_uint(v) | ((unsigned long long)t.seq << 32);
+  __hip_atomic_store(t.slots + w, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // one direction of one GRU layer over the OT steps held in LDS (gx rows incl. b_x), h ping-pong in hd
 template <bool SEQ>
@@ -532,15 +541,21 @@ __device__ __forceinline__ void cf_phases_d_to_g(const fused_args &a, float *img
       for (int k = 0; k < 2 * H; ++k) y = fmaf(w2s[lane * 64 + k], hid[k], y);
       y += b2v;
     }
+    float p;
     if (a.HEAD == 0) {
-      if (lane < a.NOUT) a.out[(size_t)w * a.NOUT + lane] = sigmoid_f(y);
+      p = sigmoid_f(y);
     } else {
       float mx = (lane < a.NOUT) ? y : -INFINITY;
       for (int o = 1; o < 8; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
       float e = (lane < a.NOUT) ? expf(y - mx) : 0.f;
       float sum = e;
       for (int o = 1; o < 8; o <<= 1) sum += __shfl_xor(sum, o);
-      if (lane < a.NOUT) a.out[(size_t)w * a.NOUT + lane] = e / sum;
+      p = e / sum;
+    }
+    if (a.tag.slots) {
+      if (lane == a.tag.pidx) tick_tag_store(a.tag, w, p);
+    } else if (lane < a.NOUT) {
+      a.out[(size_t)w * a.NOUT + lane] = p;
     }
   }
   CF_STAMP(9)
@@ -795,8 +810,36 @@ struct stream_args {
   fused_args f;
   const int32_t *aux;  // [nw] stream * WW_STREAM_GXC + (stream rows incl. this window's newest) % WW_STREAM_GXC
   float *gxc;          // [S][WW_STREAM_GXC][192]
+  // FE != 0 - ONE launch per tick: the streaming front end's side (common.h) and the model's filterbank
+  ww_tick_fe fe;
+  const int *start;
+  const float *wpad, *bias;
+  int n_mel;
+  float floor_v, log_off, scale;
+  const double *hann, *tw256, *tw512;
 };
 
+// Mel-side LDS of the one-launch tick form, in the part of the feat region the three conv rows leave free (floats from `feat`)
+#define CT_X (3 * CF_FLD)                 // [WW_ST_RING] ring | the tick's new samples
+#define CT_XS (CT_X + WW_ST_RING)         // [WW_CHUNK] int16: the raw samples
+#define CT_WL (CT_XS + WW_CHUNK / 2)      // [3 rounds x 256 x 4] the mel weights [WW_MEL_TAPS][64], padded to whole store rounds
+#define CT_MAG (CT_WL + 3 * 256 * 4)      // [2][260] magnitudes of the (at most) two new frames
+#define CT_BUF (CT_MAG + 2 * 260 + 8)     // [2][FFT_LD] complex: the transforms' exchange buffers (16-byte aligned)
+static_assert(CT_BUF % 4 == 0 && CT_BUF + 2 * FFT_LD * 4 <= CF_FEAT_FLOATS, "tick front end does not fit beside the conv rows");
+static_assert(WW_MEL_TAPS * 64 <= 3 * 256 * 4 && WW_CHUNK * 2 == 40 * 16, "tick front end: store rounds");
+
+// FE = 0: the windows of a tick come as descriptor tables behind a front-end kernel of its own (stream_frontend_kernel: two
+// launches per tick).  FE = 1 / 2 (fp32 / fp64 transform) - ONE launch per tick (round 5): workgroup 2 s + k is window k of stream
+// s's tick and transforms the new frames itself - waves 0 and 1, one frame each, straight into the window image, while the
+// other waves stage the rows that were there before; spokestack/wakeword/tflite.py:148-191 for one stream.  Two workgroups of
+// one stream run in the same launch, so exactly ONE of them writes the stream's state - the workgroup of the tick's newest
+// window (k = n_windows - 1; workgroup 2 s when the tick has no window: the ring still advances, tflite.py:163-168) stores
+// both new mel rows, the ring tail and the pre-emphasis carry - and its sibling must still see last tick's: the mel rows it
+// reads are not the slots written this tick (the mirrored ring of T + 1 slots leaves exactly those out), the sample ring and
+// the carry are kept twice and ping-pong by the stream's state parity.  The sibling transforms frame 0 a second time (same
+// instructions, same bits) rather than wait for it.  No kernel boundary, no second launch, no descriptor tables; the
+// posteriors go out as {value, tick number} pairs (ww_tick_tag) that the host polls.
+template <int FE>
 __global__ __launch_bounds__(CF_THREADS, 2) void crnn_stream_kernel(stream_args sa) {
   const fused_args &a = sa.f;
   extern __shared__ __align__(16) float cf_smem[];
@@ -806,28 +849,20 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_stream_kernel(stream_args 
   const int j = lane & 15, kk = lane >> 4;
   const int w = blockIdx.x;
   CF_STAMP(0)
-  // the window's three descriptor words (first mel row, valid rows, cache slot) in ONE load: lanes 0..3 read the two halves of
-  // row[w], valid[w] and aux[w] (three arrays, one instruction), the values come back as scalars - read one after the other they
-  // were three round trips in a row at the head of every tick's kernel (the streaming path always passes both tables)
-  const int *dp = lane == 0 ? (const int *)(a.wa.row + w) : lane == 1 ? (const int *)(a.wa.row + w) + 1
-                : lane == 2 ? (const int *)(a.wa.valid + w) : (const int *)(sa.aux + w);
-  const int dv = *dp;
-  int64_t row = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dv, 1) << 32) | (unsigned)__builtin_amdgcn_readlane(dv, 0));
-  int valid = __builtin_amdgcn_readlane(dv, 2);
-  const int aux = __builtin_amdgcn_readlane(dv, 3);
-  if (valid > a.T) valid = a.T;  // (as window_span)
-  if (row + valid > a.wa.mel_rows) valid = (int)(a.wa.mel_rows - row);
-  if (valid < 0) valid = 0;
-  const int q0 = aux % RA;
-  float *cache = sa.gxc + (size_t)(aux - q0) * (6 * H);
-
   float4 wreg[CV_KB][2];
+  float cb0, cb1;
+  float4 crow0, crow1, crow2;
+  int a_off, o_off[4];
+  int q0;
+  float *cache;
+  auto load_conv_w = [&]() {
 #pragma unroll
-  for (int kb = 0; kb < CV_KB; ++kb)
+    for (int kb = 0; kb < CV_KB; ++kb)
 #pragma unroll
-    for (int n = 0; n < 2; ++n) wreg[kb][n] = *(const float4 *)(a.w4 + ((size_t)(kb * 4 + kk) * 32 + n * 16 + j) * 4);
-  const float cb0 = a.cbias[j], cb1 = a.cbias[16 + j];
-
+      for (int n = 0; n < 2; ++n) wreg[kb][n] = *(const float4 *)(a.w4 + ((size_t)(kb * 4 + kk) * 32 + n * 16 + j) * 4);
+    cb0 = a.cbias[j];
+    cb1 = a.cbias[16 + j];
+  };
   // ---- the sixteen cached rows (positions 1..16): requested first, parked in LDS once the image is dead
   // (three named registers: as an array they stayed in scratch memory)
   auto cached = [&](int q) {
@@ -836,10 +871,48 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_stream_kernel(stream_args 
     slot = slot >= RA ? slot - RA : slot;
     return *(const float4 *)(cache + (size_t)slot * (6 * H) + c4 * 4);
   };
-  const float4 crow0 = cached(0), crow1 = cached(1), crow2 = cached(2);
-  // ---- A: mel rows 0..13 (position 0) and 130..150 (positions 17, 18) of the window -> the transposed image
-  int a_off, o_off[4];
-  {
+  // the three positions as 60 rows (p, f) of ONE m-tile per wave: p = 0, 1, 2 <-> t = 0, 17, 18
+  auto tile_offsets = [&]() {
+    constexpr int M = 3 * CV_OF;
+    int m = wave * 16 + j;
+    m = m < M ? m : M - 1;
+    const int p = m / CV_OF, f = m - p * CV_OF, t = p ? 16 + p : 0;
+    a_off = (f * CV_SF) * CV_LDT + t * CV_ST;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int mo = wave * 16 + kk * 4 + r, po = mo / CV_OF, fo = mo - po * CV_OF;
+      o_off[r] = mo < M ? po * CF_FLD + fo * 32 + j : -1;
+    }
+  };
+  auto scatter = [&](const float4 (&stage)[2], const int (&sidx)[2]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (sidx[q] >= 0) {
+        const int it = sidx[q] / 10, im = (sidx[q] - it * 10) * 4;
+        const float e[4] = {stage[q].x, stage[q].y, stage[q].z, stage[q].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) img[(im + c + CV_PF) * CV_LDT + it + CV_PT] = e[c];
+      }
+    }
+  };
+  if constexpr (FE == 0) {
+    // the window's three descriptor words (first mel row, valid rows, cache slot) in ONE load: lanes 0..3 read the two halves of
+    // row[w], valid[w] and aux[w] (three arrays, one instruction), the values come back as scalars - read one after the other they
+    // were three round trips in a row at the head of every tick's kernel (the streaming path always passes both tables)
+    const int *dp = lane == 0 ? (const int *)(a.wa.row + w) : lane == 1 ? (const int *)(a.wa.row + w) + 1
+                  : lane == 2 ? (const int *)(a.wa.valid + w) : (const int *)(sa.aux + w);
+    const int dv = *dp;
+    int64_t row = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dv, 1) << 32) | (unsigned)__builtin_amdgcn_readlane(dv, 0));
+    int valid = __builtin_amdgcn_readlane(dv, 2);
+    const int aux = __builtin_amdgcn_readlane(dv, 3);
+    if (valid > a.T) valid = a.T;  // (as window_span)
+    if (row + valid > a.wa.mel_rows) valid = (int)(a.wa.mel_rows - row);
+    if (valid < 0) valid = 0;
+    q0 = aux % RA;
+    cache = sa.gxc + (size_t)(aux - q0) * (6 * H);
+    load_conv_w();
+    crow0 = cached(0); crow1 = cached(1); crow2 = cached(2);
+    // ---- A: mel rows 0..13 (position 0) and 130..150 (positions 17, 18) of the window -> the transposed image
     const float *src = a.mel + row * CV_NMEL;  // 160-byte rows of a hipMalloc'ed history: 16-byte aligned
     float4 stage[2];
     int sidx[2];
@@ -852,29 +925,118 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_stream_kernel(stream_args 
       stage[q] = in ? *(const float4 *)(src + (size_t)f4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     for (int i = tid; i < CF_IMG_FLOATS / 4; i += CF_THREADS) ((float4 *)img)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    {
-      // the three positions as 60 rows (p, f) of ONE m-tile per wave: p = 0, 1, 2 <-> t = 0, 17, 18
-      constexpr int M = 3 * CV_OF;
-      int m = wave * 16 + j;
-      m = m < M ? m : M - 1;
-      const int p = m / CV_OF, f = m - p * CV_OF, t = p ? 16 + p : 0;
-      a_off = (f * CV_SF) * CV_LDT + t * CV_ST;
+    tile_offsets();
+    __syncthreads();
+    scatter(stage, sidx);
+  } else {
+    typedef typename std::conditional<FE == 2, double, float>::type R;
+    const ww_tick_fe &fe = sa.fe;
+    const int s = w >> 1, k = w & 1;
+    // ---- over the bus, together: the tick's 320 samples (40 x 16 bytes) and the stream's control words
+    uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < 40) raw = ((const uint4 *)(fe.frames + (size_t)s * WW_CHUNK))[tid];
+    const int4 cw = ((const int4 *)fe.ctl)[s];
+    // ---- device-side inputs that do not depend on the control words, requested while those are crossing the bus: the mel
+    // weights, the sample ring (threads 0..127 ask for the copy of parity 0, the others for parity 1: 128 x 4 = 512 > fill),
+    // both copies of the carry, the transform's constants (waves 0, 1: one new frame each), the conv weights
+    f32x4 wlq[3];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int mo = wave * 16 + kk * 4 + r, po = mo / CV_OF, fo = mo - po * CV_OF;
-        o_off[r] = mo < M ? po * CF_FLD + fo * 32 + j : -1;
+    for (int q = 0; q < 3; ++q) {
+      const int i = tid + q * CF_THREADS;
+      wlq[q] = ((const f32x4 *)sa.wpad)[i < WW_MEL_TAPS * 64 / 4 ? i : 0];
+    }
+    const int mel_st = lane < sa.n_mel ? sa.start[lane] : 0;
+    const float mel_bias = lane < sa.n_mel ? sa.bias[lane] : 0.0f;
+    const float4 ringq = ((const float4 *)(fe.ring + ((size_t)(tid >> 7) * fe.S + s) * WW_ST_RING))[tid & 127];
+    const float carry0 = fe.prev[s], carry1 = fe.prev[fe.S + s];
+    fft_consts<R> fc;
+    if (wave < 2) fft_load_consts<R>(fc, lane, sa.hann, sa.tw256, sa.tw512);
+    load_conv_w();
+    // ---- what this workgroup is (uniform over it)
+    const int fill = cw.x, nf = cw.y, flags = cw.z, pos = cw.w & 0xffff, rowq = cw.w >> 16;
+    const int par = (flags >> 2) & 1;
+    const int np = (flags & 1) ? nf : 0;  // frames are analysed only while the VAD says speech (tflite.py:166)
+    if ((flags & 2) || k >= (np > 1 ? np : 1)) return;  // an active stream is not sampled at all (tflite.py:139-140) | no second window
+    const bool window = k < np, writer = k + 1 >= np;
+    const int nfk = window ? k + 1 : 0;  // window k ends at new frame k: it needs frames 0..k
+    const int slots = a.T + 1;
+    float4 stage[2];
+    int sidx[2] = {-1, -1};
+    if (window) {
+      // the T rows that end at new row k are the contiguous block that starts at slot (pos + k + 2) % (T + 1) of the mirrored ring
+      int b = pos + k + 2;
+      b = b >= slots ? b - slots : b;
+      q0 = rowq + k + 1;  // rows since the reset incl. this window's newest, mod the cache ring
+      q0 = q0 >= RA ? q0 - RA : q0;
+      cache = sa.gxc + (size_t)s * RA * (6 * H);
+      crow0 = cached(0); crow1 = cached(1); crow2 = cached(2);
+      const float *src = a.mel + ((size_t)s * fe.HR + b) * CV_NMEL;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int i = tid + q * CF_THREADS;            // 140 + 210 float4
+        const int f4 = i < 140 ? i : 1300 + (i - 140);  // float4 index inside the [151][40] window
+        const bool in = i < 350 && f4 / 10 < a.T - nfk;  // (the rows of this tick come from waves 0, 1)
+        sidx[q] = in ? f4 : -1;
+        stage[q] = in ? *(const float4 *)(src + (size_t)f4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
+    }
+    float *fx = feat + CT_X, *fwl = feat + CT_WL, *fmag = feat + CT_MAG;
+    short *fxs = (short *)(feat + CT_XS);
+    cplx<R> *fbuf = (cplx<R> *)(feat + CT_BUF);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) ((f32x4 *)fwl)[tid + q * CF_THREADS] = wlq[q];
+    if ((tid >> 7) == par) ((float4 *)fx)[tid & 127] = ringq;
+    if (tid < 40) ((uint4 *)fxs)[tid] = raw;
+    if (window) {
+      for (int i = tid; i < CF_IMG_FLOATS / 4; i += CF_THREADS) ((float4 *)img)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      tile_offsets();
     }
     __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      if (sidx[q] >= 0) {
-        const int it = sidx[q] / 10, im = (sidx[q] - it * 10) * 4;
-        const float e[4] = {stage[q].x, stage[q].y, stage[q].z, stage[q].w};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) img[(im + c + CV_PF) * CV_LDT + it + CV_PT] = e[c];
+    // ---- [ring | new samples]: normalise, clip, pre-emphasise (the arithmetic of stream_frontend_kernel, streams.hip)
+    for (int i = tid; i < WW_CHUNK; i += CF_THREADS) {
+      float v = __fdiv_rn((float)fxs[i], fe.divisor);
+      if (fe.clip) v = fminf(fmaxf(v, -1.0f), 1.0f);
+      float p;
+      if (i == 0) {
+        p = par ? carry1 : carry0;
+      } else {
+        p = __fdiv_rn((float)fxs[i - 1], fe.divisor);
+        if (fe.clip) p = fminf(fmaxf(p, -1.0f), 1.0f);
+      }
+      fx[fill + i] = (fe.preemph != 0.0f) ? __fsub_rn(v, __fmul_rn(fe.preemph, p)) : v;
+    }
+    __syncthreads();
+    if (writer && tid == 0) {
+      float v = __fdiv_rn((float)fxs[WW_CHUNK - 1], fe.divisor);
+      if (fe.clip) v = fminf(fmaxf(v, -1.0f), 1.0f);
+      fe.prev[(size_t)(par ^ 1) * fe.S + s] = v;  // tflite.py:156-158: the carry is the un-emphasised last sample
+    }
+    // ---- new frames: wave f transforms frame f, its mel row goes straight into the window image (time T - nfk + f) and,
+    // from the writer, into the stream's mirrored ring
+    if (wave < nfk) {
+      const float *srcx = fx + wave * fe.hop;
+      auto x2 = [&](int n) -> float2 { return make_float2(srcx[2 * n], srcx[2 * n + 1]); };
+      float *mg = fmag + wave * 260;
+      frame_fft_mag<R>(x2, fc, fbuf + wave * FFT_LD, mg, lane);
+      const float mv = mel_band(mg, fwl, mel_st, mel_bias, sa.floor_v, sa.log_off, sa.scale, lane);
+      if (lane < CV_NMEL) {
+        img[(lane + CV_PF) * CV_LDT + (a.T - nfk + wave) + CV_PT] = mv;
+        if (writer) {
+          int p = pos + wave;  // mirrored ring: the row goes to p % slots and p % slots + slots
+          p = p >= slots ? p - slots : p;
+          float *h = fe.hist + ((size_t)s * fe.HR + p) * CV_NMEL + lane;
+          h[0] = mv;
+          h[(size_t)slots * CV_NMEL] = mv;
+        }
       }
     }
+    if (writer) {  // keep the ring tail (for the next tick: the other copy)
+      const int keep = fill + WW_CHUNK - nf * fe.hop;
+      float *ring = fe.ring + ((size_t)(par ^ 1) * fe.S + s) * WW_ST_RING;
+      for (int i = tid; i < keep; i += CF_THREADS) ring[i] = fx[nf * fe.hop + i];
+    }
+    if (!window) return;  // the tick has no window for this stream: its ring has advanced, that is all
+    scatter(stage, sidx);
   }
   __syncthreads();
   CF_STAMP(1)
@@ -2039,7 +2201,9 @@ static int crnn_split_threshold(const ww_model *m) { return m->opt_split_at; }
 // Every CRNN kernel that asks for more than the default 64 KB of dynamic LDS.  The attribute is per device, so it is set
 // for the device of every new context (ww_ctx_create, under its device scope) instead of once per process.
 int ww_k_crnn_init_device(ww_ctx *ctx) {
-  WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
+  WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_stream_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
+  WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_stream_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
+  WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_stream_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
   WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
   WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, CF_FUSED_SMEM_BYTES));
   WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, CF_FUSED_SMEM_BYTES));
@@ -2051,16 +2215,44 @@ int ww_k_crnn_init_device(ww_ctx *ctx) {
 // streaming form (crnn_stream_kernel): standard geometry, fp32 contractions
 bool ww_crnn_stream_capable(const ww_model *m) { return m->kind == WW_KIND_CRNN && !m->crnn.generic; }
 
+// ONE launch per tick (crnn_stream_kernel<1 | 2>): 2 S workgroups, the posteriors as tags only
+int ww_k_crnn_tick(ww_ctx *ctx, const ww_model *m, const ww_tick_fe &fe, int precise, float *d_gxc, const ww_tick_tag &tag) {
+  const ww_crnn_dev &c = m->crnn;
+  const ww_filter_dev &f = m->filt;
+  if (c.generic || f.n_mel != CV_NMEL || fe.hop != 160)
+    return ww_fail(ctx, WW_EINVAL, "one-launch streaming tick: standard conv geometry, 40 mel bands and hop 160 only");
+  if (!tag.slots || fe.S <= 0) return ww_fail(ctx, WW_EINVAL, "one-launch streaming tick: no tag slots / no streams");
+  stream_args sa = {};
+  sa.f = {fe.hist, {nullptr, nullptr, 0, 0, 0, (int64_t)fe.S * fe.HR}, c.conv_w, c.conv_b, c.wx1s, c.bx1, c.wh1, c.bh1, c.wx2s, c.bx2, c.wh2, c.bh2,
+          c.w1, c.b1, c.w2, c.b2, nullptr, nullptr, c.T, c.NOUT, c.HEAD, nullptr, nullptr, c.cwb, c.wx1b};
+  sa.f.tag = tag;
+  sa.gxc = d_gxc;
+  sa.fe = fe;
+  sa.start = f.start; sa.wpad = f.wpad; sa.bias = f.bias; sa.n_mel = f.n_mel;
+  sa.floor_v = f.floor_v; sa.log_off = f.log_off; sa.scale = f.scale;
+  sa.hann = f.hann; sa.tw256 = f.tw256; sa.tw512 = f.tw512;
+  {
+    ww_launch_scope scope(ctx, "crnn_stream_kernel<tick>");
+    if (precise) hipLaunchKernelGGL(crnn_stream_kernel<2>, dim3(2 * fe.S), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, sa);
+    else hipLaunchKernelGGL(crnn_stream_kernel<1>, dim3(2 * fe.S), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, sa);
+  }
+  WW_HIP(ctx, hipGetLastError());
+  return WW_OK;
+}
+
 int ww_k_crnn_stream_forward(ww_ctx *ctx, const ww_model *m, const float *d_hist, int64_t hist_rows, const int64_t *d_win_row,
-                             const int32_t *d_win_valid, const int32_t *d_win_aux, float *d_gxc, int nw, float *d_out) {
+                             const int32_t *d_win_valid, const int32_t *d_win_aux, float *d_gxc, int nw, float *d_out,
+                             const ww_tick_tag *tag) {
   if (nw <= 0) return WW_OK;
   const ww_crnn_dev &c = m->crnn;
   if (c.generic) return ww_fail(ctx, WW_EINVAL, "streaming CRNN kernel: standard conv geometry only");
+  if (!d_win_row || !d_win_valid || !d_win_aux) return ww_fail(ctx, WW_EINVAL, "streaming CRNN kernel: NULL window table");
   stream_args sa = {};
   sa.f = {d_hist, {d_win_row, d_win_valid, 0, 0, 0, hist_rows}, c.conv_w, c.conv_b, c.wx1s, c.bx1, c.wh1, c.bh1, c.wx2s, c.bx2, c.wh2, c.bh2,
           c.w1, c.b1, c.w2, c.b2, nullptr, d_out, c.T, c.NOUT, c.HEAD, nullptr, nullptr, c.cwb, c.wx1b};
   sa.aux = d_win_aux;
   sa.gxc = d_gxc;
+  if (tag) sa.f.tag = *tag;
   static const bool want_stamps = getenv("WWHIP_CF_STAMPS") != nullptr;  // development: phase timeline (as ww_k_crnn_forward)
   if (want_stamps) {
     WW_HIP(ctx, hipMalloc((void **)&sa.f.stamps, (size_t)nw * 40 * sizeof(long long)));
@@ -2068,7 +2260,7 @@ int ww_k_crnn_stream_forward(ww_ctx *ctx, const ww_model *m, const float *d_hist
   }
   {
     ww_launch_scope scope(ctx, "crnn_stream_kernel");
-    hipLaunchKernelGGL(crnn_stream_kernel, dim3(nw), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, sa);
+    hipLaunchKernelGGL(crnn_stream_kernel<0>, dim3(nw), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, sa);
   }
   WW_HIP(ctx, hipGetLastError());
   if (want_stamps) {
@@ -2214,9 +2406,14 @@ size_t ww_crnn_workspace(const ww_model *m, int nw, bool sliding) {
   return need;
 }
 
+// the one-kernel forms write a tick's tags (cf_phases_d_to_g); the front + tail forms and the generic path do not
+bool ww_crnn_forward_tags(const ww_model *m, int nw) {
+  return !m->crnn.generic && !(crnn_split_threshold(m) > 0 && nw > crnn_split_threshold(m));
+}
+
 int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *d_win_row,
                       const int32_t *d_win_valid, int64_t row0, int hop, int valid_const, int nw, void *ws, size_t ws_bytes,
-                      float *d_out, float *d_enc) {
+                      float *d_out, float *d_enc, const ww_tick_tag *tag) {
   if (nw <= 0) return WW_OK;
   const ww_crnn_dev &c = m->crnn;
   win_addr wa = {d_win_row, d_win_valid, row0, hop, valid_const, mel_rows};
@@ -2233,6 +2430,7 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
       return ww_fail(ctx, WW_EINVAL, "CRNN launch of %d windows needs %zu bytes of scratch, the caller reserved %zu (options changed "
                      "after the buffer was sized?)", nw, need, ws_bytes);
   }
+  if (c.generic && tag && tag->slots) return ww_fail(ctx, WW_EINVAL, "tick tags: the generic CRNN path does not write them");
   if (c.generic) return crnn_forward_generic(ctx, m, wa, d_mel, nw, ws, d_out, d_enc);
   fused_args a = {d_mel, wa, c.conv_w, c.conv_b, c.wx1s, c.bx1, c.wh1, c.bh1, c.wx2s, c.bx2, c.wh2, c.bh2,
                   c.w1, c.b1, c.w2, c.b2, d_enc, d_out, c.T, c.NOUT, c.HEAD, nullptr, nullptr, c.cwb, c.wx1b};
@@ -2265,6 +2463,10 @@ int ww_k_crnn_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
     return WW_OK;
   }
   const int thr = crnn_split_threshold(m);
+  if (tag && tag->slots) {
+    if (slide_form || (thr > 0 && nw > thr)) return ww_fail(ctx, WW_EINVAL, "tick tags: this launch form does not write them");
+    a.tag = *tag;
+  }
   if (thr > 0 && nw > thr) {
     ww_bump b(ws, ws_bytes);
     a.gx_out = b.take<float>((size_t)nw * c.OT * 6 * c.H);

@@ -24,7 +24,9 @@
 #include "common.h"
 #include "fft_device.h"
 
-#define ST_RING 832  // 511 + 320 rounded up
+#include <time.h>
+
+#define ST_RING WW_ST_RING  // 511 + 320 rounded up
 #define ST_WL_BYTES (((WW_MEL_TAPS * 64 * 4 + 2047) / 2048) * 2048)  // the mel weights in LDS, padded to whole rounds of 128 x 16 bytes
 
 struct ww_streams {
@@ -34,9 +36,9 @@ struct ww_streams {
   ww_frontend_params fp = {};
   int T = 0, F = 0, NO = 0, HR = 0;  // HR = history rows per stream = 2 (T + 1) (mirrored ring)
   // device state
-  float *ring = nullptr;      // [S][ST_RING]
-  float *hist = nullptr;      // [S][2 (T + 1)][F], mirrored ring
-  float *prev = nullptr;      // [S] pre-emphasis carry (raw previous sample)
+  float *ring = nullptr;      // [2][S][ST_RING] (the one-launch tick ping-pongs between the two copies by a stream's state parity; the
+  float *hist = nullptr;      //  two-launch forms use the first) | [S][2 (T + 1)][F], mirrored ring
+  float *prev = nullptr;      // [2][S] pre-emphasis carry (raw previous sample), likewise
   // per-tick device buffers
   int16_t *d_frames = nullptr;   // [S][320]
   int32_t *d_ctl = nullptr;      // [S][4]: fill, n_frames, flags, pos (history rows written so far, mod T + 1)
@@ -53,9 +55,20 @@ struct ww_streams {
   int16_t *h_frames = nullptr;
   // the four per-tick inputs live in ONE pinned block (frames | win_row | ctl | win_valid) that the front-end kernel
   // reads over the bus itself - no copy-engine operation on a tick's path (four back-to-back host-to-device copies
-  // cost 20 us of a 107 us tick); d_pack mirrors the layout and holds the window descriptors the kernel copies over
+  // cost 20 us of a 107 us tick); d_pack mirrors the layout and holds the window descriptors the kernel copies over.
+  // The block exists TWICE (round 5): the one-launch tick alternates between the copies - a polled tick returns as soon as its
+  // posteriors are in, while workgroups that owe none (a stream without a window only advances its ring) may not have read
+  // their samples yet; by the time a copy is written again the kernel of the tick in between has started, i.e. this one ended
   char *h_pack = nullptr, *d_pack = nullptr, *h_pack_dev = nullptr;  // h_pack_dev: the device's address of h_pack
-  size_t pack_bytes = 0;
+  size_t pack_bytes = 0;  // of ONE copy
+  // a tick's posteriors as {value, tick number} pairs the model kernels store straight into page-locked memory (ww_tick_tag):
+  // ww_stream_step polls them instead of waiting for the runtime's completion signal
+  unsigned long long *h_tag = nullptr, *h_tag_dev = nullptr;  // [2 S]
+  unsigned seq = 0;             // tick number (never 0 in a tag)
+  bool one_launch = false;      // incremental CRNN: front end inside the model kernel's workgroups (crnn_stream_kernel<1 | 2>)
+  bool poll = false;            // wait by polling the tags (a context that owns its stream; WW_STREAM_SYNC_WAIT turns it off)
+  std::vector<int> par;         // a stream's state parity (one-launch form)
+  std::vector<int> expect;      // tag slots this tick's posteriors arrive in
   std::vector<int> fill, pos;
   // incremental CRNN (crnn.hip, crnn_stream_kernel): per-stream ring of projected interior rows, the row of an all-zero
   // field every slot holds after a reset, and the number of mel rows since the reset modulo the ring size
@@ -63,7 +76,16 @@ struct ww_streams {
   int32_t *h_win_aux = nullptr, *d_win_aux = nullptr;
   std::vector<int> rowq;
   bool incremental = false;
+  // host timeline of ww_stream_step (ww_stream_timeline): nanoseconds per phase summed over the ticks since the last reset
+  uint64_t tl_ns[WW_STREAM_TL_PHASES] = {0};
+  int64_t tl_ticks = 0;
 };
+
+static inline uint64_t st_now_ns() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
 
 struct stream_fe_args {
   const int16_t *frames;   // pinned host memory, read over the bus (640 B per stream and tick)
@@ -215,7 +237,7 @@ int ww_stream_destroy(ww_streams *st) {
   void *dev[] = {st->ring, st->hist, st->prev, st->d_pack, st->ws, st->gxc, st->gx_zero};
   for (void *p : dev)
     if (p) hipFree(p);
-  void *host[] = {st->h_pack, st->h_out};
+  void *host[] = {st->h_pack, st->h_out, st->h_tag};
   for (void *p : host)
     if (p) hipHostFree(p);
   delete st;
@@ -226,7 +248,8 @@ int ww_stream_create(ww_ctx *ctx, const ww_model *model, int32_t S, const ww_fro
                      ww_streams **out) {
   if (!ctx || !model || !fp || !out) return ww_fail(ctx, WW_EINVAL, "NULL argument");
   *out = nullptr;
-  if (flags & ~(uint32_t)WW_STREAM_FULL_RECOMPUTE) return ww_fail(ctx, WW_EINVAL, "unknown stream flags 0x%x", flags);
+  if (flags & ~(uint32_t)(WW_STREAM_FULL_RECOMPUTE | WW_STREAM_TWO_LAUNCH | WW_STREAM_SYNC_WAIT))
+    return ww_fail(ctx, WW_EINVAL, "unknown stream flags 0x%x", flags);
   if (S <= 0 || S > 65535) return ww_fail(ctx, WW_EINVAL, "stream count %d out of range (1..65535)", S);
   if (fp->hop != 160) return ww_fail(ctx, WW_EINVAL, "streaming mode supports hop 160 (10 ms @ 16 kHz) only, got %d", fp->hop);
   if (!(fp->pcm_divisor > 0.f)) return ww_fail(ctx, WW_EINVAL, "pcm_divisor must be positive");
@@ -239,20 +262,25 @@ int ww_stream_create(ww_ctx *ctx, const ww_model *model, int32_t S, const ww_fro
   // for a model in split-bf16 mode: a seventh of the products in fp32 is both faster and closer).
   // WW_STREAM_FULL_RECOMPUTE keeps the per-window kernels (every window recomputed from its mel rows).
   st->incremental = ww_crnn_stream_capable(model) && !(flags & WW_STREAM_FULL_RECOMPUTE);
+  st->one_launch = st->incremental && !(flags & WW_STREAM_TWO_LAUNCH) && model->filt.n_mel == 40;
+  // a borrowed stream is the caller's: when the call returns everything enqueued on it has completed, as before
+  st->poll = ctx->own_stream && !(flags & WW_STREAM_SYNC_WAIT);
   // model scratch of the per-window kernels (explicit window rows: never the sliding form); the incremental CRNN needs none
   size_t ws_bytes = st->incremental ? 256
                     : (model->kind == WW_KIND_CRNN ? ww_crnn_workspace(model, 2 * S, false) : ww_wave_workspace(model, 2 * S));
-  bool ok = hipMalloc((void **)&st->ring, (size_t)S * ST_RING * 4) == hipSuccess &&
+  bool ok = hipMalloc((void **)&st->ring, (size_t)2 * S * ST_RING * 4) == hipSuccess &&
             hipMalloc((void **)&st->hist, hist_elems * 4) == hipSuccess &&
-            hipMalloc((void **)&st->prev, (size_t)S * 4) == hipSuccess &&
+            hipMalloc((void **)&st->prev, (size_t)2 * S * 4) == hipSuccess &&
             hipMalloc(&st->ws, ws_bytes) == hipSuccess && ((st->ws_bytes = ws_bytes), true) &&
-            hipHostMalloc((void **)&st->h_out, (size_t)2 * S * st->NO * 4) == hipSuccess;
+            hipHostMalloc((void **)&st->h_out, (size_t)2 * S * st->NO * 4) == hipSuccess &&
+            hipHostMalloc((void **)&st->h_tag, (size_t)2 * S * 8) == hipSuccess;
   {
     const size_t o_frames = 0, o_row = o_frames + (size_t)S * WW_CHUNK * 2, o_ctl = o_row + (size_t)2 * S * 8,
                  o_valid = o_ctl + (size_t)S * 16, o_aux = o_valid + (size_t)2 * S * 4;
     st->pack_bytes = o_aux + (size_t)2 * S * 4;
+    st->pack_bytes = (st->pack_bytes + 255) & ~(size_t)255;
     ok = ok && hipMalloc((void **)&st->d_pack, st->pack_bytes) == hipSuccess &&
-         hipHostMalloc((void **)&st->h_pack, st->pack_bytes) == hipSuccess;
+         hipHostMalloc((void **)&st->h_pack, 2 * st->pack_bytes) == hipSuccess;
     if (ok) {
       st->h_frames = (int16_t *)(st->h_pack + o_frames); st->d_frames = (int16_t *)(st->d_pack + o_frames);
       st->h_win_row = (int64_t *)(st->h_pack + o_row);   st->d_win_row = (int64_t *)(st->d_pack + o_row);
@@ -265,20 +293,24 @@ int ww_stream_create(ww_ctx *ctx, const ww_model *model, int32_t S, const ww_fro
     ww_stream_destroy(st);
     return ww_fail(ctx, WW_ENOMEM, "cannot allocate state for %d streams", S);
   }
+  memset(st->h_tag, 0, (size_t)2 * S * 8);
   if (hipHostGetDevicePointer((void **)&st->h_out_dev, st->h_out, 0) != hipSuccess ||
+      hipHostGetDevicePointer((void **)&st->h_tag_dev, st->h_tag, 0) != hipSuccess ||
       hipHostGetDevicePointer((void **)&st->h_pack_dev, st->h_pack, 0) != hipSuccess) {
     ww_stream_destroy(st);
     return ww_fail(ctx, WW_EHIP, "pinned staging buffers are not visible to the device");
   }
-  hipMemsetAsync(st->ring, 0, (size_t)S * ST_RING * 4, ctx->stream);
+  hipMemsetAsync(st->ring, 0, (size_t)2 * S * ST_RING * 4, ctx->stream);
   hipMemsetAsync(st->hist, 0, hist_elems * 4, ctx->stream);
-  hipMemsetAsync(st->prev, 0, (size_t)S * 4, ctx->stream);
+  hipMemsetAsync(st->prev, 0, (size_t)2 * S * 4, ctx->stream);
   hipMemsetAsync(st->d_pack, 0, st->pack_bytes, ctx->stream);
-  memset(st->h_pack, 0, st->pack_bytes);
+  memset(st->h_pack, 0, 2 * st->pack_bytes);
   WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
   st->fill.assign(S, 0);
   st->pos.assign(S, 0);
   st->rowq.assign(S, 0);
+  st->par.assign(S, 0);
+  st->expect.reserve((size_t)2 * S);
   if (st->incremental) {
     if (hipMalloc((void **)&st->gxc, (size_t)S * WW_STREAM_GXC * 192 * 4) != hipSuccess ||
         hipMalloc((void **)&st->gx_zero, 192 * 4) != hipSuccess) {
@@ -338,12 +370,48 @@ int ww_stream_reset(ww_streams *st, const int32_t *ids, int32_t n) {
   return WW_OK;
 }
 
+// Wait for a tick's posteriors by polling their {value, tick number} pairs in page-locked memory.  The runtime is asked only
+// now and then whether the stream has drained (a kernel that died would otherwise leave the host spinning for ever).
+static int st_poll_tags(ww_streams *st) {
+  ww_ctx *ctx = st->ctx;
+  const size_t n = st->expect.size();
+  const unsigned seq = st->seq;
+  size_t i = 0;
+  unsigned spins = 0;
+  while (i < n) {
+    const unsigned long long v = __atomic_load_n(st->h_tag + st->expect[i], __ATOMIC_ACQUIRE);
+    if ((unsigned)(v >> 32) == seq) {
+      ++i;
+      continue;
+    }
+    __builtin_ia32_pause();
+    if ((++spins & 0x3fffu) == 0) {
+      const hipError_t q = hipStreamQuery(ctx->stream);
+      if (q == hipErrorNotReady) continue;
+      if (q != hipSuccess) return ww_fail(ctx, WW_EHIP, "streaming tick failed: %s", hipGetErrorString(q));
+      for (size_t r = i; r < n; ++r)  // the stream has drained: what will ever arrive has
+        if ((unsigned)(__atomic_load_n(st->h_tag + st->expect[r], __ATOMIC_ACQUIRE) >> 32) != seq)
+          return ww_fail(ctx, WW_EHIP, "streaming tick %u completed without delivering posterior slot %d", seq, st->expect[r]);
+      break;
+    }
+  }
+  return WW_OK;
+}
+
 int ww_stream_step(ww_streams *st, const int16_t *frames, const uint8_t *is_speech, float *post, int32_t *n_post) {
   if (!st) return WW_EINVAL;
   ww_ctx *ctx = st->ctx;
   if (!frames || !is_speech || !post || !n_post) return ww_fail(ctx, WW_EINVAL, "NULL argument");
   WW_ON_DEVICE(ctx, dev_scope);  // the caller's current device is left as it was
-  const int S = st->S, hop = st->fp.hop;
+  const int S = st->S, hop = st->fp.hop, R = st->T + 1;
+  uint64_t tl[WW_STREAM_TL_PHASES + 1];
+  tl[0] = st_now_ns();
+  if (++st->seq == 0) st->seq = 1;  // (a tag of tick 0 is "never written")
+  // which copy of the page-locked input block this tick uses (the one-launch form alternates, see ww_streams)
+  const size_t cp = st->one_launch ? (size_t)(st->seq & 1) * st->pack_bytes : 0;
+  int16_t *h_frames = (int16_t *)((char *)st->h_frames + cp);
+  int32_t *h_ctl = (int32_t *)((char *)st->h_ctl + cp);
+  st->expect.clear();
   int nw = 0;
   for (int s = 0; s < S; ++s) {
     const int flags = is_speech[s] & 3;
@@ -352,85 +420,145 @@ int ww_stream_step(ww_streams *st, const int16_t *frames, const uint8_t *is_spee
       const int tot = st->fill[s] + WW_CHUNK;
       nf = tot >= WW_FFT_WINDOW ? (tot - WW_FFT_WINDOW) / hop + 1 : 0;
     }
-    st->h_ctl[s * 4 + 0] = st->fill[s];
-    st->h_ctl[s * 4 + 1] = nf;
-    st->h_ctl[s * 4 + 2] = flags;
-    st->h_ctl[s * 4 + 3] = st->pos[s];
     const int np = (flags & 1) && !(flags & 2) ? nf : 0;
     n_post[s] = np;
-    for (int k = 0; k < np; ++k) {
-      // the T rows that end at this tick's new row k are the contiguous block that starts at (pos + k + 2) % R
-      st->h_win_row[nw] = (int64_t)s * st->HR + (st->pos[s] + k + 2) % (st->T + 1);
-      st->h_win_valid[nw] = st->T;
-      st->h_win_aux[nw] = s * WW_STREAM_GXC + (st->rowq[s] + k + 1) % WW_STREAM_GXC;  // rows since the reset incl. this window's newest
-      ++nw;
+    h_ctl[s * 4 + 0] = st->fill[s];
+    h_ctl[s * 4 + 1] = nf;
+    if (st->one_launch) {
+      // workgroup 2 s + k of the tick's one kernel finds everything else out by itself
+      h_ctl[s * 4 + 2] = flags | (st->par[s] << 2);
+      h_ctl[s * 4 + 3] = st->pos[s] | (st->rowq[s] << 16);
+      for (int k = 0; k < np; ++k) st->expect.push_back(2 * s + k);
+      if (!(flags & 2)) st->par[s] ^= 1;
+    } else {
+      h_ctl[s * 4 + 2] = flags;
+      h_ctl[s * 4 + 3] = st->pos[s];
+      for (int k = 0; k < np; ++k) {
+        // the T rows that end at this tick's new row k are the contiguous block that starts at (pos + k + 2) % R
+        st->h_win_row[nw + k] = (int64_t)s * st->HR + (st->pos[s] + k + 2) % R;
+        st->h_win_valid[nw + k] = st->T;
+        st->h_win_aux[nw + k] = s * WW_STREAM_GXC + (st->rowq[s] + k + 1) % WW_STREAM_GXC;  // rows since the reset incl. this window's newest
+        st->expect.push_back(nw + k);
+      }
     }
+    nw += np;
     if (!(flags & 2)) st->fill[s] = st->fill[s] + WW_CHUNK - nf * hop;
-    st->pos[s] = (st->pos[s] + np) % (st->T + 1);
+    st->pos[s] = (st->pos[s] + np) % R;
     st->rowq[s] = (st->rowq[s] + np) % WW_STREAM_GXC;
   }
-  memcpy(st->h_frames, frames, (size_t)S * WW_CHUNK * 2);
+  tl[1] = st_now_ns();
+  memcpy(h_frames, frames, (size_t)S * WW_CHUNK * 2);
+  tl[2] = st_now_ns();
   const ww_model *m = st->model;
   const ww_filter_dev &f = m->filt;
-  stream_fe_args a = {};
-  // no copy engine on the tick's path: the kernel reads the pinned staging block itself
-  a.frames = (const int16_t *)(st->h_pack_dev + ((char *)st->h_frames - st->h_pack));
-  a.ctl = (const int32_t *)(st->h_pack_dev + ((char *)st->h_ctl - st->h_pack));
-  a.h_row = (const int64_t *)(st->h_pack_dev + ((char *)st->h_win_row - st->h_pack));
-  a.h_valid = (const int32_t *)(st->h_pack_dev + ((char *)st->h_win_valid - st->h_pack));
-  a.h_aux = (const int32_t *)(st->h_pack_dev + ((char *)st->h_win_aux - st->h_pack));
-  a.d_row = st->d_win_row; a.d_valid = st->d_win_valid; a.d_aux = st->d_win_aux; a.nw = nw; a.S = S;
-  a.ring = st->ring;
-  a.hist = st->hist; a.prev = st->prev;
-  a.T = st->T; a.F = st->F; a.HR = st->HR;
-  a.divisor = st->fp.pcm_divisor; a.clip = st->fp.clip; a.preemph = st->fp.pre_emphasis; a.hop = hop;
-  a.start = f.start; a.wpad = f.wpad; a.bias = f.bias;
-  a.n_mel = f.n_mel; a.floor_v = f.floor_v; a.log_off = f.log_off; a.scale = f.scale;
-  a.hann = f.hann; a.tw256 = f.tw256; a.tw512 = f.tw512;
-  {
-    ww_launch_scope scope(ctx, "stream_frontend_kernel");
-    if (st->fp.precise) {
-      size_t sm = 2 * FFT_LD * 16 + 2 * 260 * 4 + ST_WL_BYTES + ST_RING * 4 + WW_CHUNK * 2;
-      hipLaunchKernelGGL((stream_frontend_kernel<double>), dim3(S), dim3(128), sm, ctx->stream, a);
-    } else {
-      size_t sm = 2 * FFT_LD * 8 + 2 * 260 * 4 + ST_WL_BYTES + ST_RING * 4 + WW_CHUNK * 2;
-      hipLaunchKernelGGL((stream_frontend_kernel<float>), dim3(S), dim3(128), sm, ctx->stream, a);
-    }
-  }
-  WW_HIP(ctx, hipGetLastError());
-  if (nw && !st->incremental) {
-    // the per-window kernels' scratch under the model's options of THIS tick (ww_model_set_option may have lowered the
-    // front/tail threshold since the bank was created: the split form then wants nw x 19 x 192 floats)
-    const size_t need = m->kind == WW_KIND_CRNN ? ww_crnn_workspace(m, nw, false) : ww_wave_workspace(m, nw);
-    if (need > st->ws_bytes) {
-      WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      WW_HIP(ctx, hipFree(st->ws));
-      st->ws = nullptr;
-      st->ws_bytes = 0;
-      const size_t want = m->kind == WW_KIND_CRNN ? ww_crnn_workspace(m, 2 * S, false) : ww_wave_workspace(m, 2 * S);
-      if (hipMalloc(&st->ws, want > need ? want : need) != hipSuccess) return ww_fail(ctx, WW_ENOMEM, "cannot grow the model scratch of %d streams", S);
-      st->ws_bytes = want > need ? want : need;
-    }
-  }
-  if (nw) {
-    const float *d_hist = st->hist;
-    int rc = st->incremental
-                 ? ww_k_crnn_stream_forward(ctx, m, d_hist, (int64_t)S * st->HR, st->d_win_row, st->d_win_valid, st->d_win_aux, st->gxc, nw, st->h_out_dev)
-             : m->kind == WW_KIND_CRNN
-                 ? ww_k_crnn_forward(ctx, m, d_hist, (int64_t)S * st->HR, st->d_win_row, st->d_win_valid, 0, 0, 0, nw, st->ws, st->ws_bytes, st->h_out_dev, nullptr)
-                 : ww_k_wave_forward(ctx, m, d_hist, (int64_t)S * st->HR, st->d_win_row, st->d_win_valid, 0, 0, 0, nw, st->ws, st->ws_bytes, st->h_out_dev, nullptr);
-    if (rc) return rc;
-    // the head kernels store the few posteriors of a tick straight into pinned host memory: no device-to-host copy
-    // (a DMA operation of its own) between the last kernel and the host's wake-up
-  }
-  WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
   // posterior element: width-1 head -> [0]; width-2 head -> [1]  
   const int pidx = st->NO == 1 ? 0 : 1;
+  ww_tick_tag tag = {st->h_tag_dev, st->seq, pidx};
+  bool tagged = false;
+  if (st->one_launch) {
+    // ---- ONE launch: front end + incremental CRNN, workgroup 2 s + k = window k of stream s (crnn.hip)
+    ww_tick_fe fe = {};
+    fe.frames = (const int16_t *)(st->h_pack_dev + ((char *)h_frames - st->h_pack));
+    fe.ctl = (const int32_t *)(st->h_pack_dev + ((char *)h_ctl - st->h_pack));
+    fe.ring = st->ring; fe.prev = st->prev; fe.hist = st->hist;
+    fe.S = S; fe.HR = st->HR;
+    fe.divisor = st->fp.pcm_divisor; fe.clip = st->fp.clip; fe.preemph = st->fp.pre_emphasis; fe.hop = hop;
+    int rc = ww_k_crnn_tick(ctx, m, fe, st->fp.precise, st->gxc, tag);
+    if (rc) return rc;
+    tagged = true;
+    tl[3] = st_now_ns();
+  } else {
+    stream_fe_args a = {};
+    // no copy engine on the tick's path: the kernel reads the pinned staging block itself
+    a.frames = (const int16_t *)(st->h_pack_dev + ((char *)st->h_frames - st->h_pack));
+    a.ctl = (const int32_t *)(st->h_pack_dev + ((char *)st->h_ctl - st->h_pack));
+    a.h_row = (const int64_t *)(st->h_pack_dev + ((char *)st->h_win_row - st->h_pack));
+    a.h_valid = (const int32_t *)(st->h_pack_dev + ((char *)st->h_win_valid - st->h_pack));
+    a.h_aux = (const int32_t *)(st->h_pack_dev + ((char *)st->h_win_aux - st->h_pack));
+    a.d_row = st->d_win_row; a.d_valid = st->d_win_valid; a.d_aux = st->d_win_aux; a.nw = nw; a.S = S;
+    a.ring = st->ring;
+    a.hist = st->hist; a.prev = st->prev;
+    a.T = st->T; a.F = st->F; a.HR = st->HR;
+    a.divisor = st->fp.pcm_divisor; a.clip = st->fp.clip; a.preemph = st->fp.pre_emphasis; a.hop = hop;
+    a.start = f.start; a.wpad = f.wpad; a.bias = f.bias;
+    a.n_mel = f.n_mel; a.floor_v = f.floor_v; a.log_off = f.log_off; a.scale = f.scale;
+    a.hann = f.hann; a.tw256 = f.tw256; a.tw512 = f.tw512;
+    {
+      ww_launch_scope scope(ctx, "stream_frontend_kernel");
+      if (st->fp.precise) {
+        size_t sm = 2 * FFT_LD * 16 + 2 * 260 * 4 + ST_WL_BYTES + ST_RING * 4 + WW_CHUNK * 2;
+        hipLaunchKernelGGL((stream_frontend_kernel<double>), dim3(S), dim3(128), sm, ctx->stream, a);
+      } else {
+        size_t sm = 2 * FFT_LD * 8 + 2 * 260 * 4 + ST_WL_BYTES + ST_RING * 4 + WW_CHUNK * 2;
+        hipLaunchKernelGGL((stream_frontend_kernel<float>), dim3(S), dim3(128), sm, ctx->stream, a);
+      }
+    }
+    WW_HIP(ctx, hipGetLastError());
+    tl[3] = st_now_ns();
+    if (nw && !st->incremental) {
+      // the per-window kernels' scratch under the model's options of THIS tick (ww_model_set_option may have lowered the
+      // front/tail threshold since the bank was created: the split form then wants nw x 19 x 192 floats)
+      const size_t need = m->kind == WW_KIND_CRNN ? ww_crnn_workspace(m, nw, false) : ww_wave_workspace(m, nw);
+      if (need > st->ws_bytes) {
+        WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        WW_HIP(ctx, hipFree(st->ws));
+        st->ws = nullptr;
+        st->ws_bytes = 0;
+        const size_t want = m->kind == WW_KIND_CRNN ? ww_crnn_workspace(m, 2 * S, false) : ww_wave_workspace(m, 2 * S);
+        if (hipMalloc(&st->ws, want > need ? want : need) != hipSuccess) return ww_fail(ctx, WW_ENOMEM, "cannot grow the model scratch of %d streams", S);
+        st->ws_bytes = want > need ? want : need;
+      }
+    }
+    if (nw) {
+      // the heads store a tick's few posteriors straight into pinned host memory - as {value, tick number} pairs where the
+      // launch form writes them (every one-kernel form), else as rows of h_out: no device-to-host copy (a DMA operation of
+      // its own) between the last kernel and the host's wake-up
+      tagged = st->poll && (st->incremental || m->kind == WW_KIND_WAVENET || ww_crnn_forward_tags(m, nw));
+      const ww_tick_tag *tg = tagged ? &tag : nullptr;
+      const float *d_hist = st->hist;
+      int rc = st->incremental
+                   ? ww_k_crnn_stream_forward(ctx, m, d_hist, (int64_t)S * st->HR, st->d_win_row, st->d_win_valid, st->d_win_aux, st->gxc, nw, st->h_out_dev, tg)
+               : m->kind == WW_KIND_CRNN
+                   ? ww_k_crnn_forward(ctx, m, d_hist, (int64_t)S * st->HR, st->d_win_row, st->d_win_valid, 0, 0, 0, nw, st->ws, st->ws_bytes, st->h_out_dev, nullptr, tg)
+                   : ww_k_wave_forward(ctx, m, d_hist, (int64_t)S * st->HR, st->d_win_row, st->d_win_valid, 0, 0, 0, nw, st->ws, st->ws_bytes, st->h_out_dev, nullptr, tg);
+      if (rc) return rc;
+    }
+  }
+  tl[4] = st_now_ns();
+  if (tagged && st->poll && nw) {
+    int rc = st_poll_tags(st);
+    if (rc) return rc;
+  } else {
+    WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  tl[5] = st_now_ns();
   int w = 0;
   for (int s = 0; s < S; ++s) {
     post[s * 2] = 0.f;
     post[s * 2 + 1] = 0.f;
-    for (int k = 0; k < n_post[s]; ++k, ++w) post[s * 2 + k] = st->h_out[(size_t)w * st->NO + pidx];
+    for (int k = 0; k < n_post[s]; ++k, ++w) {
+      if (tagged) {
+        const unsigned bits = (unsigned)st->h_tag[st->one_launch ? 2 * s + k : w];
+        memcpy(&post[s * 2 + k], &bits, 4);
+      } else {
+        post[s * 2 + k] = st->h_out[(size_t)w * st->NO + pidx];
+      }
+    }
+  }
+  tl[6] = st_now_ns();
+  for (int i = 0; i < WW_STREAM_TL_PHASES; ++i) st->tl_ns[i] += tl[i + 1] - tl[i];
+  ++st->tl_ticks;
+  return WW_OK;
+}
+
+int ww_stream_timeline(ww_streams *st, double *mean_ns, int64_t *ticks, int32_t reset) {
+  if (!st) return WW_EINVAL;
+  if (ticks) *ticks = st->tl_ticks;
+  if (mean_ns)
+    for (int i = 0; i < WW_STREAM_TL_PHASES; ++i) mean_ns[i] = st->tl_ticks ? (double)st->tl_ns[i] / (double)st->tl_ticks : 0.0;
+  if (reset) {
+    memset(st->tl_ns, 0, sizeof(st->tl_ns));
+    st->tl_ticks = 0;
   }
   return WW_OK;
 }

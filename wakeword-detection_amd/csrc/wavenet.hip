@@ -84,6 +84,7 @@ struct wave_args {
   const float *enc_in;  // HEAD_ONLY: encoder output to run the detect graph on
   const uint4 *wpk;     // split-bf16 mode: parameter pages [NB][WV_PAGE_U4] (A operands of v_mfma_f32_16x16x32_bf16, then the vectors)
   long long *stamps;    // development (-DWV_STAMPS=1): [windows][12 waves][12] s_memtime inside block WV_STAMP_BLK of the split-bf16 loop
+  ww_tick_tag tag;      // streaming ticks: the posterior as a {value, tick number} pair instead of the row of `out`
 };
 
 #ifndef WV_STAMPS
@@ -809,7 +810,14 @@ __global__ __launch_bounds__(WV_NW * 64, WV_NW == 12 ? (SPLIT_BF16 ? WV_BF16_OCC
     float e = (tid < a.NOUT) ? expf(v - mx) : 0.f;
     float sum = e;
     for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o);
-    if (tid < a.NOUT) a.out[(size_t)w * a.NOUT + tid] = e / sum;
+    if (a.tag.slots) {  // a streaming tick: the posterior as ONE 8-byte {value, tick number} store the host polls (common.h)
+      if (tid == a.tag.pidx) {
+        const unsigned long long word = (unsigned long long)__float_as_uint(e / sum) | ((unsigned long long)a.tag.seq << 32);
+        __hip_atomic_store(a.tag.slots + w, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    } else if (tid < a.NOUT) {
+      a.out[(size_t)w * a.NOUT + tid] = e / sum;
+    }
   }
 }
 
@@ -817,7 +825,7 @@ size_t ww_wave_workspace(const ww_model *, int) { return 256; }
 
 int ww_k_wave_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *d_win_row,
                       const int32_t *d_win_valid, int64_t row0, int hop, int valid_const, int nw, void *, size_t, float *d_out,
-                      float *d_enc) {
+                      float *d_enc, const ww_tick_tag *tag) {
   if (nw <= 0) return WW_OK;
   const ww_wave_dev &v = m->wave;
   wave_args a = {};
@@ -834,6 +842,7 @@ int ww_k_wave_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
   a.w_gate4 = v.w_gate; a.b_gate = v.b_gate; a.w_rs4 = v.w_rs; a.b_rs = v.b_rs;
   a.d_w1_4 = v.d_w1; a.d_b1 = v.d_b1; a.d_w2_4 = v.d_w2; a.d_b2 = v.d_b2;
   a.out = d_out; a.enc = d_enc;
+  if (tag) a.tag = *tag;
   ww_launch_scope scope(ctx, m->precision == WW_PRECISION_BF16X3 ? "wavenet_kernel<bf16x3>" : "wavenet_kernel");
   a.wpk = (const uint4 *)v.wpk;
 #if WV_STAMPS

@@ -23,7 +23,8 @@ WW_OK, WW_EINVAL, WW_EBLOB, WW_EHIP, WW_ENOMEM, WW_ESTATE, WW_ENODEVICE = 0, -1,
 KIND_CRNN, KIND_WAVENET = 1, 2
 PRECISION_FP32, PRECISION_BF16X3 = 0, 1
 OPT_CRNN_SPLIT_AT, OPT_CRNN_SLIDE_MIN, OPT_CRNN_TAIL_MFMA, OPT_WAVENET_ROWMAJOR = 1, 2, 3, 4
-STREAM_FULL_RECOMPUTE = 1
+STREAM_FULL_RECOMPUTE, STREAM_TWO_LAUNCH, STREAM_SYNC_WAIT = 1, 2, 4
+ABI = 4  # include/wwhip.h: WW_ABI - the signatures this binding was written against
 
 
 class ModelInfo(C.Structure):
@@ -79,6 +80,7 @@ SYMBOLS: Dict[str, tuple] = {
     "ww_stream_destroy": (C.c_int, [_vp]),
     "ww_stream_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "ww_stream_reset": (C.c_int, [_vp, _vp, _i32]),
+    "ww_stream_timeline": (C.c_int, [_vp, _vp, _P(_i64), _i32]),
     "ww_superframe_smooth": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _i32, _vp, _vp]),
     "ww_far_frr": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _f64, _f64, _vp, _vp, _vp, _vp]),
 }
@@ -150,9 +152,21 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        _check_abi(lib)
         _lib = lib
         _check_runtime(lib)
         return lib
+
+
+def _check_abi(lib: C.CDLL) -> None:
+    """``ww_version()`` carries "ABI <n>": a library of another ABI (a stale ``WWHIP_LIB`` variant, say) has entry points with
+    other signatures behind the same names - refuse it here instead of crashing inside the first call that differs."""
+    import re
+    text = (lib.ww_version() or b"").decode("utf-8", "replace")
+    m = re.search(r"ABI (\d+)", text)
+    if m is None or int(m.group(1)) != ABI:
+        raise RuntimeError(f"{LIB_PATH} reports {text!r}; this binding needs ABI {ABI} (include/wwhip.h: WW_ABI). Rebuild it "
+                           "with `python __graft_entry__.py`.")
 
 
 def runtime_info() -> Dict[str, int]:

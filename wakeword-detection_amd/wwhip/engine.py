@@ -245,35 +245,63 @@ class StreamBank:
     """S device-resident streams advanced 20 ms per :meth:`step` (``ww_stream_*``)."""
 
     def __init__(self, engine: Engine, n_streams: int, fp: Optional[_lib.FrontendParams] = None,
-                 full_recompute: bool = False) -> None:
+                 full_recompute: bool = False, two_launch: bool = False, sync_wait: bool = False) -> None:
         """``full_recompute``: every streaming CRNN window recomputed from its mel rows (``WW_STREAM_FULL_RECOMPUTE``)
-        instead of the incremental kernel."""
+        instead of the incremental kernel.  ``two_launch``: the incremental CRNN's tick as a front-end kernel + a model kernel
+        (``WW_STREAM_TWO_LAUNCH``; default: ONE launch per tick).  ``sync_wait``: wait for a tick with ``hipStreamSynchronize``
+        instead of polling its posteriors in page-locked memory (``WW_STREAM_SYNC_WAIT``).  Same bits in every form."""
         self.engine = engine
         self.S = int(n_streams)
         self._lib = _lib.load()
         fp = fp or frontend_params()
         h = C.c_void_p()
-        _lib.raise_for(self._lib.ww_stream_create(engine.ctx.handle, engine.handle, self.S, C.byref(fp),
-                                                  _lib.STREAM_FULL_RECOMPUTE if full_recompute else 0, C.byref(h)),
+        flags = ((_lib.STREAM_FULL_RECOMPUTE if full_recompute else 0) | (_lib.STREAM_TWO_LAUNCH if two_launch else 0)
+                 | (_lib.STREAM_SYNC_WAIT if sync_wait else 0))
+        _lib.raise_for(self._lib.ww_stream_create(engine.ctx.handle, engine.handle, self.S, C.byref(fp), flags, C.byref(h)),
                        engine.ctx.handle)
         self._h = h
         _lib.register("streams", self)
         self._post = np.zeros((self.S, 2), np.float32)
         self._n = np.zeros(self.S, np.int32)
+        self._flags = np.zeros(self.S, np.uint8)
+        # a tick is host-paced (spokestack/pipeline.py:25-28): the addresses of the bank's own arrays are taken once, not per call
+        self._p_post, self._p_n, self._p_flags = (C.c_void_p(a.ctypes.data) for a in (self._post, self._n, self._flags))
+        self._step = self._lib.ww_stream_step
+        self._shape = (self.S, 320)
 
     def step(self, frames: np.ndarray, is_speech: np.ndarray, is_active: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
-        f = np.ascontiguousarray(frames, dtype=np.int16)
-        if f.shape != (self.S, 320):
+        f = frames
+        if not (type(f) is np.ndarray and f.dtype == np.int16 and f.flags.c_contiguous):
+            f = np.ascontiguousarray(frames, dtype=np.int16)
+        if f.shape != self._shape:
             raise ValueError(f"frames must be [{self.S}, 320] int16")
-        flags = np.ascontiguousarray(is_speech, dtype=np.uint8).ravel() & 1
-        if is_active is not None:
-            flags = flags | ((np.ascontiguousarray(is_active, dtype=np.uint8).ravel() & 1) << 1)
-        flags = np.ascontiguousarray(flags, dtype=np.uint8)
-        if flags.size != self.S:
+        sp = is_speech
+        if not (type(sp) is np.ndarray and sp.dtype == np.uint8 and sp.ndim == 1):
+            sp = np.ascontiguousarray(is_speech, dtype=np.uint8).ravel()
+        if sp.size != self.S:
             raise ValueError("is_speech must have one entry per stream")
-        _lib.raise_for(self._lib.ww_stream_step(self._h, _lib.ptr(f), _lib.ptr(flags), _lib.ptr(self._post), _lib.ptr(self._n)),
-                       self.engine.ctx.handle)
+        np.bitwise_and(sp, 1, out=self._flags)
+        if is_active is not None:
+            self._flags |= (np.ascontiguousarray(is_active, dtype=np.uint8).ravel() & 1) << 1
+        try:
+            pf = C.addressof(C.c_char.from_buffer(f))  # (a third of the cost of f.ctypes.data_as)
+        except (TypeError, ValueError):                 # a read-only array
+            pf = f.ctypes.data
+        rc = self._step(self._h, pf, self._p_flags, self._p_post, self._p_n)
+        if rc:
+            _lib.raise_for(rc, self.engine.ctx.handle)
         return self._post.copy(), self._n.copy()  # the caller owns what it gets (like TFLiteModel's get_tensor copies)
+
+    TIMELINE_PHASES = ("plan", "frames_in", "launch_1", "launch_2", "wait", "copy_out")
+
+    def timeline(self, reset: bool = False) -> dict:
+        """Mean host-side microseconds per phase of ``ww_stream_step`` since the last reset (``ww_stream_timeline``)."""
+        ns = (C.c_double * len(self.TIMELINE_PHASES))()
+        ticks = C.c_int64(0)
+        _lib.raise_for(self._lib.ww_stream_timeline(self._h, ns, C.byref(ticks), int(reset)), self.engine.ctx.handle)
+        out = {k: ns[i] * 1e-3 for i, k in enumerate(self.TIMELINE_PHASES)}
+        out["ticks"] = int(ticks.value)
+        return out
 
     def reset(self, ids: Optional[Sequence[int]] = None) -> None:
         if ids is None:
