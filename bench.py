@@ -130,7 +130,8 @@ def kernel_work(eng, n_clips):
     out = {}
     fe_bytes = n_clips * (SAMPLES * 2 + nf * 40 * 4)
     fe_flops = n_clips * nf * 13.9e3
-    out["logmel_kernel<f64>"] = ("hbm", fe_bytes, fe_flops)
+    out["logmel_rows_kernel"] = ("hbm", fe_bytes, fe_flops)  # the fp64 front end (round 4's kernel, under its own name since round 5)
+    out["logmel_kernel<f64>"] = ("hbm", fe_bytes, fe_flops)  # (-DWW_FE_OLD=1 builds: rounds 1-3's fp64 kernel)
     out["logmel_kernel<f32>"] = ("hbm", fe_bytes, fe_flops)
     if eng.is_crnn:
         c = eng.bundle.crnn
@@ -410,7 +411,7 @@ def roofline_of(eng, prof, clips, fast_frontend, step_s=None):
                 every[name]["fp64_valu"] = {"achieved_TFLOPs": fl / t / 1e12, "peak_TFLOPs": PEAK_F64_VALU / 1e12,
                                             "frac": fl / t / PEAK_F64_VALU,
                                             "note": "13.9 kFLOP per frame (SURVEY 8d), mostly adds: half of the FMA peak is the ceiling; "
-                                                    "vector ALUs 58 % busy over the kernel (profiles/r02/sq_logmel_256_*.txt)"}
+                                                    "vector ALU 55 % busy over the kernel (profiles/r04/pmc_counters.json: SQ_ACTIVE_INST_VALU x 3.7 cycles per SIMD over SQ_BUSY_CYCLES)"}
         elif name.endswith("<bf16x3>"):
             every[name] = {"bound": "mfma", "achieved": 3.0 * fl / t / 1e12, "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s",
                            "frac": 3.0 * fl / t / PEAK_BF16_MFMA}
@@ -466,38 +467,88 @@ def eval_at_scale(torch, np, dist, comm_dev, rank, world, eng, n_wake, with_orac
     other clips joined into ONE ~1.2 h stream (concatenate_FA joins exactly num_wakewords of them, :299) - sharded over the
     ranks, with where the time goes: host phases (plan, slicing = staging the samples, upload, gather, sweep; staging runs beside the kernels) against the
     kernels' own time (HIP events, ww_profile_read).  Next to it the C oracle on a bounded sample of the same flow."""
-    from wwhip.evaluate import synth_testset_scaled, evaluate_reference_flow_sharded
+    from wwhip.evaluate import synth_testset_scaled, evaluate_reference_flow_sharded, SHARE_ONLY
     clips, labels = synth_testset_scaled(n_wake, n_wake)
-    best = None
-    for attempt in range(3):  # the first pass sizes staging buffers and workspaces; the faster of the next two is reported
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        tm = {}
-        t0 = time.perf_counter()
-        r = evaluate_reference_flow_sharded(eng, clips, labels, rank, world, comm_dev, timing=tm)
-        el = time.perf_counter() - t0
-        if attempt and (best is None or el < best[0]):
-            best = (el, tm, r)
+    SERIAL = ("prepare", "plan", "gather", "sweep", "d2h", "profile_read")  # what every rank repeats whatever the world size
+
+    def passes(cl, lb, n, rk, wd, comm):
+        runs = []
+        for attempt in range(n + 1):  # the first pass sizes staging buffers and workspaces
+            if dist is not None and comm != SHARE_ONLY:
+                dist.barrier()
+            torch.cuda.synchronize()
+            tm = {}
+            t0 = time.perf_counter()
+            r = evaluate_reference_flow_sharded(eng, cl, lb, rk, wd, comm, timing=tm)
+            el = time.perf_counter() - t0
+            if attempt:
+                runs.append((el, tm, r))
+        runs.sort(key=lambda x: x[0])
+        return runs
+
+    def describe(runs, cl, n_w):
+        el, tm, r = runs[0]
+        audio_s = (sum(len(c) for c in cl[:n_w]) + r["hours"] * 3600 * 16000) / 16000.0
+        ph_ms = {k: v * 1e3 for k, v in tm.items() if isinstance(v, float) and k != "device_ms"}
+        serial = sum(ph_ms.get(k, 0.0) for k in SERIAL)
+        return r, audio_s, {
+            "seconds_host_pcm_in_to_curves_out": el, "median_seconds": runs[len(runs) // 2][0], "passes": len(runs),
+            "audio_hours": audio_s / 3600.0, "audio_frames_per_s": audio_s * 100.0 / el, "realtime_factor": audio_s / el,
+            "windows": r["windows"], "device_ms": tm["device_ms"], "kernels_ms": tm.get("kernels_ms"), "host_phases_ms": ph_ms,
+            "chunks": tm.get("chunks"), "host_share": 1.0 - tm["device_ms"] * 1e-3 / el,
+            "serial_ms": serial,
+            "predicted_seconds": {str(w): serial * 1e-3 + (el - serial * 1e-3) / w for w in (2, 4, 8)},
+            "predicted_efficiency_8_ranks": el / (8 * (serial * 1e-3 + (el - serial * 1e-3) / 8))}
+
+    runs = passes(clips, labels, 3, rank, world, comm_dev)
+    one_of_8 = x16 = x16_of_8 = None
+    if world == 1:
+        # what ONE rank of eight costs, measured: rank 0's share of a world of 8 on this GPU, no communicator (its peers' slots
+        # stay zero; the posterior gather - one RCCL all_gather per leg, latency - is what this leaves out)
+        one_of_8 = passes(clips, labels, 3, 0, 8, SHARE_ONLY)
+        # the same flow over 16 x the clips (each clip object referenced 16 times: ~38 h of audio, 5.7 GB uploaded): a device
+        # time large enough to show a curve
+        clips16 = clips[:n_wake] * 16 + clips[n_wake:] * 16
+        labels16 = np.concatenate((np.ones(16 * n_wake, np.uint8), np.zeros(16 * (len(clips) - n_wake), np.uint8)))
+        x16 = passes(clips16, labels16, 2, 0, 1, None)
+        x16_of_8 = passes(clips16, labels16, 2, 0, 8, SHARE_ONLY)
     if rank != 0:
         return None
-    el, tm, r = best
-    audio_s = (sum(len(c) for c in clips[:n_wake]) + r["hours"] * 3600 * 16000) / 16000.0
+    r, audio_s, out = describe(runs, clips, n_wake)
+    el = out["seconds_host_pcm_in_to_curves_out"]
     out = {"workload": f"{n_wake} wake-word clips (file by file, C2 carry) + the first {n_wake} other clips joined by 100 ms of silence "
                        f"into one {r['hours']:.2f} h stream; synthetic clips 0.8-2.5 s (float32 generator, seed 4321), CRNN_softmax",
-           "world_size": world, "seconds_host_pcm_in_to_curves_out": el, "audio_hours": audio_s / 3600.0,
-           "audio_frames_per_s": audio_s * 100.0 / el, "realtime_factor": audio_s / el, "windows": r["windows"],
-           "device_ms": tm["device_ms"], "kernels_ms": tm.get("kernels_ms"),
-           "host_phases_ms": {k: v * 1e3 for k, v in tm.items() if isinstance(v, float) and k != "device_ms"},
-           "chunks": tm.get("chunks"),
-           "host_share": 1.0 - tm["device_ms"] * 1e-3 / el,
-           "note": "rank 0's clock and phases (every rank stages, uploads and runs only its share); host_share = 1 - device_ms / "
+           "world_size": world, **out,
+           "note": "rank 0's clock and phases of the FASTEST of three passes (median beside it); every rank stages, uploads and runs "
+                   "only its share; host_share = 1 - device_ms / "
                    "seconds; the share goes to the GPU in chunks of up to ~26 min of audio: this thread plans a chunk (prepare / plan / slicing: "
                    "which samples of which clips), submits it to the library's uploader (ww_uploader: its threads write the chunk "
                    "into page-locked memory once and start the upload) and enqueues the kernels over the chunk before, behind its "
-                   "upload (upload_wait = waiting for the uploader, device_wall = launches + the final wait for the GPU)",
+                   "upload (upload_wait = waiting for the uploader, device_wall = launches + the final wait for the GPU).  "
+                   "serial_ms = the phases every rank repeats whatever the world size (prepare + plan: lengths of ALL clips, every "
+                   "rank's share; gather; sweep; d2h; profile_read); predicted_seconds[w] = serial + (seconds - serial) / w from "
+                   "THIS pass's phases (no collective latency in it)",
            "frr_at_0.5_fa_per_hour": r["frr_at_0.5_fa_per_hour"], "fa_count_at_threshold_0.5": int(r["fa_count"][0]),
            "posterior_checksum": r["posterior_checksum"]}
+    if one_of_8 is not None:
+        _, _, d8 = describe(one_of_8, clips, n_wake)
+        out["one_rank_of_8_measured"] = {
+            "seconds": d8["seconds_host_pcm_in_to_curves_out"], "median_seconds": d8["median_seconds"], "device_ms": d8["device_ms"],
+            "host_phases_ms": d8["host_phases_ms"], "chunks": d8["chunks"],
+            "speedup_vs_one_rank": el / d8["seconds_host_pcm_in_to_curves_out"],
+            "efficiency_8_ranks": el / (8 * d8["seconds_host_pcm_in_to_curves_out"]),
+            "note": "rank 0's share of a world of 8 run alone on this GPU (no communicator: the two posterior all_gathers are "
+                    "left out, their latency is timed_regions.collective_ms of an N > 1 line); the longest-first deal and the "
+                    "equal posterior ranges make every rank's share the same size within a clip"}
+        r16, _, d16 = describe(x16, clips16, 16 * n_wake)
+        _, _, d16_8 = describe(x16_of_8, clips16, 16 * n_wake)
+        out["at_scale_x16"] = {
+            "workload": f"the same flow over 16 x the clips ({16 * n_wake} + {16 * n_wake}; every clip object referenced 16 times), "
+                        f"{r16['hours']:.1f} h joined stream", **d16,
+            "one_rank_of_8_measured": {"seconds": d16_8["seconds_host_pcm_in_to_curves_out"], "device_ms": d16_8["device_ms"],
+                                       "host_phases_ms": d16_8["host_phases_ms"],
+                                       "speedup_vs_one_rank": d16["seconds_host_pcm_in_to_curves_out"] / d16_8["seconds_host_pcm_in_to_curves_out"],
+                                       "efficiency_8_ranks": d16["seconds_host_pcm_in_to_curves_out"] / (8 * d16_8["seconds_host_pcm_in_to_curves_out"])}}
     if with_oracle:
         # the C oracle (the checker) on a bounded sample of the same flow: the first 32 wake-word clips and the first 120 s of
         # the joined stream, on the granted cores; its time scaled by the audio ratio is what the whole flow would take
@@ -543,20 +594,20 @@ def eval_leg(torch, np, dist, comm_dev, rank, world, local_rank, n_clips, with_o
     clips, labels = synth_testset(n_clips)
 
     def timed(fn):
-        best = None
-        for attempt in range(4):  # the first pass sizes page-locked slots and workspaces; the fastest of the next three is reported
+        els = []
+        for attempt in range(6):  # the first pass sizes page-locked slots and workspaces; the fastest AND the median of the next five
             if dist is not None:  # (a 3 ms job on a shared host: single passes were seen between 2.4 and 10 ms box to box)
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             r = fn()
-            el = time.perf_counter() - t0
-            if attempt and (best is None or el < best):
-                best = el
-        return r, best
+            if attempt:
+                els.append(time.perf_counter() - t0)
+        els.sort()
+        return r, els[0], els[len(els) // 2]
 
-    r, el = timed(lambda: evaluate_reference_flow_sharded(eng, clips, labels, rank, world, comm_dev))
-    pc, el_pc = timed(lambda: evaluate_testset_sharded(eng, clips, labels, rank, world, comm_dev))
+    r, el, el_med = timed(lambda: evaluate_reference_flow_sharded(eng, clips, labels, rank, world, comm_dev))
+    pc, el_pc, el_pc_med = timed(lambda: evaluate_testset_sharded(eng, clips, labels, rank, world, comm_dev))
     fast = evaluate_reference_flow_sharded(eng, clips, labels, rank, world, comm_dev, precise=False)  # fp32-FFT front end
     at_scale = eval_at_scale(torch, np, dist, comm_dev, rank, world, eng, n_scale, with_oracle) if n_scale > 0 else None
     if rank != 0:
@@ -577,7 +628,8 @@ def eval_leg(torch, np, dist, comm_dev, rank, world, local_rank, n_clips, with_o
            "sharding": "positives: whole files longest-first round-robin; negative stream: contiguous posterior ranges "
                        "(each rank re-reads a T-2-frame overlap); posterior all_gather; rank 0 sweeps",
            "world_size": world, "num_wakewords": r["num_wakewords"], "negative_clips_joined": r["negative_clips_joined"],
-           "seconds_host_pcm_in_to_curves_out": el, "timing": "fastest of three passes after one warm-up pass", "audio_frames_per_s": audio_frames / el,
+           "seconds_host_pcm_in_to_curves_out": el, "median_seconds": el_med,
+           "timing": "fastest (seconds) and median (median_seconds) of five passes after one warm-up pass", "audio_frames_per_s": audio_frames / el,
            "windows": r["windows"], "negative_hours": r["hours"],
            "frr_at_0.5_fa_per_hour": r["frr_at_0.5_fa_per_hour"], "fa_count_at_threshold_0.5": int(r["fa_count"][0]),
            "posterior_checksum": r["posterior_checksum"],
@@ -589,7 +641,7 @@ def eval_leg(torch, np, dist, comm_dev, rank, world, local_rank, n_clips, with_o
                                              "reference's float64 STFT): FA counts and FRR array against the default profile's"},
            "per_clip_variant": {"note": "round 2's stand-in: every clip evaluated on its own (ring reset, 0.5 s of zeros each side), ALL "
                                         "negatives concatenated as posteriors, + one end-padded window per clip (evaluate_tf_lite_opts.py)",
-                                "seconds_host_pcm_in_to_curves_out": el_pc, "windows": pc["windows"], "negative_hours": pc["hours"],
+                                "seconds_host_pcm_in_to_curves_out": el_pc, "median_seconds": el_pc_med, "windows": pc["windows"], "negative_hours": pc["hours"],
                                 "audio_frames_per_s": sum((len(c) + 16000) // 160 for c in clips) / el_pc,
                                 "frr_at_0.5_fa_per_hour": pc["frr_at_0.5_fa_per_hour"], "fa_count_at_threshold_0.5": int(pc["fa_count"][0]),
                                 "one_window_accuracy": pc["one_window_accuracy"], "posterior_checksum": pc["posterior_checksum"]},

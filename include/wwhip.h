@@ -292,6 +292,22 @@ int ww_far_frr(ww_ctx *ctx, const float *pos, int64_t n_pos, const float *neg, i
                const double *thr, int32_t n_thr, double num_wakewords, double hours, double *frr,
                double *fa_per_h, int64_t *fa_count, double *smoothed);
 
+/* The same sweep over posteriors that are already on the context's device (the sharded evaluators: the values a rank's
+ * kernels produced, or what the posterior gather delivered) - d_pos / d_neg are device pointers, nothing but the thresholds goes
+ * up and nothing but the n_thr counters comes back; d_smoothed (device, [n_neg] fp64) may be NULL.  Returns after the
+ * counters are on the host. */
+int ww_far_frr_dev(ww_ctx *ctx, const float *d_pos, int64_t n_pos, const float *d_neg, int64_t n_neg, int32_t win,
+                   const double *thr, int32_t n_thr, double num_wakewords, double hours, double *frr, double *fa_per_h,
+                   int64_t *fa_count, double *d_smoothed);
+
+/* Posterior pick + per-clip reduction on the device (utils/evaluate_models.py:80,86: element [1] of a detect row - pidx per
+ * SURVEY quirk C1 -; :98-99: the max over a wake-word clip's windows).  d_rows: [n][n_out] detect rows as the model entry points
+ * leave them.  d_seg_offs == NULL: d_out[i] = d_rows[i][pidx] for all n rows (:105-106, the negative stream: every window
+ * counts); otherwise d_seg_offs is a device table of n_seg + 1 ascending row offsets and d_out[s] = max over rows
+ * [d_seg_offs[s], d_seg_offs[s + 1]).  Enqueues on the context's stream, no synchronisation. */
+int ww_posterior_pick_dev(ww_ctx *ctx, const float *d_rows, int64_t n, int32_t n_out, int32_t pidx, const int64_t *d_seg_offs,
+                          int64_t n_seg, float *d_out);
+
 /* ---- superframe shortest-path smoothing -------------------------------------------------
  * Replaces wwdetect/wfst.py:17-71 `smooth()` (pynini 2-state x T lattice, tropical shortest path) as
  * wired in utils/CRNN_files/tflite.py:252-263 (superframe of 10 posteriors; trigger if the best path

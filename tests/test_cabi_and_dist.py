@@ -79,6 +79,22 @@ def test_no_gpu_means_loud_failure():
         _lib.Context(0)
 
 
+def test_a_device_index_that_does_not_exist_is_an_error_message_not_an_abort():
+    """The first lines of the multi-device path that can run anywhere: a context on a device index at or past the visible
+    count (a rank whose LOCAL_RANK exceeds the node's GPUs) fails with the library's own text - "no HIP device visible" in a
+    container without a GPU, "device N out of range" on a GPU box - never with a HIP abort; negative indices likewise."""
+    import torch
+    from wwhip import _lib
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    for dev in (n, n + 7, -1):
+        if n == 0:
+            with pytest.raises(RuntimeError, match="no HIP device visible"):
+                _lib.Context(dev)
+        else:
+            with pytest.raises(ValueError, match=r"device -?\d+ out of range \(0\.\.%d\)" % (n - 1)):
+                _lib.Context(dev)
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "wakeword-detection_amd")
     for d, _, files in os.walk(pkg):
@@ -159,9 +175,15 @@ for eval_type in ("false_negatives", "false_accepts"):
     p2 = job.plan
     assert (p2.n_win > 0).all()
     assert [tuple(r) for r in job.mine] == [tuple(r) for r in p2.shares(eval_type, world)[rank]]
-    assert [r for ch in job.chunks for r in ch.runs] == list(job.mine)          # the share, cut into chunks, nothing lost
+    assert [tuple(r) for ch in job.chunks for r in ch.runs.tolist()] == [tuple(r) for r in job.mine.tolist()]  # the share, cut into chunks, nothing lost
     name = lambda k, i0, i1: (p2.F[k] + 2 * np.arange(i0, i1)) * 0.25           # a "posterior" that names its first global frame
-    job.vals = np.concatenate([name(k, i0, i1) for k, i0, i1 in job.mine]).astype(np.float32) if job.mine else np.zeros(0, np.float32)
+    # what a rank contributes (the device picks it: ww_posterior_pick_dev): every window's value for the negative stream, the
+    # maximum of every run for the wake-word clips
+    mine = [name(k, i0, i1) for k, i0, i1 in job.mine]
+    if eval_type == "false_negatives":
+        mine = [np.array([v.max()]) for v in mine]
+    job.vals = np.concatenate(mine).astype(np.float32) if len(mine) else np.zeros(0, np.float32)
+    assert len(job.vals) == job.n_values(job.mine)
     got = job.finish(None, E._Phases(None), True)
     every = [name(k, 0, p2.n_win[k]).astype(np.float32) for k in range(len(lens))]
     want2 = np.array([v.max() for v in every], np.float32) if eval_type == "false_negatives" else np.concatenate(every)
@@ -208,6 +230,26 @@ def test_default_context_fails_fast_without_a_gpu(tmp_path):
             "try:\n    _lib.default_context(0)\nexcept RuntimeError as e:\n    print('raised', e)\n" % (ROOT, os.path.join(ROOT, "wakeword-detection_amd")))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=90)
     assert r.returncode == 0 and "raised" in r.stdout, r.stdout + r.stderr
+
+
+def test_a_file_shorter_than_its_planned_length_is_refused():
+    """The copy runs of a chunk take their counts from the plan and hand raw addresses to the library's copy threads: a
+    plan built on more samples than a file holds (a truncated wav whose header promises more, a caller's own `lengths`) must
+    be refused on the host - StreamPlan([30000]) over a 20,000-sample array used to mean a 20,000-byte read past its end."""
+    import types
+    from wwhip import evaluate as E
+    plan = E.StreamPlan([30000], 151)
+    ch = E._Chunk()
+    ch.runs = plan.shares("false_negatives", 1)[0]
+    ch.n_win = np.array([i1 - i0 for _, i0, i1 in ch.runs], np.int64)
+    ch.host_pieces = None
+    for dtype in (np.int16, np.float32):
+        ch.job = types.SimpleNamespace(plan=plan, load=lambda f: np.zeros(20000, dtype))
+        with pytest.raises(ValueError, match="20000 samples"):
+            E._prep_chunk(ch, E._Phases(None))
+    ch.job = types.SimpleNamespace(plan=plan, load=lambda f: np.zeros(30000, np.int16))
+    E._prep_chunk(ch, E._Phases(None))
+    assert int(ch.copy[2].sum()) == 30000
 
 
 def test_host_staging_equals_the_padded_stream():

@@ -644,6 +644,49 @@ def test_stream_incremental_kernel_matches_full_recompute(assets, name):
         e.close()
 
 
+def test_posterior_pick_and_sweep_on_the_device(assets):
+    """a13 / a14 / a15 / a16 without leaving the device (round 5: what the sharded evaluators keep of a chunk and how they
+    finish): ww_posterior_pick_dev = element [posterior_index] of detect rows, as they are or as the maximum of each run of
+    windows (utils/evaluate_models.py:80,98-99) - bit for bit against NumPy, runs of one window and ragged runs included; and
+    ww_far_frr_dev over device pointers = ww_far_frr over host arrays = the reference's loop restated in oracle/numpy_ref.py."""
+    import torch
+    from wwhip.engine import Engine
+    from oracle import numpy_ref as NR
+    rng = np.random.default_rng(8)
+    for name in ("CRNN_softmax", "CRNN"):
+        e = Engine(os.path.join(assets, name))
+        try:
+            n = 50_000
+            rows = rng.uniform(0, 1, (n, e.n_out)).astype(np.float32)
+            lens = rng.integers(1, 120, 2000)
+            lens = lens[np.cumsum(lens) <= n]
+            offs = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+            d_rows, d_offs = torch.from_numpy(rows).cuda(), torch.from_numpy(offs).cuda()
+            d_all, d_max = torch.empty(n, device="cuda"), torch.empty(len(lens), device="cuda")
+            torch.cuda.synchronize()
+            e.posterior_pick_dev(d_rows.data_ptr(), n, d_all.data_ptr())
+            e.posterior_pick_dev(d_rows.data_ptr(), n, d_max.data_ptr(), d_offs.data_ptr(), len(lens))
+            e.ctx.synchronize()
+            col = rows[:, e.posterior_index]
+            np.testing.assert_array_equal(d_all.cpu().numpy(), col)
+            np.testing.assert_array_equal(d_max.cpu().numpy(), np.maximum.reduceat(col, offs[:-1]))
+            # the sweep over device pointers
+            pos = rng.uniform(0.3, 1, 700).astype(np.float32)
+            neg = np.clip(rng.normal(0.45, 0.2, 12_000), 0, 1).astype(np.float32)
+            thr = np.arange(0.3, 0.99999, 0.005)
+            d_pos, d_neg = torch.from_numpy(pos).cuda(), torch.from_numpy(neg).cuda()
+            torch.cuda.synchronize()
+            got = e.far_frr_dev(d_pos.data_ptr(), len(pos), d_neg.data_ptr(), len(neg), thr, 700.0, 1.25)
+            want = e.far_frr(pos, neg, thr, 700.0, 1.25)
+            ref = NR.far_frr(pos, neg, 700, 1.25, thr)
+            for g, w in zip(got, want):
+                np.testing.assert_array_equal(g, w)
+            np.testing.assert_array_equal(got[2], ref[2])   # FA counts: the reference's loop
+            assert got[2].max() > 50
+        finally:
+            e.close()
+
+
 @pytest.mark.parametrize("name,precise", [("CRNN", True), ("CRNN_softmax", True), ("CRNN", False)])
 def test_one_launch_tick_equals_the_two_launch_form(assets, name, precise):
     """Round 5: a tick of the incremental CRNN bank is ONE launch - the front end of a stream's new frames runs inside the

@@ -245,6 +245,77 @@ def test_stream_plan_matches_reference_loop_over_files():
             assert max(sizes) - min(sizes) <= 1                     # contiguous ranges of equal size (dist.split_stream)
 
 
+def test_shares_and_chunk_cuts_as_arrays_equal_the_per_file_loops():
+    """Round 5: every rank works out every rank's share and cuts its own into chunks WITHOUT a Python-level pass over the files
+    (`StreamPlan.shares_arr`, `_PosteriorJob._cut`: the part of an evaluation call that no rank count divides).  Against the
+    loops they replace, restated here: the longest-first round-robin deal / the contiguous posterior ranges walked file by
+    file, and the run-by-run chunk grouping - over random file lists incl. files without a window, several world sizes and
+    first-chunk sizes."""
+    from wwhip import dist as D
+    rng = np.random.default_rng(31)
+
+    def shares_loop(plan, eval_type, world):
+        out = [[] for _ in range(world)]
+        if eval_type == "false_negatives":
+            nw = plan.n_win.tolist()
+            for r, files in enumerate(D.shard_by_length(plan.lengths.tolist(), world)):
+                out[r] = [(k, 0, nw[k]) for k in sorted(files) if nw[k] > 0]
+        else:
+            for r, (lo, hi) in enumerate(D.split_stream(plan.total, world)):
+                k = int(np.searchsorted(plan.offs, lo, side="right")) - 1
+                while lo < hi:
+                    end = min(hi, int(plan.offs[k + 1]))
+                    if end > lo:
+                        out[r].append((k, lo - int(plan.offs[k]), end - int(plan.offs[k])))
+                    lo, k = end, k + 1
+        return out
+
+    def cut_loop(plan, runs, first):
+        per_win = 160 * plan.hop
+        out, cur, cur_n = [], [], 0
+        size = max(min(first, E._CHUNK_SAMPLES), per_win)
+        for k, i0, i1 in runs:
+            while i1 - i0 > (size + size // 2) // per_win:
+                if cur:
+                    out.append(cur); cur, cur_n = [], 0; size = min(2 * size, E._CHUNK_SAMPLES)
+                w = max(size // per_win, 1)
+                out.append([(k, i0, i0 + w)]); size = min(2 * size, E._CHUNK_SAMPLES)
+                i0 += w
+            n = 160 * (plan.hop * (i1 - i0 - 1) + plan.T - 1) + 512
+            if cur and cur_n + n > size:
+                out.append(cur); cur, cur_n = [], 0; size = min(2 * size, E._CHUNK_SAMPLES)
+            cur.append((k, i0, i1))
+            cur_n += n
+        if cur:
+            out.append(cur)
+        return out
+
+    class Eng:
+        window = 151
+
+    for trial in range(25):
+        n = int(rng.integers(1, 400))
+        lens = rng.integers(200, 50000, n).tolist()
+        if trial % 3 == 0:
+            lens[int(rng.integers(0, n))] = 3_000_000        # one long file: cut into window ranges
+        plan = E.StreamPlan(lens, 151)
+        for world in (1, 2, 3, 8):
+            for et in ("false_negatives", "false_accepts"):
+                want = shares_loop(plan, et, world)
+                assert plan.shares(et, world) == want
+                got = plan.shares_arr(et, world)
+                assert all(a.dtype == np.int64 and a.shape == (len(w), 3) for a, w in zip(got, want))
+                for first in (1 << 14, 1 << 18, 1 << 21):
+                    for rank in {0, world - 1}:
+                        job = E._PosteriorJob(Eng, et, [np.zeros(1, np.int16)] * n, 20, 16000, rank, world, None, lens, True,
+                                              E._Phases(None), None, first_chunk=first)
+                        cuts = [[tuple(r) for r in c.runs.tolist()] for c in job.chunks]
+                        assert cuts == cut_loop(plan, want[rank], first), (trial, world, et, first)
+                        sl = job.slots_of(job.mine)
+                        idx = np.arange(plan.total)[sl] if isinstance(sl, slice) else sl
+                        assert idx.tolist() == [plan.offs[k] + i for k, i0, i1 in want[rank] for i in range(i0, i1)]
+
+
 def test_stream_plan_closed_form_equals_the_per_file_schedules():
     """StreamPlan computes the layout of a whole test split at once when a chunk is exactly `hop` mel hops (the reference's
     320-sample chunks and hop 2): the same pos / F / n_frames / n_win as the per-file frame_schedule + window_schedule (which the
@@ -284,8 +355,14 @@ def test_joined_pcm_is_concatenate_fa_without_the_copy():
             for arr, aa, nn, o in j.runs(a, n):
                 got[o:o + nn] = arr[aa:aa + nn]
             np.testing.assert_array_equal(got, want[a:a + n])
-    with pytest.raises(TypeError):
-        E.JoinedPCM([np.zeros(4, np.float32)], 1600)
+    bad = E.JoinedPCM([np.zeros(4, np.int16), np.zeros(4, np.float32)], 1600)   # a clip is looked at where it is first used
+    assert len(bad) == 1608 and bad.part(0).dtype == np.int16
+    for use in (lambda: bad.to_array(), lambda: bad.addresses(0, 2), lambda: list(bad.runs(0, 1608))):
+        with pytest.raises(TypeError):
+            use()
+    lists = E.JoinedPCM([[1, 2, 3], np.arange(10, dtype=np.int32)[::2]], 2)      # integer clips of another layout: converted once
+    np.testing.assert_array_equal(lists.to_array(), [1, 2, 3, 0, 0, 0, 2, 4, 6, 8])
+    assert lists.addresses(0, 2).all()
 
 
 @pytest.mark.parametrize("frame_width", [10, 20, 25, 40])

@@ -17,8 +17,8 @@ def short(name: str) -> str:
     n = name.replace("void ", "")
     m = re.match(r"(\w+)(<[^>]*>)?\(", n)
     base, targs = (m.group(1), m.group(2) or "") if m else (n, "")
-    if base == "logmel_rows_kernel":  # round 4: the fp64 front end (the library's own profile keeps the label)
-        return "logmel_kernel<f64>"
+    if base == "logmel_rows_kernel":  # round 4's fp64 front end (its own label in the library's profile since round 5)
+        return "logmel_rows_kernel"
     if base == "logmel_kernel":
         return "logmel_kernel<f64>" if targs.startswith("<double") else "logmel_kernel<f32>"
     if base == "crnn_fused_kernel":

@@ -16,13 +16,14 @@ t0 = int(rows[0]["Start_Timestamp"]); t1 = max(int(r["End_Timestamp"]) for r in 
 print(f"wall {(t1-t0)/1e3:.1f} us for {len(rows)} launches -> {(t1-t0)/1e3/(len(rows)/2):.2f} us per step (2 launches per step)")
 ev = []
 for r in rows:
-    ev.append((int(r["Start_Timestamp"]), 1, r["Kernel_Name"][:1])); ev.append((int(r["End_Timestamp"]), -1, r["Kernel_Name"][:1]))
+    kind = "l" if "logmel" in r["Kernel_Name"] or "frontend" in r["Kernel_Name"] else "c"  # (names start with "void ...": classify by what they contain)
+    ev.append((int(r["Start_Timestamp"]), 1, kind)); ev.append((int(r["End_Timestamp"]), -1, kind))
 ev.sort()
 hist = collections.Counter(); cur = collections.Counter(); last = None
 for t, d_, nm in ev:
     if last is not None:
         hist[(cur["l"], cur["c"])] += t - last
-    cur["l" if nm == "v" or nm == "l" else "c"] += d_; last = t
+    cur[nm] += d_; last = t
 tot = sum(hist.values())
 print("share of wall time by (front-end kernels, crnn kernels) in flight:")
 for k, v in sorted(hist.items()):

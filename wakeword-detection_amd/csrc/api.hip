@@ -1195,31 +1195,37 @@ int ww_clips_forward_dev(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, i
 // ------------------------------------------------------------------------------------------
 // posterior smoothing + sweep
 // ------------------------------------------------------------------------------------------
-int ww_far_frr(ww_ctx *ctx, const float *pos, int64_t n_pos, const float *neg, int64_t n_neg, int32_t win,
-               const double *thr, int32_t n_thr, double num_wakewords, double hours, double *frr, double *fa_per_h,
-               int64_t *fa_count, double *smoothed) {
+// pos / neg: host pointers (uploaded here) or, with on_device, device pointers the kernels read where they are
+static int far_frr_impl(ww_ctx *ctx, bool on_device, const float *pos, int64_t n_pos, const float *neg, int64_t n_neg, int32_t win,
+                        const double *thr, int32_t n_thr, double num_wakewords, double hours, double *frr, double *fa_per_h,
+                        int64_t *fa_count, double *smoothed_host, double *smoothed_dev) {
   if (!ctx || !thr || !frr || !fa_per_h) return ww_fail(ctx, WW_EINVAL, "NULL argument");
   if (n_pos < 0 || n_neg < 0 || n_thr <= 0) return ww_fail(ctx, WW_EINVAL, "bad sizes");
   if ((n_pos && !pos) || (n_neg && !neg)) return ww_fail(ctx, WW_EINVAL, "NULL posterior buffer");
   if (win > 0 && n_neg > 0 && n_neg < win)
     return ww_fail(ctx, WW_EINVAL, "negative stream shorter than the smoothing window (np.convolve 'same' would change its length)");
   WW_ON_DEVICE(ctx, dev_scope);  // the caller's current device is left as it was
-  const size_t b_p = ww_bump::need((size_t)n_pos + 1, 4), b_n = ww_bump::need((size_t)n_neg + 1, 4);
-  const size_t b_s = ww_bump::need((size_t)n_neg + 1, 8), b_t = ww_bump::need((size_t)n_thr, 8);
+  const size_t b_p = on_device ? 0 : ww_bump::need((size_t)n_pos + 1, 4), b_n = on_device ? 0 : ww_bump::need((size_t)n_neg + 1, 4);
+  const size_t b_s = smoothed_dev ? 0 : ww_bump::need((size_t)n_neg + 1, 8), b_t = ww_bump::need((size_t)n_thr, 8);
   int rc = ww_ensure(ctx, ctx->dev, b_p + b_n + b_s + 3 * b_t + 1024, false);
   if (rc) return rc;
   ww_bump bump(ctx->dev.ptr, ctx->dev.cap);
-  float *d_pos = bump.take<float>(n_pos + 1), *d_neg = bump.take<float>(n_neg + 1);
-  double *d_sm = bump.take<double>(n_neg + 1), *d_thr = bump.take<double>(n_thr);
+  const float *d_pos = pos, *d_neg = neg;
+  if (!on_device) {
+    float *up = bump.take<float>(n_pos + 1), *un = bump.take<float>(n_neg + 1);
+    if (n_pos) WW_HIP(ctx, hipMemcpyAsync(up, pos, (size_t)n_pos * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (n_neg) WW_HIP(ctx, hipMemcpyAsync(un, neg, (size_t)n_neg * 4, hipMemcpyHostToDevice, ctx->stream));
+    d_pos = up;
+    d_neg = un;
+  }
+  double *d_sm = smoothed_dev ? smoothed_dev : bump.take<double>(n_neg + 1), *d_thr = bump.take<double>(n_thr);
   unsigned long long *d_pc = bump.take<unsigned long long>(n_thr), *d_fc = bump.take<unsigned long long>(n_thr);
-  if (n_pos) WW_HIP(ctx, hipMemcpyAsync(d_pos, pos, (size_t)n_pos * 4, hipMemcpyHostToDevice, ctx->stream));
-  if (n_neg) WW_HIP(ctx, hipMemcpyAsync(d_neg, neg, (size_t)n_neg * 4, hipMemcpyHostToDevice, ctx->stream));
   WW_HIP(ctx, hipMemcpyAsync(d_thr, thr, (size_t)n_thr * 8, hipMemcpyHostToDevice, ctx->stream));
   if ((rc = ww_k_far_frr(ctx, d_pos, n_pos, d_neg, n_neg, win, d_thr, n_thr, d_sm, d_pc, d_fc))) return rc;
   std::vector<unsigned long long> pc(n_thr), fc(n_thr);
   WW_HIP(ctx, hipMemcpyAsync(pc.data(), d_pc, (size_t)n_thr * 8, hipMemcpyDeviceToHost, ctx->stream));
   WW_HIP(ctx, hipMemcpyAsync(fc.data(), d_fc, (size_t)n_thr * 8, hipMemcpyDeviceToHost, ctx->stream));
-  if (smoothed && n_neg) WW_HIP(ctx, hipMemcpyAsync(smoothed, d_sm, (size_t)n_neg * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (smoothed_host && n_neg) WW_HIP(ctx, hipMemcpyAsync(smoothed_host, d_sm, (size_t)n_neg * 8, hipMemcpyDeviceToHost, ctx->stream));
   WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (int k = 0; k < n_thr; ++k) {
     frr[k] = (num_wakewords - (double)pc[k]) / num_wakewords;
@@ -1227,6 +1233,27 @@ int ww_far_frr(ww_ctx *ctx, const float *pos, int64_t n_pos, const float *neg, i
     if (fa_count) fa_count[k] = (int64_t)fc[k];
   }
   return WW_OK;
+}
+
+int ww_far_frr(ww_ctx *ctx, const float *pos, int64_t n_pos, const float *neg, int64_t n_neg, int32_t win,
+               const double *thr, int32_t n_thr, double num_wakewords, double hours, double *frr, double *fa_per_h,
+               int64_t *fa_count, double *smoothed) {
+  return far_frr_impl(ctx, false, pos, n_pos, neg, n_neg, win, thr, n_thr, num_wakewords, hours, frr, fa_per_h, fa_count, smoothed, nullptr);
+}
+
+int ww_far_frr_dev(ww_ctx *ctx, const float *d_pos, int64_t n_pos, const float *d_neg, int64_t n_neg, int32_t win,
+                   const double *thr, int32_t n_thr, double num_wakewords, double hours, double *frr, double *fa_per_h,
+                   int64_t *fa_count, double *d_smoothed) {
+  return far_frr_impl(ctx, true, d_pos, n_pos, d_neg, n_neg, win, thr, n_thr, num_wakewords, hours, frr, fa_per_h, fa_count, nullptr, d_smoothed);
+}
+
+int ww_posterior_pick_dev(ww_ctx *ctx, const float *d_rows, int64_t n, int32_t n_out, int32_t pidx, const int64_t *d_seg_offs,
+                          int64_t n_seg, float *d_out) {
+  if (!ctx) return WW_EINVAL;
+  if (n < 0 || n_seg < 0 || n_out <= 0 || pidx < 0 || pidx >= n_out) return ww_fail(ctx, WW_EINVAL, "posterior pick: bad sizes");
+  if ((n > 0 && !d_rows) || ((d_seg_offs ? n_seg : n) > 0 && !d_out)) return ww_fail(ctx, WW_EINVAL, "NULL argument");
+  WW_ON_DEVICE(ctx, dev_scope);  // the caller's current device is left as it was
+  return ww_k_posterior_pick(ctx, d_rows, n, n_out, pidx, d_seg_offs, n_seg, d_out);
 }
 
 int ww_superframe_smooth(ww_ctx *ctx, const float *in, int64_t n, int32_t T, float stay_bonus, int32_t in_is_cost,

@@ -257,6 +257,8 @@ size_t ww_wave_workspace(const ww_model *m, int n_windows);
 int ww_k_wave_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *d_win_row,
                       const int32_t *d_win_valid, int64_t row0, int hop, int valid_const, int n_windows, void *ws, size_t ws_bytes,
                       float *d_out, float *d_enc, const ww_tick_tag *tag = nullptr);
+int ww_k_posterior_pick(ww_ctx *ctx, const float *d_rows, int64_t n, int n_out, int pidx, const int64_t *d_seg_offs, int64_t n_seg,
+                        float *d_out);
 int ww_k_far_frr(ww_ctx *ctx, const float *d_pos, int64_t n_pos, const float *d_neg, int64_t n_neg, int win,
                  const double *d_thr, int n_thr, double *d_smoothed, unsigned long long *d_pos_cnt,
                  unsigned long long *d_fa_cnt);

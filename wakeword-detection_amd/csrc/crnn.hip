@@ -1918,17 +1918,13 @@ __global__ __launch_bounds__(128, 2) void gru_tail16_kernel(tail16_args aa) {
 #pragma unroll
     for (int nt = 0; nt < 6; ++nt) gx2[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #define GT16_PROJ(q_, kb_)                                                                           \
-  for (int nt = 0; nt < 6; ++nt) gx2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.x, wx[nt][4 * kb_ + 0], gx2[nt], 0, 0, 0); \
-  for (int nt = 0; nt < 6; ++nt) gx2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.y, wx[nt][4 * kb_ + 1], gx2[nt], 0, 0, 0); \
-  for (int nt = 0; nt < 6; ++nt) gx2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.z, wx[nt][4 * kb_ + 2], gx2[nt], 0, 0, 0); \
-  for (int nt = 0; nt < 6; ++nt) gx2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.w, wx[nt][4 * kb_ + 3], gx2[nt], 0, 0, 0);
-#pragma unroll
+  _Pragma("unroll") for (int nt = 0; nt < 6; ++nt) gx2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.x, wx[nt][4 * kb_ + 0], gx2[nt], 0, 0, 0); \
+  _Pragma("unroll") for (int nt = 0; nt < 6; ++nt) gx2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.y, wx[nt][4 * kb_ + 1], gx2[nt], 0, 0, 0); \
+  _Pragma("unroll") for (int nt = 0; nt < 6; ++nt) gx2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.z, wx[nt][4 * kb_ + 2], gx2[nt], 0, 0, 0); \
+  _Pragma("unroll") for (int nt = 0; nt < 6; ++nt) gx2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.w, wx[nt][4 * kb_ + 3], gx2[nt], 0, 0, 0);
     GT16_PROJ(q0, 0)
-#pragma unroll
     GT16_PROJ(q1, 1)
-#pragma unroll
     GT16_PROJ(q2, 2)
-#pragma unroll
     GT16_PROJ(q3, 3)
 #undef GT16_PROJ
 #pragma unroll

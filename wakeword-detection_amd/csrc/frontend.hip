@@ -1217,7 +1217,7 @@ int ww_k_logmel(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, const floa
     if (n_wg > 0x7fffffff) return ww_fail(ctx, WW_EINVAL, "front-end launch too large (%lld workgroups): split the batch", (long long)n_wg);
     const dim3 grid_w((unsigned)n_wg), block_w(64 * LW_WPB);
     const size_t sm = (size_t)LW_WPB * LW_WBUF;
-    ww_launch_scope scope(ctx, "logmel_kernel<f64>");
+    ww_launch_scope scope(ctx, "logmel_rows_kernel");
     if (small_w) {
       if (f32in) hipLaunchKernelGGL((logmel_rows_kernel<true, true, true>), grid_w, block_w, sm, ctx->stream, a);
       else hipLaunchKernelGGL((logmel_rows_kernel<false, true, true>), grid_w, block_w, sm, ctx->stream, a);

@@ -91,6 +91,42 @@ int ww_k_far_frr(ww_ctx *ctx, const float *d_pos, int64_t n_pos, const float *d_
   return WW_OK;
 }
 
+// ---- posterior pick + per-clip reduction (a13 / a14: evaluate_models.py:80,86 take element [1] of a detect row, :98-99 the
+// max over a wake-word clip's windows) on the rows the model kernels left in HBM: element `pidx` of rows [n][n_out], either
+// as they are (the negative stream: every window counts) or reduced to one maximum per run of windows (seg_offs[s] ..
+// seg_offs[s + 1]: the windows of one clip).  4 bytes in per window; one lane per run walks its ~50 windows.
+__global__ __launch_bounds__(256) void pick_kernel(const float *__restrict__ rows, int64_t n, int n_out, int pidx,
+                                                   const int64_t *__restrict__ seg_offs, int64_t n_seg, float *__restrict__ out) {
+  if (!seg_offs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = rows[i * n_out + pidx];
+    return;
+  }
+  // one wave per run: its ~50 windows are ONE round of loads (a lane per window), not a chain of them
+  const int lane = threadIdx.x & 63;
+  const int64_t s = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (s >= n_seg) return;
+  int64_t lo = seg_offs[s], hi = seg_offs[s + 1];
+  lo = lo < 0 ? 0 : lo;
+  hi = hi > n ? n : hi;
+  float m = -INFINITY;  // (an empty run: the caller never asks for one - np.max of an empty list raises in the reference)
+  for (int64_t w = lo + lane; w < hi; w += 64) m = fmaxf(m, rows[w * n_out + pidx]);
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if (lane == 0) out[s] = m;
+}
+
+int ww_k_posterior_pick(ww_ctx *ctx, const float *d_rows, int64_t n, int n_out, int pidx, const int64_t *d_seg_offs, int64_t n_seg,
+                        float *d_out) {
+  const int64_t work = d_seg_offs ? n_seg : n;
+  if (work <= 0) return WW_OK;
+  const int64_t blocks = d_seg_offs ? (work + 3) / 4 : (work + 255) / 256;
+  if (blocks > 0x7fffffff) return ww_fail(ctx, WW_EINVAL, "posterior pick: too many rows for one launch");
+  ww_launch_scope scope(ctx, "pick_kernel");
+  hipLaunchKernelGGL(pick_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_rows, n, n_out, pidx, d_seg_offs, n_seg, d_out);
+  WW_HIP(ctx, hipGetLastError());
+  return WW_OK;
+}
+
 // ---- superframe shortest-path smoothing (wwdetect/wfst.py:17-71; wiring utils/CRNN_files/tflite.py:252-263)
 // The reference builds a 2-state x T lattice with pynini and takes the single shortest path in the
 // tropical semiring (float32 weights): start arcs cost ln 2 + c[0][p]; an arc into state p at time t

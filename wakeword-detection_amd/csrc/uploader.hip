@@ -237,16 +237,26 @@ struct ww_uploader {
     if (b_meta) memcpy((char *)s.pin + b_pcm, j.meta.data(), b_meta);
     if (j.total > 0 && (e = hipMemcpyAsync(j.d_pcm, s.pin, (size_t)j.total * 2, hipMemcpyHostToDevice, copy_stream)) != hipSuccess)
       return fail(WW_EHIP, "ww_uploader: hipMemcpyAsync (samples)", e);
-    if (b_meta && (e = hipMemcpyAsync(j.d_meta, (char *)s.pin + b_pcm, b_meta, hipMemcpyHostToDevice, copy_stream)) != hipSuccess)
+    // from here on a copy out of the slot may be in flight: a failure must not hand the slot back (the next chunk that lands
+    // on it would rewrite - or free - page-locked memory under that DMA) before the copy stream has drained
+    if (b_meta && (e = hipMemcpyAsync(j.d_meta, (char *)s.pin + b_pcm, b_meta, hipMemcpyHostToDevice, copy_stream)) != hipSuccess) {
+      (void)hipStreamSynchronize(copy_stream);
       return fail(WW_EHIP, "ww_uploader: hipMemcpyAsync (tables)", e);
-    if ((e = hipEventRecord(s.ev, copy_stream)) != hipSuccess) return fail(WW_EHIP, "ww_uploader: hipEventRecord", e);
+    }
+    if ((e = hipEventRecord(s.ev, copy_stream)) != hipSuccess) {
+      (void)hipStreamSynchronize(copy_stream);
+      return fail(WW_EHIP, "ww_uploader: hipEventRecord", e);
+    }
     s.busy = true;
     r.slot = si;
     return r;
   }
 
+  // The worker is a thread of the LIBRARY's: nothing may leave it as an exception (std::terminate in the host program).
+  // process() and the bookkeeping around it allocate (strings, a map node): whatever they throw becomes a failed ticket, and a
+  // ticket whose result could not even be recorded is remembered by number (lost_ticket) so that its waiter gets WW_ENOMEM.
   void loop() {
-    (void)hipSetDevice(device);
+    const hipError_t dev_err = hipSetDevice(device);
     for (;;) {
       job_t j;
       {
@@ -256,10 +266,26 @@ struct ww_uploader {
         j = std::move(queue.front());
         queue.pop_front();
       }
-      result_t r = process(j);
+      result_t r;
+      try {
+        if (dev_err != hipSuccess) {
+          r.rc = WW_EHIP;
+          r.what = std::string("ww_uploader: hipSetDevice: ") + hipGetErrorString(dev_err);
+        } else {
+          r = process(j);
+        }
+      } catch (...) {
+        (void)hipStreamSynchronize(copy_stream);  // (as process()'s own failure paths: nothing may still read a slot)
+        r = result_t();
+        r.rc = WW_ENOMEM;  // (what is left empty: it would have to allocate)
+      }
       {
         std::lock_guard<std::mutex> lk(m);
-        results[j.ticket] = std::move(r);
+        try {
+          results[j.ticket] = std::move(r);
+        } catch (...) {
+          lost_ticket = j.ticket;
+        }
         done_ticket = j.ticket;
         // results nobody came for (a caller that gave up on its chunks): only the most recent ones are kept
         while (!results.empty() && results.begin()->first + 4096 < j.ticket) results.erase(results.begin());
@@ -267,6 +293,7 @@ struct ww_uploader {
       cv_done.notify_all();
     }
   }
+  int64_t lost_ticket = 0;  // the last ticket whose result could not be stored (out of memory inside the worker)
 };
 
 extern "C" {
@@ -385,6 +412,7 @@ int ww_uploader_wait(ww_uploader *up, int64_t ticket, ww_ctx *ctx) {
     if (ticket < 1 || ticket >= up->next_ticket) return ww_fail(ctx, WW_EINVAL, "ww_uploader_wait: no such ticket (%lld)", (long long)ticket);
     up->cv_done.wait(lk, [&] { return up->done_ticket >= ticket; });
     auto it = up->results.find(ticket);
+    if (it == up->results.end() && ticket == up->lost_ticket) return ww_fail(ctx, WW_ENOMEM, "ww_uploader: out of memory while chunk %lld was processed", (long long)ticket);
     if (it == up->results.end()) return ww_fail(ctx, WW_EINVAL, "ww_uploader_wait: ticket %lld was waited for before (or left unclaimed for 4,096 chunks)", (long long)ticket);
     r = std::move(it->second);
     up->results.erase(it);

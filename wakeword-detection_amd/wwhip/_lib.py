@@ -83,6 +83,8 @@ SYMBOLS: Dict[str, tuple] = {
     "ww_stream_timeline": (C.c_int, [_vp, _vp, _P(_i64), _i32]),
     "ww_superframe_smooth": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _i32, _vp, _vp]),
     "ww_far_frr": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _f64, _f64, _vp, _vp, _vp, _vp]),
+    "ww_far_frr_dev": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _f64, _f64, _vp, _vp, _vp, _vp]),
+    "ww_posterior_pick_dev": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -77,3 +77,26 @@ def gather_values(local: np.ndarray, counts: Sequence[int], group=None, device=N
     bufs = [torch.empty_like(payload) for _ in range(world)]
     dist.all_gather(bufs, payload, group=group)
     return [b[:int(c)].cpu().numpy() for b, c in zip(bufs, counts)]
+
+
+def gather_values_t(local, counts: Sequence[int], group=None, device=None) -> list:
+    """:func:`gather_values` on torch tensors: ``local`` (float32, on any device - normally the GPU that produced it) goes into
+    ONE all_gather padded to the largest count and every rank's values come back as tensors on ``local``'s device (through
+    ``device`` when the communicator lives elsewhere: gloo rehearsals exchange on the CPU).  With the ``nccl`` backend nothing
+    touches the host: the values a rank's kernels produced are gathered, smoothed and swept where they are."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    assert len(counts) == world and local.numel() == counts[dist.get_rank(group)]
+    dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
+    comm = torch.device(dev) if not isinstance(dev, torch.device) else dev
+    if comm.type == "cuda" and comm.index is None and local.device.type == "cuda":
+        comm = local.device
+    mx = int(max(counts)) if len(counts) else 0
+    payload = torch.zeros(max(mx, 1), dtype=torch.float32, device=comm)
+    if local.numel():
+        payload[: local.numel()] = local.to(comm)
+    bufs = [torch.empty_like(payload) for _ in range(world)]
+    dist.all_gather(bufs, payload, group=group)
+    return [b[:int(c)].to(local.device) for b, c in zip(bufs, counts)]

@@ -208,6 +208,23 @@ class Engine:
                                        _lib.ptr(fa), _lib.ptr(cnt), _lib.ptr(sm)))
         return (frr, fa, cnt, sm) if want_smoothed else (frr, fa, cnt)
 
+    def far_frr_dev(self, d_pos_ptr: int, n_pos: int, d_neg_ptr: int, n_neg: int, thresholds: np.ndarray, num_wakewords: float,
+                    hours: float, window: int = 30):
+        """:meth:`far_frr` over posteriors that are already on the device (``ww_far_frr_dev``): only the counters come back."""
+        thr = np.ascontiguousarray(thresholds, dtype=np.float64).ravel()
+        frr, fa, cnt = np.empty(thr.size, np.float64), np.empty(thr.size, np.float64), np.empty(thr.size, np.int64)
+        self._chk(self._lib.ww_far_frr_dev(self.ctx.handle, C.c_void_p(d_pos_ptr), int(n_pos), C.c_void_p(d_neg_ptr), int(n_neg),
+                                           int(window), _lib.ptr(thr), thr.size, float(num_wakewords), float(hours), _lib.ptr(frr),
+                                           _lib.ptr(fa), _lib.ptr(cnt), None))
+        return frr, fa, cnt
+
+    def posterior_pick_dev(self, d_rows_ptr: int, n: int, d_out_ptr: int, d_seg_offs_ptr: int = 0, n_seg: int = 0) -> None:
+        """Element ``posterior_index`` of ``n`` detect rows on the device -> ``d_out``: one value per row, or - with a device
+        table of ``n_seg + 1`` row offsets - the maximum of each run (``ww_posterior_pick_dev``).  Enqueued, not waited for."""
+        self._chk(self._lib.ww_posterior_pick_dev(self.ctx.handle, C.c_void_p(d_rows_ptr), int(n), self.n_out, self.posterior_index,
+                                                  C.c_void_p(d_seg_offs_ptr) if d_seg_offs_ptr else None, int(n_seg),
+                                                  C.c_void_p(d_out_ptr)))
+
     # ------------------------------------------------------------------ device-resident paths (torch plumbing)
     def clips_forward_dev(self, d_pcm_ptr: int, n_clips: int, samples_per_clip: int, d_out_ptr: int,
                           fp: Optional[_lib.FrontendParams] = None) -> None:

@@ -216,20 +216,33 @@ class StreamPlan:
         """Per rank: ``(file, i0, i1)`` runs of windows.  Positives: whole files dealt longest-first round-robin
         (``dist.shard_by_length``); the negative stream: contiguous posterior ranges (``dist.split_stream``), cut
         where a range crosses a file boundary."""
+        return [[tuple(r) for r in a.tolist()] for a in self.shares_arr(eval_type, world)]
+
+    def shares_arr(self, eval_type: str, world: int) -> List[np.ndarray]:
+        """:meth:`shares` as one ``int64 [n, 3]`` array per rank, built without a Python-level pass over the files (every
+        rank works out EVERY rank's share - the gather needs to know where any rank's values go - so at 5,000 files and 8
+        ranks the per-file loops were the part of a call that no rank count divides)."""
         from . import dist as D
-        out: List[List[Tuple[int, int, int]]] = [[] for _ in range(world)]
+        out: List[np.ndarray] = []
         if eval_type == "false_negatives":
-            nw = self.n_win.tolist()  # (Python ints once: indexing the array per file costs more than the rest of the plan)
-            for r, files in enumerate(D.shard_by_length(self.lengths.tolist(), world)):
-                out[r] = [(k, 0, nw[k]) for k in sorted(files) if nw[k] > 0]
+            order = np.argsort(-self.lengths, kind="stable")  # = dist.shard_by_length: rank r gets order[r::world]
+            for r in range(world):
+                files = np.sort(order[r::world])
+                files = files[self.n_win[files] > 0]
+                out.append(np.stack((files, np.zeros_like(files), self.n_win[files]), axis=1) if len(files) else np.zeros((0, 3), np.int64))
         else:
-            for r, (lo, hi) in enumerate(D.split_stream(self.total, world)):
-                k = int(np.searchsorted(self.offs, lo, side="right")) - 1
-                while lo < hi:
-                    end = min(hi, int(self.offs[k + 1]))
-                    if end > lo:
-                        out[r].append((k, lo - int(self.offs[k]), end - int(self.offs[k])))
-                    lo, k = end, k + 1
+            offs = self.offs
+            for lo, hi in D.split_stream(self.total, world):
+                if hi <= lo:
+                    out.append(np.zeros((0, 3), np.int64))
+                    continue
+                k0 = int(np.searchsorted(offs, lo, side="right")) - 1
+                k1 = int(np.searchsorted(offs, hi, side="left"))
+                ks = np.arange(k0, k1, dtype=np.int64)
+                i0 = np.maximum(lo, offs[ks]) - offs[ks]
+                i1 = np.minimum(hi, offs[ks + 1]) - offs[ks]
+                ok = i1 > i0
+                out.append(np.stack((ks[ok], i0[ok], i1[ok]), axis=1))
         return out
 
     def sample_range(self, k: int, i0: int, i1: int) -> Tuple[int, int]:
@@ -248,20 +261,38 @@ class JoinedPCM:
     dtype = np.dtype(np.int16)
 
     def __init__(self, clips: Sequence[np.ndarray], gap: int) -> None:
-        self.parts = [c if type(c) is np.ndarray and c.flags.c_contiguous else np.ascontiguousarray(c) for c in clips]
-        if any(c.dtype != np.int16 for c in self.parts):
-            raise TypeError("JoinedPCM holds int16 PCM")
-        n = np.fromiter(map(len, self.parts), np.int64, len(self.parts))
+        # the clips are LOOKED AT where they are used (part()): building the object is a length per clip and nothing else - a
+        # rank of eight reads an eighth of a two-hour stream, and what every rank does for every clip is time no rank count
+        # divides (round 5: the per-clip dtype / layout checks moved from here to first use)
+        self._raw = list(clips)
+        self._ok = np.zeros(len(self._raw), bool)
+        n = np.fromiter(map(len, self._raw), np.int64, len(self._raw))
         self.lens = n
-        self._addrs = np.zeros(len(n), np.int64)  # filled range by range (addresses): a dict lookup per clip, paid where it is used
+        self._addrs = np.zeros(len(n), np.int64)  # filled range by range (addresses): paid where it is used
         self.starts = np.concatenate(([0], np.cumsum(n + gap)))[:-1] if len(n) else np.zeros(0, np.int64)
         self.size = int(n.sum() + gap * max(len(n) - 1, 0))
+
+    def part(self, i: int) -> np.ndarray:
+        """Clip ``i`` as contiguous int16 PCM (converted once, on first use; anything that is not integer PCM is refused)."""
+        c = self._raw[i]
+        if not self._ok[i]:
+            if not (type(c) is np.ndarray and c.dtype == np.int16 and c.flags.c_contiguous):
+                c = np.asarray(c)
+                if c.dtype.kind not in "iu":
+                    raise TypeError("JoinedPCM holds int16 PCM")
+                c = self._raw[i] = np.ascontiguousarray(c, np.int16)
+            self._ok[i] = True
+        return c
+
+    @property
+    def parts(self) -> List[np.ndarray]:
+        return [self.part(i) for i in range(len(self._raw))]
 
     def addresses(self, c0: int, c1: int) -> np.ndarray:
         """Addresses of the first samples of clips ``c0 .. c1 - 1`` (the staging copies read from there)."""
         a = self._addrs[c0:c1]
-        for i in np.flatnonzero(a == 0):
-            a[i] = self.parts[c0 + i].__array_interface__["data"][0]
+        for i in np.flatnonzero(a == 0).tolist():
+            a[i] = self.part(c0 + i).__array_interface__["data"][0]
         return a
 
     def __len__(self) -> int:
@@ -270,16 +301,17 @@ class JoinedPCM:
     def runs(self, a: int, n: int):
         """``(array, first element, count, offset inside [a, a + n))`` for every clip that overlaps ``[a, a + n)``."""
         i = max(int(np.searchsorted(self.starts, a, side="right")) - 1, 0)
-        while i < len(self.parts) and self.starts[i] < a + n:
+        while i < len(self._raw) and self.starts[i] < a + n:
             st = int(self.starts[i])
-            lo, hi = max(a, st), min(a + n, st + len(self.parts[i]))
+            lo, hi = max(a, st), min(a + n, st + int(self.lens[i]))
             if hi > lo:
-                yield self.parts[i], lo - st, hi - lo, lo - a
+                yield self.part(i), lo - st, hi - lo, lo - a
             i += 1
 
     def to_array(self) -> np.ndarray:
         out = np.zeros(self.size, np.int16)
-        for c, st in zip(self.parts, self.starts):
+        for i, st in enumerate(self.starts.tolist()):
+            c = self.part(i)
             out[st:st + len(c)] = c
         return out
 
@@ -352,7 +384,7 @@ def _uploader(eng: Engine):
 
 class _Chunk:
     """One step of a rank's share on its way to the GPU: ``runs`` (file, i0, i1) -> samples in a page-locked slot -> device."""
-    __slots__ = ("job", "runs", "n_win", "copy", "keep", "soffs", "foffs", "nf_max", "total_f", "d_pcm", "d_so", "d_fo", "ticket",
+    __slots__ = ("job", "runs", "n_win", "copy", "keep", "soffs", "foffs", "nf_max", "total_f", "d_pcm", "d_so", "d_fo", "d_wo", "ticket",
                  "host_pieces", "d_mel", "d_out")
 
 
@@ -363,20 +395,27 @@ def _prep_chunk(ch: "_Chunk", ph: _Phases) -> None:
     (``ch.host_pieces``)."""
     plan, runs, load = ch.job.plan, ch.runs, ch.job.load
     with ph("slicing"):
-        files = sorted({f for k, _, _ in runs for f in ((k - 1, k) if plan.carry and k > 0 else (k,))})
+        runs = np.asarray(runs, np.int64).reshape(-1, 3)
+        ks = np.unique(runs[:, 0])
+        files = np.unique(np.concatenate((ks, ks[ks > 0] - 1))).tolist() if plan.carry else ks.tolist()
         data = {}
         for f in files:
             x = load(f)
             if isinstance(x, JoinedPCM) and len(plan.lengths) > 1:
                 x = x.to_array()  # a joined stream among other files: as an ordinary array
             data[f] = x if isinstance(x, JoinedPCM) else np.ascontiguousarray(x)
+            # the copy runs below take their counts from the plan and hand raw addresses to the library's copy threads: a file
+            # that holds fewer samples than the plan was built on (a truncated wav whose header says more, a caller's own
+            # `lengths`) would be read past its end - and its window counts would be wrong anyway
+            if len(data[f]) != int(plan.lengths[f]):
+                raise ValueError(f"file {f} holds {len(data[f])} samples, the plan was built on {int(plan.lengths[f])}")
         if any(x.dtype != np.int16 for x in data.values()):
             # not PCM16 everywhere: float32 samples (librosa's scale) for every file
             data = {f: (x.to_array() if isinstance(x, JoinedPCM) else x) for f, x in data.items()}
             data = {f: (x.astype(np.float32) / np.float32(32768.0) if x.dtype == np.int16 else x.astype(np.float32, copy=False))
                     for f, x in data.items()}
             pieces = []
-            for k, i0, i1 in runs:
+            for k, i0, i1 in runs.tolist():
                 s0, s1 = plan.sample_range(k, i0, i1)
                 out = np.zeros(s1 - s0, np.float32)
                 for f in ((k - 1, k) if plan.carry and k > 0 else (k,)):
@@ -394,7 +433,8 @@ def _prep_chunk(ch: "_Chunk", ph: _Phases) -> None:
         ch.copy = (d, pp, c)
         ch.soffs, ch.foffs = soffs, np.concatenate(([0], np.cumsum(nf)))
         ch.nf_max, ch.total_f = int(nf.max()) if len(nf) else 0, int(ch.foffs[-1])
-        assert all(w == 0 or (w - 1) * plan.hop + plan.T <= f for f, w in zip(nf, ch.n_win)), "piece too short for its windows"
+        n_win = np.asarray(ch.n_win, np.int64)
+        assert ((n_win == 0) | ((n_win - 1) * plan.hop + plan.T <= nf)).all(), "piece too short for its windows"
 
 
 def _submit_chunk(eng: Engine, ch: "_Chunk", ph: _Phases) -> None:
@@ -410,9 +450,10 @@ def _submit_chunk(eng: Engine, ch: "_Chunk", ph: _Phases) -> None:
         need = int(ch.soffs[-1]) + 16  # (the kernel's vector loads may run a few samples past the end: zeros there too)
         dev = torch.device("cuda", eng.ctx.device)
         ch.d_pcm = torch.empty(need, dtype=torch.int16, device=dev)
-        d_meta = torch.empty(2 * (n + 1), dtype=torch.int64, device=dev)
-        ch.d_so, ch.d_fo = d_meta[:n + 1], d_meta[n + 1:]
-        ch.ticket = _uploader(eng).submit(need, d, pp, c, ch.d_pcm.data_ptr(), np.concatenate((ch.soffs, ch.foffs)), d_meta.data_ptr())
+        d_meta = torch.empty(3 * (n + 1), dtype=torch.int64, device=dev)
+        ch.d_so, ch.d_fo, ch.d_wo = d_meta[:n + 1], d_meta[n + 1:2 * (n + 1)], d_meta[2 * (n + 1):]
+        woffs = np.concatenate(([0], np.cumsum(ch.n_win)))  # first window of every piece: the per-clip max needs it (ww_posterior_pick_dev)
+        ch.ticket = _uploader(eng).submit(need, d, pp, c, ch.d_pcm.data_ptr(), np.concatenate((ch.soffs, ch.foffs, woffs)), d_meta.data_ptr())
         ch.copy = None  # (ch.keep: the clips stay where they are until the uploader has read them)
 
 
@@ -425,7 +466,7 @@ def _chunk_forward(eng: Engine, ch: "_Chunk", precise: bool, ph: _Phases) -> Non
     dev = torch.device("cuda", eng.ctx.device)
     hop = ch.job.plan.hop
     n = len(ch.n_win)
-    ch.d_out = torch.empty((int(sum(ch.n_win)), eng.n_out), dtype=torch.float32, device=dev)
+    ch.d_out = torch.empty((int(np.sum(ch.n_win)), eng.n_out), dtype=torch.float32, device=dev)
     if ch.host_pieces is None:
         # librosa's floats are int16 / 32768 exactly: the device front end divides (correctly rounded) by the same 32768
         with ph("upload_wait"):
@@ -452,7 +493,25 @@ def _chunk_forward(eng: Engine, ch: "_Chunk", precise: bool, ph: _Phases) -> Non
         # way (csrc/crnn.hip: gru_step), so a posterior does not depend on how many windows its launch holds - nor on how a
         # share is cut into chunks
         eng.forward_segments_dev(ch.d_mel.data_ptr(), total_f, foffs[:-1], np.asarray(ch.n_win, np.int32), hop, ch.d_out.data_ptr())
+        # what the flow keeps of a chunk, picked where the rows are: the posterior element of every window (the negative
+        # stream) or its maximum over each piece (a wake-word clip) - a14 on the device, 4 or 0.1 bytes per window to keep
+        job, n_rows = ch.job, int(ch.d_out.shape[0])
+        per_piece = job.eval_type == "false_negatives"
+        if job.d_vals is None:
+            job.d_vals = torch.empty(job.n_values(job.mine), dtype=torch.float32, device=dev)
+            job.val_off = 0
+        n_vals = n if per_piece else n_rows
+        out = job.d_vals[job.val_off: job.val_off + n_vals]
+        job.val_off += n_vals
+        if per_piece and ch.d_wo is None:  # (pieces staged through NumPy: their window offsets go up here)
+            ch.d_wo = torch.from_numpy(np.concatenate(([0], np.cumsum(ch.n_win))).astype(np.int64)).to(dev)
+            torch.cuda.current_stream(dev).synchronize()
+        if n_vals:
+            eng.posterior_pick_dev(ch.d_out.data_ptr(), n_rows, out.data_ptr(), ch.d_wo.data_ptr() if per_piece else 0, n if per_piece else 0)
     # (nothing here waits for the GPU: ch.d_pcm / ch.d_mel / ch.d_out stay alive until _run_jobs has synchronised)
+
+
+SHARE_ONLY = "share-only"  # comm_device: run ONE rank's share of a world without a communicator (what a rank of N costs, measured on one GPU)
 
 
 class _PosteriorJob:
@@ -476,34 +535,49 @@ class _PosteriorJob:
             self.plan = plan = StreamPlan(lengths, eng.window, frame_length, sample_rate, 2, carry_over)
             if info is not None:
                 info["windows"] = info.get("windows", 0) + plan.total  # inferences of the whole call, all ranks
-            self.shares = plan.shares(eval_type, world)
+            self.shares = plan.shares_arr(eval_type, world)
             self.mine = self.shares[rank]
             self.chunks: List[_Chunk] = []
             for runs in self._cut(self.mine, first_chunk):
                 ch = _Chunk()
-                ch.job, ch.runs, ch.n_win = self, runs, [i1 - i0 for _, i0, i1 in runs]
-                ch.host_pieces = ch.d_pcm = ch.d_mel = ch.d_out = ch.ticket = ch.copy = ch.keep = None
+                ch.job, ch.runs, ch.n_win = self, runs, runs[:, 2] - runs[:, 1]
+                ch.host_pieces = ch.d_pcm = ch.d_mel = ch.d_out = ch.d_wo = ch.ticket = ch.copy = ch.keep = None
                 self.chunks.append(ch)
-        self.vals: Optional[np.ndarray] = None
+        self.vals: Optional[np.ndarray] = None  # the share's values on the host (tests feed them in; finish() falls back to them)
+        self.d_vals = None                       # ... on the device: one per window (negative stream) / per run (wake-word clips)
+        self.val_off = 0
 
-    def _cut(self, runs, first: int):
-        """The share as consecutive groups of runs; a run longer than a chunk (the negative stream is ONE file) is cut into
-        window ranges - each re-reads the ``T - hop`` frames it shares with its neighbour.  Chunk sizes (samples) grow from
-        ``first`` by doubling up to ``_CHUNK_SAMPLES``: a small first chunk is on the GPU early, large later ones keep the
-        launches efficient."""
+    def _cut(self, runs: np.ndarray, first: int) -> List[np.ndarray]:
+        """The share (``[n, 3]`` runs) as consecutive groups of runs; a run longer than a chunk (the negative stream is ONE
+        file) is cut into window ranges - each re-reads the ``T - hop`` frames it shares with its neighbour.  Chunk sizes
+        (samples) grow from ``first`` by doubling up to ``_CHUNK_SAMPLES``: a small first chunk is on the GPU early, large
+        later ones keep the launches efficient.  A share of many short runs (the wake-word clips: thousands) is grouped by
+        its cumulative sample counts, one step per CHUNK; only runs that need cutting are walked one by one."""
         plan = self.plan
         per_win = 160 * plan.hop
-        out, cur, cur_n = [], [], 0
         size = max(min(first, _CHUNK_SAMPLES), per_win)
+        if len(runs) == 0:
+            return []
+        nw = runs[:, 2] - runs[:, 1]
+        if int(nw.max()) <= (size + size // 2) // per_win:  # no run is ever cut: sizes only grow
+            c = np.cumsum(160 * (plan.hop * (nw - 1) + plan.T - 1) + WINDOW)
+            out, j0, base = [], 0, 0
+            while j0 < len(runs):
+                j1 = max(int(np.searchsorted(c, base + size, side="right")), j0 + 1)  # (a chunk holds at least one run)
+                out.append(runs[j0:j1])
+                base, j0 = int(c[j1 - 1]), j1
+                size = min(2 * size, _CHUNK_SAMPLES)
+            return out
+        out, cur, cur_n = [], [], 0
 
         def close():
             nonlocal cur, cur_n, size
             if cur:
-                out.append(cur)
+                out.append(np.array(cur, np.int64).reshape(-1, 3))
                 cur, cur_n = [], 0
                 size = min(2 * size, _CHUNK_SAMPLES)
 
-        for k, i0, i1 in runs:
+        for k, i0, i1 in runs.tolist():
             while i1 - i0 > (size + size // 2) // per_win:  # (a remainder below half a chunk stays with the last cut)
                 close()
                 w = max(size // per_win, 1)
@@ -518,48 +592,72 @@ class _PosteriorJob:
         close()
         return out
 
-    def slots_of(self, runs) -> np.ndarray:
+    def slots_of(self, runs: np.ndarray):
         """Global slot of every window of the runs: offs[k] + i0 .. offs[k] + i1 - 1, run after run."""
-        if not runs:
+        if len(runs) == 0:
             return np.zeros(0, np.int64)
-        plan = self.plan
-        nw = np.array([i1 - i0 for _, i0, i1 in runs], np.int64)
-        first = np.array([plan.offs[k] + i0 for k, i0, _ in runs], np.int64)
+        nw = runs[:, 2] - runs[:, 1]
+        first = self.plan.offs[runs[:, 0]] + runs[:, 1]
         ends = np.cumsum(nw)
         if (first[1:] == first[:-1] + nw[:-1]).all():
             return slice(int(first[0]), int(first[0] + ends[-1]))  # consecutive slots (one rank; a contiguous range of the stream)
         return np.arange(int(ends[-1]), dtype=np.int64) + np.repeat(first - (ends - nw), nw)
 
-    def collect(self, ph: _Phases) -> None:
-        """Detect rows of the share from the device (after :func:`_run_jobs`: every kernel has finished)."""
-        import torch
-        with ph("d2h"):
-            outs = [ch.d_out for ch in self.chunks if ch.d_out is not None and ch.d_out.shape[0]]
-            if outs:
-                self.vals = (outs[0] if len(outs) == 1 else torch.cat(outs))[:, self.eng.posterior_index].cpu().numpy()
-            else:
-                self.vals = np.zeros(0, np.float32)
-            for ch in self.chunks:
-                ch.d_out = None
+    def n_values(self, share: np.ndarray) -> int:
+        """Values a rank contributes: one per run of its share for the wake-word clips (the maximum over the run's windows,
+        ``evaluate_models.py:98-99``), one per window for the negative stream."""
+        return len(share) if self.eval_type == "false_negatives" else int((share[:, 2] - share[:, 1]).sum())
 
-    def finish(self, comm_device: Optional[str], ph: _Phases, as_array: bool):
-        """The gather (the one exchange) and what ``get_posterior`` returns, on every rank."""
+    def collect(self, ph: _Phases) -> None:
+        """After :func:`_run_jobs` (every kernel has finished): the share's values stay on the device (``d_vals``); the
+        detect rows go."""
+        import torch
+        if self.d_vals is None:  # (a share without a window)
+            self.d_vals = torch.empty(0, dtype=torch.float32, device=torch.device("cuda", self.eng.ctx.device))
+        for ch in self.chunks:
+            ch.d_out = None
+
+    def finish_dev(self, comm_device: Optional[str], ph: _Phases):
+        """The gather (the one exchange).  Returns, on every rank, what ``get_posterior`` returns - the wake-word clips' maxima
+        as a host array (one float per file), the negative stream's posteriors as a tensor on the device that produced them
+        (smoothing and sweep read them there: :func:`evaluate_reference_flow_sharded`)."""
+        import torch
         plan = self.plan
+        vals = self.d_vals if self.d_vals is not None else torch.from_numpy(np.ascontiguousarray(self.vals, np.float32))
+        per_run = self.eval_type == "false_negatives"
         with ph("gather"):
-            post = np.zeros(plan.total, np.float32)
-            if self.world > 1:
+            if per_run and (plan.n_win == 0).any():
+                raise ValueError("max() arg is an empty sequence")  # an empty clip: what np.max raises in the reference's loop
+            every: list = [None] * self.world
+            if self.world > 1 and comm_device != SHARE_ONLY:
                 # the plan is the same arithmetic on every rank, so every rank knows which slots any rank's values fill: the
                 # exchange is the values alone (float32, padded to the largest share)
                 from . import dist as D
-                every = D.gather_values(self.vals, [sum(i1 - i0 for _, i0, i1 in sh) for sh in self.shares], device=comm_device)
-                for sh, v in zip(self.shares, every):
-                    post[self.slots_of(sh)] = v
+                every = D.gather_values_t(vals, [self.n_values(sh) for sh in self.shares], device=comm_device)
             else:
-                post[self.slots_of(self.mine)] = self.vals
-        if self.eval_type == "false_negatives":
-            if (plan.n_win == 0).any():
-                raise ValueError("max() arg is an empty sequence")  # an empty clip: what np.max raises in the reference's loop
-            post = np.maximum.reduceat(post, plan.offs[:-1])
+                every[self.rank] = vals  # (SHARE_ONLY: one rank's share timed without its peers - their slots stay zero)
+            if per_run:
+                # a file's windows are one run unless the file is longer than a chunk: the maximum over its runs, on the host
+                # (one float per run; 2,529 of them at hey-snips size)
+                post = np.full(len(plan.lengths), -np.inf if self.world == 1 or comm_device != SHARE_ONLY else 0.0, np.float32)
+                for sh, v in zip(self.shares, every):
+                    if v is not None and len(sh):
+                        np.maximum.at(post, sh[:, 0], v.cpu().numpy())
+                return post
+            if self.world == 1:
+                return vals  # (one rank: its windows are the stream, in order)
+            post_t = torch.zeros(plan.total, dtype=torch.float32, device=vals.device)
+            for sh, v in zip(self.shares, every):
+                if v is not None and len(sh):
+                    post_t[self.slots_of(sh)] = v  # (a rank's windows are a contiguous range of the stream: a slice)
+            return post_t
+
+    def finish(self, comm_device: Optional[str], ph: _Phases, as_array: bool):
+        """:meth:`finish_dev` on the host: what ``get_posterior`` returns, on every rank."""
+        post = self.finish_dev(comm_device, ph)
+        if not isinstance(post, np.ndarray):
+            with ph("d2h"):
+                post = post.cpu().numpy()
         return post if as_array else post.tolist()
 
 
@@ -672,8 +770,7 @@ def join_negatives(clips: Sequence[np.ndarray], num_files: int, sample_rate: int
 
 def join_negatives_lazy(clips: Sequence[np.ndarray], num_files: int, sample_rate: int = 16000) -> JoinedPCM:
     """:func:`join_negatives` as a :class:`JoinedPCM` (no copy of the clips)."""
-    return JoinedPCM([c if type(c) is np.ndarray and c.dtype == np.int16 else np.asarray(c, np.int16) for c in clips[:max(num_files, 1)]],
-                     sample_rate // 10)
+    return JoinedPCM(clips[:max(num_files, 1)], sample_rate // 10)
 
 
 def evaluate_negative_stream_sharded(engine: Engine, stream_pcm, rank: int = 0, world: int = 1,
@@ -685,6 +782,21 @@ def evaluate_negative_stream_sharded(engine: Engine, stream_pcm, rank: int = 0, 
     stream = stream_pcm if isinstance(stream_pcm, JoinedPCM) else np.asarray(stream_pcm)
     return get_posterior_sharded(engine.model_dir, "CRNN" if engine.is_crnn else "Wavenet", "false_accepts", [stream], 20, 16000,
                                  rank, world, comm_device, engine=engine, precise=precise, timing=timing, as_array=True, info=info)
+
+
+class _Int16Clips:
+    """Labelled clips in memory as the int16 PCM the reference flow feeds (``evaluate_models.py:45-61``), each converted when it
+    is first asked for - by the rank that stages it."""
+
+    def __init__(self, raw: list) -> None:
+        self.raw = raw
+
+    def __len__(self) -> int:
+        return len(self.raw)
+
+    def __getitem__(self, k: int) -> np.ndarray:
+        c = self.raw[k]
+        return c if type(c) is np.ndarray and c.dtype == np.int16 else np.asarray(c, np.int16)
 
 
 def evaluate_reference_flow_sharded(engine: Engine, clips: Sequence[np.ndarray], labels: Sequence[int], rank: int = 0,
@@ -707,10 +819,10 @@ def evaluate_reference_flow_sharded(engine: Engine, clips: Sequence[np.ndarray],
     # half seconds of padding around every clip), so the GPU has work for the time the wake-word clips take to stage
     def negative_job():
         with ph("prepare"):
-            idx = np.flatnonzero(~labels)[:max(num_wakewords, 1)]
+            idx = np.flatnonzero(~labels)[:max(num_wakewords, 1)].tolist()
             other = [clips[i] for i in idx]
             made["n_joined"] = len(other)
-            stream = made["stream"] = join_negatives_lazy(other, num_wakewords) if other else None
+            stream = made["stream"] = join_negatives_lazy(other, num_wakewords) if other else None  # (a length per clip, nothing else)
         if stream is None or len(stream) == 0:
             return None
         made["neg"] = _PosteriorJob(engine, "false_accepts", [stream], 20, 16000, rank, world, None, None, True, ph, info)
@@ -720,20 +832,36 @@ def evaluate_reference_flow_sharded(engine: Engine, clips: Sequence[np.ndarray],
         if num_wakewords == 0:
             return None
         with ph("prepare"):
-            wake = [c if type(c) is np.ndarray and c.dtype == np.int16 else np.asarray(c, np.int16) for c in (clips[i] for i in np.flatnonzero(labels))]
-        made["wake"] = _PosteriorJob(engine, "false_negatives", wake, 20, 16000, rank, world, None, None, True, ph, info,
+            # what every rank needs of every clip is its LENGTH (the plan); a clip itself is looked at by the rank whose share
+            # holds it, when its chunk is staged (_prep_chunk)
+            wake = _Int16Clips([clips[i] for i in np.flatnonzero(labels).tolist()])
+            lengths = np.fromiter(map(len, wake.raw), np.int64, len(wake.raw))
+        made["wake"] = _PosteriorJob(engine, "false_negatives", wake, 20, 16000, rank, world, None, lengths, True, ph, info,
                                      first_chunk=_CHUNK_SAMPLES if "neg" in made else 1 << 21)  # (the pipeline is full by then)
         return made["wake"]
 
     _run_jobs(engine, [negative_job, wake_job], precise, ph, timing)
-    pos = made["wake"].finish(comm_device, ph, True) if "wake" in made else np.zeros(0, np.float32)
-    neg = made["neg"].finish(comm_device, ph, True) if "neg" in made else np.zeros(0, np.float32)
+    import torch
+    pos = made["wake"].finish_dev(comm_device, ph) if "wake" in made else np.zeros(0, np.float32)
+    neg_t = made["neg"].finish_dev(comm_device, ph) if "neg" in made else None
     stream = made.get("stream")
     if rank != 0:
         return None
     hours = (len(stream) if stream is not None else 0) / 16000.0 / 3600.0
-    with _Phases(timing)("sweep"):
-        thr, frr, fa, cnt = far_frr(pos, neg, max(num_wakewords, 1), hours, thresholds, windowsize, engine=engine)
+    thr = default_thresholds() if thresholds is None else np.asarray(thresholds, np.float64)
+    if neg_t is not None and neg_t.is_cuda and len(neg_t):
+        # smoothing + sweep where the gathered values are (ww_far_frr_dev): the thresholds go up, 2 x 100 counters come back
+        with ph("sweep"):
+            d_pos = torch.from_numpy(pos).to(neg_t.device)
+            torch.cuda.current_stream(neg_t.device).synchronize()  # (the gather's copies, this upload: done before the library's stream reads)
+            frr, fa, cnt = engine.far_frr_dev(d_pos.data_ptr(), len(pos), neg_t.data_ptr(), len(neg_t), thr, float(max(num_wakewords, 1)),
+                                              hours, windowsize)
+        with ph("d2h"):
+            neg = neg_t.cpu().numpy()  # (for the caller: the curves above did not need it)
+    else:
+        neg = np.zeros(0, np.float32) if neg_t is None else neg_t.cpu().numpy()
+        with ph("sweep"):
+            thr, frr, fa, cnt = far_frr(pos, neg, max(num_wakewords, 1), hours, thr, windowsize, engine=engine)
     return {"thresholds": thr, "frr": frr, "fa_per_hour": fa, "fa_count": cnt, "frr_at_0.5_fa_per_hour": frr_at_fa(frr, fa, 0.5),
             "positives": pos, "negatives": neg, "hours": hours, "num_wakewords": num_wakewords,
             "negative_clips_joined": made.get("n_joined", 0), "windows": int(info.get("windows", 0)),
