@@ -842,6 +842,30 @@ def test_wavenet_split_bf16_launch_forms_agree(assets):
         e.close()
 
 
+@pytest.mark.parametrize("name", ["Wavenet", "Wavenet_alt"])
+def test_wavenet_fp32_launch_forms_agree(assets, oracles, name):
+    """fp32 Wavenet (round 5): the transposed block loop is written over a wave's tiles like the split-bf16 one, so launches of
+    more than 256 windows run four waves x three tiles with two workgroups per CU, smaller ones twelve waves x one tile.  The
+    per-tile arithmetic is one source: 700 windows in one launch (wide), in launches of 200 (one tile per wave) and of 300
+    (wide) give the same bits, encoder output included, windows of partial validity among them - and the oracle's posteriors."""
+    from wwhip.engine import Engine
+    e = Engine(os.path.join(assets, name))
+    try:
+        rng = np.random.default_rng(43)
+        wins = rng.uniform(0, 6.5, (700, e.window, 40)).astype(np.float32)
+        wins[::9, 150:] = 0
+        wins[5] = 0
+        whole, whole_enc = e.forward(wins, want_enc=True)
+        for step in (200, 300):
+            parts = [e.forward(wins[i:i + step], want_enc=True) for i in range(0, 700, step)]
+            np.testing.assert_array_equal(np.concatenate([p[0] for p in parts]), whole)
+            np.testing.assert_array_equal(np.concatenate([p[1] for p in parts]), whole_enc)
+        idx = np.arange(0, 700, 37)
+        assert np.abs(whole[idx] - oracles[name].forward(wins[idx])).max() < TOL_POST
+    finally:
+        e.close()
+
+
 def test_crnn_default_dispatch_crossover_leaves_posteriors_alone(engines):
     """With the library's default options the tail kernel changes at 9,216 windows per launch (gru_tail_kernel below,
     gru_tail16_kernel from there on) and public calls chunk at 16,384: a posterior must not depend on the size of the call it

@@ -46,6 +46,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef WV_BF16_NW
 #define WV_BF16_NW 12
 #endif
+#ifndef WV_F32_WIDE_FROM
+#define WV_F32_WIDE_FROM 256   // the fp32 transposed loop likewise (round 5)
+#endif
 #ifndef WV_BF16_WIDE_FROM
 #define WV_BF16_WIDE_FROM 256  // launches of more windows than this (= CUs of the chip) take the 4-wave x 3-tile form, two workgroups per CU
 #endif
@@ -214,7 +217,7 @@ template <bool HEAD_ONLY, bool SPLIT_BF16, int WV_NW, bool FP32T = false>
 __global__ __launch_bounds__(WV_NW * 64, WV_NW == 12 ? (SPLIT_BF16 ? WV_BF16_OCC : 3) : 2) void wavenet_kernel(wave_args a) {
   constexpr int WV_MPW = 12 / WV_NW, WV_THREADS = WV_NW * 64;
   constexpr bool TRANSPOSED = SPLIT_BF16 || FP32T;  // state layout: lane = time column, four consecutive channels per register quad
-  static_assert(!(SPLIT_BF16 && FP32T) && (!FP32T || WV_NW == 12), "one arithmetic mode; the fp32 transposed loop is written for 12 x 1 tiles");
+  static_assert(!(SPLIT_BF16 && FP32T), "one arithmetic mode");
   static_assert(WV_MPW * WV_NW == 12, "12 row tiles");
   // LDS: region A = staged input [192][48] (prologue only), later u[2][208][16] + g[192][16]
   // split-bf16: u planes (same bytes as the fp32 u buffers) + two parameter pages (next to / under the head's tile)
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(WV_NW * 64, WV_NW == 12 ? (SPLIT_BF16 ? WV_BF16_OCC
     };
     wblk_t pw[2];
     wload(0, pw[0]);
-    const int tl = wave * 16 + j;  // this lane's time column
+    const int tl = wave * WV_MPW * 16 + j;  // this lane's time column in the wave's first tile (tile mi: + 16 mi)
     __syncthreads();               // table + zero rows
     // a block's seven small vectors (this lane's channel group): read from the table one block AHEAD, behind the barrier, so
     // that no LDS round trip sits in front of the u write, the accumulators' initial values or the res | skip products
@@ -419,43 +422,64 @@ __global__ __launch_bounds__(WV_NW * 64, WV_NW == 12 ? (SPLIT_BF16 ? WV_BF16_OCC
     vblk_t pv[2];
     vload(0, pv[0]);
     auto f4 = [](const float4 &v) { return (f32x4){v.x, v.y, v.z, v.w}; };
+    // Written over a wave's WV_MPW tiles (round 5: launches of more than 256 windows run FOUR waves x three tiles, two
+    // workgroups per CU - the form that gave the split-bf16 loop 14 % at scale; up to 256 windows - one per CU - twelve waves x
+    // one tile): the tiles' MFMAs and gate evaluations are independent instructions back to back, the per-tile arithmetic is
+    // the same source in both forms, so a posterior does not depend on the launch size.
     auto run_block_t = [&](int blk, const wblk_t &P, wblk_t &Pnext, const vblk_t &V, vblk_t &Vnext) {
       float *u = ubuf + (blk & 1) * 4 * UPL + kk * UPL + WV_PAD * 4;          // row 0 of this lane's channel-group plane
       const int d = (int)((a.dil4[blk >> 4] >> (4 * (blk & 15))) & 15);
       const float4 *vt = (const float4 *)(vtab + blk * 112) + kk;
       const float4 bres = vt[16], bsk0 = vt[20], bsk1 = vt[24];
-      const float4 uv = make_float4(x[0][0] * V.bns.x + V.bnt.x, x[0][1] * V.bns.y + V.bnt.y, x[0][2] * V.bns.z + V.bnt.z,
-                                    x[0][3] * V.bns.w + V.bnt.w);
-      *(float4 *)(u + tl * 4) = uv;
-      const float *tap0 = u + (tl - 2 * d) * 4, *tap1 = u + (tl - d) * 4;     // rows < 0 hit the zero pad (d <= 8)
+      f32x4 uv[WV_MPW], as[WV_MPW], at[WV_MPW];
+#pragma unroll
+      for (int mi = 0; mi < WV_MPW; ++mi) {
+        uv[mi] = (f32x4){x[mi][0] * V.bns.x + V.bnt.x, x[mi][1] * V.bns.y + V.bnt.y, x[mi][2] * V.bns.z + V.bnt.z,
+                         x[mi][3] * V.bns.w + V.bnt.w};
+        *(f32x4 *)(u + (tl + 16 * mi) * 4) = uv[mi];
+      }
       const int nb = blk + 1 < a.NB ? blk + 1 : blk;
       wload(nb, Pnext);  // unconditional (clamped) prefetch, as the row-major loop
-      f32x4 as = f4(V.bsig), at = f4(V.btanh);
-      MFMA4(as, P.wg[2][0], uv);                     // tap 2 = this row: runs while the other waves arrive
-      MFMA4(at, P.wg[2][1], uv);
-      __syncthreads();  // u complete (all rows, all waves)
-      const float4 t0v = *(const float4 *)tap0;
-      const float4 t1v = *(const float4 *)tap1;
-      vload(nb, Vnext);
-      __builtin_amdgcn_sched_barrier(0);  // both tap reads (and the table reads behind them) are in flight before the first wait
-      MFMA4(as, P.wg[0][0], t0v);
-      MFMA4(at, P.wg[0][1], t0v);
-      MFMA4(as, P.wg[1][0], t1v);
-      MFMA4(at, P.wg[1][1], t1v);
-      const float4 gv = make_float4(fast_tanh_w(at[0]) * fast_sigmoid_w(as[0]), fast_tanh_w(at[1]) * fast_sigmoid_w(as[1]),
-                                    fast_tanh_w(at[2]) * fast_sigmoid_w(as[2]), fast_tanh_w(at[3]) * fast_sigmoid_w(as[3]));
-      f32x4 ar = f4(bres), s0 = f4(bsk0), s1 = f4(bsk1);
-      const int has_res = (a.has_res_mask >> blk) & 1;
-      // (hand-interleaving the k-steps of the accumulators - dependent MFMAs issue after 40 cycles, independent ones after 32 - was
-      //  1 % SLOWER: with three waves per SIMD the other waves fill those 8 cycles, and the compiler's own order keeps fewer values live)
-      if (has_res) { MFMA4(ar, P.wrs[0], gv); }
-      MFMA4(s0, P.wrs[1], gv);
-      MFMA4(s1, P.wrs[2], gv);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (has_res) x[0][r] = relu1(ar[r]) + x[0][r];
-        skip[0][0][r] = skip[0][0][r] + relu1(s0[r]);
-        skip[0][1][r] = skip[0][1][r] + relu1(s1[r]);
+      for (int mi = 0; mi < WV_MPW; ++mi) {
+        as[mi] = f4(V.bsig);
+        at[mi] = f4(V.btanh);
+        MFMA4(as[mi], P.wg[2][0], uv[mi]);             // tap 2 = this row: runs while the other waves arrive
+        MFMA4(at[mi], P.wg[2][1], uv[mi]);
+      }
+      __syncthreads();  // u complete (all rows, all waves)
+      f32x4 t0v[WV_MPW], t1v[WV_MPW];
+#pragma unroll
+      for (int mi = 0; mi < WV_MPW; ++mi) {            // rows < 0 hit the zero pad (d <= 8)
+        t0v[mi] = *(const f32x4 *)(u + (tl + 16 * mi - 2 * d) * 4);
+        t1v[mi] = *(const f32x4 *)(u + (tl + 16 * mi - d) * 4);
+      }
+      vload(nb, Vnext);
+      __builtin_amdgcn_sched_barrier(0);  // the tap reads (and the table reads behind them) are in flight before the first wait
+      const int has_res = (a.has_res_mask >> blk) & 1;
+#pragma unroll
+      for (int mi = 0; mi < WV_MPW; ++mi) {
+        MFMA4(as[mi], P.wg[0][0], t0v[mi]);
+        MFMA4(at[mi], P.wg[0][1], t0v[mi]);
+        MFMA4(as[mi], P.wg[1][0], t1v[mi]);
+        MFMA4(at[mi], P.wg[1][1], t1v[mi]);
+      }
+#pragma unroll
+      for (int mi = 0; mi < WV_MPW; ++mi) {
+        const f32x4 gv = {fast_tanh_w(at[mi][0]) * fast_sigmoid_w(as[mi][0]), fast_tanh_w(at[mi][1]) * fast_sigmoid_w(as[mi][1]),
+                          fast_tanh_w(at[mi][2]) * fast_sigmoid_w(as[mi][2]), fast_tanh_w(at[mi][3]) * fast_sigmoid_w(as[mi][3])};
+        f32x4 ar = f4(bres), s0 = f4(bsk0), s1 = f4(bsk1);
+        // (hand-interleaving the k-steps of the accumulators - dependent MFMAs issue after 40 cycles, independent ones after 32 - was
+        //  1 % SLOWER: with three waves per SIMD the other waves fill those 8 cycles, and the compiler's own order keeps fewer values live)
+        if (has_res) { MFMA4(ar, P.wrs[0], gv); }
+        MFMA4(s0, P.wrs[1], gv);
+        MFMA4(s1, P.wrs[2], gv);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (has_res) x[mi][r] = relu1(ar[r]) + x[mi][r];
+          skip[mi][0][r] = skip[mi][0][r] + relu1(s0[r]);
+          skip[mi][1][r] = skip[mi][1][r] + relu1(s1[r]);
+        }
       }
     };
     for (int blk = 0; blk < a.NB; blk += 2) {
@@ -887,6 +911,8 @@ int ww_k_wave_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
     hipLaunchKernelGGL((wavenet_kernel<false, true, WV_BF16_NW>), dim3(nw), dim3(WV_BF16_NW * 64), 0, ctx->stream, a);
   else if (m->opt_wave_rowmajor)
     hipLaunchKernelGGL((wavenet_kernel<false, false, 12>), dim3(nw), dim3(12 * 64), 0, ctx->stream, a);
+  else if (nw > WV_F32_WIDE_FROM)  // (round 5) fp32: the same two forms as the split-bf16 loop, the same bits in both
+    hipLaunchKernelGGL((wavenet_kernel<false, false, 4, true>), dim3(nw), dim3(4 * 64), 0, ctx->stream, a);
   else
     hipLaunchKernelGGL((wavenet_kernel<false, false, 12, true>), dim3(nw), dim3(12 * 64), 0, ctx->stream, a);
   WW_HIP(ctx, hipGetLastError());
