@@ -111,11 +111,11 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-PMC_FILE = os.path.join("profiles", "r04", "pmc_counters.json")
+PMC_FILE = os.path.join("profiles", "r05", "pmc_counters.json")
 
 
 def pmc_counters():
-    """profiles/r04/pmc_counters.json (tools/pmc_collect.py: rocprofv3 --pmc passes, mean per launch and kernel) if it
+    """profiles/r05/pmc_counters.json (tools/pmc_collect.py: rocprofv3 --pmc passes, mean per launch and kernel) if it
     was measured on THESE kernel sources, else None."""
     try:
         pmc = json.load(open(os.path.join(ROOT, PMC_FILE)))
@@ -362,7 +362,7 @@ def roofline_of(eng, prof, clips, fast_frontend, step_s=None):
         roof["traffic"] = (2 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024
         roof["traffic_note"] = ("2 x FETCH_SIZE + WRITE_SIZE (KiB; gfx950 reports half of 16-byte-per-lane streaming reads: "
                                 "MI355X_MICROARCH.md), rocprofv3 --pmc in separate passes, mean bytes per launch "
-                                f"(profiles/r04/pmc_counters.json, kernel sources {pmc['source_sha']})")
+                                f"({PMC_FILE}, kernel sources {pmc['source_sha']})")
         roof["algorithmic_bytes"] = nbytes
         if dom.startswith("crnn_fused_kernel"):
             # SURVEY 8(d) counts the 622,724 B of weights ONCE; each of the 8 XCDs has an L2 of its own and fetches them once,
@@ -371,7 +371,7 @@ def roofline_of(eng, prof, clips, fast_frontend, step_s=None):
             roof["algorithmic_bytes_note"] = ("algorithmic_bytes = windows in + posteriors out + the weights once PER XCD L2 (8 x 622,724 B); "
                                               "algorithmic_bytes_weights_once = SURVEY 8(d)'s definition (weights once per launch)")
     elif pmc is None:
-        roof["traffic_note"] = "no PMC pass on these kernel sources (profiles/r04/pmc_counters.json absent or of another source_sha)"
+        roof["traffic_note"] = f"no PMC pass on these kernel sources ({PMC_FILE} absent or of another source_sha)"
     # how busy the shared vector / matrix datapath is over a STEP (the fp32 MFMA and the vector ALU of a SIMD do not
     # co-execute on gfx950: tools/pmc_calib.hip, profiles/r04/README.md): per kernel, busy cycles per SIMD =
     # SQ_VALU_MFMA_BUSY_CYCLES / 1024 + 3.7 x (SQ_INSTS_VALU - SQ_INSTS_MFMA) / 1024 over the kernel's own SQ_BUSY_CYCLES / 32
@@ -411,7 +411,7 @@ def roofline_of(eng, prof, clips, fast_frontend, step_s=None):
                 every[name]["fp64_valu"] = {"achieved_TFLOPs": fl / t / 1e12, "peak_TFLOPs": PEAK_F64_VALU / 1e12,
                                             "frac": fl / t / PEAK_F64_VALU,
                                             "note": "13.9 kFLOP per frame (SURVEY 8d), mostly adds: half of the FMA peak is the ceiling; "
-                                                    "vector ALU 55 % busy over the kernel (profiles/r04/pmc_counters.json: SQ_ACTIVE_INST_VALU x 3.7 cycles per SIMD over SQ_BUSY_CYCLES)"}
+                                                    "vector ALU 55 % busy over the kernel (pmc_counters.json: 3.7 cycles x non-MFMA vector instructions per SIMD over SQ_BUSY_CYCLES / 32)"}
         elif name.endswith("<bf16x3>"):
             every[name] = {"bound": "mfma", "achieved": 3.0 * fl / t / 1e12, "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s",
                            "frac": 3.0 * fl / t / PEAK_BF16_MFMA}

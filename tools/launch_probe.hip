@@ -51,6 +51,12 @@ struct stats {
   }
 };
 
+// one dependent read over the bus per workgroup (what a tick's control words cost a kernel that waits for them)
+__global__ void k_read1(const unsigned *host_src, unsigned *dst) {
+  const unsigned v = host_src[blockIdx.x & 15];
+  if (v == 0x12345u) dst[blockIdx.x] = v;
+}
+
 int main() {
   hipStream_t s;
   hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
@@ -138,6 +144,21 @@ int main() {
       b.add(now_us() - t0);
     }
     b.print("kernel reading 82 KB of pinned host memory: launch + sync");
+  }
+  {
+    stats a, b;
+    for (int i = 0; i < N; ++i) {
+      const double t0 = now_us();
+      hipLaunchKernelGGL(k_read1, dim3(256), dim3(256), 0, s, (const unsigned *)hsrc_dev, dst);
+      hipStreamSynchronize(s);
+      b.add(now_us() - t0);
+      const double t1 = now_us();
+      hipLaunchKernelGGL(k_read1, dim3(256), dim3(256), 0, s, (const unsigned *)counter, dst);
+      hipStreamSynchronize(s);
+      a.add(now_us() - t1);
+    }
+    b.print("kernel waiting for ONE word of pinned host memory: launch + sync");
+    a.print("the same kernel reading the word from device memory: launch + sync");
   }
   {
     // two launches, the second polled by flag

@@ -29,13 +29,15 @@ def short(name: str) -> str:
         return "wavenet_kernel<bf16x3>" if re.match(r"<\w+, true", targs) else "wavenet_kernel"
     if base == "stream_frontend_kernel":
         return "stream_frontend_kernel"
+    if base == "crnn_stream_kernel":  # <0>: behind a front-end kernel of its own; <1 | 2>: ONE launch per tick (round 5)
+        return "crnn_stream_kernel" if targs.startswith("<0") else "crnn_stream_kernel<tick>"
     return base
 
 
 def main():
     import bench
     out = {"source_sha": bench.kernel_source_sha(),
-           "note": "rocprofv3 --pmc passes (tools/r04_prof.sh), mean per launch.  FETCH_SIZE / WRITE_SIZE in KiB as reported "
+           "note": "rocprofv3 --pmc passes (tools/r05_prof.sh), mean per launch.  FETCH_SIZE / WRITE_SIZE in KiB as reported "
                    "(gfx950: FETCH_SIZE counts half of 16-byte-per-lane streaming reads -> traffic = 2 x FETCH + WRITE, "
                    "MI355X_MICROARCH.md); SQ_VALU_MFMA_BUSY_CYCLES in cycles summed over SIMDs; SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / "
                    "SQ_WAIT_* in quad-cycles summed over waves (same guide, s_memtime row).",

@@ -6,16 +6,16 @@ import numpy as np
 from wwhip.engine import Engine, StreamBank
 S = 128
 rng = np.random.default_rng(0)
-for name, prec in (("CRNN", "fp32"), ("Wavenet", "bf16x3")):
+for name, prec, kw in (("CRNN", "fp32", {}), ("CRNN", "fp32", {"two_launch": True, "sync_wait": True}), ("Wavenet", "bf16x3", {})):
     eng = Engine(os.path.join(ROOT, "wakeword-detection_amd/assets/tf_lite_models", name), precision=prec)
-    bank = StreamBank(eng, S)
+    bank = StreamBank(eng, S, **kw)
     frames = np.clip(rng.normal(0, 2500, (64, S, 320)), -32768, 32767).astype(np.int16)
     speech = np.ones(S, np.uint8)
     for t in range(200): bank.step(frames[t % 64], speech)
     eng.ctx.profile(True)
     for t in range(200): bank.step(frames[t % 64], speech)
     p = eng.ctx.profile_read(); eng.ctx.profile(False)
-    print(name, prec, {k: round(v["total_ms"] / v["calls"] * 1e3, 2) for k, v in p.items()})
+    print(name, prec, kw or "(default: one launch per tick where the bank can, polled posteriors)", {k: round(v["total_ms"] / v["calls"] * 1e3, 2) for k, v in p.items()})
     t0 = time.perf_counter()
     for t in range(2000): bank.step(frames[t % 64], speech)
     print("  tick us", (time.perf_counter() - t0) / 2000 * 1e6)

@@ -817,7 +817,10 @@ struct stream_args {
   int n_mel;
   float floor_v, log_off, scale;
   const double *hann, *tw256, *tw512;
+  long long *tstamps;  // development (WWHIP_CF_STAMPS): [workgroups][4 waves][6] s_memtime inside the tick prologue
 };
+#define CT_STAMP(i_) \
+  if (sa.tstamps && lane == 0) sa.tstamps[((size_t)blockIdx.x * 4 + wave) * 6 + (i_)] = __builtin_amdgcn_s_memtime();
 
 // Mel-side LDS of the one-launch tick form, in the part of the feat region the three conv rows leave free (floats from `feat`)
 #define CT_X (3 * CF_FLD)                 // [WW_ST_RING] ring | the tick's new samples
@@ -955,6 +958,7 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_stream_kernel(stream_args 
     // ---- what this workgroup is (uniform over it)
     const int fill = cw.x, nf = cw.y, flags = cw.z, pos = cw.w & 0xffff, rowq = cw.w >> 16;
     const int par = (flags >> 2) & 1;
+    CT_STAMP(0)  // the control words are here
     const int np = (flags & 1) ? nf : 0;  // frames are analysed only while the VAD says speech (tflite.py:166)
     if ((flags & 2) || k >= (np > 1 ? np : 1)) return;  // an active stream is not sampled at all (tflite.py:139-140) | no second window
     const bool window = k < np, writer = k + 1 >= np;
@@ -991,7 +995,9 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_stream_kernel(stream_args 
       for (int i = tid; i < CF_IMG_FLOATS / 4; i += CF_THREADS) ((float4 *)img)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       tile_offsets();
     }
+    CT_STAMP(1)
     __syncthreads();
+    CT_STAMP(2)
     // ---- [ring | new samples]: normalise, clip, pre-emphasise (the arithmetic of stream_frontend_kernel, streams.hip)
     for (int i = tid; i < WW_CHUNK; i += CF_THREADS) {
       float v = __fdiv_rn((float)fxs[i], fe.divisor);
@@ -1006,6 +1012,7 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_stream_kernel(stream_args 
       fx[fill + i] = (fe.preemph != 0.0f) ? __fsub_rn(v, __fmul_rn(fe.preemph, p)) : v;
     }
     __syncthreads();
+    CT_STAMP(3)
     if (writer && tid == 0) {
       float v = __fdiv_rn((float)fxs[WW_CHUNK - 1], fe.divisor);
       if (fe.clip) v = fminf(fmaxf(v, -1.0f), 1.0f);
@@ -1035,8 +1042,10 @@ __global__ __launch_bounds__(CF_THREADS, 2) void crnn_stream_kernel(stream_args 
       float *ring = fe.ring + ((size_t)(par ^ 1) * fe.S + s) * WW_ST_RING;
       for (int i = tid; i < keep; i += CF_THREADS) ring[i] = fx[nf * fe.hop + i];
     }
+    CT_STAMP(4)  // (waves 0, 1: the new frames are in the image)
     if (!window) return;  // the tick has no window for this stream: its ring has advanced, that is all
     scatter(stage, sidx);
+    CT_STAMP(5)
   }
   __syncthreads();
   CF_STAMP(1)
@@ -2227,12 +2236,40 @@ int ww_k_crnn_tick(ww_ctx *ctx, const ww_model *m, const ww_tick_fe &fe, int pre
   sa.start = f.start; sa.wpad = f.wpad; sa.bias = f.bias; sa.n_mel = f.n_mel;
   sa.floor_v = f.floor_v; sa.log_off = f.log_off; sa.scale = f.scale;
   sa.hann = f.hann; sa.tw256 = f.tw256; sa.tw512 = f.tw512;
+  static const bool want_stamps = getenv("WWHIP_CF_STAMPS") != nullptr;  // development: phase timeline (the call then waits for its kernel)
+  const int nwg = 2 * fe.S;
+  if (want_stamps) {
+    WW_HIP(ctx, hipMalloc((void **)&sa.f.stamps, (size_t)nwg * 64 * sizeof(long long)));
+    WW_HIP(ctx, hipMemsetAsync(sa.f.stamps, 0, (size_t)nwg * 64 * sizeof(long long), ctx->stream));
+    sa.tstamps = sa.f.stamps + (size_t)nwg * 40;
+  }
   {
     ww_launch_scope scope(ctx, "crnn_stream_kernel<tick>");
-    if (precise) hipLaunchKernelGGL(crnn_stream_kernel<2>, dim3(2 * fe.S), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, sa);
-    else hipLaunchKernelGGL(crnn_stream_kernel<1>, dim3(2 * fe.S), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, sa);
+    if (precise) hipLaunchKernelGGL(crnn_stream_kernel<2>, dim3(nwg), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, sa);
+    else hipLaunchKernelGGL(crnn_stream_kernel<1>, dim3(nwg), dim3(CF_THREADS), CF_SMEM_BYTES, ctx->stream, sa);
   }
   WW_HIP(ctx, hipGetLastError());
+  if (want_stamps) {
+    std::vector<long long> h((size_t)nwg * 64);
+    WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    WW_HIP(ctx, hipMemcpy(h.data(), sa.f.stamps, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    WW_HIP(ctx, hipFree(sa.f.stamps));
+    for (int wv : {0, 3}) {  // wave 0 transforms a frame, wave 3 only stages: mean cycles since the workgroup's entry
+      double sum[16] = {0};
+      int cnt = 0;
+      for (int b = 0; b < nwg; ++b) {
+        const long long *c = &h[((size_t)b * 4 + wv) * 10], *t = &h[(size_t)nwg * 40 + ((size_t)b * 4 + wv) * 6];
+        if (!c[0] || !c[9]) continue;  // (a workgroup without a window)
+        for (int i = 0; i < 6; ++i) sum[i] += (double)(t[i] - c[0]);
+        for (int i = 1; i < 10; ++i) sum[5 + i] += (double)(c[i] - c[0]);
+        ++cnt;
+      }
+      fprintf(stderr, "crnn_stream_kernel<tick>, %d window workgroups, wave %d, mean cycles since entry: ctl | pre-barrier barrier normalised "
+              "frames staged | image conv conv-barrier proj proj-barrier D E F G:", cnt, wv);
+      for (int i = 0; i < 15; ++i) fprintf(stderr, "%s %.0f", i == 1 || i == 6 ? " |" : "", cnt ? sum[i] / cnt : 0.0);
+      fprintf(stderr, "\n");
+    }
+  }
   return WW_OK;
 }
 
