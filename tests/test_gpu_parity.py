@@ -687,17 +687,18 @@ def test_posterior_pick_and_sweep_on_the_device(assets):
             e.close()
 
 
-@pytest.mark.parametrize("name,precise", [("CRNN", True), ("CRNN_softmax", True), ("CRNN", False)])
-def test_one_launch_tick_equals_the_two_launch_form(assets, name, precise):
-    """Round 5: a tick of the incremental CRNN bank is ONE launch - the front end of a stream's new frames runs inside the
-    workgroups of that stream's new windows, the workgroup of the newest window alone writes the stream's state (sample ring
-    and carry ping-pong by the stream's parity so that its sibling still reads last tick's) - and the host polls the
+@pytest.mark.parametrize("name,precise,prec", [("CRNN", True, "fp32"), ("CRNN_softmax", True, "fp32"), ("CRNN", False, "fp32"),
+                                               ("Wavenet", True, "fp32"), ("Wavenet", True, "bf16x3"), ("Wavenet_alt", False, "fp32")])
+def test_one_launch_tick_equals_the_two_launch_form(assets, name, precise, prec):
+    """Round 5: a tick of the incremental CRNN bank - and of the Wavenet banks - is ONE launch: the front end of a stream's new
+    frames runs inside the workgroups of that stream's new windows, the workgroup of the newest window alone writes the stream's
+    state (sample ring and carry ping-pong by the stream's parity so that its sibling still reads last tick's) - and the host polls the
     posteriors' {value, tick number} pairs.  Against the front-end kernel + model kernel form waited for with
     hipStreamSynchronize: 320 ticks with the VAD bit going on and off per stream (a silent stream's ring still advances; a
     whole tick without a window), streams that are active for a while (not sampled at all: tflite.py:139-140), resets of
     single streams and of the whole bank, pre-emphasis on - bit for bit, every tick."""
     from wwhip.engine import Engine, StreamBank, frontend_params
-    e = Engine(os.path.join(assets, name))
+    e = Engine(os.path.join(assets, name), precision=prec)
     S, ticks = 9, 320
     rng = np.random.default_rng(505)
     pcm = np.clip(rng.normal(0, 2500, (ticks, S, 320)), -32768, 32767).astype(np.int16)
@@ -730,6 +731,10 @@ def test_one_launch_tick_equals_the_two_launch_form(assets, name, precise):
             np.testing.assert_array_equal(p0, p1, err_msg=f"tick {t}")
         assert sum(int(n.sum()) for _, n in one) > 3500
         assert any(int(n.sum()) == 0 for _, n in one[10:])
+        if not e.is_crnn:  # the fp32 Wavenet's row-major block loop (an option of the model) in both tick forms
+            with e.options(wavenet_rowmajor=1):
+                for (p0, n0), (p1, n1) in zip(run(), run(two_launch=True, sync_wait=True)):
+                    np.testing.assert_array_equal(p0, p1)
         for kw in ({"two_launch": True}, {"sync_wait": True}):   # the other two combinations: polled two-launch, waited one-launch
             other = run(**kw)
             for t, ((p0, n0), (p1, n1)) in enumerate(zip(one, other)):

@@ -262,7 +262,9 @@ int ww_stream_create(ww_ctx *ctx, const ww_model *model, int32_t S, const ww_fro
   // for a model in split-bf16 mode: a seventh of the products in fp32 is both faster and closer).
   // WW_STREAM_FULL_RECOMPUTE keeps the per-window kernels (every window recomputed from its mel rows).
   st->incremental = ww_crnn_stream_capable(model) && !(flags & WW_STREAM_FULL_RECOMPUTE);
-  st->one_launch = st->incremental && !(flags & WW_STREAM_TWO_LAUNCH) && model->filt.n_mel == 40;
+  // ONE launch per tick: the incremental CRNN, and the Wavenet (its per-window kernel with the front end inside)
+  st->one_launch = (st->incremental || model->kind == WW_KIND_WAVENET) && !(flags & WW_STREAM_TWO_LAUNCH) && model->filt.n_mel == 40 &&
+                   model->info.window <= 182;
   // a borrowed stream is the caller's: when the call returns everything enqueued on it has completed, as before
   st->poll = ctx->own_stream && !(flags & WW_STREAM_SYNC_WAIT);
   // model scratch of the per-window kernels (explicit window rows: never the sliding form); the incremental CRNN needs none
@@ -456,14 +458,14 @@ int ww_stream_step(ww_streams *st, const int16_t *frames, const uint8_t *is_spee
   ww_tick_tag tag = {st->h_tag_dev, st->seq, pidx};
   bool tagged = false;
   if (st->one_launch) {
-    // ---- ONE launch: front end + incremental CRNN, workgroup 2 s + k = window k of stream s (crnn.hip)
+    // ---- ONE launch: front end + model, workgroup 2 s + k = window k of stream s (crnn.hip: crnn_stream_kernel<FE>; wavenet.hip)
     ww_tick_fe fe = {};
     fe.frames = (const int16_t *)(st->h_pack_dev + ((char *)h_frames - st->h_pack));
     fe.ctl = (const int32_t *)(st->h_pack_dev + ((char *)h_ctl - st->h_pack));
     fe.ring = st->ring; fe.prev = st->prev; fe.hist = st->hist;
     fe.S = S; fe.HR = st->HR;
     fe.divisor = st->fp.pcm_divisor; fe.clip = st->fp.clip; fe.preemph = st->fp.pre_emphasis; fe.hop = hop;
-    int rc = ww_k_crnn_tick(ctx, m, fe, st->fp.precise, st->gxc, tag);
+    int rc = m->kind == WW_KIND_CRNN ? ww_k_crnn_tick(ctx, m, fe, st->fp.precise, st->gxc, tag) : ww_k_wave_tick(ctx, m, fe, st->fp.precise, tag);
     if (rc) return rc;
     tagged = true;
     tl[3] = st_now_ns();

@@ -28,7 +28,11 @@
 //
 // The detect head (ReLU, 1x1 32->32 ReLU, 1x1 32->2, max over time, softmax) runs in the same launch.
 #include "common.h"
+#include "fft_device.h"
+#undef NB   // (fft_device.h: bins of the transform; here NB is the model's block count)
+#undef WIN
 
+#include <type_traits>
 #include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -88,7 +92,22 @@ struct wave_args {
   const uint4 *wpk;     // split-bf16 mode: parameter pages [NB][WV_PAGE_U4] (A operands of v_mfma_f32_16x16x32_bf16, then the vectors)
   long long *stamps;    // development (-DWV_STAMPS=1): [windows][12 waves][12] s_memtime inside block WV_STAMP_BLK of the split-bf16 loop
   ww_tick_tag tag;      // streaming ticks: the posterior as a {value, tick number} pair instead of the row of `out`
+  // TICK != 0 - ONE launch per tick (round 5): the streaming front end's side (common.h) and the model's filterbank
+  ww_tick_fe fe;
+  const int *mel_start;
+  const float *mel_wpad, *mel_bias;
+  float floor_v, log_off, scale;
+  const double *hann, *tw256, *tw512;
 };
+
+// Mel-side LDS of the one-launch tick form, behind the staged input [WV_T][WV_INLD] (floats from `lds`); dead before the block loop
+#define WT_X (WV_T * WV_INLD)          // [WW_ST_RING] ring | the tick's new samples
+#define WT_XS (WT_X + WW_ST_RING)      // [WW_CHUNK] int16: the raw samples
+#define WT_WL (WT_XS + WW_CHUNK / 2)   // [768 x 4] the mel weights [WW_MEL_TAPS][64], padded to one store round of 12 waves
+#define WT_MAG (WT_WL + 768 * 4)       // [2][260] magnitudes of the (at most) two new frames
+#define WT_BUF (WT_MAG + 2 * 260 + 8)  // [2][FFT_LD] complex (16-byte aligned)
+#define WT_END (WT_BUF + 2 * FFT_LD * 4)
+static_assert(WT_BUF % 4 == 0 && WW_MEL_TAPS * 64 <= 768 * 4, "tick front end: LDS layout");
 
 #ifndef WV_STAMPS
 #define WV_STAMPS 0
@@ -213,9 +232,15 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define WV_PAGE_U4 (WV_SLOTS * 64)  // one block's parameter page in 16-byte units (the conv biases sit in padded k-slots)
 
 // FP32T: the fp32 block loop in the TRANSPOSED form of the split-bf16 loop (channels x time; round 3) - see its comment below.
-template <bool HEAD_ONLY, bool SPLIT_BF16, int WV_NW, bool FP32T = false>
+// TICK = 1 / 2 (fp32 / fp64 transform) - ONE launch per streaming tick (round 5; crnn.hip's crnn_stream_kernel<FE> has the full
+// story): workgroup 2 s + k is window k of stream s's tick; it reads the stream's control words and samples over the bus, waves
+// 0 and 1 transform the new frames (one each) straight into the staged input while the others stage the rows that were
+// there before; the workgroup of the tick's newest window alone writes the stream's state (mel rows, sample ring and carry -
+// the latter two ping-pong by the stream's parity, so its sibling still reads last tick's).  Twelve waves x one tile only.
+template <bool HEAD_ONLY, bool SPLIT_BF16, int WV_NW, bool FP32T = false, int TICK = 0>
 __global__ __launch_bounds__(WV_NW * 64, WV_NW == 12 ? (SPLIT_BF16 ? WV_BF16_OCC : 3) : 2) void wavenet_kernel(wave_args a) {
   constexpr int WV_MPW = 12 / WV_NW, WV_THREADS = WV_NW * 64;
+  static_assert(!TICK || (WV_NW == 12 && !HEAD_ONLY), "the one-launch tick runs twelve waves x one tile");
   constexpr bool TRANSPOSED = SPLIT_BF16 || FP32T;  // state layout: lane = time column, four consecutive channels per register quad
   static_assert(!(SPLIT_BF16 && FP32T), "one arithmetic mode");
   static_assert(WV_MPW * WV_NW == 12, "12 row tiles");
@@ -226,7 +251,8 @@ __global__ __launch_bounds__(WV_NW * 64, WV_NW == 12 ? (SPLIT_BF16 ? WV_BF16_OCC
   constexpr int LDS_BF16 = 2 * (WV_T + WV_PAD) * WV_C + 3 * WV_PAGE_U4 * 4 + 32 * 8 * 4;  // u planes + 3 pages + BatchNorm table (NB <= 32)
   constexpr int LDS_F32T = 2 * (WV_T + WV_PAD) * WV_C + WV_T * WV_S + 32 * 7 * 16;        // u buffers + head tile + per-block vectors (NB <= 32)
   constexpr int LDS_A = SPLIT_BF16 && LDS_BF16 > LDS_FP32 ? LDS_BF16 : LDS_FP32;
-  __shared__ __align__(16) float lds[FP32T && LDS_F32T > LDS_A ? LDS_F32T : LDS_A];
+  constexpr int LDS_B = FP32T && LDS_F32T > LDS_A ? LDS_F32T : LDS_A;
+  __shared__ __align__(16) float lds[TICK && WT_END > LDS_B ? WT_END : LDS_B];
   __shared__ float red[WV_NW][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kk = lane >> 4;
@@ -250,9 +276,16 @@ __global__ __launch_bounds__(WV_NW * 64, WV_NW == 12 ? (SPLIT_BF16 ? WV_BF16_OCC
       }
     (void)x; (void)ubuf;
   } else {
-  int64_t row;
-  int valid;
-  if (a.wa.row && a.wa.valid) {  // (both tables: the two loads go out together)
+  int64_t row = 0;
+  int valid = 0;
+  // ---- TICK: over the bus, together: the tick's 320 samples (40 x 16 bytes) and the stream's control words
+  typedef typename std::conditional<TICK == 2, double, float>::type RT;
+  uint4 t_raw = make_uint4(0u, 0u, 0u, 0u);
+  int4 t_cw = make_int4(0, 0, 0, 0);
+  if (TICK) {
+    if (tid < 40) t_raw = ((const uint4 *)(a.fe.frames + (size_t)(w >> 1) * WW_CHUNK))[tid];
+    t_cw = ((const int4 *)a.fe.ctl)[w >> 1];
+  } else if (a.wa.row && a.wa.valid) {  // (both tables: the two loads go out together)
     const int64_t r_ = a.wa.row[w];
     const int v_ = a.wa.valid[w];
     row = r_;
@@ -263,9 +296,11 @@ __global__ __launch_bounds__(WV_NW * 64, WV_NW == 12 ? (SPLIT_BF16 ? WV_BF16_OCC
     if (a.wa.row) row = a.wa.row[w];
     if (a.wa.valid) valid = a.wa.valid[w];
   }
-  if (valid > T) valid = T;
-  if (row + valid > a.wa.mel_rows) valid = (int)(a.wa.mel_rows - row);
-  if (valid < 0) valid = 0;
+  if (!TICK) {
+    if (valid > T) valid = T;
+    if (row + valid > a.wa.mel_rows) valid = (int)(a.wa.mel_rows - row);
+    if (valid < 0) valid = 0;
+  }
 
   // the input conv's operands: requested now, used behind the staging
   float4 bw[3];
@@ -307,7 +342,105 @@ __global__ __launch_bounds__(WV_NW * 64, WV_NW == 12 ? (SPLIT_BF16 ? WV_BF16_OCC
 
   // ---- stage the window: in_lds[t][0..47], zero outside [0,valid) x [0,n_mel)
   float *in_lds = lds;
-  {
+  if constexpr (TICK != 0) {
+    const ww_tick_fe &fe = a.fe;
+    const int s = w >> 1, k = w & 1;
+    // device-side inputs of the front end that do not depend on the control words: requested while those cross the bus
+    const f32x4 wlq = ((const f32x4 *)a.mel_wpad)[tid < WW_MEL_TAPS * 64 / 4 ? tid : 0];
+    const int mel_st = lane < a.n_mel ? a.mel_start[lane] : 0;
+    const float mel_bias = lane < a.n_mel ? a.mel_bias[lane] : 0.0f;
+    // the sample ring: threads 0..127 ask for the copy of parity 0, threads 128..255 for parity 1 (128 x 4 = 512 > fill)
+    const f32x4 ringq = ((const f32x4 *)(fe.ring + ((size_t)((tid >> 7) & 1) * fe.S + s) * WW_ST_RING))[tid & 127];
+    const float carry0 = fe.prev[s], carry1 = fe.prev[fe.S + s];
+    fft_consts<RT> fc;
+    if (wave < 2) fft_load_consts<RT>(fc, lane, a.hann, a.tw256, a.tw512);
+    // ---- what this workgroup is (uniform over it; as crnn_stream_kernel<FE>)
+    const int fill = t_cw.x, nf = t_cw.y, flags = t_cw.z, pos = t_cw.w & 0xffff;
+    const int par = (flags >> 2) & 1;
+    const int np = (flags & 1) ? nf : 0;  // frames are analysed only while the VAD says speech (tflite.py:166)
+    if ((flags & 2) || k >= (np > 1 ? np : 1)) return;  // an active stream is not sampled at all (tflite.py:139-140) | no second window
+    const bool window = k < np, writer = k + 1 >= np;
+    const int nfk = window ? k + 1 : 0;  // window k ends at new frame k: it needs frames 0..k
+    const int slots = T + 1;
+    // the rows that were there before: the block [(pos + k + 2) % (T + 1), + T - nfk) of the stream's mirrored ring
+    constexpr int SQ = (WV_T * WV_INLD / 4 + WV_THREADS - 1) / WV_THREADS;
+    f32x4 st[SQ];
+    int n4 = 0;
+    if (window) {
+      int b = pos + k + 2;
+      b = b >= slots ? b - slots : b;
+      const float *src = a.mel + ((size_t)s * fe.HR + b) * a.n_mel;  // (160-byte rows of a hipMalloc'ed history: 16-byte aligned)
+      n4 = ((T - nfk) * a.n_mel) >> 2;
+#pragma unroll
+      for (int q = 0; q < SQ; ++q) {
+        const int i = tid + q * WV_THREADS;
+        st[q] = *(const f32x4 *)(src + 4 * (i < n4 ? i : n4 - 1));
+      }
+    }
+    float *fx = lds + WT_X, *fwl = lds + WT_WL, *fmag = lds + WT_MAG;
+    short *fxs = (short *)(lds + WT_XS);
+    cplx<RT> *fbuf = (cplx<RT> *)(lds + WT_BUF);
+    ((f32x4 *)fwl)[tid] = wlq;
+    if (tid < 256 && (tid >> 7) == par) ((f32x4 *)fx)[tid & 127] = ringq;
+    if (tid < 40) ((uint4 *)fxs)[tid] = t_raw;
+    if (window)
+      for (int i = tid; i < WV_T * WV_INLD / 4; i += WV_THREADS) ((float4 *)in_lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    // ---- [ring | new samples]: normalise, clip, pre-emphasise (the arithmetic of stream_frontend_kernel, streams.hip)
+    for (int i = tid; i < WW_CHUNK; i += WV_THREADS) {
+      float v = __fdiv_rn((float)fxs[i], fe.divisor);
+      if (fe.clip) v = fminf(fmaxf(v, -1.0f), 1.0f);
+      float p;
+      if (i == 0) {
+        p = par ? carry1 : carry0;
+      } else {
+        p = __fdiv_rn((float)fxs[i - 1], fe.divisor);
+        if (fe.clip) p = fminf(fmaxf(p, -1.0f), 1.0f);
+      }
+      fx[fill + i] = (fe.preemph != 0.0f) ? __fsub_rn(v, __fmul_rn(fe.preemph, p)) : v;
+    }
+    if (window) {  // (the zero fill is complete: the old rows go in beside the normalisation)
+#pragma unroll
+      for (int q = 0; q < SQ; ++q) {
+        const int i = tid + q * WV_THREADS;
+        if (i < n4) {
+          const int e = i * 4, t = e / a.n_mel, c = e - t * a.n_mel;
+          *(f32x4 *)(in_lds + t * WV_INLD + c) = st[q];
+        }
+      }
+    }
+    __syncthreads();
+    if (writer && tid == 0) {
+      float v = __fdiv_rn((float)fxs[WW_CHUNK - 1], fe.divisor);
+      if (fe.clip) v = fminf(fmaxf(v, -1.0f), 1.0f);
+      fe.prev[(size_t)(par ^ 1) * fe.S + s] = v;  // tflite.py:156-158: the carry is the un-emphasised last sample
+    }
+    // ---- new frames: wave f transforms frame f; its mel row goes straight into the staged input (row T - nfk + f) and, from
+    // the writer, into the stream's mirrored ring
+    if (wave < nfk) {
+      const float *srcx = fx + wave * fe.hop;
+      auto x2 = [&](int n) -> float2 { return make_float2(srcx[2 * n], srcx[2 * n + 1]); };
+      float *mg = fmag + wave * 260;
+      frame_fft_mag<RT>(x2, fc, fbuf + wave * FFT_LD, mg, lane);
+      const float mv = mel_band(mg, fwl, mel_st, mel_bias, a.floor_v, a.log_off, a.scale, lane);
+      if (lane < a.n_mel) {
+        in_lds[(T - nfk + wave) * WV_INLD + lane] = mv;
+        if (writer) {
+          int p = pos + wave;  // mirrored ring: the row goes to p % slots and p % slots + slots
+          p = p >= slots ? p - slots : p;
+          float *h = fe.hist + ((size_t)s * fe.HR + p) * a.n_mel + lane;
+          h[0] = mv;
+          h[(size_t)slots * a.n_mel] = mv;
+        }
+      }
+    }
+    if (writer) {  // keep the ring tail (for the next tick: the other copy)
+      const int keep = fill + WW_CHUNK - nf * fe.hop;
+      float *ring = fe.ring + ((size_t)(par ^ 1) * fe.S + s) * WW_ST_RING;
+      for (int i = tid; i < keep; i += WV_THREADS) ring[i] = fx[nf * fe.hop + i];
+    }
+    if (!window) return;  // the tick has no window for this stream: its ring has advanced, that is all
+  } else {
     const float *src = a.mel + row * a.n_mel;
     const int n = valid * a.n_mel;
     if ((a.n_mel & 3) == 0 && ((((uintptr_t)src) & 15) == 0)) {
@@ -915,6 +1048,48 @@ int ww_k_wave_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
     hipLaunchKernelGGL((wavenet_kernel<false, false, 4, true>), dim3(nw), dim3(4 * 64), 0, ctx->stream, a);
   else
     hipLaunchKernelGGL((wavenet_kernel<false, false, 12, true>), dim3(nw), dim3(12 * 64), 0, ctx->stream, a);
+  WW_HIP(ctx, hipGetLastError());
+  return WW_OK;
+}
+
+// ONE launch per tick (wavenet_kernel<..., TICK>): 2 S workgroups of twelve waves, the posteriors as tags only
+int ww_k_wave_tick(ww_ctx *ctx, const ww_model *m, const ww_tick_fe &fe, int precise, const ww_tick_tag &tag) {
+  const ww_wave_dev &v = m->wave;
+  const ww_filter_dev &f = m->filt;
+  if (f.n_mel != 40 || v.n_mel != 40 || fe.hop != 160 || v.T + 10 > WV_T)
+    return ww_fail(ctx, WW_EINVAL, "one-launch streaming tick: 40 mel bands, hop 160 and a window of at most %d rows only", WV_T - 10);
+  if (!tag.slots || fe.S <= 0) return ww_fail(ctx, WW_EINVAL, "one-launch streaming tick: no tag slots / no streams");
+  wave_args a = {};
+  a.mel = fe.hist;
+  a.wa = {nullptr, nullptr, 0, 0, 0, (int64_t)fe.S * fe.HR};
+  a.T = v.T; a.n_mel = v.n_mel; a.NB = v.NB; a.NOUT = v.NOUT;
+  if (v.NB > 32) return ww_fail(ctx, WW_EINVAL, "Wavenet with %d blocks: kernel limit 32", v.NB);
+  for (int b = 0; b < v.NB; ++b) {
+    if (v.dil[b] < 1 || v.dil[b] > 8) return ww_fail(ctx, WW_EINVAL, "dilation %d of block %d outside 1..8", v.dil[b], b);
+    a.dil4[b >> 4] |= (unsigned long long)v.dil[b] << (4 * (b & 15));
+    if (v.has_res[b]) a.has_res_mask |= 1u << b;
+  }
+  a.w_in4 = v.w_in; a.b_in = v.b_in; a.bn_s = v.bn_s; a.bn_t = v.bn_t;
+  a.w_gate4 = v.w_gate; a.b_gate = v.b_gate; a.w_rs4 = v.w_rs; a.b_rs = v.b_rs;
+  a.d_w1_4 = v.d_w1; a.d_b1 = v.d_b1; a.d_w2_4 = v.d_w2; a.d_b2 = v.d_b2;
+  a.wpk = (const uint4 *)v.wpk;
+  a.tag = tag;
+  a.fe = fe;
+  a.mel_start = f.start; a.mel_wpad = f.wpad; a.mel_bias = f.bias;
+  a.floor_v = f.floor_v; a.log_off = f.log_off; a.scale = f.scale;
+  a.hann = f.hann; a.tw256 = f.tw256; a.tw512 = f.tw512;
+  const dim3 grid(2 * fe.S), block(12 * 64);
+  ww_launch_scope scope(ctx, m->precision == WW_PRECISION_BF16X3 ? "wavenet_kernel<bf16x3,tick>" : "wavenet_kernel<tick>");
+  if (m->precision == WW_PRECISION_BF16X3) {
+    if (precise) hipLaunchKernelGGL((wavenet_kernel<false, true, 12, false, 2>), grid, block, 0, ctx->stream, a);
+    else hipLaunchKernelGGL((wavenet_kernel<false, true, 12, false, 1>), grid, block, 0, ctx->stream, a);
+  } else if (m->opt_wave_rowmajor) {
+    if (precise) hipLaunchKernelGGL((wavenet_kernel<false, false, 12, false, 2>), grid, block, 0, ctx->stream, a);
+    else hipLaunchKernelGGL((wavenet_kernel<false, false, 12, false, 1>), grid, block, 0, ctx->stream, a);
+  } else {
+    if (precise) hipLaunchKernelGGL((wavenet_kernel<false, false, 12, true, 2>), grid, block, 0, ctx->stream, a);
+    else hipLaunchKernelGGL((wavenet_kernel<false, false, 12, true, 1>), grid, block, 0, ctx->stream, a);
+  }
   WW_HIP(ctx, hipGetLastError());
   return WW_OK;
 }
