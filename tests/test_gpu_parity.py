@@ -743,6 +743,32 @@ def test_one_launch_tick_equals_the_two_launch_form(assets, name, precise, prec)
         e.close()
 
 
+@pytest.mark.parametrize("name", ["CRNN_softmax", "Wavenet"])
+def test_one_launch_tick_with_many_streams_per_gpu(assets, name):
+    """The one-launch tick past one workgroup per CU: 700 streams = 1,400 workgroups (several co-resident per CU, siblings of
+    one stream anywhere on the chip), every third stream silent, against the two-launch form - bit for bit - over 14 ticks
+    from an empty history (the first ticks yield 0, 1, 2 windows per stream)."""
+    from wwhip.engine import Engine, StreamBank
+    e = Engine(os.path.join(assets, name))
+    S, ticks = 700, 14
+    rng = np.random.default_rng(3)
+    pcm = np.clip(rng.normal(0, 2500, (ticks, S, 320)), -32768, 32767).astype(np.int16)
+    speech = np.ones(S, np.uint8)
+    speech[::3] = 0
+    try:
+        outs = []
+        for kw in ({}, {"two_launch": True, "sync_wait": True}):
+            bank = StreamBank(e, S, **kw)
+            outs.append([bank.step(pcm[t], speech) for t in range(ticks)])
+            bank.close()
+        for (p0, n0), (p1, n1) in zip(*outs):
+            np.testing.assert_array_equal(n0, n1)
+            np.testing.assert_array_equal(p0, p1)
+        assert sum(int(n.sum()) for _, n in outs[0]) > 10000
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("name,prec", [("Wavenet", "fp32"), ("Wavenet", "bf16x3"), ("CRNN", "bf16x3")])
 def test_polled_tick_equals_the_waited_one(assets, name, prec):
     """Every bank whose context owns its stream waits for a tick by polling the {value, tick number} pairs the heads store into

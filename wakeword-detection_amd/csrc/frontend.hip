@@ -1216,7 +1216,10 @@ int ww_k_logmel(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, const floa
     const int64_t n_wg = 8 * ((((n_waves + LW_WPB - 1) / LW_WPB) + 7) / 8);
     if (n_wg > 0x7fffffff) return ww_fail(ctx, WW_EINVAL, "front-end launch too large (%lld workgroups): split the batch", (long long)n_wg);
     const dim3 grid_w((unsigned)n_wg), block_w(64 * LW_WPB);
-    const size_t sm = (size_t)LW_WPB * LW_WBUF;
+#ifndef LW_LDS_PAD
+#define LW_LDS_PAD 0  // development: extra LDS per workgroup - fewer resident waves with the same instruction stream (occupancy probe)
+#endif
+    const size_t sm = (size_t)LW_WPB * LW_WBUF + LW_LDS_PAD;
     ww_launch_scope scope(ctx, "logmel_rows_kernel");
     if (small_w) {
       if (f32in) hipLaunchKernelGGL((logmel_rows_kernel<true, true, true>), grid_w, block_w, sm, ctx->stream, a);

@@ -603,6 +603,11 @@ class _PosteriorJob:
             return slice(int(first[0]), int(first[0] + ends[-1]))  # consecutive slots (one rank; a contiguous range of the stream)
         return np.arange(int(ends[-1]), dtype=np.int64) + np.repeat(first - (ends - nw), nw)
 
+    def share_samples(self) -> int:
+        """Samples this rank's share is a function of (what it stages and uploads)."""
+        nw = self.mine[:, 2] - self.mine[:, 1]
+        return int((160 * (self.plan.hop * (nw - 1) + self.plan.T - 1) + WINDOW).sum()) if len(nw) else 0
+
     def n_values(self, share: np.ndarray) -> int:
         """Values a rank contributes: one per run of its share for the wake-word clips (the maximum over the run's windows,
         ``evaluate_models.py:98-99``), one per window for the negative stream."""
@@ -836,8 +841,13 @@ def evaluate_reference_flow_sharded(engine: Engine, clips: Sequence[np.ndarray],
             # holds it, when its chunk is staged (_prep_chunk)
             wake = _Int16Clips([clips[i] for i in np.flatnonzero(labels).tolist()])
             lengths = np.fromiter(map(len, wake.raw), np.int64, len(wake.raw))
+        # full-size chunks at once when the negative share keeps the pipeline busy for a while (two full chunks or more: one GPU at
+        # hey-snips size); a rank of eight holds a ninth of that - its wake-word clips start small again, so that the first of
+        # them are on the GPU while the rest are still being staged (one 27 MB chunk: stage, upload, compute, one after the other)
+        neg = made.get("neg")
+        busy = neg is not None and neg.share_samples() >= 2 * _CHUNK_SAMPLES
         made["wake"] = _PosteriorJob(engine, "false_negatives", wake, 20, 16000, rank, world, None, lengths, True, ph, info,
-                                     first_chunk=_CHUNK_SAMPLES if "neg" in made else 1 << 21)  # (the pipeline is full by then)
+                                     first_chunk=_CHUNK_SAMPLES if busy else 1 << 21)
         return made["wake"]
 
     _run_jobs(engine, [negative_job, wake_job], precise, ph, timing)
