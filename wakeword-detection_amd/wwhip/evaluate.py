@@ -316,7 +316,7 @@ class JoinedPCM:
         return out
 
 
-def _piece_runs(plan: StreamPlan, runs, data: dict):
+def _piece_runs(plan: StreamPlan, runs, data: dict, addr: Optional[np.ndarray] = None):
     """For the window runs ``(file, i0, i1)``: the sample range ``[s0, s1)`` each is a function of (its piece), and the copy
     runs that fill the pieces laid end to end: ``(dst_off, src address, count)`` arrays, ascending in ``dst_off``; whatever
     they leave uncovered is zero padding.  A piece of file ``k`` reaches back at most 511 samples into file ``k - 1``.
@@ -343,10 +343,10 @@ def _piece_runs(plan: StreamPlan, runs, data: dict):
                 p_all.append((j.addresses(c0, c1) + 2 * (q0 - st[c0:c1]))[ok])
                 c_all.append((q1 - q0)[ok])
     else:
-        n_files = len(plan.lengths)
-        addr = np.zeros(n_files, np.int64)
-        for f, x in data.items():
-            addr[f] = x.__array_interface__["data"][0]
+        if addr is None:  # (the caller keeps the addresses of the files it has looked at: _prep_chunk)
+            addr = np.zeros(len(plan.lengths), np.int64)
+            for f, x in data.items():
+                addr[f] = x.__array_interface__["data"][0]
         for back in ((1, 0) if plan.carry else (0,)):
             f = ks - back
             ok = f >= 0
@@ -397,19 +397,37 @@ def _prep_chunk(ch: "_Chunk", ph: _Phases) -> None:
     with ph("slicing"):
         runs = np.asarray(runs, np.int64).reshape(-1, 3)
         ks = np.unique(runs[:, 0])
-        files = np.unique(np.concatenate((ks, ks[ks > 0] - 1))).tolist() if plan.carry else ks.tolist()
-        data = {}
-        for f in files:
+        files = np.unique(np.concatenate((ks, ks[ks > 0] - 1))) if plan.carry else ks
+        # a file is looked at ONCE per job (it turns up in two chunks at most, and with the carry as its successor's predecessor
+        # too): array, address and "is int16 PCM" are kept with the job
+        fc = getattr(ch.job, "_files", None)
+        if fc is None:
+            n_all = len(plan.lengths)
+            fc = ch.job._files = (([None] * n_all), np.zeros(n_all, np.int64), np.ones(n_all, bool), plan.lengths.tolist())
+        arrs, addr, is_i16, lens_l = fc
+        for f in files[addr[files] == 0].tolist():
+            if arrs[f] is not None:
+                continue
             x = load(f)
-            if isinstance(x, JoinedPCM) and len(plan.lengths) > 1:
-                x = x.to_array()  # a joined stream among other files: as an ordinary array
-            data[f] = x if isinstance(x, JoinedPCM) else np.ascontiguousarray(x)
+            if isinstance(x, JoinedPCM):
+                if len(lens_l) > 1:
+                    x = x.to_array()  # a joined stream among other files: as an ordinary array
+            elif not (type(x) is np.ndarray and x.flags.c_contiguous):
+                x = np.ascontiguousarray(x)
             # the copy runs below take their counts from the plan and hand raw addresses to the library's copy threads: a file
             # that holds fewer samples than the plan was built on (a truncated wav whose header says more, a caller's own
             # `lengths`) would be read past its end - and its window counts would be wrong anyway
-            if len(data[f]) != int(plan.lengths[f]):
-                raise ValueError(f"file {f} holds {len(data[f])} samples, the plan was built on {int(plan.lengths[f])}")
-        if any(x.dtype != np.int16 for x in data.values()):
+            if len(x) != lens_l[f]:
+                raise ValueError(f"file {f} holds {len(x)} samples, the plan was built on {lens_l[f]}")
+            arrs[f] = x
+            if isinstance(x, JoinedPCM):
+                continue
+            if x.dtype == np.int16:
+                addr[f] = x.__array_interface__["data"][0]
+            else:
+                is_i16[f] = False
+        data = {f: arrs[f] for f in files.tolist()}
+        if not is_i16[files].all():
             # not PCM16 everywhere: float32 samples (librosa's scale) for every file
             data = {f: (x.to_array() if isinstance(x, JoinedPCM) else x) for f, x in data.items()}
             data = {f: (x.astype(np.float32) / np.float32(32768.0) if x.dtype == np.int16 else x.astype(np.float32, copy=False))
@@ -426,7 +444,7 @@ def _prep_chunk(ch: "_Chunk", ph: _Phases) -> None:
                 pieces.append(out)
             ch.host_pieces = pieces
             return
-        soffs, d, pp, c = _piece_runs(plan, runs, data)
+        soffs, d, pp, c = _piece_runs(plan, runs, data, addr)
         lens = np.diff(soffs)
         nf = np.where(lens >= WINDOW, (lens - WINDOW) // 160 + 1, 0).astype(np.int64)
         ch.keep = data  # (the clips must stay where they are until the copy threads have read them)
