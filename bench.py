@@ -429,9 +429,12 @@ def stream_leg(torch, np, dist, comm_dev, local_rank, S, ticks, warm=100):
     stream and tick); latency = tick submitted on the host -> posteriors visible on the host."""
     from wwhip.engine import Engine, StreamBank
     out = {"streams_per_gpu": S, "ticks": ticks, "warmup_ticks": warm,
-           "note": "per-tick latency, host frames in -> host posteriors out; MAX over ranks of each rank's percentile; "
-                   "CRNN: crnn_stream_kernel (3 of the 19 time positions of a window are new per mel row, the other 16 "
-                   "projected rows come from a per-stream ring; results within 2e-6 of the full recompute)"}
+           "note": "per-tick latency, host frames in -> host posteriors out; MAX over ranks of each rank's percentile; a tick is ONE "
+                   "kernel launch (round 5: the front end of a stream's new frames runs inside the workgroups of its new windows - "
+                   "crnn_stream_kernel<FE>: 3 of the 19 time positions of a window are new per mel row, the other 16 projected rows "
+                   "come from a per-stream ring; wavenet_kernel<tick>) and the host polls {posterior, tick} pairs the heads store into "
+                   "page-locked memory instead of hipStreamSynchronize; host_phases_us = ww_stream_timeline (rank 0's mean per tick: "
+                   "plan, frames into the pinned block, launch 1, launch 2, wait, copy-out) + python_wrapper_us = step mean - their sum"}
     rng = np.random.default_rng(5)
     frames = np.clip(rng.normal(0, 2500, (64, S, 320)), -32768, 32767).astype(np.int16)
     speech = np.ones(S, np.uint8)
@@ -440,6 +443,7 @@ def stream_leg(torch, np, dist, comm_dev, local_rank, S, ticks, warm=100):
         bank = StreamBank(eng, S)
         for t in range(warm):
             bank.step(frames[t % 64], speech)
+        bank.timeline(reset=True)
         lat = np.empty(ticks)
         n_post = 0
         for t in range(ticks):
@@ -447,15 +451,19 @@ def stream_leg(torch, np, dist, comm_dev, local_rank, S, ticks, warm=100):
             _, n = bank.step(frames[t % 64], speech)
             lat[t] = time.perf_counter() - t0
             n_post += int(n.sum())
+        tl = bank.timeline()
+        tl.pop("ticks", None)
         stats = [float(np.percentile(lat, 50) * 1e3), float(np.percentile(lat, 99) * 1e3), float(lat.mean() * 1e3),
                  float(np.percentile(lat, 99.9) * 1e3)]
+        own_mean_us = stats[2] * 1e3
         if dist is not None:
             t = torch.tensor(stats, dtype=torch.float64, device=comm_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             stats = [float(v) for v in t.tolist()]
         out[name.lower() if prec == "fp32" else f"{name.lower()}_{prec}"] = {
             "p50_ms": stats[0], "p99_ms": stats[1], "p99.9_ms": stats[3], "mean_ms": stats[2], "posteriors_per_tick": n_post / ticks,
-            "realtime_factor": 0.020 / (stats[2] * 1e-3)}
+            "realtime_factor": 0.020 / (stats[2] * 1e-3), "host_phases_us": {k: round(v, 3) for k, v in tl.items()},
+            "python_wrapper_us": round(own_mean_us - sum(tl.values()), 3)}
         bank.close()
         eng.close()
     return out

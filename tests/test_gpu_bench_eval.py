@@ -58,10 +58,23 @@ def test_bench_line_honours_the_contract():
     for k in ("crnn", "wavenet_bf16x3", "wavenet"):
         assert 0 < st[k]["p50_ms"] <= st[k]["p99_ms"] < 20.0  # a tick is 20 ms of audio
         assert st[k]["posteriors_per_tick"] == 256.0
+        # (round 5) where a tick's host time goes: the C entry point's phases + the Python wrapper; a tick is ONE launch
+        hp = st[k]["host_phases_us"]
+        assert set(hp) == {"plan", "frames_in", "launch_1", "launch_2", "wait", "copy_out"} and hp["launch_2"] < 0.5 < hp["launch_1"]
+        assert abs(sum(hp.values()) + st[k]["python_wrapper_us"] - st[k]["mean_ms"] * 1e3) < 1e-2
     ev = d["eval_testset"]
     assert ev["world_size"] == 1 and 0.0 <= ev["frr_at_0.5_fa_per_hour"] <= 1.0
     assert ev["oracle"]["fa_counts_identical"] and ev["oracle"]["frr_identical"] and ev["oracle"]["max_abs_posterior_diff"] < TOL
     assert d["frr_at_0.5_fa_per_hour"] == ev["frr_at_0.5_fa_per_hour"] == ev["oracle"]["frr_at_0.5_fa_per_hour"]
+    # (round 5) configs[3] at the size it names says what 8 GPUs can give: the phases every rank repeats, the prediction
+    # from this pass's phases, one rank's share of a world of 8 measured alone, and the same over 16 x the clips
+    sc = ev["at_scale"]
+    assert 0 < sc["serial_ms"] < 3.0 and sc["median_seconds"] >= sc["seconds_host_pcm_in_to_curves_out"]
+    assert sc["predicted_seconds"]["8"] < sc["predicted_seconds"]["2"] < sc["seconds_host_pcm_in_to_curves_out"]
+    assert 1.0 < sc["one_rank_of_8_measured"]["speedup_vs_one_rank"] <= 8.0
+    x16 = sc["at_scale_x16"]
+    assert x16["windows"] > 15 * sc["windows"] and x16["one_rank_of_8_measured"]["speedup_vs_one_rank"] > sc["one_rank_of_8_measured"]["speedup_vs_one_rank"] * 0.9
+    assert ev["median_seconds"] >= ev["seconds_host_pcm_in_to_curves_out"]
 
 
 def test_bench_starts_its_own_ranks():
