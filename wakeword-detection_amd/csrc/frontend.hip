@@ -1136,6 +1136,402 @@ __global__ __launch_bounds__(64 * LW_WPB) __attribute__((amdgpu_num_vgpr(LW_VGPR
   FE_STAMP(11)
 }
 
+#ifndef WW_FE8
+#define WW_FE8 0  // development: 1 = build and use logmel_rows8_kernel (below)
+#endif
+#if WW_FE8
+// ---------------------------------------------------------------------------------------------------------------------
+// logmel_rows8_kernel (round 5, a PROBE: compiled only with -DWW_FE8=1, tools/build_variant.sh fe8 "-DWW_FE8=1" frontend.hip) -
+// the fp64 front end as 32 lanes x 8 points per frame, TWO frames per wave - half the
+// registers of logmel_rows_kernel (its 16 complex fp64 points per lane are 64 registers before anything else), so that twice
+// as many waves share a SIMD's latencies (profiles/r05/frontend_occupancy_probe.txt: t(w) = 225 + 503 / w us per 4,096 clips).
+// 256 = 8 x 8 x 4: three DFT passes in registers, two transposes through the wave's own LDS buffer:
+//   pass 1  lane n2 (0..31) holds z[32 n1 + n2], n1 = 0..7 (Hann product in fp64) -> 8-point DFT over n1 -> Y[k1][n2],
+//           times W256^(n2 k1);   T1[k1][n2], row pitch 36 doubles: lane 4 k1 + m2 reads T1[k1][4 m1 + m2] conflict-free
+//   pass 2  8-point DFT over m1 -> U[j1], times W32^(m2 j1);   T2[j1][4 k1 + m2], row pitch 33 doubles: lane 4 k1 + jp
+//           reads T2[jp + 4 e][4 k1 + m2] conflict-free
+//   pass 3  two 4-point DFTs over m2 (e = 0, 1) -> Z[k1 + 8 (jp + 4 e) + 64 j2]: lane column c = k1 + 8 jp holds the bins
+//           c + 32 q, q = e + 2 j2 = 0..7
+// Untangling: the partner of bin c + 32 q is 256 - k = (32 - c) + 32 (7 - q): column (32 - c) % 32 (column 0: itself, row
+// 8 - q); a lane evaluates its q = 0..3 and their mirrors, so every pair is formed once.  Magnitudes, the mel filter (slots
+// dealt as in logmel_rows_kernel: lane = slot + 16 half + 32 frame, half 0 = the 36-tap group, half 1 = the 16- and 12-tap
+// groups) and the output tile go through the same buffer.  4.6 KB of LDS per wave.  Same formulas as logmel_rows_kernel; the
+// transform's factorisation differs, so results agree to fp64 rounding (the same fp32 magnitude in all but ~1 of 10^7 bins).
+// OUTCOME (profiles/r05/frontend_8point_probe.txt): correct (every front-end test passes on it) and NOT faster - 49.7 us per 256
+// clips untuned against 27.6, and not tunable past the 16-point kernel: what a wave pays once (row -> clip lookup, staging its
+// tile, the mel tail's three logarithms) is shared by two frames instead of four, 631 vector instructions per wave = 315 per
+// frame against 229 (PMC), ~280 at best; its 78 registers give six waves per SIMD, not eight.  Kept for the record.
+// ---------------------------------------------------------------------------------------------------------------------
+#ifndef L8_WPB
+#define L8_WPB 4    // waves per workgroup (they share nothing)
+#endif
+#ifndef L8_VGPR
+#define L8_VGPR 32  // amdgpu_num_vgpr counts in units of two on gfx90a+: 64 registers = eight waves per SIMD
+#endif
+#define L8_T1 36
+#define L8_T2 33
+#define L8_FBUF (8 * L8_T1 * 8)   // 2,304 B per frame: T1 / T2 / partner rows, then its 272 magnitudes
+#define L8_WBUF (2 * L8_FBUF)     // 4,608 B per wave; before the transform its sample tile
+#define L8_ROWF 528
+static_assert(2 * L8_ROWF * 4 <= L8_WBUF && (WIN + 512 + 16) * 4 <= L8_WBUF && MAG_LD * 4 <= L8_FBUF && 8 * L8_T2 * 8 <= L8_FBUF, "per-wave buffer too small");
+
+// Forward 8-point DFT, in place, natural order (A[k] at position k).
+template <typename R>
+__device__ __forceinline__ void dft8(cplx<R> (&a)[8]) {
+  constexpr R H = (R)0.70710678118654752440;
+  radix4(a[0], a[2], a[4], a[6]);  // E[0..3] at 0, 2, 4, 6
+  radix4(a[1], a[3], a[5], a[7]);  // O[0..3] at 1, 3, 5, 7
+  const cplx<R> o1 = mulc(a[3], H, -H), o2 = cplx<R>{a[5].im, -a[5].re}, o3 = mulc(a[7], -H, -H);  // O[k] W8^k
+  const cplx<R> e0 = a[0], e1 = a[2], e2 = a[4], e3 = a[6], o0 = a[1];
+  a[0] = {e0.re + o0.re, e0.im + o0.im}; a[4] = {e0.re - o0.re, e0.im - o0.im};
+  a[1] = {e1.re + o1.re, e1.im + o1.im}; a[5] = {e1.re - o1.re, e1.im - o1.im};
+  a[2] = {e2.re + o2.re, e2.im + o2.im}; a[6] = {e2.re - o2.re, e2.im - o2.im};
+  a[3] = {e3.re + o3.re, e3.im + o3.im}; a[7] = {e3.re - o3.re, e3.im - o3.im};
+}
+
+template <bool F32IN, bool SIMPLE, bool SMALL = false>
+__global__ __launch_bounds__(64 * L8_WPB) __attribute__((amdgpu_num_vgpr(L8_VGPR))) void logmel_rows8_kernel(logmel_args a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  typedef double R;
+  constexpr int VEC = F32IN ? 4 : 8;  // elements per 16-byte load
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l32 = lane & 31, sub = lane >> 5;  // lane inside its frame, frame of the wave
+  const int nper = gridDim.x >> 3;             // XCD-aware order, as logmel_rows_kernel
+  const int64_t W = ((int64_t)(blockIdx.x & 7) * nper + (blockIdx.x >> 3)) * L8_WPB + wave;
+  const int64_t g0 = W * 2;
+  if (g0 >= a.total_frames) return;  // no barrier anywhere below: a wave may simply leave
+  unsigned char *wb = smem + (size_t)wave * L8_WBUF;
+  float *tile = (float *)wb;
+
+  // ---- which clip does this 32-lane row's frame belong to, and where do its samples start (as logmel_rows_kernel)
+  typedef typename lw_idx<SMALL>::type idx_t;
+  idx_t s_begin, b;
+  bool rv;
+  {
+    const int64_t g = g0 + sub;
+    rv = g < a.total_frames;
+    const int64_t gc = rv ? g : g0;
+    if (SMALL && a.uni_magic) {
+      const unsigned g0u = (unsigned)g0, nfu = (unsigned)a.uniform_nf;
+      const unsigned u0 = __umulhi(g0u, a.uni_magic) >> a.uni_shift;
+      unsigned f = g0u - u0 * nfu + (unsigned)sub;
+      const bool next = f >= nfu;
+      f -= next ? nfu : 0u;
+      s_begin = (idx_t)((u0 + (next ? 1u : 0u)) * (unsigned)a.uniform_ns);
+      b = s_begin + (idx_t)(f * (unsigned)a.hop);
+    } else if (a.uniform_nf > 0) {
+      const unsigned gu = (unsigned)gc, nfu = (unsigned)a.uniform_nf;
+      const unsigned u = gu / nfu, f = gu - u * nfu;
+      s_begin = (idx_t)((int64_t)u * a.uniform_ns);
+      b = s_begin + (idx_t)(f * (unsigned)a.hop);
+    } else {
+      int lo = 0, hi = a.n_utt;  // the last clip whose first mel row is <= g
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a.frame_offs[mid] <= gc) lo = mid; else hi = mid;
+      }
+      const int64_t sb = a.sample_offs[lo];
+      const int64_t f = gc - a.frame_offs[lo];
+      const int64_t bb = sb + f * a.hop;
+      rv = rv && f >= 0 && bb + WIN <= a.sample_offs[lo + 1];  // a row the offset tables do not cover is never stored
+      s_begin = (idx_t)sb;
+      b = (idx_t)bb;
+    }
+  }
+  const unsigned long long vm = __ballot(rv);
+  if (vm == 0) return;
+  const int r_first = __builtin_ctzll(vm) >> 5, r_last = (63 - __builtin_clzll(vm)) >> 5;
+  const idx_t b0 = lw_readlane64(b, 32 * r_first), s0 = lw_readlane64(s_begin, 32 * r_first);
+  if (!rv) {  // a surplus row recomputes the first valid frame (results unused)
+    b = b0;
+    s_begin = s0;
+  }
+  const idx_t total = (idx_t)a.sample_offs[a.n_utt];
+  const bool contig = __all(s_begin == s0 && b >= b0 && b - b0 <= (idx_t)a.hop);
+  const float *src;
+  if (contig) {
+    const idx_t bmax = lw_readlane64(b, 32 * r_last);
+    const int shift = (int)(b0 % VEC);
+    const idx_t ga = b0 - shift;  // multiple of VEC, >= 0
+    const int n_vec = (shift + (int)(bmax - b0) + WIN + VEC - 1) / VEC;
+    if (SIMPLE) {
+      // no pre-emphasis, divisor 32767 / 32768, hop <= 168 (host checks): NV vectors per lane, all loads in flight together
+      constexpr int NV = F32IN ? 3 : 2;
+      const idx_t last = (total - VEC) & ~(idx_t)(VEC - 1);
+      const idx_t tile_last = ga + (idx_t)(n_vec - 1) * VEC;
+      idx_t gq[NV];
+      uint4 raw[NV];
+#pragma unroll
+      for (int h = 0; h < NV; ++h) {
+        gq[h] = ga + (idx_t)(lane + 64 * h) * VEC;
+        idx_t gl = gq[h] < tile_last ? gq[h] : tile_last;
+        gl = gl < last ? gl : last;
+        raw[h] = F32IN ? *(const uint4 *)(a.f32 + gl) : *(const uint4 *)(a.pcm + gl);
+      }
+      const float lim = a.clip ? 1.0f : __builtin_inff();
+#pragma unroll
+      for (int h = 0; h < NV; ++h) {
+        const int q = lane + 64 * h;
+        if (q < n_vec) {
+          float o[VEC];
+          if (gq[h] <= last) {
+            const unsigned int w32[4] = {raw[h].x, raw[h].y, raw[h].z, raw[h].w};
+            if (F32IN) {
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) o[e] = __uint_as_float(w32[e]);
+            } else {
+              typedef float f32x2 __attribute__((ext_vector_type(2)));
+              const f32x2 r2 = {a.rdiv, a.rdiv}, nb2 = {-a.divisor, -a.divisor};
+#pragma unroll
+              for (int e = 0; e < VEC; e += 2) {
+                const f32x2 x = {(float)(int)(short)(w32[e >> 1] & 0xffffu), (float)((int)w32[e >> 1] >> 16)};
+                const f32x2 q0 = x * r2;
+                const f32x2 er = __builtin_elementwise_fma(nb2, q0, x);
+                const f32x2 qq = __builtin_elementwise_fma(er, r2, q0);
+                o[e] = __builtin_amdgcn_fmed3f(qq.x, -lim, lim);
+                o[e + 1] = __builtin_amdgcn_fmed3f(qq.y, -lim, lim);
+              }
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = (gq[h] + e < total) ? norm_sample<F32IN>(a, (int64_t)gq[h] + e) : 0.0f;
+          }
+          float4 *d4 = (float4 *)(tile + (size_t)q * VEC);
+          d4[0] = make_float4(o[0], o[1], o[2], o[3]);
+          if (VEC == 8) d4[1] = make_float4(o[4], o[5], o[6], o[7]);
+        }
+      }
+    } else {
+      lw_stage_generic<F32IN>(a, tile, (int64_t)ga, n_vec, (int64_t)s0, (int64_t)total, lane);
+    }
+    src = tile + shift + (int)(b - b0);
+  } else {
+    // frames of two clips in this wave: frame by frame
+    for (int r = 0; r < 2; ++r) {
+      if (!((vm >> (32 * r)) & 1)) continue;
+      const int64_t br = lw_readlane64(b, 32 * r), sr = lw_readlane64(s_begin, 32 * r);
+      const int sh = (int)(br % VEC);
+      lw_stage_generic<F32IN>(a, tile + r * L8_ROWF, br - sh, (sh + WIN + VEC - 1) / VEC, sr, (int64_t)total, lane);
+    }
+    src = tile + (rv ? sub : r_first) * L8_ROWF + (int)(b % VEC);
+  }
+  lds_fence();
+
+  // ---- pass 1: z[32 n1 + n2] = (x[2n] h[2n], x[2n + 1] h[2n + 1]) in fp64 (tflite.py:175), 8-point DFT over n1
+  R *fb = (R *)(wb + (size_t)sub * L8_FBUF);  // this frame's buffer
+  cplx<R> v[8];
+  {
+    const double2 *hb = (const double2 *)a.hann;  // half table of 128 pairs (h[m] = h[511 - m])
+    float2 xs[8];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) {
+      const float *p = src + 64 * n1 + 2 * l32;
+      xs[n1] = make_float2(p[0], p[1]);
+    }
+    lds_fence();  // every sample is in registers: the tile is dead from here on
+    // Hann pairs four at a time (sixteen registers instead of thirty-two at once)
+#pragma unroll
+    for (int c4 = 0; c4 < 2; ++c4) {
+      double2 h[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int n1 = 4 * c4 + i;
+        if (n1 < 4) {
+          h[i] = hb[32 * n1 + l32];
+        } else {
+          const double2 m = hb[32 * (7 - n1) + 31 - l32];
+          h[i] = make_double2(m.y, m.x);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[4 * c4 + i].re = (R)xs[4 * c4 + i].x * h[i].x;
+        v[4 * c4 + i].im = (R)xs[4 * c4 + i].y * h[i].y;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const double2 *tw = (const double2 *)a.tw256;  // [256] e^{-2 pi i k / 256}
+  dft8<R>(v);
+  // inter-pass twiddles W256^(n2 k1), k1 = 1..7: four, then three (the table lives in the vector L1)
+  {
+    double2 t1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t1[i] = tw[(l32 * (1 + i)) & 255];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[1 + i] = cmul(v[1 + i], cplx<R>{t1[i].x, t1[i].y});
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t1[i] = tw[(l32 * (5 + i)) & 255];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) v[5 + i] = cmul(v[5 + i], cplx<R>{t1[i].x, t1[i].y});
+  }
+  // ---- transpose 1 (real parts, then imaginary parts, same buffer): T1[k1][n2] -> lane 4 k1 + m2 takes T1[k1][4 m1 + m2]
+  {
+    const int k1r = l32 >> 2, m2 = l32 & 3;
+    const R *rd = fb + k1r * L8_T1 + m2;
+    R re[8];
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) fb[k1 * L8_T1 + l32] = v[k1].re;
+    lds_fence();
+#pragma unroll
+    for (int m1 = 0; m1 < 8; ++m1) re[m1] = rd[4 * m1];
+    lds_fence();
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) fb[k1 * L8_T1 + l32] = v[k1].im;
+    lds_fence();
+#pragma unroll
+    for (int m1 = 0; m1 < 8; ++m1) {
+      v[m1].im = rd[4 * m1];
+      v[m1].re = re[m1];
+    }
+    lds_fence();
+    // ---- pass 2: 8-point DFT over m1, times W32^(m2 j1)
+    dft8<R>(v);
+    double2 t2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t2[i] = tw[8 * m2 * (1 + i)];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[1 + i] = cmul(v[1 + i], cplx<R>{t2[i].x, t2[i].y});
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t2[i] = tw[8 * m2 * (5 + i)];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) v[5 + i] = cmul(v[5 + i], cplx<R>{t2[i].x, t2[i].y});
+  }
+  // ---- transpose 2: T2[j1][4 k1 + m2] -> lane 4 k1 + jp takes T2[jp + 4 e][4 k1 + m2], m2 = 0..3, e = 0, 1
+  const int jp = l32 & 3, c = (l32 >> 2) + 8 * jp;  // this lane's bin column: it ends up with Z[c + 32 q], q = e + 2 j2
+  {
+    const R *rd = fb + jp * L8_T2 + (l32 & ~3);
+    R re[8];
+#pragma unroll
+    for (int j1 = 0; j1 < 8; ++j1) fb[j1 * L8_T2 + l32] = v[j1].re;
+    lds_fence();
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int m2 = 0; m2 < 4; ++m2) re[4 * e + m2] = rd[4 * e * L8_T2 + m2];
+    lds_fence();
+#pragma unroll
+    for (int j1 = 0; j1 < 8; ++j1) fb[j1 * L8_T2 + l32] = v[j1].im;
+    lds_fence();
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int m2 = 0; m2 < 4; ++m2) {
+        v[4 * e + m2].im = rd[4 * e * L8_T2 + m2];
+        v[4 * e + m2].re = re[4 * e + m2];
+      }
+    lds_fence();
+    // ---- pass 3: 4-point DFTs over m2: v[4 e + j2] = Z[c + 32 (e + 2 j2)]
+    radix4(v[0], v[1], v[2], v[3]);
+    radix4(v[4], v[5], v[6], v[7]);
+  }
+  // ---- untangle: partner rows through the buffer, P[q][column] (pitch 36), q = e + 2 j2 <-> v[4 e + j2]
+  float *mrow = (float *)fb;  // overlay (after the partner reads): this frame's magnitudes [MAG_LD]
+  {
+    const int pc = (32 - c) & 31;
+    cplx<R> pz[4];
+    // partner of own row q (0..3): row 7 - q of column pc; column 0 pairs with itself: row (8 - q) % 8
+    const R *prd = fb + pc;
+    const int prow[4] = {c == 0 ? 0 : 7, c == 0 ? 7 : 6, c == 0 ? 6 : 5, c == 0 ? 5 : 4};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) fb[q * L8_T1 + c] = v[4 * (q & 1) + (q >> 1)].re;
+    lds_fence();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pz[q].re = prd[prow[q] * L8_T1];
+    lds_fence();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) fb[q * L8_T1 + c] = v[4 * (q & 1) + (q >> 1)].im;
+    lds_fence();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pz[q].im = prd[prow[q] * L8_T1];
+    lds_fence();
+    const double2 *unp = (const double2 *)a.tw512 + c;  // W512^(c + 32 q) at [32 q]
+    double2 un[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) un[q] = unp[32 * q];
+    const cplx<R> z4 = v[2];  // q = 4 (e = 0, j2 = 2): bin 128 in column 0
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const cplx<R> own = v[4 * (q & 1) + (q >> 1)];
+      const R er = own.re + pz[q].re, ei = own.im - pz[q].im;
+      const R orr = own.im + pz[q].im, oi = pz[q].re - own.re;
+      const R tr_ = orr * un[q].x - oi * un[q].y, ti_ = orr * un[q].y + oi * un[q].x;
+      const R pr = er + tr_, pi = ei + ti_, qr = er - tr_, qi = ei - ti_;
+      const int k = c + 32 * q;
+      mrow[k] = __builtin_amdgcn_sqrtf((float)(pr * pr + pi * pi));        // 2|X[k]|: the mel weights carry the 0.5
+      mrow[256 - k] = __builtin_amdgcn_sqrtf((float)(qr * qr + qi * qi));  // k = 0 -> bin 256
+    }
+    // bin 128 pairs with itself: X[128] = conj(Z[128]) (column 0, row 4); bins 257..271 are zero padding
+    if (c == 0) mrow[128] = 2.0f * __builtin_amdgcn_sqrtf((float)(z4.re * z4.re + z4.im * z4.im));
+    else if (c < 16) mrow[256 + c] = 0.0f;
+  }
+  lds_fence();
+
+  // ---- mel filterbank on the vector ALU: lane = slot + 16 half + 32 frame; half 0 = the 36-tap group (9 float4 chunks),
+  //      half 1 = the 16- and 12-tap groups (4 + 3 chunks); tables as logmel_rows_kernel's
+  {
+    const int slot = lane & 15, half = (lane >> 4) & 1;
+    const float4 *wv = (const float4 *)a.melV + slot;
+    const float *mr = (const float *)(wb + (size_t)sub * L8_FBUF);
+    float res[2];
+    int band[2];
+    auto group = [&](int g, int c0, int nq) -> float {  // one band slot: nq chunks of 4 taps from chunk c0 of the table
+      const int meta = a.melVmeta[g * 16 + slot];
+      const int bnd = (int)((unsigned)meta >> 16);
+      const float bias = a.bias[bnd < a.n_mel ? bnd : 0];
+      const float *mb = mr + (meta & 0xffff);
+      float acc = 0.f, acc1 = 0.f;
+      if (a.melv_aligned) {
+        for (int q = 0; q < nq; ++q) {
+          const float4 w4 = wv[(c0 + q) * 16];
+          const float4 m4 = *(const float4 *)(mb + 4 * q);
+          acc = fmaf(m4.x, w4.x, acc);
+          acc1 = fmaf(m4.y, w4.y, acc1);
+          acc = fmaf(m4.z, w4.z, acc);
+          acc1 = fmaf(m4.w, w4.w, acc1);
+        }
+        acc += acc1;
+      } else {
+        for (int q = 0; q < nq; ++q) {
+          const float4 w4 = wv[(c0 + q) * 16];
+          acc = fmaf(mb[4 * q + 0], w4.x, acc);
+          acc = fmaf(mb[4 * q + 1], w4.y, acc);
+          acc = fmaf(mb[4 * q + 2], w4.z, acc);
+          acc = fmaf(mb[4 * q + 3], w4.w, acc);
+        }
+      }
+      band[g == 2 ? 1 : 0] = bnd;
+      return (logf(fmaxf(acc + bias, a.floor_v)) + a.log_off) * a.scale;
+    };
+    if (half == 0) {
+      res[0] = group(0, 0, 9);
+      res[1] = 0.f;
+      band[1] = 0xffff;
+    } else {
+      res[0] = group(1, 9, 4);
+      res[1] = group(2, 13, 3);
+    }
+    // park the wave's 2 x n_mel tile in LDS (frame 0's buffer; every magnitude has been read), then one contiguous store
+    lds_fence();
+    float *mt = (float *)wb;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) mt[band[i] < a.n_mel ? sub * a.n_mel + band[i] : 2 * a.n_mel + lane] = res[i];
+    lds_fence();
+    float *dstf = a.mel + g0 * (int64_t)a.n_mel;
+    const bool both = (vm >> 32) & (vm & 1);
+    if (both && (((uintptr_t)dstf) & 15) == 0 && (a.n_mel & 3) == 0) {
+      for (int i = lane; i < 2 * a.n_mel / 4; i += 64) ((float4 *)dstf)[i] = ((const float4 *)mt)[i];
+    } else {
+      for (int i = lane; i < 2 * a.n_mel; i += 64)
+        if ((vm >> (32 * (i / a.n_mel))) & 1) dstf[i] = mt[i];
+    }
+  }
+}
+
+#endif  // WW_FE8
+
 // STFT magnitude of explicit frames [n][512] -> [n][257]; one wave per frame.
 template <typename R>
 __global__ __launch_bounds__(256) void stft_mag_kernel(logmel_args a) {
@@ -1212,6 +1608,28 @@ int ww_k_logmel(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, const floa
       a.uni_magic = (unsigned)(((1ull << (31 + l)) + (unsigned)a.uniform_nf - 1) / (unsigned)a.uniform_nf);
       a.uni_shift = l - 1;
     }
+#if WW_FE8
+    {
+      const int64_t n_waves8 = (total_frames + 1) / 2;
+      const int64_t n_wg8 = 8 * ((((n_waves8 + L8_WPB - 1) / L8_WPB) + 7) / 8);
+      if (n_wg8 > 0x7fffffff) return ww_fail(ctx, WW_EINVAL, "front-end launch too large (%lld workgroups): split the batch", (long long)n_wg8);
+      const dim3 grid8((unsigned)n_wg8), block8(64 * L8_WPB);
+      const size_t sm8 = (size_t)L8_WPB * L8_WBUF;
+      ww_launch_scope scope(ctx, "logmel_rows8_kernel");
+      if (small_w) {
+        if (f32in) hipLaunchKernelGGL((logmel_rows8_kernel<true, true, true>), grid8, block8, sm8, ctx->stream, a);
+        else hipLaunchKernelGGL((logmel_rows8_kernel<false, true, true>), grid8, block8, sm8, ctx->stream, a);
+      } else if (simple_w) {
+        if (f32in) hipLaunchKernelGGL((logmel_rows8_kernel<true, true>), grid8, block8, sm8, ctx->stream, a);
+        else hipLaunchKernelGGL((logmel_rows8_kernel<false, true>), grid8, block8, sm8, ctx->stream, a);
+      } else {
+        if (f32in) hipLaunchKernelGGL((logmel_rows8_kernel<true, false>), grid8, block8, sm8, ctx->stream, a);
+        else hipLaunchKernelGGL((logmel_rows8_kernel<false, false>), grid8, block8, sm8, ctx->stream, a);
+      }
+      WW_HIP(ctx, hipGetLastError());
+      return WW_OK;
+    }
+#endif
     const int64_t n_waves = (total_frames + 3) / 4;
     const int64_t n_wg = 8 * ((((n_waves + LW_WPB - 1) / LW_WPB) + 7) / 8);
     if (n_wg > 0x7fffffff) return ww_fail(ctx, WW_EINVAL, "front-end launch too large (%lld workgroups): split the batch", (long long)n_wg);

@@ -24,6 +24,7 @@
 #include "common.h"
 #include "fft_device.h"
 
+#include <sched.h>
 #include <time.h>
 
 #define ST_RING WW_ST_RING  // 511 + 320 rounded up
@@ -387,6 +388,7 @@ static int st_poll_tags(ww_streams *st) {
       continue;
     }
     __builtin_ia32_pause();
+    if (spins > (1u << 18)) sched_yield();  // (a tick that is milliseconds late - a GPU busy elsewhere - stops pinning the core)
     if ((++spins & 0x3fffu) == 0) {
       const hipError_t q = hipStreamQuery(ctx->stream);
       if (q == hipErrorNotReady) continue;
