@@ -782,9 +782,18 @@ def test_polled_tick_equals_the_waited_one(assets, name, prec):
     speech = (rng.uniform(size=(ticks, S)) < 0.8).astype(np.uint8)
     try:
         outs = []
+        ro = pcm.copy()
+        ro.setflags(write=False)  # (the wrapper takes a frame array's address without a ctypes round trip; a read-only one the slow way)
         for kw in ({}, {"sync_wait": True}, {"full_recompute": True}, {"full_recompute": True, "sync_wait": True}):
             bank = StreamBank(e, S, **kw)
-            outs.append([bank.step(pcm[t], speech[t]) for t in range(ticks)])
+            if kw:
+                outs.append([bank.step(pcm[t], speech[t]) for t in range(ticks)])
+            else:  # the same ticks from a read-only array, a Fortran-ordered one, plain lists and booleans
+                forms = (lambda t: ro[t], lambda t: np.asfortranarray(pcm[t]), lambda t: pcm[t].tolist(), lambda t: pcm[t])
+                outs.append([bank.step(forms[t % 4](t), speech[t].astype(bool) if t % 3 == 0 else speech[t].tolist() if t % 3 == 1 else speech[t])
+                             for t in range(ticks)])
+            with pytest.raises(ValueError):
+                bank.step(pcm[0][:-1], speech[0])
             bank.close()
         for a, b in ((0, 1), (2, 3)):
             for (p0, n0), (p1, n1) in zip(outs[a], outs[b]):
