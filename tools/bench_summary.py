@@ -13,7 +13,7 @@ if d.get("wavenet"):
     print("wavenet bf16x3 %.2f us/step, fp32 %.2f" % (d["wavenet"]["bf16x3"]["ms_per_step"] * 1e3, d["wavenet"]["fp32_mfma_parity_mode"]["ms_per_step"] * 1e3),
           d["wavenet"]["bf16x3"]["roofline"]["all_kernels_avg_us"])
 if d.get("streaming"):
-    print("streaming", {k: {a: round(b, 4) for a, b in v.items()} for k, v in d["streaming"].items() if isinstance(v, dict)})
+    print("streaming", {k: {a: (round(b, 4) if isinstance(b, (int, float)) else b) for a, b in v.items()} for k, v in d["streaming"].items() if isinstance(v, dict)})
 ev = d.get("eval_testset")
 if ev:
     print("eval: %.4f s, frr %.6f, oracle %s" % (ev["seconds_host_pcm_in_to_curves_out"], ev["frr_at_0.5_fa_per_hour"], ev.get("oracle", {}).get("fa_counts_identical")))
