@@ -526,6 +526,47 @@ def test_context_adopts_a_torch_stream(assets, oracles):
         ctx.close()
 
 
+def test_stream_bank_on_a_borrowed_stream_and_its_timeline(assets):
+    """A bank whose context BORROWS its stream (here torch's) keeps the old contract - when ww_stream_step returns, the stream
+    has drained - so it waits with hipStreamSynchronize, never by polling; same posteriors as a bank on a stream of the
+    library's own, one launch per tick in both.  And ww_stream_timeline: per-tick means of the six host phases, launch 2 is
+    nothing in the one-launch form, the count resets."""
+    import torch
+    from wwhip import _lib
+    from wwhip.engine import Engine, StreamBank
+    side = torch.cuda.Stream()
+    ctx = _lib.Context(0, stream=side.cuda_stream)
+    e_own, e_bor = Engine(os.path.join(assets, "CRNN")), Engine(os.path.join(assets, "CRNN"), ctx=ctx)
+    S, ticks = 5, 30
+    rng = np.random.default_rng(17)
+    pcm = np.clip(rng.normal(0, 2500, (ticks, S, 320)), -32768, 32767).astype(np.int16)
+    speech = np.ones(S, np.uint8)
+    try:
+        own, bor = StreamBank(e_own, S), StreamBank(e_bor, S)
+        for t in range(ticks):
+            (p0, n0), (p1, n1) = own.step(pcm[t], speech), bor.step(pcm[t], speech)
+            np.testing.assert_array_equal(n0, n1)
+            np.testing.assert_array_equal(p0, p1)
+            assert side.query()                      # nothing of the tick is still in flight on the borrowed stream
+        for bank in (own, bor):
+            tl = bank.timeline()
+            assert tl["ticks"] == ticks and tl["launch_2"] < 0.5 and tl["launch_1"] > 0.5 and tl["wait"] > 5.0
+            assert set(tl) == set(StreamBank.TIMELINE_PHASES) | {"ticks"}
+            assert bank.timeline(reset=True)["ticks"] == ticks and bank.timeline()["ticks"] == 0
+        two = StreamBank(e_own, S, two_launch=True)
+        two.step(pcm[0], speech)
+        assert two.timeline()["launch_2"] < 0.2      # (no window in a bank's first tick: the front end alone)
+        two.step(pcm[1], speech)
+        two.step(pcm[2], speech)
+        assert two.timeline()["launch_2"] > 0.3      # front-end kernel + model kernel
+        for bank in (own, bor, two):
+            bank.close()
+    finally:
+        e_own.close()
+        e_bor.close()
+        ctx.close()
+
+
 def _engine_with_filter(assets, monkeypatch, weight):
     """A CRNN engine whose filter.tflite weights are replaced by ``weight`` [40][257]."""
     import dataclasses

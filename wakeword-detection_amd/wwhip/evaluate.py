@@ -757,15 +757,17 @@ def get_posterior_sharded(models_dir, model_type, eval_type, test_files, frame_w
     ``"false_accepts"``: the window list - for the reference's evaluator ONE long wav (``evaluate_models.py:317-321``) -
     cut into ``world`` contiguous posterior ranges (``dist.split_stream``).  A rank loads and front-ends only the samples
     its windows are functions of: posterior ``i`` of a file needs the global frames ``[F + 2 i, F + 2 i + T)``, i.e. each
-    range re-reads a ``T - 2``-frame overlap and the results are exact.  The share goes to the GPU in chunks of ~13 minutes
-    of audio through a staging pipeline (:func:`_run_jobs`).  The one exchange is the posterior gather.  Every rank returns
-    the full list :func:`get_posterior` returns.
+    range re-reads a ``T - 2``-frame overlap and the results are exact.  The share goes to the GPU in chunks (2 M samples
+    doubling up to ``_CHUNK_SAMPLES`` = 24 M, ~26 minutes of audio) through the library's uploader (:func:`_run_jobs`).  The one
+    exchange is the posterior gather.  Every rank returns the full list :func:`get_posterior` returns.
 
     ``test_files``: paths (default loader :func:`read_wav_pcm`; ``lengths`` default = wav headers) or arrays already in
     memory (int16 PCM, or float32 samples in [-1, 1)).  ``precise=False``: the fp32-FFT front end (``ww_frontend_params.precise``
     = 0) instead of the reference's float64 STFT.  ``timing``: a dict that receives this rank's wall-clock seconds per host
-    phase (``plan``; ``slicing`` and ``upload_enqueue`` on the staging thread, i.e. beside the others; ``stage_wait`` = this thread waiting
-    for a staged chunk, ``device_wall`` = launches + the final wait for the GPU, ``d2h``, ``gather``), ``device_ms`` (HIP events around every kernel of the call, ``ww_profile_read``) and
+    phase - ``plan`` (lengths, shares, chunk cuts), ``slicing`` (which samples of which clips a chunk holds), ``submit`` (handing a
+    chunk to ``ww_uploader``: its threads stage and upload it beside everything else), ``upload_wait`` (this thread waiting for a
+    submitted chunk's copies to be enqueued), ``device_wall`` (launches + the final wait for the GPU), ``gather``, ``d2h``,
+    ``profile_read`` - plus ``device_ms`` / ``kernels_ms`` (HIP events around every kernel of the call, ``ww_profile_read``) and
     ``chunks``; ``info`` receives ``windows`` (inferences of the whole call, all ranks).  ``as_array``: a float32 array
     instead of the reference's list (two hours of negatives are 360,000 Python floats)."""
     if model_type not in ("CRNN", "Wavenet"):
