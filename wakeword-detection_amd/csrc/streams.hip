@@ -67,6 +67,7 @@ struct ww_streams {
   unsigned long long *h_tag = nullptr, *h_tag_dev = nullptr;  // [2 S]
   unsigned seq = 0;             // tick number (never 0 in a tag)
   bool one_launch = false;      // incremental CRNN: front end inside the model kernel's workgroups (crnn_stream_kernel<1 | 2>)
+  bool broken = false;          // a tick failed half way (ww_stream_step): no further ticks
   bool poll = false;            // wait by polling the tags (a context that owns its stream; WW_STREAM_SYNC_WAIT turns it off)
   std::vector<int> par;         // a stream's state parity (one-launch form)
   std::vector<int> expect;      // tag slots this tick's posteriors arrive in
@@ -402,11 +403,11 @@ static int st_poll_tags(ww_streams *st) {
   return WW_OK;
 }
 
-int ww_stream_step(ww_streams *st, const int16_t *frames, const uint8_t *is_speech, float *post, int32_t *n_post) {
-  if (!st) return WW_EINVAL;
+static int stream_step_impl(ww_streams *st, const int16_t *frames, const uint8_t *is_speech, float *post, int32_t *n_post, bool *mutated) {
   ww_ctx *ctx = st->ctx;
   if (!frames || !is_speech || !post || !n_post) return ww_fail(ctx, WW_EINVAL, "NULL argument");
   WW_ON_DEVICE(ctx, dev_scope);  // the caller's current device is left as it was
+  *mutated = true;  // from here on the host's mirrors of the streams' state advance
   const int S = st->S, hop = st->fp.hop, R = st->T + 1;
   uint64_t tl[WW_STREAM_TL_PHASES + 1];
   tl[0] = st_now_ns();
@@ -553,6 +554,17 @@ int ww_stream_step(ww_streams *st, const int16_t *frames, const uint8_t *is_spee
   for (int i = 0; i < WW_STREAM_TL_PHASES; ++i) st->tl_ns[i] += tl[i + 1] - tl[i];
   ++st->tl_ticks;
   return WW_OK;
+}
+
+int ww_stream_step(ww_streams *st, const int16_t *frames, const uint8_t *is_speech, float *post, int32_t *n_post) {
+  if (!st) return WW_EINVAL;
+  // a tick that failed after the host's mirrors (fill, ring positions, state parity) had advanced leaves them out of step with
+  // the device: the bank refuses further ticks instead of producing posteriors of a state that never existed
+  if (st->broken) return ww_fail(st->ctx, WW_ESTATE, "this stream bank failed in an earlier tick: destroy it and create a new one");
+  bool mutated = false;
+  const int rc = stream_step_impl(st, frames, is_speech, post, n_post, &mutated);
+  if (rc != WW_OK && mutated) st->broken = true;
+  return rc;
 }
 
 int ww_stream_timeline(ww_streams *st, double *mean_ns, int64_t *ticks, int32_t reset) {
