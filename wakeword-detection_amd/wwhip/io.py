@@ -4,7 +4,7 @@ from a 16 kHz mono PCM16 wav file (or an array) and stops it at the end of the d
 from __future__ import annotations
 
 import wave
-from typing import Optional, Union
+from typing import Union
 
 import numpy as np
 

@@ -12,11 +12,10 @@ from __future__ import annotations
 
 import os
 import threading
-from typing import Any, Dict, List
+from typing import Any, List
 
 import numpy as np
 
-from . import _lib
 from . import tflite_reader as R
 from .engine import Engine
 

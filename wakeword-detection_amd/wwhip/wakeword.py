@@ -10,7 +10,7 @@ host logic: VAD-edge reset, activation, running maximum.
 from __future__ import annotations
 
 import logging
-from typing import Callable, List, Optional, Sequence
+from typing import Callable, Optional, Sequence
 
 import numpy as np
 
