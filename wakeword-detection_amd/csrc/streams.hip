@@ -66,6 +66,7 @@ struct ww_streams {
   // ww_stream_step polls them instead of waiting for the runtime's completion signal
   unsigned long long *h_tag = nullptr, *h_tag_dev = nullptr;  // [2 S]
   unsigned seq = 0;             // tick number (never 0 in a tag)
+  unsigned flip = 0;            // which copy of the input block the tick at hand uses
   bool one_launch = false;      // incremental CRNN: front end inside the model kernel's workgroups (crnn_stream_kernel<1 | 2>)
   bool broken = false;          // a tick failed half way (ww_stream_step): no further ticks
   bool poll = false;            // wait by polling the tags (a context that owns its stream; WW_STREAM_SYNC_WAIT turns it off)
@@ -413,7 +414,8 @@ static int stream_step_impl(ww_streams *st, const int16_t *frames, const uint8_t
   tl[0] = st_now_ns();
   if (++st->seq == 0) st->seq = 1;  // (a tag of tick 0 is "never written")
   // which copy of the page-locked input block this tick uses (the one-launch form alternates, see ww_streams)
-  const size_t cp = st->one_launch ? (size_t)(st->seq & 1) * st->pack_bytes : 0;
+  st->flip ^= 1u;  // (a bit of its own: the tick number skips 0 when it wraps)
+  const size_t cp = st->one_launch ? (size_t)st->flip * st->pack_bytes : 0;
   int16_t *h_frames = (int16_t *)((char *)st->h_frames + cp);
   int32_t *h_ctl = (int32_t *)((char *)st->h_ctl + cp);
   st->expect.clear();
