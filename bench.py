@@ -678,6 +678,18 @@ def eval_leg(torch, np, dist, comm_dev, rank, world, local_rank, n_clips, with_o
         o_pos = np.array([ora.slide_forward(mel[plan.F[k]: plan.F[k] + plan.n_frames[k]], 2)[:plan.n_win[k], pidx].max()
                           for k in range(len(wake))], np.float32)
         of, oa, oc, _ = NR.far_frr(o_pos, o_neg, len(wake), r["hours"])
+        # the stand-in's joined stream never crosses 0.5 after smoothing (fa_count_at_threshold_0.5 = 0: FRR @ 0.5 FA/h is FRR at
+        # t = 0.5).  The same sweep from 0.02 up, where rising edges exist, on the same posteriors: the device's smoothing + edge
+        # counting against the reference's loop (oracle/numpy_ref.py) on the oracle's posteriors
+        from wwhip.evaluate import far_frr as gpu_far_frr
+        low = np.arange(0.02, 0.5, 0.005)
+        _, lf, la, lc = gpu_far_frr(r["positives"], r["negatives"], len(wake), r["hours"], low, engine=eng)
+        olf, ola, olc, _ = NR.far_frr(o_pos, o_neg, len(wake), r["hours"], low)
+        res["sweep_below_0.5"] = {"thresholds": "arange(0.02, 0.5, 0.005)", "fa_count_max": int(lc.max()), "fa_count_sum": int(lc.sum()),
+                                  "thresholds_with_false_accepts": int((lc > 0).sum()),
+                                  "frr_at_0.5_fa_per_hour": frr_at_fa(lf, la, 0.5),
+                                  "fa_counts_identical_to_oracle": bool(np.array_equal(lc, olc)),
+                                  "frr_identical_to_oracle": bool(np.array_equal(lf, olf))}
         res["oracle"] = {"frr_at_0.5_fa_per_hour": frr_at_fa(of, oa, 0.5), "fa_count_at_threshold_0.5": int(oc[0]),
                          "fa_counts_identical": bool(np.array_equal(oc, r["fa_count"])),
                          "frr_identical": bool(np.array_equal(of, r["frr"])),

@@ -66,6 +66,9 @@ def test_bench_line_honours_the_contract():
     assert ev["world_size"] == 1 and 0.0 <= ev["frr_at_0.5_fa_per_hour"] <= 1.0
     assert ev["oracle"]["fa_counts_identical"] and ev["oracle"]["frr_identical"] and ev["oracle"]["max_abs_posterior_diff"] < TOL
     assert d["frr_at_0.5_fa_per_hour"] == ev["frr_at_0.5_fa_per_hour"] == ev["oracle"]["frr_at_0.5_fa_per_hour"]
+    # the stand-in is FA-free at the reference's thresholds: the sweep below 0.5, where rising edges exist, against the reference's loop
+    lo = ev["sweep_below_0.5"]
+    assert lo["fa_count_max"] > 0 and lo["fa_counts_identical_to_oracle"] and lo["frr_identical_to_oracle"]
     # (round 5) configs[3] at the size it names says what 8 GPUs can give: the phases every rank repeats, the prediction
     # from this pass's phases, one rank's share of a world of 8 measured alone, and the same over 16 x the clips
     sc = ev["at_scale"]
