@@ -784,14 +784,15 @@ def test_one_launch_tick_equals_the_two_launch_form(assets, name, precise, prec)
         e.close()
 
 
-@pytest.mark.parametrize("name", ["CRNN_softmax", "Wavenet"])
-def test_one_launch_tick_with_many_streams_per_gpu(assets, name):
-    """The one-launch tick past one workgroup per CU: 700 streams = 1,400 workgroups (several co-resident per CU, siblings of
-    one stream anywhere on the chip), every third stream silent, against the two-launch form - bit for bit - over 14 ticks
-    from an empty history (the first ticks yield 0, 1, 2 windows per stream)."""
+@pytest.mark.parametrize("name,S", [("CRNN_softmax", 700), ("Wavenet", 128), ("Wavenet", 300)])
+def test_one_launch_tick_with_many_streams_per_gpu(assets, name, S):
+    """The one-launch tick past one workgroup per CU: 700 CRNN streams = 1,400 workgroups (several co-resident per CU, siblings
+    of one stream anywhere on the chip), every third stream silent, against the two-launch form - bit for bit - over 14 ticks
+    from an empty history (the first ticks yield 0, 1, 2 windows per stream).  Wavenet banks take the one-launch form up to 128
+    streams (a tick's 256 windows are the twelve-wave kernel's range) and the two-launch form with the wide kernel above."""
     from wwhip.engine import Engine, StreamBank
     e = Engine(os.path.join(assets, name))
-    S, ticks = 700, 14
+    ticks = 14
     rng = np.random.default_rng(3)
     pcm = np.clip(rng.normal(0, 2500, (ticks, S, 320)), -32768, 32767).astype(np.int16)
     speech = np.ones(S, np.uint8)
@@ -805,7 +806,12 @@ def test_one_launch_tick_with_many_streams_per_gpu(assets, name):
         for (p0, n0), (p1, n1) in zip(*outs):
             np.testing.assert_array_equal(n0, n1)
             np.testing.assert_array_equal(p0, p1)
-        assert sum(int(n.sum()) for _, n in outs[0]) > 10000
+        assert sum(int(n.sum()) for _, n in outs[0]) > 14 * S
+        tl = StreamBank(e, S)
+        for t in range(4):
+            tl.step(pcm[t], speech)
+        assert (tl.timeline()["launch_2"] < 0.3) == (e.is_crnn or S <= 128)   # which form the bank took
+        tl.close()
     finally:
         e.close()
 

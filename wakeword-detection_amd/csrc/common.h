@@ -259,6 +259,7 @@ int ww_k_wave_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
                       float *d_out, float *d_enc, const ww_tick_tag *tag = nullptr);
 int ww_k_posterior_pick(ww_ctx *ctx, const float *d_rows, int64_t n, int n_out, int pidx, const int64_t *d_seg_offs, int64_t n_seg,
                         float *d_out);
+bool ww_wave_tick_capable(const ww_model *m, int n_streams);
 int ww_k_wave_tick(ww_ctx *ctx, const ww_model *m, const ww_tick_fe &fe, int precise, const ww_tick_tag &tag);
 int ww_k_far_frr(ww_ctx *ctx, const float *d_pos, int64_t n_pos, const float *d_neg, int64_t n_neg, int win,
                  const double *d_thr, int n_thr, double *d_smoothed, unsigned long long *d_pos_cnt,

@@ -1052,6 +1052,15 @@ int ww_k_wave_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
   return WW_OK;
 }
 
+// Which banks take the one-launch tick: those whose ticks stay within the twelve-wave form's range (2 S windows <= 256: one
+// workgroup per CU).  Larger banks keep the front-end kernel + the model kernel in its four-wave x three-tile form, which is worth
+// more than the launch it costs (tools/stream_forms.py, split-bf16 p50: 128 streams 49.3 vs 54.5 us, 192: 84.9 vs 82.6, 512: 158.7 vs
+// 149.2, 1,024: 306.2 vs 273.1; fp32 alike)
+bool ww_wave_tick_capable(const ww_model *m, int S) {
+  const int wide_from = m->precision == WW_PRECISION_BF16X3 ? WV_BF16_WIDE_FROM : WV_F32_WIDE_FROM;
+  return m->kind == WW_KIND_WAVENET && m->filt.n_mel == 40 && m->wave.n_mel == 40 && m->wave.T + 10 <= WV_T && 2 * S <= wide_from;
+}
+
 // ONE launch per tick (wavenet_kernel<..., TICK>): 2 S workgroups of twelve waves, the posteriors as tags only
 int ww_k_wave_tick(ww_ctx *ctx, const ww_model *m, const ww_tick_fe &fe, int precise, const ww_tick_tag &tag) {
   const ww_wave_dev &v = m->wave;
