@@ -371,7 +371,7 @@ def test_bench_rccl_path_at_world_size_one():
 
 
 def test_posterior_gather_over_rccl(tmp_path):
-    """wwhip.dist.gather_posteriors with the nccl backend and CUDA payloads (one rank: the collective still runs)."""
+    """wwhip.dist.gather_posteriors and gather_values_t with the nccl backend and CUDA payloads (one rank: the collectives still run)."""
     script = tmp_path / "g.py"
     script.write_text(f"""
 import os, sys
@@ -383,6 +383,12 @@ dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cu
 idx = [4, 0, 2]
 full = D.gather_posteriors(np.array([0.4, 0.0, 0.2], np.float32), idx, 6, device="cuda")
 assert full.tolist() == [0.0, 0.0, np.float32(0.2), 0.0, np.float32(0.4), 0.0], full
+# the sharded evaluators' exchange (round 5): values stay on the GPU - device tensor in, one all_gather, device tensors out
+vals = torch.arange(1000, dtype=torch.float32, device="cuda") * 0.5
+(back,) = D.gather_values_t(vals, [1000], device="cuda")
+assert back.is_cuda and back.device == vals.device and torch.equal(back, vals)
+(empty,) = D.gather_values_t(vals[:0], [0], device=torch.device("cuda", 0))
+assert empty.numel() == 0 and empty.is_cuda
 dist.barrier(); dist.destroy_process_group(); print("ok")
 """)
     env = dict({k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")},
