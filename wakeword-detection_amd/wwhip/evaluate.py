@@ -403,7 +403,9 @@ def _prep_chunk(ch: "_Chunk", ph: _Phases) -> None:
         fc = getattr(ch.job, "_files", None)
         if fc is None:
             n_all = len(plan.lengths)
-            fc = ch.job._files = (([None] * n_all), np.zeros(n_all, np.int64), np.ones(n_all, bool), plan.lengths.tolist())
+            fc = (([None] * n_all), np.zeros(n_all, np.int64), np.ones(n_all, bool), plan.lengths.tolist())
+            if getattr(ch.job, "cache_files", True):
+                ch.job._files = fc  # (clips that are in memory anyway; files read from disk are held per chunk only: ch.keep)
         arrs, addr, is_i16, lens_l = fc
         for f in files[addr[files] == 0].tolist():
             if arrs[f] is not None:
@@ -541,6 +543,7 @@ class _PosteriorJob:
         self.eng, self.eval_type, self.rank, self.world = eng, eval_type, rank, world
         frame_length = sample_rate // 1000 * frame_width
         in_memory = len(test_files) > 0 and not isinstance(test_files[0], (str, bytes)) and not hasattr(test_files[0], "__fspath__")
+        self.cache_files = in_memory  # (_prep_chunk: what it learns about a clip is kept with the job only when the clip stays in memory anyway)
         with ph("plan"):
             if in_memory:
                 self.load = lambda k: test_files[k]  # noqa: E731
