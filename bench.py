@@ -293,7 +293,9 @@ class Job:
         import numpy as np
         both = np.array([self.region(fp, only0) for _ in range(n)])
         ts, own = both[:, 0], both[:, 1]
-        stats = {"n": int(n), "min_ms": float(ts.min() * 1e3), "median_ms": float(np.median(ts) * 1e3), "max_ms": float(ts.max() * 1e3)}
+        stats = {"n": int(n), "min_ms": float(ts.min() * 1e3), "p10_ms": float(np.percentile(ts, 10) * 1e3),
+                 "median_ms": float(np.median(ts) * 1e3), "p90_ms": float(np.percentile(ts, 90) * 1e3), "max_ms": float(ts.max() * 1e3),
+                 "timed_seconds": float(ts.sum())}
         if self.dist is not None:
             # every rank's own median region (its clock stops at ITS gather's completion): the spread says who waits for whom
             t = self.torch.tensor([float(np.median(own))], dtype=self.torch.float64, device=self.comm_dev)
@@ -427,8 +429,17 @@ def roofline_of(eng, prof, clips, fast_frontend, step_s=None):
 def stream_leg(torch, np, dist, comm_dev, local_rank, S, ticks, warm=100):
     """BASELINE configs[4] per GPU: S streams x int16[320] per 20 ms tick, is_speech = 1 (2 posteriors per
     stream and tick); latency = tick submitted on the host -> posteriors visible on the host."""
-    from wwhip.engine import Engine, StreamBank
+    from wwhip.activation_timeout import ActivationTimeoutBank
+    from wwhip.context import ContextBank
+    from wwhip.engine import Engine, StreamBank, frontend_params
+    from wwhip.vad import VadBank
+    from wwhip.wakeword import WakewordBank
     out = {"streams_per_gpu": S, "ticks": ticks, "warmup_ticks": warm,
+           "pipeline_note": "pipeline = the same tick at the plugin surface (spokestack/pipeline.py:25-28 with demo.py's stage list, "
+                            "for S streams): VadBank -> WakewordBank -> ActivationTimeoutBank on a ContextBank, one library pass per "
+                            "stage and tick (ww_vad_bank_step, ww_stream_step_trigger, ww_timeout_bank_step), raw VAD decision = "
+                            "speech on every stream (the worst case: every stream owes 2 posteriors), threshold 0.5; "
+                            "over_tick_us = pipeline p50 - StreamBank.step p50 of the same bank kind, measured back to back",
            "note": "per-tick latency, host frames in -> host posteriors out; MAX over ranks of each rank's percentile; a tick is ONE "
                    "kernel launch (round 5: the front end of a stream's new frames runs inside the workgroups of its new windows - "
                    "crnn_stream_kernel<FE>: 3 of the 19 time positions of a window are new per mel row, the other 16 projected rows "
@@ -465,6 +476,36 @@ def stream_leg(torch, np, dist, comm_dev, local_rank, S, ticks, warm=100):
             "realtime_factor": 0.020 / (stats[2] * 1e-3), "host_phases_us": {k: round(v, 3) for k, v in tl.items()},
             "python_wrapper_us": round(own_mean_us - sum(tl.values()), 3)}
         bank.close()
+        # ---- the same tick at the plugin surface: three banked stages on a ContextBank
+        wake = WakewordBank(S, posterior_threshold=0.5, bank=StreamBank(eng, S, frontend_params(32767.0, True, 0.0, 160, True)))
+        vad, timeout, ctxs = VadBank(S), ActivationTimeoutBank(S), ContextBank(S)
+        events = []
+        ctxs.add_handler("activate", lambda c: events.append(1))
+        ctxs.add_handler("deactivate", lambda c: events.append(0))
+        raw = np.ones(S, bool)
+
+        def pipeline_tick(f):
+            vad(ctxs, f, raw=raw)
+            wake.step(ctxs, f)
+            timeout(ctxs, f)
+        for t in range(warm):
+            pipeline_tick(frames[t % 64])
+        plat = np.empty(ticks)
+        for t in range(ticks):
+            f = frames[t % 64]
+            t0 = time.perf_counter()
+            pipeline_tick(f)
+            plat[t] = time.perf_counter() - t0
+        pstats = [float(np.percentile(plat, 50) * 1e3), float(np.percentile(plat, 99) * 1e3), float(plat.mean() * 1e3)]
+        if dist is not None:
+            t = torch.tensor(pstats, dtype=torch.float64, device=comm_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            pstats = [float(v) for v in t.tolist()]
+        key = name.lower() if prec == "fp32" else f"{name.lower()}_{prec}"
+        out[key]["pipeline"] = {"p50_ms": pstats[0], "p99_ms": pstats[1], "mean_ms": pstats[2],
+                                "over_tick_us": round((pstats[0] - out[key]["p50_ms"]) * 1e3, 3),
+                                "activations": int(sum(events)), "deactivations": len(events) - int(sum(events))}
+        wake.close()
         eng.close()
     return out
 
@@ -699,13 +740,62 @@ def eval_leg(torch, np, dist, comm_dev, rank, world, local_rank, n_clips, with_o
     return res
 
 
+def summary_of(line):
+    """Every BASELINE config's figures in one compact object (<= 1.5 KB) at the END of the JSON line: the driver's record keeps
+    the last 8 KB of a ~60 KB line, so whatever is to be read from BENCH_rNN.json has to stand here.  Nothing is measured in this
+    function; every number is copied from the line (r3 = three significant digits are enough for a record)."""
+    def r(v, nd=4):
+        return None if v is None else float(f"{float(v):.{nd}g}")
+
+    def g(d, *path):
+        for k in path:
+            if not isinstance(d, dict) or d.get(k) is None:
+                return None
+            d = d[k]
+        return d
+    tr = line.get("timed_regions") or {}
+    roof = line.get("roofline") or {}
+    s = {"cfg2_crnn": {"value": r(line["value"]), "ms_per_step": r(line["ms_per_step"]), "regions": tr.get("n"),
+                       "region_ms_p10_p50_p90": [r(tr.get("p10_ms")), r(tr.get("median_ms")), r(tr.get("p90_ms"))],
+                       "timed_s": r(tr.get("timed_seconds"), 3), "kernel": roof.get("kernel"), "kernel_us": r(roof.get("kernel_avg_us")),
+                       "frac": r(roof.get("frac"), 3), "single_stream_value": r(g(line, "single_stream", "value")),
+                       "fast_profile_value": r(g(line, "fast_profile", "value"))}}
+    wv = line.get("wavenet")
+    if wv:
+        s["cfg3_wavenet"] = {"bf16x3_value": r(g(wv, "bf16x3", "value")), "bf16x3_kernel_us": r(g(wv, "bf16x3", "roofline", "kernel_avg_us")),
+                             "bf16x3_frac": r(g(wv, "bf16x3", "roofline", "frac"), 3), "fp32_value": r(g(wv, "fp32_mfma_parity_mode", "value"))}
+    st = line.get("streaming")
+    if st:
+        s["cfg5_tick_ms_p50_p99"] = {k: {"step": [r(v["p50_ms"]), r(v["p99_ms"])],
+                                         "pipeline": [r(g(v, "pipeline", "p50_ms")), r(g(v, "pipeline", "p99_ms"))],
+                                         "pipeline_over_tick_us": r(g(v, "pipeline", "over_tick_us"), 3)}
+                                     for k, v in st.items() if isinstance(v, dict) and "p50_ms" in v}
+        s["cfg5_streams_per_gpu"] = st.get("streams_per_gpu")
+    ev = line.get("eval_testset")
+    if ev:
+        sc = ev.get("at_scale") or {}
+        s["cfg4"] = {"standin_seconds": r(ev.get("seconds_host_pcm_in_to_curves_out")), "seconds": r(sc.get("seconds_host_pcm_in_to_curves_out")),
+                     "serial_ms": r(sc.get("serial_ms")), "one_rank_of_8_s": r(g(sc, "one_rank_of_8_measured", "seconds")),
+                     "eff_8_ranks": r(g(sc, "one_rank_of_8_measured", "efficiency_8_ranks"), 3),
+                     "x16_seconds": r(g(sc, "at_scale_x16", "seconds_host_pcm_in_to_curves_out")),
+                     "x16_one_rank_of_8_s": r(g(sc, "at_scale_x16", "one_rank_of_8_measured", "seconds")),
+                     "x16_eff_8_ranks": r(g(sc, "at_scale_x16", "one_rank_of_8_measured", "efficiency_8_ranks"), 3)}
+        s["frr_at_0.5_fa_per_hour"] = r(ev.get("frr_at_0.5_fa_per_hour"), 6)
+        s["frr_oracle"] = r(g(ev, "oracle", "frr_at_0.5_fa_per_hour"), 6)
+        s["fa_frr_identical_to_oracle"] = [g(ev, "oracle", "fa_counts_identical"), g(ev, "oracle", "frr_identical")]
+    cb = line.get("cpu_baseline")
+    if cb:
+        s["cpu_baseline"] = {"value": r(cb.get("value")), "cores": cb.get("cores"), "one_thread": r(g(cb, "one_thread", "value")), "kind": cb.get("kind")}
+    return s
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--repeats", type=int, default=0, help="timed regions of K steps each (median reported); 0 = auto: "
-                    "enough regions for >= 0.25 s of timed work, between 5 and 41")
+                    "enough regions for >= 1 s of timed work, between 5 and 2001")
     ap.add_argument("--model", choices=["crnn", "wavenet"], default="crnn")
     ap.add_argument("--clips", type=int, default=256)
     ap.add_argument("--rotate", type=int, default=24, help="distinct resident input batches to rotate over")
@@ -793,7 +883,8 @@ def main():
         n_rep = args.repeats
         if n_rep <= 0:
             probe = job.region(fp)[0]
-            n_rep = int(min(41, max(5, 0.25 / max(probe, 1e-6)))) | 1
+            # >= 1 s of timed headline work (round 5 timed 41 regions of 1 ms under the driver's --steps 20: 39 ms in all)
+            n_rep = int(min(2001, max(5, 1.1 / max(probe, 1e-6)))) | 1
         stats, med = job.regions(n_rep, fp)
         res = {"engs": engs, "job": job, "stats": stats, "median_s": med}
         res["posts"] = job.d_all[:min(K, R)].cpu().numpy()
@@ -935,6 +1026,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(eng, pcm0, float(os.environ.get("WW_BENCH_CPU_SECONDS", "10")))
         elif not args.no_cpu_baseline:
             line["cpu_baseline"] = None
+        line["summary"] = summary_of(line)  # LAST key: the driver's record keeps the last 8 KB of this line
         print(json.dumps(line), flush=True)
     close(head)
     if dist is not None:

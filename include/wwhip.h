@@ -36,6 +36,7 @@ extern "C" {
 #define WW_ENOMEM (-4)    /* allocation failure (MemoryError) */
 #define WW_ESTATE (-5)    /* object used in the wrong state (RuntimeError) */
 #define WW_ENODEVICE (-6) /* no usable gfx950 device (RuntimeError) */
+#define WW_EINTERNAL (-7) /* an exception stopped at the C boundary (RuntimeError); ww_last_error has its text */
 
 #define WW_KIND_CRNN 1
 #define WW_KIND_WAVENET 2
@@ -274,6 +275,38 @@ int ww_stream_destroy(ww_streams *st);
 int ww_stream_step(ww_streams *st, const int16_t *frames, const uint8_t *is_speech, float *post, int32_t *n_post);
 /* WakewordTrigger.reset (tflite.py:241-246) for the listed streams (ids NULL -> all). */
 int ww_stream_reset(ww_streams *st, const int32_t *ids, int32_t n);
+/* ---- the pipeline's host stages for S streams in lock step (BASELINE config 5 at the plugin surface) --------------------------
+ * The reference drives three stage objects per stream and 20 ms frame (spokestack/pipeline.py:25-28, stage list of demo.py:29-36),
+ * each a few comparisons on the shared SpeechContext.  For S streams each stage is ONE pass over plain arrays the caller owns
+ * (uint8 is_speech[S] / is_active[S] are the S SpeechContexts' flags, wwhip/context.py: ContextBank); a stage returns the ids whose
+ * flag it changed, so that activate / deactivate events (spokestack/context.py:71-85) are raised for those streams only.  No GPU
+ * call in the first three; ctx-less, errors are WW_EINVAL.
+ *
+ * ww_vad_bank_step - VoiceActivityDetector.__call__ after the classifier (spokestack/vad/webrtc.py:59-77): raw[s] = the frame
+ * classifier's decision; run_value / run_length = the detector's run state; is_speech is read and updated in place;
+ * rise_frames / fall_frames = vad_rise_delay // frame_width, vad_fall_delay // frame_width.  n_changed (may be NULL) = streams
+ * whose is_speech moved. */
+int ww_vad_bank_step(int32_t n_streams, const uint8_t *raw, int32_t rise_frames, int32_t fall_frames, uint8_t *run_value,
+                     int64_t *run_length, uint8_t *is_speech, int32_t *n_changed);
+/* ww_trigger_bank_step - WakewordTrigger.__call__ around the models (spokestack/wakeword/tflite.py:134-146,232-239) over the
+ * posteriors post[S][2] / n_post[S] a tick delivered: running maximum, `posterior > threshold` (float32 against a Python
+ * float: compared in double), is_active[s] set for the streams that fire and were not active (their ids -> fired_ids), VAD
+ * falling edges against was_speech (updated) -> fall_ids, whose posterior_max is cleared; the caller resets those streams
+ * (ww_stream_reset).  fired_ids / fall_ids hold up to S entries. */
+int ww_trigger_bank_step(int32_t n_streams, const uint8_t *is_speech, uint8_t *is_active, const float *post, const int32_t *n_post,
+                         double threshold, uint8_t *was_speech, float *posterior_max, int32_t *fired_ids, int32_t *n_fired,
+                         int32_t *fall_ids, int32_t *n_fall);
+/* ww_timeout_bank_step - ActivationTimeout.__call__ (spokestack/activation_timeout.py:25-38): min_frames / max_frames are
+ * min_active / frame_width and max_active / frame_width as the reference keeps them (floats); is_active[s] cleared and
+ * active_frames[s] zeroed for the streams that time out (-> deact_ids). */
+int ww_timeout_bank_step(int32_t n_streams, const uint8_t *is_speech, uint8_t *is_active, uint8_t *was_speech, int32_t *active_frames,
+                         double min_frames, double max_frames, int32_t *deact_ids, int32_t *n_deact);
+/* ww_stream_step_trigger - the wake-word stage of S streams as ONE call: ww_stream_step with bit 0 = is_speech[s], bit 1 =
+ * is_active[s] as they stand before the tick, ww_trigger_bank_step over its posteriors, ww_stream_reset of the streams whose
+ * VAD bit fell (tflite.py:143-146). */
+int ww_stream_step_trigger(ww_streams *st, const int16_t *frames, const uint8_t *is_speech, uint8_t *is_active, double threshold,
+                           uint8_t *was_speech, float *posterior_max, float *post, int32_t *n_post, int32_t *fired_ids,
+                           int32_t *n_fired, int32_t *fall_ids, int32_t *n_fall);
 /* Where a tick's time goes on the HOST side of ww_stream_step (the loop of spokestack/pipeline.py:25-28 is host-paced, so
  * BASELINE config 5's per-tick latency is this call): mean nanoseconds per phase over the ticks since the last reset -
  * [0] plan (control words and window descriptors of the tick), [1] the caller's frames into the page-locked block,

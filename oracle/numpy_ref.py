@@ -278,3 +278,49 @@ class RefKeywordRecognizer:
         self.frame_window.reset().fill(0.0)
         self.encode_window.reset().fill(-1.0)
         self.state[:] = 0.0
+
+
+class RefGatedStream:
+    """The gating of reference ``WakewordTrigger`` around its models, one stream (``spokestack/wakeword/tflite.py``):
+    ``__call__`` :123-146 (VAD falling edge; an ACTIVE context is not sampled at all; ``reset()`` on the fall), ``_sample``
+    :148-168 (normalise, clip, pre-emphasis with ``_prev_sample`` carried over - and NOT touched by a reset -, the sample ring
+    always advances, a full ring is analysed only while ``is_speech``), ``_filter`` :181-191 (the mel window slides by one row per
+    analysed frame), ``reset`` :241-246 (sample ring emptied, mel window zeroed).
+
+    The models are left out: :meth:`tick` returns the mel WINDOWS ``[k][T][40]`` (k = 0, 1 or 2) the encoder would see in this
+    tick, for the caller to evaluate in one batch; ``mel_row(frame512 float32) -> [40]`` is the STFT + filter graph (the C
+    oracle's ``logmel_f32`` on one frame).  The sample ring is kept as an array and cut at 512 instead of written sample by
+    sample - the same frames as the reference's per-sample loop (framing pinned by tests/golden/framing.npz)."""
+
+    def __init__(self, mel_row: Callable[[np.ndarray], np.ndarray], mel_length: int, mel_width: int = 40,
+                 pre_emphasis: float = 0.0, window: int = 512, hop: int = 160) -> None:
+        self.mel_row, self.T, self.F = mel_row, mel_length, mel_width
+        self.pre_emphasis, self.window, self.hop = pre_emphasis, window, hop
+        self._is_speech = False
+        self._prev_sample = np.float32(0.0)
+        self.samples = np.zeros(0, np.float32)
+        self.frames = np.zeros((self.T, self.F), np.float32)
+
+    def tick(self, frame_i16: np.ndarray, is_speech: bool, is_active: bool) -> List[np.ndarray]:
+        vad_fall = self._is_speech and not is_speech  # :134
+        self._is_speech = is_speech
+        out: List[np.ndarray] = []
+        if not is_active:  # :139-140
+            frame = normalise_pcm(frame_i16)  # :150-151
+            prev_sample = frame[-1]  # :156
+            frame = frame - np.float32(self.pre_emphasis) * np.append(self._prev_sample, frame[:-1]).astype(np.float32)  # :157
+            self._prev_sample = prev_sample
+            self.samples = np.concatenate([self.samples, frame.astype(np.float32)])
+            while len(self.samples) >= self.window:  # :163-168
+                if is_speech:
+                    row = self.mel_row(self.samples[:self.window])
+                    self.frames = np.concatenate([self.frames[1:], row.reshape(1, self.F)])  # :186-187
+                    out.append(self.frames.copy())
+                self.samples = self.samples[self.hop:]
+        if vad_fall:  # :143-146
+            self.reset()
+        return out
+
+    def reset(self) -> None:
+        self.samples = np.zeros(0, np.float32)  # :243
+        self.frames = np.zeros((self.T, self.F), np.float32)  # :244

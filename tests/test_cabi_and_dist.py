@@ -29,6 +29,39 @@ def test_library_exports_every_declared_symbol():
     assert lib.ww_num_frames(24000, 160) == 147 and lib.ww_num_frames(511, 160) == 0
 
 
+def test_no_exception_can_leave_the_c_abi():
+    """"all functions return int status 0/negative, never throw".  Every exported definition under csrc/ either
+    has its whole body between WW_GUARD_BEGIN and WW_GUARD_END (std::bad_alloc -> WW_ENOMEM, anything else -> WW_EINTERNAL,
+    csrc/common.h) or is marked WW_NOTHROW (a constant or a field read); the create functions hold what they allocated in a
+    ww_scoped owner, so that an early exit frees it."""
+    csrc = os.path.join(ROOT, "wakeword-detection_amd", "csrc")
+    text = {f: open(os.path.join(csrc, f)).read() for f in sorted(os.listdir(csrc)) if f.endswith(".hip")}
+    seen = {}
+    for name in header_symbols():
+        hits = [(f, m) for f, t in text.items() for m in re.finditer(r"^[A-Za-z_][A-Za-z0-9_ \*]*\b" + name + r"\(", t, flags=re.M)]
+        assert len(hits) == 1, (name, [f for f, _ in hits])
+        f, m = hits[0]
+        t = text[f]
+        open_brace = t.index("{", m.end())  # (no parameter list under csrc/ holds a brace)
+        head = t[m.start():open_brace]
+        eol = t.index("\n", open_brace)
+        end = eol - 1 if t[eol - 1] == "}" else t.index("\n}\n", open_brace)  # a one-line definition, or the brace in column 0
+        body = t[open_brace + 1:end].strip()
+        if "WW_NOTHROW" in head:
+            assert "new " not in body and "push_back" not in body and "std::" not in body, name
+            seen[name] = "nothrow"
+            continue
+        assert body.startswith("WW_GUARD_BEGIN"), f"{name} ({f}): body does not open with WW_GUARD_BEGIN"
+        assert re.search(r"WW_GUARD_END\([^\n]*\)$", body), f"{name} ({f}): body does not close with WW_GUARD_END(ctx)"
+        assert body.count("WW_GUARD_BEGIN") == 1 and body.count("WW_GUARD_END(") == 1, name
+        seen[name] = "guard"
+    assert sum(v == "nothrow" for v in seen.values()) == 4, seen  # ww_version, ww_last_error, ww_ctx_stream, ww_num_frames
+    for f, name in (("api.hip", "ww_ctx"), ("api.hip", "ww_model"), ("streams.hip", "ww_streams"), ("uploader.hip", "ww_uploader")):
+        assert re.search(r"ww_scoped<" + name + r", ", text[f]), f"{f}: the {name} create function does not own its object"
+    from wwhip import _lib
+    assert _lib.WW_EINTERNAL == -7
+
+
 def test_library_carries_gfx950_code(tmp_path):
     import shutil
     from wwhip import _lib

@@ -550,6 +550,97 @@ def test_many_stream_pipeline_matches_single_stream_stages(assets):
     assert np.isfinite(np.array(b_post)).all()
 
 
+def test_banked_pipeline_on_a_context_bank_equals_the_per_context_form(assets):
+    """BASELINE configs[4] at the plugin surface, the fast form: SpeechPipelineBank([VadBank, WakewordBank, ActivationTimeoutBank])
+    on a ContextBank - one library pass per stage and tick, events only for the streams that change - against the form the test
+    above holds equal to 128 single-stream chains (a list of SpeechContext objects, one ActivationTimeout per stream): the same
+    is_speech / is_active after every tick, the same activate / deactivate events per stream, the same posteriors, bit for bit."""
+    from wwhip.activation_timeout import ActivationTimeout, ActivationTimeoutBank
+    from wwhip.context import SpeechContext
+    from wwhip.pipeline import SpeechPipelineBank
+    from wwhip.vad import VadBank
+    from wwhip.wakeword import WakewordBank
+    S, TICKS, THR = 128, 90, 0.02
+    mdir = os.path.join(assets, "CRNN")
+    rng = np.random.default_rng(77)
+    frames = np.clip(rng.normal(0, 2500, (TICKS, S, 320)), -32768, 32767).astype(np.int16)
+    raw = np.zeros((TICKS, S), bool)
+    for s in range(S):
+        t, v = 0, bool(rng.random() < 0.5)
+        while t < TICKS:
+            n = int(rng.integers(1, 25))
+            raw[t:t + n, s] = v
+            t, v = t + n, not v
+    kw_vad = dict(frame_width=20, vad_rise_delay=40, vad_fall_delay=60)
+    kw_to = dict(frame_width=20, min_active=60, max_active=200)
+
+    # ---- per-context form (as in test_many_stream_pipeline_matches_single_stream_stages)
+    a_logs = [[] for _ in range(S)]
+    a_ctx = []
+    for s in range(S):
+        c = SpeechContext()
+        for name in ("activate", "deactivate"):
+            c.add_handler(name, (lambda s, n: (lambda ctx: a_logs[s].append(n)))(s, name))
+        a_ctx.append(c)
+    vad_a, wake_a = VadBank(S, **kw_vad), WakewordBank(S, mdir, posterior_threshold=THR)
+    to_a = [ActivationTimeout(**kw_to) for _ in range(S)]
+    a_state = np.zeros((TICKS, S, 2), bool)
+    a_post = []
+    for t in range(TICKS):
+        speech = vad_a.step(raw[t])
+        for s in range(S):
+            a_ctx[s].is_speech = bool(speech[s])
+        a_post.append(wake_a.step(a_ctx, frames[t]))
+        for s in range(S):
+            to_a[s](a_ctx[s], frames[t, s])
+            a_state[t, s] = (a_ctx[s].is_speech, a_ctx[s].is_active)
+    wake_a.close()
+
+    # ---- the pipeline on a ContextBank
+    class Source:
+        t = 0
+
+        def read(self):
+            self.t += 1
+            return frames[self.t - 1]
+
+        def start(self):
+            pass
+
+        def stop(self):
+            pass
+
+        def close(self):
+            pass
+
+    src = Source()
+    woke = []
+    pipe = SpeechPipelineBank(src, [VadBank(S, classifier=lambda f: raw[src.t - 1], **kw_vad),
+                                    WakewordBank(S, mdir, posterior_threshold=THR, on_wake=lambda ids: woke.extend(int(i) for i in ids)),
+                                    ActivationTimeoutBank(S, **kw_to)], S)
+    b_logs = [[] for _ in range(S)]
+    for s in range(0, S, 3):  # per-stream handlers on a third of the streams ...
+        for name in ("activate", "deactivate"):
+            pipe.context[s].add_handler(name, (lambda s, n: (lambda ctx: b_logs[s].append(n)))(s, name))
+    all_b = [[] for _ in range(S)]
+    pipe.event(lambda ctx: all_b[ctx._s].append("activate"), name="activate")      # ... and one handler for every stream
+    pipe.event(lambda ctx: all_b[ctx._s].append("deactivate"), name="deactivate")
+    wake_b = pipe._stages[1]
+    pipe.start()
+    for t in range(TICKS):
+        pipe.step()
+        assert np.array_equal(pipe.context.is_speech.astype(bool), a_state[t, :, 0]), t
+        assert np.array_equal(pipe.context.is_active.astype(bool), a_state[t, :, 1]), t
+        np.testing.assert_array_equal(wake_b._post, a_post[t])
+    for s in range(S):
+        assert all_b[s] == a_logs[s], s
+        assert b_logs[s] == (a_logs[s] if s % 3 == 0 else [])
+    assert sorted(woke) == sorted(s for s in range(S) for ev in a_logs[s] if ev == "activate")
+    assert 4 <= sum("activate" in lg for lg in a_logs) <= S - 4 and any("deactivate" in lg for lg in a_logs)
+    pipe.stop()
+    pipe.cleanup()
+
+
 def test_keyword_recognizer_matches_the_reference_loop(assets, oracle_dirs):
     """``KeywordRecognizer`` (spokestack/asr/keyword/tflite.py:99-184) - HIP front end, frames analysed
     only while the context is active, autoregressive encoder, detection on the falling edge of ``is_active`` - against the

@@ -465,8 +465,10 @@ def test_logmel_parameter_sweep_vs_oracle(engines, oracles):
 
 @pytest.mark.parametrize("name", ["CRNN", "Wavenet"])
 def test_stream_bank_at_config5_width(engines, oracles, name):
-    """BASELINE config 5 geometry on one GPU: 128 streams in lock step (every CU busy), mixed speech flags;
-    a sample of streams is checked posterior by posterior against the batch oracle, and two runs must agree."""
+    """BASELINE config 5 geometry on one GPU: 128 streams in lock step (every CU busy), is_speech = 1 on every stream (the
+    configuration's worst case: two posteriors per stream and tick); a sample of streams is checked posterior by posterior
+    against the batch oracle, and two runs must agree.  Mixed VAD bits, active stretches and resets at this width:
+    test_stream_bank_mixed_state_at_width_vs_oracle below."""
     from wwhip.engine import StreamBank
     rng = np.random.default_rng(43)
     e = engines[name]
@@ -493,6 +495,80 @@ def test_stream_bank_at_config5_width(engines, oracles, name):
         want = oracles[name].slide_forward(hist, 1)[1:, pidx]
         assert len(a[s]) == len(want)
         assert np.abs(np.array(a[s]) - want).max() < TOL_POST
+
+
+@pytest.mark.parametrize("name", ["CRNN", "Wavenet"])
+def test_stream_bank_mixed_state_at_width_vs_oracle(engines, oracles, name):
+    """The default tick (ONE launch, polled posteriors) at BASELINE config 5's width with everything that makes streams differ:
+    128 streams x 160 ticks, per-stream random VAD runs, two active stretches per stream (an active stream is not sampled: its
+    rings stand still), WakewordTrigger.reset of single streams on every VAD fall and of the whole bank once, pre-emphasis 0.97
+    (the carry survives resets).  Against the ORACLE, not against another launch form: n_post of every stream and tick against
+    the closed form of the reference's sample loop, and the posteriors of 16 sampled streams one by one against the reference's
+    gating restated (oracle/numpy_ref.RefGatedStream, spokestack/wakeword/tflite.py:123-168,241-246) feeding the C oracle's
+    front end and model.  The single-writer / sibling logic of the one-launch kernels is exactly what differs between streams
+    that gain 0, 1 or 2 frames, sit still, or restart in the same tick."""
+    from oracle.numpy_ref import RefGatedStream
+    from wwhip.engine import StreamBank, frontend_params
+    rng = np.random.default_rng(2026)
+    e, o = engines[name], oracles[name]
+    S, TICKS, PRE, BANK_RESET_AT = 128, 160, 0.97, 101
+    pcm = np.clip(rng.normal(0, 2500, (TICKS, S, 320)), -32768, 32767).astype(np.int16)
+    speech = np.zeros((TICKS, S), bool)
+    active = np.zeros((TICKS, S), bool)
+    for s in range(S):
+        t, v = 0, bool(rng.random() < 0.6)
+        while t < TICKS:
+            n = int(rng.integers(3, 30)) if v else int(rng.integers(1, 9))
+            speech[t:t + n, s] = v
+            t, v = t + n, not v
+        for _ in range(2):
+            a = int(rng.integers(5, TICKS - 25))
+            active[a:a + int(rng.integers(3, 20)), s] = True
+    bank = StreamBank(e, S, frontend_params(32767.0, True, PRE, 160, True))
+    got = [[] for _ in range(S)]
+    counts = np.zeros((TICKS, S), np.int32)
+    try:
+        for t in range(TICKS):
+            if t == BANK_RESET_AT:
+                bank.reset()
+            p, n = bank.step(pcm[t], speech[t].astype(np.uint8), active[t].astype(np.uint8))
+            counts[t] = n
+            for s in np.nonzero(n)[0]:
+                got[s] += [float(p[s, k]) for k in range(n[s])]
+            fell = np.nonzero(speech[t - 1] & ~speech[t])[0] if t else np.zeros(0, np.int64)
+            if len(fell):
+                bank.reset(fell)  # tflite.py:143-146
+    finally:
+        bank.close()
+    # ---- counts, all streams: f samples in the ring; a tick adds 320 and emits a frame per 160 while >= 512 are buffered
+    fill = np.zeros(S, np.int64)
+    for t in range(TICKS):
+        if t == BANK_RESET_AT:
+            fill[:] = 0
+        live = ~active[t]
+        tot = fill + 320
+        nf = np.where(live & (tot >= 512), (tot - 512) // 160 + 1, 0)
+        assert np.array_equal(counts[t], np.where(speech[t], nf, 0)), t
+        fill = np.where(live, tot - 160 * nf, fill)
+        if t:
+            fill[speech[t - 1] & ~speech[t]] = 0
+    assert {0, 1, 2} <= set(np.unique(counts)) and counts.sum() > 10000
+    # ---- posteriors, 16 sampled streams: the reference's gating feeding the oracle
+    pidx = e.posterior_index
+    worst = 0.0
+    for s in rng.choice(S, 16, replace=False):
+        ref = RefGatedStream(lambda fr: o.logmel_f32(fr, 0.0, 160)[0], e.window, 40, pre_emphasis=PRE)
+        wins = []
+        for t in range(TICKS):
+            if t == BANK_RESET_AT:
+                ref.reset()
+            w = ref.tick(pcm[t, s], bool(speech[t, s]), bool(active[t, s]))
+            assert len(w) == counts[t, s], (s, t)
+            wins += w
+        assert len(wins) == len(got[s]) > 50, (s, len(wins))
+        want = o.forward(np.array(wins))[:, pidx]
+        worst = max(worst, float(np.abs(np.array(got[s]) - want).max()))
+    assert worst < TOL_POST, worst
 
 
 def test_context_adopts_a_torch_stream(assets, oracles):

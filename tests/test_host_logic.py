@@ -560,3 +560,216 @@ def test_staging_pipeline_hands_a_planning_failure_to_the_caller():
                                                    [20000] * 8, True, ph, None, first_chunk=1 << 30)], True, ph, None)
     with pytest.raises(ZeroDivisionError):
         E._run_jobs(Eng, [lambda: 1 // 0], True, ph, None)
+
+
+# ---- the banked stages (BASELINE config 5 at the plugin surface): host logic only, a stub in place of the device bank -------
+
+class _StubStreamBank:
+    """Stands where ``StreamBank`` stands in ``WakewordBank``: 'delivers' scripted posteriors (an active stream is not sampled,
+    a frame is analysed only while the stream's VAD bit is set - spokestack/wakeword/tflite.py:139-140,166), then runs the
+    library's host pass ``ww_trigger_bank_step`` exactly as ``ww_stream_step_trigger`` does after the tick."""
+
+    def __init__(self, owner_arrays, script_post, script_n):
+        from wwhip import _lib
+        self.lib = _lib.load()
+        self.post, self.n = script_post, script_n  # [T][S][2], [T][S]
+        self.t = 0
+        self.resets = []
+        self.arr = owner_arrays  # () -> (is_speech, is_active, post, n_post) arrays the addresses point at
+
+    def step_trigger(self, frames, p_speech, p_active, threshold, st):
+        speech, active, post, n = self.arr()
+        n[:] = np.where((speech != 0) & (active == 0), self.n[self.t], 0)
+        post[:] = np.where(np.arange(2)[None, :] < n[:, None], self.post[self.t], 0.0)
+        self.t += 1
+        S = len(n)
+        assert self.lib.ww_trigger_bank_step(S, p_speech, p_active, st[2], st[3], threshold, st[0], st[1], st[4], st[5], st[6], st[7]) == 0
+
+    def reset(self, ids=None):
+        self.resets.append(None if ids is None else list(ids))
+
+    def close(self):
+        pass
+
+
+class _RefTrigger:
+    """``WakewordTrigger.__call__`` / ``_detect`` of the reference with the models replaced by scripted posteriors
+    (spokestack/wakeword/tflite.py:123-146,228-239), one stream."""
+
+    def __init__(self, threshold):
+        self.thr, self.was, self.pmax, self.resets = threshold, False, np.float32(0.0), 0
+
+    def __call__(self, ctx, posts):
+        fall = self.was and not ctx.is_speech
+        self.was = ctx.is_speech
+        if not ctx.is_active and ctx.is_speech:
+            for p in posts:
+                if p > self.pmax:
+                    self.pmax = p
+                if float(p) > self.thr and not ctx.is_active:
+                    ctx.is_active = True
+        if fall:
+            self.pmax = np.float32(0.0)
+            self.resets += 1
+
+
+def _bank_script(S, T, seed):
+    rng = np.random.default_rng(seed)
+    raw = np.zeros((T, S), bool)
+    for s in range(S):
+        t, v = 0, bool(rng.random() < 0.5)
+        while t < T:
+            n = int(rng.integers(1, 30))
+            raw[t:t + n, s] = v
+            t, v = t + n, not v
+    post = rng.random((T, S, 2)).astype(np.float32) ** 4  # mostly small, now and then above the threshold
+    n = rng.integers(0, 3, (T, S)).astype(np.int32)
+    return raw, post, n
+
+
+def test_banked_stages_equal_the_single_stream_stages():
+    """VadBank -> WakewordBank -> ActivationTimeoutBank on a ContextBank (one library pass per stage and tick) against S chains of
+    the single-stream classes on SpeechContext objects: the same flags after every stage of every tick, the same activate /
+    deactivate events in the same order, the same running maxima and resets.  Host logic only (scripted posteriors)."""
+    from wwhip.activation_timeout import ActivationTimeoutBank
+    from wwhip.context import ContextBank
+    from wwhip.vad import VadBank, VoiceActivityDetector
+    from wwhip.wakeword import WakewordBank
+    S, T, THR = 37, 400, 0.6
+    raw, post, n = _bank_script(S, T, 5)
+    kw_vad = dict(frame_width=20, vad_rise_delay=40, vad_fall_delay=60)
+    kw_to = dict(frame_width=20, min_active=100, max_active=400)
+    cb = ContextBank(S)
+    logs = [[] for _ in range(S)]
+    for s in range(0, S, 2):  # every other stream has handlers (a view exists only where one was asked for)
+        for name in ("activate", "deactivate"):
+            cb[s].add_handler(name, (lambda s, nm: (lambda c: logs[s].append(nm)))(s, name))
+    bank_log = []
+    cb.add_handler("activate", lambda c: bank_log.append(("activate", c._s)))
+    cb.add_handler("deactivate", lambda c: bank_log.append(("deactivate", c._s)))
+    vad, to = VadBank(S, **kw_vad), ActivationTimeoutBank(S, **kw_to)
+    wake = WakewordBank(S, posterior_threshold=THR, bank=_StubStreamBank(lambda: (cb.is_speech, cb.is_active, wake._post, wake._n), post, n))
+    woke = []
+    wake._on_wake = lambda ids: woke.extend(int(i) for i in ids)
+
+    ref_ctx = [SpeechContext() for _ in range(S)]
+    ref_logs = [[] for _ in range(S)]
+    ref_all = []
+    for s in range(S):
+        for name in ("activate", "deactivate"):
+            ref_ctx[s].add_handler(name, (lambda s, nm: (lambda c: (ref_logs[s].append(nm), ref_all.append((nm, s)))))(s, name))
+    tick = {"t": 0}
+    ref_vad = [VoiceActivityDetector(classifier=(lambda s: (lambda fb, sr: bool(raw[tick["t"], s])))(s), **kw_vad) for s in range(S)]
+    ref_trig = [_RefTrigger(THR) for _ in range(S)]
+    ref_to = [ActivationTimeout(**kw_to) for _ in range(S)]
+    frame = np.zeros(320, np.int16)
+    frames = np.zeros((S, 320), np.int16)
+    for t in range(T):
+        tick["t"] = t
+        n_ref = len(ref_all)
+        # stage by stage, all streams (events of one stage come out in stream order, as the bank raises them)
+        vad(cb, frames, raw=raw[t])
+        for s in range(S):
+            ref_vad[s](ref_ctx[s], frame)
+        assert [bool(c.is_speech) for c in ref_ctx] == list(cb.is_speech.astype(bool)), t
+        got_post = wake.step(cb, frames)
+        for s in range(S):
+            sampled = ref_ctx[s].is_speech and not ref_ctx[s].is_active
+            ref_trig[s](ref_ctx[s], post[t, s, :n[t, s]])
+            assert wake.n_post[s] == (n[t, s] if sampled else 0)
+            assert np.array_equal(got_post[s, :wake.n_post[s]], post[t, s, :wake.n_post[s]])
+        assert [bool(c.is_active) for c in ref_ctx] == list(cb.is_active.astype(bool)), t
+        assert np.array_equal(wake.posterior_max, np.array([r.pmax for r in ref_trig], np.float32)), t
+        to(cb, frames)
+        for s in range(S):
+            ref_to[s](ref_ctx[s], frame)
+        assert [bool(c.is_active) for c in ref_ctx] == list(cb.is_active.astype(bool)), t
+        assert bank_log[n_ref:] == ref_all[n_ref:], t
+    for s in range(S):
+        assert logs[s] == (ref_logs[s] if s % 2 == 0 else [])
+        assert cb[s].is_active == ref_ctx[s].is_active and cb[s].is_speech == ref_ctx[s].is_speech
+    assert woke == [s for (nm, s) in ref_all if nm == "activate"]
+    n_resets = sum(len(r) for r in wake._bank.resets)
+    assert n_resets == 0  # (the stub is not asked: ww_stream_step_trigger resets inside the library; the ids are in wake._fall)
+    acts = sum(nm == "activate" for nm, _ in ref_all)
+    assert acts >= S and sum(nm == "deactivate" for nm, _ in ref_all) >= acts - S  # the script exercises both edges, many times
+
+
+def test_activation_timeout_bank_replays_reference_trace(golden):
+    """The recorded trace of the reference's ActivationTimeout (tests/golden/activation_timeout_trace.json) through the banked
+    stage: every case as one stream of ONE bank per parameter set would need equal lengths, so each case runs as a bank of three
+    identical streams - same is_active after every frame, same events, on all three."""
+    from wwhip.activation_timeout import ActivationTimeoutBank
+    from wwhip.context import ContextBank
+    cases = json.load(open(os.path.join(golden, "activation_timeout_trace.json")))
+    for case in cases:
+        cb = ContextBank(3)
+        events = [[] for _ in range(3)]
+        for s in range(3):
+            for name in ("activate", "deactivate"):
+                cb[s].add_handler(name, (lambda s, n: (lambda c: events[s].append(n)))(s, name))
+        stage = ActivationTimeoutBank(3, **case["kwargs"])
+        got = [[] for _ in range(3)]
+        for t, (sp, act, rst, want) in enumerate(zip(case["is_speech"], case["activate"], case["reset"], case["is_active"])):
+            cb.is_speech[:] = sp == "1"
+            if act == "1":
+                for c in cb:
+                    c.is_active = True
+            if rst == "1":
+                stage.reset()
+            n_ev = [len(e) for e in events]
+            stage(cb, None)
+            assert list(cb.is_active) == [int(want == "1")] * 3, (case["kwargs"], t)
+            for s in range(3):
+                got[s] += [[t, e] for e in events[s][n_ev[s]:]]
+        assert got == [case["events"]] * 3
+
+
+def test_a_quiet_tick_costs_no_per_stream_python():
+    """A tick in which no stream changes state makes no per-stream Python call: the number of Python-level function calls of
+    VadBank -> WakewordBank -> ActivationTimeoutBank on a ContextBank is the same for 8 streams and for 512, and small; a tick
+    in which k streams change adds calls for those k only."""
+    import sys
+    from wwhip.activation_timeout import ActivationTimeoutBank
+    from wwhip.context import ContextBank
+    from wwhip.vad import VadBank
+    from wwhip.wakeword import WakewordBank
+
+    def calls_per_tick(S, loud_at=None):
+        T = 12
+        post = np.full((T, S, 2), 0.1, np.float32)
+        n = np.full((T, S), 2, np.int32)
+        if loud_at is not None:
+            post[loud_at, :3, 1] = 0.9  # three streams fire in that tick
+        cb = ContextBank(S)
+        handled = []
+        for s in range(S):
+            cb[s].add_handler("activate", lambda c: handled.append(c._s))
+        wake = WakewordBank(S, posterior_threshold=0.5, bank=_StubStreamBank(lambda: (cb.is_speech, cb.is_active, wake._post, wake._n), post, n))
+        vad, to = VadBank(S), ActivationTimeoutBank(S)
+        frames, raw = np.zeros((S, 320), np.int16), np.ones(S, bool)
+        counts = []
+        for t in range(T):
+            k = [0]
+
+            def prof(frame, event, arg):
+                if event == "call":  # Python-level calls (the stub bank's two included: constant in S)
+                    k[0] += 1
+            sys.setprofile(prof)
+            try:
+                vad(cb, frames, raw=raw)
+                wake.step(cb, frames)
+                to(cb, frames)
+            finally:
+                sys.setprofile(None)
+            counts.append(k[0])
+        return counts, handled
+
+    small, _ = calls_per_tick(8)
+    large, _ = calls_per_tick(512)
+    assert small[2:] == large[2:], (small, large)       # (the first ticks bind the stages to the ContextBank)
+    assert max(large[2:]) <= 16, large                   # three stage calls and their few helpers, whatever S is
+    loud, handled = calls_per_tick(512, loud_at=6)
+    assert handled == [0, 1, 2]
+    quiet = large[5]
+    assert loud[5] == quiet and loud[7] == quiet and quiet < loud[6] <= quiet + 3 * 8, loud

@@ -69,9 +69,10 @@ struct ww_small_io {
 extern "C" {
 
 static_assert(WW_ABI == 4, "ww_version's text carries the ABI number");
-const char *ww_version(void) { return "wwhip 0.5 (gfx950; ABI 4: ww_stream_create takes flags, ww_host_stage_i16, ww_uploader_*, ww_stream_timeline)"; }
+const char *ww_version(void) WW_NOTHROW { return "wwhip 0.5 (gfx950; ABI 4: ww_stream_create takes flags, ww_host_stage_i16, ww_uploader_*, ww_stream_timeline)"; }
 
 int ww_runtime_info(int32_t *built_hip_version, int32_t *runtime_version, int32_t *driver_version) {
+  WW_GUARD_BEGIN
   if (built_hip_version) *built_hip_version = HIP_VERSION;  // headers the library was compiled against
   int rt = 0, drv = 0;
   const hipError_t e1 = hipRuntimeGetVersion(&rt);
@@ -79,11 +80,13 @@ int ww_runtime_info(int32_t *built_hip_version, int32_t *runtime_version, int32_
   if (runtime_version) *runtime_version = e1 == hipSuccess ? rt : 0;
   if (driver_version) *driver_version = e2 == hipSuccess ? drv : 0;
   return e1 == hipSuccess ? WW_OK : WW_EHIP;
+  WW_GUARD_END(nullptr)
 }
 
-const char *ww_last_error(const ww_ctx *ctx) { return ctx ? ctx->err : g_err; }
+const char *ww_last_error(const ww_ctx *ctx) WW_NOTHROW { return ctx ? ctx->err : g_err; }
 
 int ww_ctx_create(int device, void *external_stream, ww_ctx **out) {
+  WW_GUARD_BEGIN
   if (!out) return ww_fail(nullptr, WW_EINVAL, "out is NULL");
   *out = nullptr;
   int n = 0;
@@ -106,19 +109,21 @@ int ww_ctx_create(int device, void *external_stream, ww_ctx **out) {
     }
     c->own_stream = true;
   }
+  ww_scoped<ww_ctx, ww_ctx_destroy> own(c);
   hipEventCreate(&c->t0);
   hipEventCreate(&c->t1);
   // kernel attributes are per device: set them for this context's device (a second GPU of the process gets its own)
   if (int rc = ww_k_crnn_init_device(c)) {
     snprintf(g_err, sizeof g_err, "%s", c->err);
-    ww_ctx_destroy(c);
     return rc;
   }
-  *out = c;
+  *out = own.release();
   return WW_OK;
+  WW_GUARD_END(nullptr)
 }
 
 int ww_ctx_destroy(ww_ctx *ctx) {
+  WW_GUARD_BEGIN
   if (!ctx) return WW_OK;
   ww_device_scope dev_scope(ctx->device);
   hipStreamSynchronize(ctx->stream);
@@ -142,23 +147,29 @@ int ww_ctx_destroy(ww_ctx *ctx) {
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return WW_OK;
+  WW_GUARD_END(nullptr)
 }
 
 int ww_ctx_synchronize(ww_ctx *ctx) {
+  WW_GUARD_BEGIN
   if (!ctx) return WW_EINVAL;
   WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return WW_OK;
+  WW_GUARD_END(ctx)
 }
 
-void *ww_ctx_stream(ww_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+void *ww_ctx_stream(ww_ctx *ctx) WW_NOTHROW { return ctx ? (void *)ctx->stream : nullptr; }
 
 int ww_profile_enable(ww_ctx *ctx, int on) {
+  WW_GUARD_BEGIN
   if (!ctx) return WW_EINVAL;
   ctx->profiling = on != 0;
   return WW_OK;
+  WW_GUARD_END(ctx)
 }
 
 int ww_profile_read(ww_ctx *ctx, char *json, size_t cap) {
+  WW_GUARD_BEGIN
   if (!ctx || !json || cap < 8) return WW_EINVAL;
   WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
   std::string s = "{";
@@ -183,20 +194,25 @@ int ww_profile_read(ww_ctx *ctx, char *json, size_t cap) {
   if (s.size() + 1 > cap) return ww_fail(ctx, WW_EINVAL, "profile buffer too small (%zu needed)", s.size() + 1);
   memcpy(json, s.c_str(), s.size() + 1);
   return WW_OK;
+  WW_GUARD_END(ctx)
 }
 
 int ww_timer_start(ww_ctx *ctx) {
+  WW_GUARD_BEGIN
   if (!ctx) return WW_EINVAL;
   WW_HIP(ctx, hipEventRecord(ctx->t0, ctx->stream));
   return WW_OK;
+  WW_GUARD_END(ctx)
 }
 
 int ww_timer_stop(ww_ctx *ctx, float *ms) {
+  WW_GUARD_BEGIN
   if (!ctx || !ms) return WW_EINVAL;
   WW_HIP(ctx, hipEventRecord(ctx->t1, ctx->stream));
   WW_HIP(ctx, hipEventSynchronize(ctx->t1));
   WW_HIP(ctx, hipEventElapsedTime(ms, ctx->t0, ctx->t1));
   return WW_OK;
+  WW_GUARD_END(ctx)
 }
 
 }  // extern "C"
@@ -700,6 +716,7 @@ static int load_wave(ww_ctx *ctx, ww_model *m, const blob_view &bv) {
 extern "C" {
 
 int ww_model_load(ww_ctx *ctx, const void *blob, size_t len, ww_model **out) {
+  WW_GUARD_BEGIN
   if (!ctx || !blob || !out) return ww_fail(ctx, WW_EINVAL, "NULL argument");
   *out = nullptr;
   if (len < 16) return ww_fail(ctx, WW_EBLOB, "blob too short");
@@ -711,22 +728,22 @@ int ww_model_load(ww_ctx *ctx, const void *blob, size_t len, ww_model **out) {
   if (bv.kind != WW_KIND_CRNN && bv.kind != WW_KIND_WAVENET) return ww_fail(ctx, WW_EBLOB, "unknown model kind %u", bv.kind);
   WW_ON_DEVICE(ctx, dev_scope);  // the caller's current device is left as it was
   ww_model *m = new ww_model();
+  ww_scoped<ww_model, ww_model_free> own(m);
   m->ctx = ctx;
   m->kind = (int)bv.kind;
   int rc = load_filter(ctx, m, bv);
   if (rc == WW_OK) rc = bv.kind == WW_KIND_CRNN ? load_crnn(ctx, m, bv) : load_wave(ctx, m, bv);
-  if (rc != WW_OK) {
-    ww_model_free(m);
-    return rc;
-  }
+  if (rc != WW_OK) return rc;  // (`own` frees what was uploaded so far)
   m->info.kind = m->kind;
   m->info.n_mel = m->filt.n_mel;
   m->info.n_bins = m->filt.n_bins;
-  *out = m;
+  *out = own.release();
   return WW_OK;
+  WW_GUARD_END(ctx)
 }
 
 int ww_model_free(ww_model *m) {
+  WW_GUARD_BEGIN
   if (!m) return WW_OK;
   if (m->ctx) {
     ww_device_scope dev_scope(m->ctx->device);
@@ -735,23 +752,29 @@ int ww_model_free(ww_model *m) {
   for (void *p : m->allocs) hipFree(p);
   delete m;
   return WW_OK;
+  WW_GUARD_END(nullptr)
 }
 
 int ww_model_get_info(const ww_model *m, ww_model_info *out) {
+  WW_GUARD_BEGIN
   if (!m || !out) return WW_EINVAL;
   *out = m->info;
   return WW_OK;
+  WW_GUARD_END(m ? m->ctx : nullptr)
 }
 
 int ww_model_set_precision(ww_model *m, int precision) {
+  WW_GUARD_BEGIN
   if (!m) return WW_EINVAL;
   if (precision != WW_PRECISION_FP32 && precision != WW_PRECISION_BF16X3)
     return ww_fail(m->ctx, WW_EINVAL, "unknown precision %d", precision);
   m->precision = precision;
   return WW_OK;
+  WW_GUARD_END(m ? m->ctx : nullptr)
 }
 
 int ww_model_set_option(ww_model *m, int key, int64_t value) {
+  WW_GUARD_BEGIN
   if (!m) return WW_EINVAL;
   if (value < 0 || value > 0x7fffffff) return ww_fail(m->ctx, WW_EINVAL, "option value %lld out of range", (long long)value);
   switch (key) {
@@ -764,9 +787,10 @@ int ww_model_set_option(ww_model *m, int key, int64_t value) {
     case WW_OPT_WAVENET_ROWMAJOR: m->opt_wave_rowmajor = value != 0; return WW_OK;
     default: return ww_fail(m->ctx, WW_EINVAL, "unknown model option %d", key);
   }
+  WW_GUARD_END(m ? m->ctx : nullptr)
 }
 
-int64_t ww_num_frames(int64_t n, int32_t hop) {
+int64_t ww_num_frames(int64_t n, int32_t hop) WW_NOTHROW {
   if (hop <= 0 || n < WW_FFT_WINDOW) return 0;
   return (n - WW_FFT_WINDOW) / hop + 1;
 }
@@ -844,26 +868,33 @@ extern "C" {
 
 int ww_logmel(ww_ctx *ctx, const ww_model *m, const int16_t *pcm, const int64_t *sample_offs, int32_t n_utt,
               const ww_frontend_params *fp, float *mel, int64_t *frame_offs) {
+  WW_GUARD_BEGIN
   return logmel_host(ctx, m, pcm, 2, sample_offs, n_utt, fp, mel, frame_offs);
+  WW_GUARD_END(ctx)
 }
 
 int ww_logmel_f32(ww_ctx *ctx, const ww_model *m, const float *samples, const int64_t *sample_offs, int32_t n_utt,
                   const ww_frontend_params *fp, float *mel, int64_t *frame_offs) {
+  WW_GUARD_BEGIN
   return logmel_host(ctx, m, samples, 4, sample_offs, n_utt, fp, mel, frame_offs);
+  WW_GUARD_END(ctx)
 }
 
 int ww_logmel_dev(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, const int64_t *d_sample_offs,
                   const int64_t *d_frame_offs, int32_t n_utt, int64_t total_frames, int64_t max_frames_per_utt,
                   const ww_frontend_params *fp, float *d_mel) {
+  WW_GUARD_BEGIN
   if (!ctx || !m || !d_pcm || !d_sample_offs || !d_frame_offs || !d_mel) return ww_fail(ctx, WW_EINVAL, "NULL argument");
   if (((uintptr_t)d_pcm & 15) != 0) return ww_fail(ctx, WW_EINVAL, "d_pcm must be 16-byte aligned");
   int rc = check_fp(ctx, fp, true);
   if (rc) return rc;
   WW_ON_DEVICE(ctx, dev);
   return ww_k_logmel(ctx, m, d_pcm, nullptr, d_sample_offs, d_frame_offs, n_utt, total_frames, max_frames_per_utt, fp, d_mel);
+  WW_GUARD_END(ctx)
 }
 
 int ww_stft_mag(ww_ctx *ctx, const ww_model *m, const float *frames, int64_t n, int32_t precise, float *mag) {
+  WW_GUARD_BEGIN
   if (!ctx || !m) return ww_fail(ctx, WW_EINVAL, "NULL argument");
   if (n < 0) return ww_fail(ctx, WW_EINVAL, "negative frame count");
   if (n == 0) return WW_OK;
@@ -890,6 +921,7 @@ int ww_stft_mag(ww_ctx *ctx, const ww_model *m, const float *frames, int64_t n, 
   WW_HIP(ctx, hipMemcpyAsync(mag, d_m, (size_t)n * WW_FFT_BINS * 4, hipMemcpyDeviceToHost, ctx->stream));
   WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return WW_OK;
+  WW_GUARD_END(ctx)
 }
 
 }  // extern "C"
@@ -897,6 +929,7 @@ int ww_stft_mag(ww_ctx *ctx, const ww_model *m, const float *frames, int64_t n, 
 extern "C" {
 
 int ww_filter_apply(ww_ctx *ctx, const ww_model *m, const float *mag, int64_t n, float *mel) {
+  WW_GUARD_BEGIN
   if (!ctx || !m) return ww_fail(ctx, WW_EINVAL, "NULL argument");
   if (n < 0) return ww_fail(ctx, WW_EINVAL, "negative row count");
   if (n == 0) return WW_OK;
@@ -924,9 +957,11 @@ int ww_filter_apply(ww_ctx *ctx, const ww_model *m, const float *mag, int64_t n,
   WW_HIP(ctx, hipMemcpyAsync(mel, d_b, (size_t)n * F * 4, hipMemcpyDeviceToHost, ctx->stream));
   WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return WW_OK;
+  WW_GUARD_END(ctx)
 }
 
 int ww_detect(ww_ctx *ctx, const ww_model *m, const float *enc, int32_t n, float *out) {
+  WW_GUARD_BEGIN
   if (!ctx || !m) return ww_fail(ctx, WW_EINVAL, "NULL argument");
   if (n < 0) return ww_fail(ctx, WW_EINVAL, "negative row count");
   if (n == 0) return WW_OK;
@@ -956,6 +991,7 @@ int ww_detect(ww_ctx *ctx, const ww_model *m, const float *enc, int32_t n, float
   WW_HIP(ctx, hipMemcpyAsync(out, d_b, (size_t)n * m->info.n_out * 4, hipMemcpyDeviceToHost, ctx->stream));
   WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return WW_OK;
+  WW_GUARD_END(ctx)
 }
 
 }  // extern "C"
@@ -1049,20 +1085,25 @@ __global__ void iota_offs_kernel(int64_t *sample_offs, int64_t *frame_offs, int 
 extern "C" {
 
 int ww_forward_enc(ww_ctx *ctx, const ww_model *m, const float *windows, int32_t nw, float *out, float *enc) {
+  WW_GUARD_BEGIN
   if (!ctx || !m) return ww_fail(ctx, WW_EINVAL, "NULL argument");
   if (nw < 0) return ww_fail(ctx, WW_EINVAL, "negative window count");
   if (nw == 0) return WW_OK;
   if (!windows || !out) return ww_fail(ctx, WW_EINVAL, "NULL buffer");
   // B stacked windows are one mel sequence of B*T rows read with hop = T
   return forward_host(ctx, m, windows, (int64_t)nw * m->info.window, m->info.window, nw, out, enc);
+  WW_GUARD_END(ctx)
 }
 
 int ww_forward(ww_ctx *ctx, const ww_model *m, const float *windows, int32_t nw, float *out) {
+  WW_GUARD_BEGIN
   return ww_forward_enc(ctx, m, windows, nw, out, nullptr);
+  WW_GUARD_END(ctx)
 }
 
 int ww_slide_forward(ww_ctx *ctx, const ww_model *m, const float *mel, int64_t rows, int32_t hop, float *out,
                      int64_t *n_windows) {
+  WW_GUARD_BEGIN
   if (!ctx || !m || !n_windows) return ww_fail(ctx, WW_EINVAL, "NULL argument");
   if (hop <= 0) return ww_fail(ctx, WW_EINVAL, "hop must be positive");
   if (rows < 0) return ww_fail(ctx, WW_EINVAL, "negative row count");
@@ -1072,10 +1113,12 @@ int ww_slide_forward(ww_ctx *ctx, const ww_model *m, const float *mel, int64_t r
   if (nw == 0) return WW_OK;
   if (!mel || !out) return ww_fail(ctx, WW_EINVAL, "NULL buffer");
   return forward_host(ctx, m, mel, rows, hop, nw, out, nullptr);
+  WW_GUARD_END(ctx)
 }
 
 int ww_forward_windows_dev(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *d_win_row,
                            const int32_t *d_win_valid, int32_t nw, float *d_out) {
+  WW_GUARD_BEGIN
   if (!ctx || !m || !d_mel || !d_out) return ww_fail(ctx, WW_EINVAL, "NULL argument");
   if (nw < 0) return ww_fail(ctx, WW_EINVAL, "negative window count");
   if (nw == 0) return WW_OK;
@@ -1092,10 +1135,12 @@ int ww_forward_windows_dev(ww_ctx *ctx, const ww_model *m, const float *d_mel, i
     if (rc) return rc;
   }
   return WW_OK;
+  WW_GUARD_END(ctx)
 }
 
 int ww_forward_segments_dev(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_t mel_rows, const int64_t *seg_row0,
                             const int32_t *seg_nw, int32_t n_seg, int32_t hop, float *d_out) {
+  WW_GUARD_BEGIN
   if (!ctx || !m || !d_mel || !d_out) return ww_fail(ctx, WW_EINVAL, "NULL argument");
   if (n_seg < 0) return ww_fail(ctx, WW_EINVAL, "negative sequence count");
   if (hop <= 0) return ww_fail(ctx, WW_EINVAL, "hop must be positive");
@@ -1133,10 +1178,12 @@ int ww_forward_segments_dev(ww_ctx *ctx, const ww_model *m, const float *d_mel, 
     if (rc) return rc;
   }
   return WW_OK;
+  WW_GUARD_END(ctx)
 }
 
 int ww_clips_forward_dev(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, int32_t n_clips, int32_t samples,
                          const ww_frontend_params *fp, float *d_out) {
+  WW_GUARD_BEGIN
   if (!ctx || !m || !d_pcm || !d_out) return ww_fail(ctx, WW_EINVAL, "NULL argument");
   if (n_clips < 0 || samples < 0) return ww_fail(ctx, WW_EINVAL, "negative size");
   if (n_clips == 0) return WW_OK;
@@ -1190,6 +1237,7 @@ int ww_clips_forward_dev(ww_ctx *ctx, const ww_model *m, const int16_t *d_pcm, i
   // Plain stream launches: measured on MI355X (round 1) the chain replays slower as a hipGraph (93 vs 88 us: the queue stays
   // full, so launch latency is hidden, while a graph replay has a 10-16 us floor); the capture path was removed in round 3.
   return enqueue();
+  WW_GUARD_END(ctx)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1238,26 +1286,33 @@ static int far_frr_impl(ww_ctx *ctx, bool on_device, const float *pos, int64_t n
 int ww_far_frr(ww_ctx *ctx, const float *pos, int64_t n_pos, const float *neg, int64_t n_neg, int32_t win,
                const double *thr, int32_t n_thr, double num_wakewords, double hours, double *frr, double *fa_per_h,
                int64_t *fa_count, double *smoothed) {
+  WW_GUARD_BEGIN
   return far_frr_impl(ctx, false, pos, n_pos, neg, n_neg, win, thr, n_thr, num_wakewords, hours, frr, fa_per_h, fa_count, smoothed, nullptr);
+  WW_GUARD_END(ctx)
 }
 
 int ww_far_frr_dev(ww_ctx *ctx, const float *d_pos, int64_t n_pos, const float *d_neg, int64_t n_neg, int32_t win,
                    const double *thr, int32_t n_thr, double num_wakewords, double hours, double *frr, double *fa_per_h,
                    int64_t *fa_count, double *d_smoothed) {
+  WW_GUARD_BEGIN
   return far_frr_impl(ctx, true, d_pos, n_pos, d_neg, n_neg, win, thr, n_thr, num_wakewords, hours, frr, fa_per_h, fa_count, nullptr, d_smoothed);
+  WW_GUARD_END(ctx)
 }
 
 int ww_posterior_pick_dev(ww_ctx *ctx, const float *d_rows, int64_t n, int32_t n_out, int32_t pidx, const int64_t *d_seg_offs,
                           int64_t n_seg, float *d_out) {
+  WW_GUARD_BEGIN
   if (!ctx) return WW_EINVAL;
   if (n < 0 || n_seg < 0 || n_out <= 0 || pidx < 0 || pidx >= n_out) return ww_fail(ctx, WW_EINVAL, "posterior pick: bad sizes");
   if ((n > 0 && !d_rows) || ((d_seg_offs ? n_seg : n) > 0 && !d_out)) return ww_fail(ctx, WW_EINVAL, "NULL argument");
   WW_ON_DEVICE(ctx, dev_scope);  // the caller's current device is left as it was
   return ww_k_posterior_pick(ctx, d_rows, n, n_out, pidx, d_seg_offs, n_seg, d_out);
+  WW_GUARD_END(ctx)
 }
 
 int ww_superframe_smooth(ww_ctx *ctx, const float *in, int64_t n, int32_t T, float stay_bonus, int32_t in_is_cost,
                          uint8_t *path, uint8_t *wake) {
+  WW_GUARD_BEGIN
   if (!ctx || (n > 0 && (!in || !wake))) return ww_fail(ctx, WW_EINVAL, "NULL argument");
   if (n < 0) return ww_fail(ctx, WW_EINVAL, "bad sizes");
   if (n == 0) return WW_OK;
@@ -1274,6 +1329,7 @@ int ww_superframe_smooth(ww_ctx *ctx, const float *in, int64_t n, int32_t T, flo
   WW_HIP(ctx, hipMemcpyAsync(wake, d_w, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   WW_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return WW_OK;
+  WW_GUARD_END(ctx)
 }
 
 }  // extern "C"

@@ -7,7 +7,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <map>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -128,6 +130,35 @@ struct ww_model {
 
 int ww_fail(ww_ctx *ctx, int code, const char *fmt, ...);
 int ww_ensure(ww_ctx *ctx, ww_arena &a, size_t bytes, bool pinned);
+
+// No exception crosses the C ABI (every entry point returns a status, never throws): the body of every exported
+// function sits between WW_GUARD_BEGIN and WW_GUARD_END(ctx) - std::bad_alloc from a container or `new` becomes WW_ENOMEM,
+// anything else WW_EINTERNAL, with the text where ww_last_error finds it (ctx may be nullptr: the thread's text).  The few
+// exported functions that only read a field or return a constant carry WW_NOTHROW instead (tests/test_cabi_and_dist.py
+// checks that every definition has one or the other).
+#define WW_GUARD_BEGIN try {
+#define WW_GUARD_END(ctx_)                                                                                  \
+  }                                                                                                         \
+  catch (const std::bad_alloc &) { return ww_fail((ctx_), WW_ENOMEM, "%s: out of host memory", __func__); } \
+  catch (const std::exception &e_) { return ww_fail((ctx_), WW_EINTERNAL, "%s: %s", __func__, e_.what()); } \
+  catch (...) { return ww_fail((ctx_), WW_EINTERNAL, "%s: unknown exception", __func__); }
+// An object a create function has allocated and not yet handed out: destroyed if the function leaves early (an error
+// return, or an exception on its way to WW_GUARD_END).
+template <typename T, int (*Destroy)(T *)>
+struct ww_scoped {
+  T *p;
+  explicit ww_scoped(T *q) : p(q) {}
+  ww_scoped(const ww_scoped &) = delete;
+  ~ww_scoped() {
+    if (p) Destroy(p);
+  }
+  T *release() {
+    T *r = p;
+    p = nullptr;
+    return r;
+  }
+};
+#define WW_NOTHROW /* marker: the body allocates nothing and calls nothing that can throw */
 
 #define WW_HIP(ctx, expr)                                                                       \
   do {                                                                                          \

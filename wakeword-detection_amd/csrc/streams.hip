@@ -82,6 +82,7 @@ struct ww_streams {
   // host timeline of ww_stream_step (ww_stream_timeline): nanoseconds per phase summed over the ticks since the last reset
   uint64_t tl_ns[WW_STREAM_TL_PHASES] = {0};
   int64_t tl_ticks = 0;
+  std::vector<uint8_t> stage_flags;  // ww_stream_step_trigger: bit 0 = is_speech, bit 1 = is_active per stream
 };
 
 static inline uint64_t st_now_ns() {
@@ -234,6 +235,7 @@ __global__ void stream_reset_kernel(float *hist, const int32_t *ids, int S, int 
 extern "C" {
 
 int ww_stream_destroy(ww_streams *st) {
+  WW_GUARD_BEGIN
   if (!st) return WW_OK;
   ww_device_scope dev_scope(st->ctx->device);
   hipStreamSynchronize(st->ctx->stream);
@@ -245,10 +247,12 @@ int ww_stream_destroy(ww_streams *st) {
     if (p) hipHostFree(p);
   delete st;
   return WW_OK;
+  WW_GUARD_END(nullptr)
 }
 
 int ww_stream_create(ww_ctx *ctx, const ww_model *model, int32_t S, const ww_frontend_params *fp, uint32_t flags,
                      ww_streams **out) {
+  WW_GUARD_BEGIN
   if (!ctx || !model || !fp || !out) return ww_fail(ctx, WW_EINVAL, "NULL argument");
   *out = nullptr;
   if (flags & ~(uint32_t)(WW_STREAM_FULL_RECOMPUTE | WW_STREAM_TWO_LAUNCH | WW_STREAM_SYNC_WAIT))
@@ -258,6 +262,7 @@ int ww_stream_create(ww_ctx *ctx, const ww_model *model, int32_t S, const ww_fro
   if (!(fp->pcm_divisor > 0.f)) return ww_fail(ctx, WW_EINVAL, "pcm_divisor must be positive");
   WW_ON_DEVICE(ctx, dev_scope);  // the caller's current device is left as it was
   ww_streams *st = new ww_streams();
+  ww_scoped<ww_streams, ww_stream_destroy> own(st);  // (freed on every early return below)
   st->ctx = ctx; st->model = model; st->S = S; st->fp = *fp;
   st->T = model->info.window; st->F = model->info.n_mel; st->NO = model->info.n_out; st->HR = 2 * (st->T + 1);
   const size_t hist_elems = (size_t)S * st->HR * st->F;
@@ -296,14 +301,12 @@ int ww_stream_create(ww_ctx *ctx, const ww_model *model, int32_t S, const ww_fro
     }
   }
   if (!ok) {
-    ww_stream_destroy(st);
     return ww_fail(ctx, WW_ENOMEM, "cannot allocate state for %d streams", S);
   }
   memset(st->h_tag, 0, (size_t)2 * S * 8);
   if (hipHostGetDevicePointer((void **)&st->h_out_dev, st->h_out, 0) != hipSuccess ||
       hipHostGetDevicePointer((void **)&st->h_tag_dev, st->h_tag, 0) != hipSuccess ||
       hipHostGetDevicePointer((void **)&st->h_pack_dev, st->h_pack, 0) != hipSuccess) {
-    ww_stream_destroy(st);
     return ww_fail(ctx, WW_EHIP, "pinned staging buffers are not visible to the device");
   }
   hipMemsetAsync(st->ring, 0, (size_t)2 * S * ST_RING * 4, ctx->stream);
@@ -320,7 +323,6 @@ int ww_stream_create(ww_ctx *ctx, const ww_model *model, int32_t S, const ww_fro
   if (st->incremental) {
     if (hipMalloc((void **)&st->gxc, (size_t)S * WW_STREAM_GXC * 192 * 4) != hipSuccess ||
         hipMalloc((void **)&st->gx_zero, 192 * 4) != hipSuccess) {
-      ww_stream_destroy(st);
       return ww_fail(ctx, WW_ENOMEM, "cannot allocate the projected-row cache of %d streams", S);
     }
     // the row of an all-zero field: position 17 of one window over the (all-zero) history of stream 0, which the kernel
@@ -329,22 +331,22 @@ int ww_stream_create(ww_ctx *ctx, const ww_model *model, int32_t S, const ww_fro
     int rc = ww_k_crnn_stream_forward(ctx, model, st->hist, (int64_t)S * st->HR, st->d_win_row, st->d_win_valid, st->d_win_aux,
                                       st->gxc, 1, st->h_out_dev);  // d_pack is zeroed: window row 0, aux 0 (valid 0 = all-zero window)
     if (rc) {
-      ww_stream_destroy(st);
       return rc;
     }
     hipMemcpyAsync(st->gx_zero, st->gxc + (size_t)(128 % WW_STREAM_GXC) * 192, 192 * 4, hipMemcpyDeviceToDevice, ctx->stream);
     hipLaunchKernelGGL(stream_reset_kernel, dim3(S), dim3(256), 0, ctx->stream, st->hist, (const int32_t *)nullptr, S, st->HR, st->F,
                        st->gxc, (const float *)st->gx_zero);
     if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
-      ww_stream_destroy(st);
       return ww_fail(ctx, WW_EHIP, "streaming CRNN set-up failed");
     }
   }
-  *out = st;
+  *out = own.release();
   return WW_OK;
+  WW_GUARD_END(ctx)
 }
 
 int ww_stream_reset(ww_streams *st, const int32_t *ids, int32_t n) {
+  WW_GUARD_BEGIN
   if (!st) return WW_EINVAL;
   ww_ctx *ctx = st->ctx;
   if (ids && n < 0) return ww_fail(ctx, WW_EINVAL, "negative id count");
@@ -374,6 +376,7 @@ int ww_stream_reset(ww_streams *st, const int32_t *ids, int32_t n) {
     st->rowq[s] = 0;
   }
   return WW_OK;
+  WW_GUARD_END(st ? st->ctx : nullptr)
 }
 
 // Wait for a tick's posteriors by polling their {value, tick number} pairs in page-locked memory.  The runtime is asked only
@@ -560,6 +563,7 @@ static int stream_step_impl(ww_streams *st, const int16_t *frames, const uint8_t
 }
 
 int ww_stream_step(ww_streams *st, const int16_t *frames, const uint8_t *is_speech, float *post, int32_t *n_post) {
+  WW_GUARD_BEGIN
   if (!st) return WW_EINVAL;
   // a tick that failed after the host's mirrors (fill, ring positions, state parity) had advanced leaves them out of step with
   // the device: the bank refuses further ticks instead of producing posteriors of a state that never existed
@@ -568,9 +572,131 @@ int ww_stream_step(ww_streams *st, const int16_t *frames, const uint8_t *is_spee
   const int rc = stream_step_impl(st, frames, is_speech, post, n_post, &mutated);
   if (rc != WW_OK && mutated) st->broken = true;
   return rc;
+  WW_GUARD_END(st ? st->ctx : nullptr)
+}
+
+// ---- host stages of the streaming pipeline for S streams in lock step -------------------------------------------------------
+// The reference runs three stage objects per stream and frame (spokestack/pipeline.py:25-28 with demo.py:29-36's stage list):
+// VoiceActivityDetector -> WakewordTrigger -> ActivationTimeout, each a few comparisons on the shared SpeechContext.  For S
+// streams that is 3 S Python calls per 20 ms tick (round 5: ~220 us of interpreter at 128 streams around a 35 us device tick).
+// Here each stage is ONE pass over S streams on plain arrays the host language owns (wwhip/context.py: ContextBank); a stage
+// reports the ids whose state changed, so the caller raises activate / deactivate events for those streams only.
+
+// spokestack/vad/webrtc.py:59-77 - run-length hysteresis on the classifier's raw decision; context.is_speech is the state.
+int ww_vad_bank_step(int32_t S, const uint8_t *raw, int32_t rise_frames, int32_t fall_frames, uint8_t *run_value,
+                     int64_t *run_length, uint8_t *is_speech, int32_t *n_changed) {
+  WW_GUARD_BEGIN
+  if (S < 0 || (S > 0 && (!raw || !run_value || !run_length || !is_speech))) return WW_EINVAL;
+  int changed = 0;
+  for (int s = 0; s < S; ++s) {
+    const uint8_t r = raw[s] != 0;
+    if (r == run_value[s]) {
+      ++run_length[s];
+    } else {
+      run_value[s] = r;
+      run_length[s] = 1;
+    }
+    if (r != (is_speech[s] != 0)) {
+      if (r && run_length[s] >= rise_frames) { is_speech[s] = 1; ++changed; }
+      if (!r && run_length[s] >= fall_frames) { is_speech[s] = 0; ++changed; }
+    }
+  }
+  if (n_changed) *n_changed = changed;
+  return WW_OK;
+  WW_GUARD_END(nullptr)
+}
+
+// spokestack/wakeword/tflite.py:134-146 (VAD edge, reset on the fall) and :232-239 (running maximum, threshold, activation)
+// over the posteriors a tick delivered.  The comparison with the threshold is the reference's: a float32 posterior against a
+// Python float, i.e. in double.
+static void trigger_update(int S, const uint8_t *is_speech, uint8_t *is_active, const float *post, const int32_t *n_post,
+                           double threshold, uint8_t *was_speech, float *posterior_max, int32_t *fired_ids, int32_t *n_fired,
+                           int32_t *fall_ids, int32_t *n_fall) {
+  int nf = 0, nl = 0;
+  for (int s = 0; s < S; ++s) {
+    const uint8_t sp = is_speech[s] != 0;
+    const bool fall = was_speech[s] && !sp;
+    was_speech[s] = sp;
+    bool fire = false;
+    for (int k = 0; k < n_post[s]; ++k) {
+      const float p = post[s * 2 + k];
+      if (p > posterior_max[s]) posterior_max[s] = p;
+      if ((double)p > threshold) fire = true;
+    }
+    if (fire && !is_active[s]) {
+      is_active[s] = 1;
+      fired_ids[nf++] = s;
+    }
+    if (fall) {
+      posterior_max[s] = 0.f;
+      fall_ids[nl++] = s;
+    }
+  }
+  *n_fired = nf;
+  *n_fall = nl;
+}
+
+int ww_trigger_bank_step(int32_t S, const uint8_t *is_speech, uint8_t *is_active, const float *post, const int32_t *n_post,
+                         double threshold, uint8_t *was_speech, float *posterior_max, int32_t *fired_ids, int32_t *n_fired,
+                         int32_t *fall_ids, int32_t *n_fall) {
+  WW_GUARD_BEGIN
+  if (S < 0 || !n_fired || !n_fall || (S > 0 && (!is_speech || !is_active || !post || !n_post || !was_speech || !posterior_max ||
+                                                   !fired_ids || !fall_ids)))
+    return WW_EINVAL;
+  for (int s = 0; s < S; ++s)
+    if (n_post[s] < 0 || n_post[s] > 2) return WW_EINVAL;
+  trigger_update(S, is_speech, is_active, post, n_post, threshold, was_speech, posterior_max, fired_ids, n_fired, fall_ids, n_fall);
+  return WW_OK;
+  WW_GUARD_END(nullptr)
+}
+
+// spokestack/activation_timeout.py:25-38.  min_frames / max_frames are the reference's quotients (min_active / frame_width), kept
+// as doubles: the comparisons are int > float there.
+int ww_timeout_bank_step(int32_t S, const uint8_t *is_speech, uint8_t *is_active, uint8_t *was_speech, int32_t *active_frames,
+                         double min_frames, double max_frames, int32_t *deact_ids, int32_t *n_deact) {
+  WW_GUARD_BEGIN
+  if (S < 0 || !n_deact || (S > 0 && (!is_speech || !is_active || !was_speech || !active_frames || !deact_ids))) return WW_EINVAL;
+  int nd = 0;
+  for (int s = 0; s < S; ++s) {
+    const uint8_t sp = is_speech[s] != 0;
+    const bool fell = was_speech[s] && !sp;
+    was_speech[s] = sp;
+    if (!is_active[s]) continue;
+    const int len = ++active_frames[s];
+    if ((double)len > min_frames && (fell || (double)len > max_frames)) {
+      active_frames[s] = 0;
+      is_active[s] = 0;
+      deact_ids[nd++] = s;
+    }
+  }
+  *n_deact = nd;
+  return WW_OK;
+  WW_GUARD_END(nullptr)
+}
+
+// WakewordTrigger.__call__ for S streams as ONE call: the tick (ww_stream_step with bit 0 = is_speech, bit 1 = is_active as they
+// stand BEFORE the tick), then ww_trigger_bank_step over its posteriors, then WakewordTrigger.reset for the streams whose VAD bit
+// fell (tflite.py:143-146).  is_active is updated in place.
+int ww_stream_step_trigger(ww_streams *st, const int16_t *frames, const uint8_t *is_speech, uint8_t *is_active, double threshold,
+                           uint8_t *was_speech, float *posterior_max, float *post, int32_t *n_post, int32_t *fired_ids,
+                           int32_t *n_fired, int32_t *fall_ids, int32_t *n_fall) {
+  WW_GUARD_BEGIN
+  if (!st) return WW_EINVAL;
+  if (!is_speech || !is_active || !was_speech || !posterior_max || !fired_ids || !n_fired || !fall_ids || !n_fall)
+    return ww_fail(st->ctx, WW_EINVAL, "NULL argument");
+  *n_fired = *n_fall = 0;
+  st->stage_flags.resize((size_t)st->S);
+  for (int s = 0; s < st->S; ++s) st->stage_flags[s] = (uint8_t)((is_speech[s] != 0) | ((is_active[s] != 0) << 1));
+  int rc = ww_stream_step(st, frames, st->stage_flags.data(), post, n_post);
+  if (rc) return rc;
+  trigger_update(st->S, is_speech, is_active, post, n_post, threshold, was_speech, posterior_max, fired_ids, n_fired, fall_ids, n_fall);
+  if (*n_fall) rc = ww_stream_reset(st, fall_ids, *n_fall);
+  return rc;
+  WW_GUARD_END(st ? st->ctx : nullptr)
 }
 
 int ww_stream_timeline(ww_streams *st, double *mean_ns, int64_t *ticks, int32_t reset) {
+  WW_GUARD_BEGIN
   if (!st) return WW_EINVAL;
   if (ticks) *ticks = st->tl_ticks;
   if (mean_ns)
@@ -580,6 +706,7 @@ int ww_stream_timeline(ww_streams *st, double *mean_ns, int64_t *ticks, int32_t 
     st->tl_ticks = 0;
   }
   return WW_OK;
+  WW_GUARD_END(st ? st->ctx : nullptr)
 }
 
 }  // extern "C"

@@ -300,6 +300,7 @@ extern "C" {
 
 int ww_host_stage_i16(int16_t *dst, int64_t total, int64_t n_runs, const int64_t *dst_off, const int16_t *const *src,
                       const int64_t *count, int64_t lo_all, int64_t hi_all, int32_t threads) {
+  WW_GUARD_BEGIN
   if (total < 0 || n_runs < 0 || (total > 0 && !dst) || (n_runs > 0 && (!dst_off || !src || !count))) return WW_EINVAL;
   if (lo_all < 0 || lo_all > hi_all || hi_all > total) return WW_EINVAL;
   const stage_runs runs = {n_runs, dst_off, src, count};
@@ -319,34 +320,33 @@ int ww_host_stage_i16(int16_t *dst, int64_t total, int64_t n_runs, const int64_t
   }
   for (auto &th : pool) th.join();
   return WW_OK;
+  WW_GUARD_END(nullptr)
 }
 
 int ww_uploader_create(ww_ctx *ctx, int32_t slots, int32_t copy_threads, ww_uploader **out) {
+  WW_GUARD_BEGIN
   if (!ctx || !out) return ww_fail(ctx, WW_EINVAL, "NULL argument");
   *out = nullptr;
   if (slots < 2 || slots > 16) return ww_fail(ctx, WW_EINVAL, "ww_uploader_create: 2 .. 16 slots (got %d)", slots);
   if (copy_threads < 1 || copy_threads > 64) return ww_fail(ctx, WW_EINVAL, "ww_uploader_create: 1 .. 64 copy threads (got %d)", copy_threads);
   WW_ON_DEVICE(ctx, dev_scope);
   ww_uploader *up = new ww_uploader();
+  ww_scoped<ww_uploader, ww_uploader_destroy> own(up);  // (stream, events, pool and thread released on every early return)
   up->device = ctx->device;
   hipError_t e = hipStreamCreateWithFlags(&up->copy_stream, hipStreamNonBlocking);
   up->slots.resize((size_t)slots);
   for (auto &s : up->slots)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev, hipEventDisableTiming);
-  if (e != hipSuccess) {
-    for (auto &s : up->slots)
-      if (s.ev) hipEventDestroy(s.ev);
-    if (up->copy_stream) hipStreamDestroy(up->copy_stream);
-    delete up;
-    return ww_fail(ctx, WW_EHIP, "ww_uploader_create: %s", hipGetErrorString(e));
-  }
+  if (e != hipSuccess) return ww_fail(ctx, WW_EHIP, "ww_uploader_create: %s", hipGetErrorString(e));
   up->pool = new copy_pool(copy_threads);
   up->worker = std::thread([up] { up->loop(); });
-  *out = up;
+  *out = own.release();
   return WW_OK;
+  WW_GUARD_END(ctx)
 }
 
 int ww_uploader_destroy(ww_uploader *up) {
+  WW_GUARD_BEGIN
   if (!up) return WW_OK;
   {
     std::lock_guard<std::mutex> lk(up->m);
@@ -364,46 +364,50 @@ int ww_uploader_destroy(ww_uploader *up) {
   hipStreamDestroy(up->copy_stream);
   delete up;
   return WW_OK;
+  WW_GUARD_END(nullptr)
 }
 
 int ww_uploader_submit(ww_uploader *up, int64_t total, int64_t n_runs, const int64_t *dst_off, const int16_t *const *src,
                        const int64_t *count, int16_t *d_pcm, int64_t n_meta, const int64_t *meta, int64_t *d_meta, int64_t *ticket) {
+  WW_GUARD_BEGIN
   if (!up || !ticket) return WW_EINVAL;
   *ticket = 0;
   if (total < 0 || n_runs < 0 || n_meta < 0 || (total > 0 && !d_pcm) || (n_meta > 0 && (!meta || !d_meta)) ||
       (n_runs > 0 && (!dst_off || !src || !count)))
     return WW_EINVAL;
-  try {  // (the copies of the caller's arrays allocate: no exception may cross the C boundary)
-    ww_uploader::job_t j;
-    j.total = total;
-    j.dst_off.assign(dst_off, dst_off + n_runs);
-    j.count.assign(count, count + n_runs);
-    j.src.assign(src, src + n_runs);
-    j.meta.assign(meta, meta + n_meta);
-    j.d_pcm = d_pcm;
-    j.d_meta = d_meta;
-    {
-      std::lock_guard<std::mutex> lk(up->m);
-      if (up->quit) return WW_EINVAL;
-      j.ticket = up->next_ticket;
-      up->queue.push_back(std::move(j));
-      *ticket = up->next_ticket++;
-    }
-  } catch (const std::bad_alloc &) {
-    return WW_ENOMEM;
+  {  // (the copies of the caller's arrays allocate: WW_GUARD_END turns a std::bad_alloc into WW_ENOMEM)
+  ww_uploader::job_t j;
+  j.total = total;
+  j.dst_off.assign(dst_off, dst_off + n_runs);
+  j.count.assign(count, count + n_runs);
+  j.src.assign(src, src + n_runs);
+  j.meta.assign(meta, meta + n_meta);
+  j.d_pcm = d_pcm;
+  j.d_meta = d_meta;
+  {
+    std::lock_guard<std::mutex> lk(up->m);
+    if (up->quit) return WW_EINVAL;
+    j.ticket = up->next_ticket;
+    up->queue.push_back(std::move(j));
+    *ticket = up->next_ticket++;
+  }
   }
   up->cv_work.notify_one();
   return WW_OK;
+  WW_GUARD_END(nullptr)
 }
 
 int ww_uploader_poll(ww_uploader *up, int64_t ticket) {
+  WW_GUARD_BEGIN
   if (!up || ticket < 1) return WW_EINVAL;
   std::lock_guard<std::mutex> lk(up->m);
   if (ticket >= up->next_ticket) return WW_EINVAL;
   return up->done_ticket >= ticket ? 1 : 0;
+  WW_GUARD_END(nullptr)
 }
 
 int ww_uploader_wait(ww_uploader *up, int64_t ticket, ww_ctx *ctx) {
+  WW_GUARD_BEGIN
   if (!up || !ctx) return ww_fail(ctx, WW_EINVAL, "NULL argument");
   if (ctx->device != up->device) return ww_fail(ctx, WW_EINVAL, "ww_uploader_wait: the uploader works for device %d, the context for %d", up->device, ctx->device);
   ww_uploader::result_t r;
@@ -423,6 +427,7 @@ int ww_uploader_wait(ww_uploader *up, int64_t ticket, ww_ctx *ctx) {
   // same in-order stream (the uploader itself waited for this ticket's before it reused the slot)
   WW_HIP(ctx, hipStreamWaitEvent(ctx->stream, up->slots[(size_t)r.slot].ev, 0));
   return WW_OK;
+  WW_GUARD_END(ctx)
 }
 
 }  // extern "C"

@@ -4,7 +4,8 @@ Importing this package touches no GPU and loads no native code; the HIP library 
 first use and there is no CPU fallback for the hot path.
 """
 __all__ = ["RingBuffer", "SpeechContext", "SpeechPipeline", "ActivationTimeout", "TFLiteModel", "Filter",
-           "WakewordTrigger", "WakewordBank", "Engine", "StreamBank", "get_posterior", "far_frr"]
+           "WakewordTrigger", "WakewordBank", "Engine", "StreamBank", "get_posterior", "far_frr",
+           "ContextBank", "SpeechPipelineBank", "VadBank", "ActivationTimeoutBank"]
 
 
 def __getattr__(name):
@@ -14,6 +15,7 @@ def __getattr__(name):
         "ActivationTimeout": "activation_timeout", "TFLiteModel": "models", "Filter": "filter",
         "WakewordTrigger": "wakeword", "WakewordBank": "wakeword", "Engine": "engine", "StreamBank": "engine",
         "get_posterior": "evaluate", "far_frr": "evaluate",
+        "ContextBank": "context", "SpeechPipelineBank": "pipeline", "VadBank": "vad", "ActivationTimeoutBank": "activation_timeout",
     }
     if name in table:
         return getattr(importlib.import_module(f"{__name__}.{table[name]}"), name)

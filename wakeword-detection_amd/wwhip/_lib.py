@@ -19,7 +19,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # WWHIP_LIB: development only - an alternative build of the same library (kernel A/B comparisons)
 LIB_PATH = os.environ.get("WWHIP_LIB") or os.path.join(_PKG, "libwwhip.so")
 
-WW_OK, WW_EINVAL, WW_EBLOB, WW_EHIP, WW_ENOMEM, WW_ESTATE, WW_ENODEVICE = 0, -1, -2, -3, -4, -5, -6
+WW_OK, WW_EINVAL, WW_EBLOB, WW_EHIP, WW_ENOMEM, WW_ESTATE, WW_ENODEVICE, WW_EINTERNAL = 0, -1, -2, -3, -4, -5, -6, -7
 KIND_CRNN, KIND_WAVENET = 1, 2
 PRECISION_FP32, PRECISION_BF16X3 = 0, 1
 OPT_CRNN_SPLIT_AT, OPT_CRNN_SLIDE_MIN, OPT_CRNN_TAIL_MFMA, OPT_WAVENET_ROWMAJOR = 1, 2, 3, 4
@@ -81,6 +81,10 @@ SYMBOLS: Dict[str, tuple] = {
     "ww_stream_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "ww_stream_reset": (C.c_int, [_vp, _vp, _i32]),
     "ww_stream_timeline": (C.c_int, [_vp, _vp, _P(_i64), _i32]),
+    "ww_vad_bank_step": (C.c_int, [_i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "ww_trigger_bank_step": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ww_timeout_bank_step": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _f64, _f64, _vp, _vp]),
+    "ww_stream_step_trigger": (C.c_int, [_vp, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ww_superframe_smooth": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _i32, _vp, _vp]),
     "ww_far_frr": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _f64, _f64, _vp, _vp, _vp, _vp]),
     "ww_far_frr_dev": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _f64, _f64, _vp, _vp, _vp, _vp]),
@@ -194,6 +198,14 @@ def _check_runtime(lib: C.CDLL) -> None:
 
 def ptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def addr(a: np.ndarray) -> C.c_void_p:
+    """The address of an array that stays where it is (a bank's state, a ContextBank's flags), taken ONCE: the per-tick stage
+    calls pass these objects as they are (a tick is host-paced; ``a.ctypes.data_as`` per argument and call is microseconds)."""
+    if not a.flags.c_contiguous:
+        raise ValueError("a contiguous array is needed")
+    return C.c_void_p(a.ctypes.data)
 
 
 def raise_for(rc: int, ctx_handle) -> None:

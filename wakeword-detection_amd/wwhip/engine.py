@@ -285,13 +285,30 @@ class StreamBank:
         self._p_post, self._p_n, self._p_flags = (C.c_void_p(a.ctypes.data) for a in (self._post, self._n, self._flags))
         self._step = self._lib.ww_stream_step
         self._shape = (self.S, 320)
+        self._keep = None
 
-    def step(self, frames: np.ndarray, is_speech: np.ndarray, is_active: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
+    def _frames_address(self, frames: np.ndarray) -> int:
         f = frames
         if not (type(f) is np.ndarray and f.dtype == np.int16 and f.flags.c_contiguous):
-            f = np.ascontiguousarray(frames, dtype=np.int16)
+            f = self._keep = np.ascontiguousarray(frames, dtype=np.int16)  # (kept alive until the call has returned)
         if f.shape != self._shape:
             raise ValueError(f"frames must be [{self.S}, 320] int16")
+        try:
+            return C.addressof(C.c_char.from_buffer(f))  # (a third of the cost of f.ctypes.data_as)
+        except (TypeError, ValueError):                   # a read-only array
+            return f.ctypes.data
+
+    def step_trigger(self, frames: np.ndarray, p_is_speech, p_is_active, threshold: float, p_state) -> None:
+        """The wake-word stage of all streams as ONE library call (``ww_stream_step_trigger``): the tick, the trigger logic of
+        ``WakewordTrigger.__call__`` over its posteriors and the reset of the streams whose VAD bit fell.  Every argument but
+        ``frames`` is an address taken once with ``_lib.addr`` (``WakewordBank`` owns the arrays): ``p_state`` =
+        (was_speech, posterior_max, post, n_post, fired_ids, n_fired, fall_ids, n_fall)."""
+        rc = self._lib.ww_stream_step_trigger(self._h, self._frames_address(frames), p_is_speech, p_is_active, threshold, *p_state)
+        if rc:
+            _lib.raise_for(rc, self.engine.ctx.handle)
+
+    def step(self, frames: np.ndarray, is_speech: np.ndarray, is_active: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
+        pf = self._frames_address(frames)
         sp = is_speech
         if not (type(sp) is np.ndarray and sp.dtype == np.uint8 and sp.ndim == 1):
             sp = np.ascontiguousarray(is_speech, dtype=np.uint8).ravel()
@@ -300,10 +317,6 @@ class StreamBank:
         np.bitwise_and(sp, 1, out=self._flags)
         if is_active is not None:
             self._flags |= (np.ascontiguousarray(is_active, dtype=np.uint8).ravel() & 1) << 1
-        try:
-            pf = C.addressof(C.c_char.from_buffer(f))  # (a third of the cost of f.ctypes.data_as)
-        except (TypeError, ValueError):                 # a read-only array
-            pf = f.ctypes.data
         rc = self._step(self._h, pf, self._p_flags, self._p_post, self._p_n)
         if rc:
             _lib.raise_for(rc, self.engine.ctx.handle)

@@ -80,3 +80,31 @@ class SpeechPipeline:
     @property
     def context(self) -> SpeechContext:
         return self._context
+
+
+class SpeechPipelineBank(SpeechPipeline):
+    """The same loop for S streams in lock step (BASELINE config 5): ``input_source.read()`` returns one 20 ms frame per stream
+    (``int16[S, 320]``), the context is a :class:`~wwhip.context.ContextBank`, the stages are the banked ones -
+    ``VadBank``, ``WakewordBank``, ``ActivationTimeoutBank`` - called as ``stage(contexts, frames)`` in list order, one call per
+    stage and tick whatever S is.  ``pipeline.context[s]`` is stream ``s``'s ``SpeechContext``; ``pipeline.event`` registers a
+    handler for every stream (it receives the stream's context)."""
+
+    def __init__(self, input_source, stages: List, n_streams: int) -> None:
+        from .context import ContextBank
+        super().__init__(input_source, stages)
+        self._context = ContextBank(n_streams)
+
+    def activate(self) -> None:
+        for c in self._context:
+            c.is_active = True
+
+    def deactivate(self) -> None:
+        for c in self._context:
+            c.is_active = False
+
+    def step(self) -> None:
+        if self._is_paused:
+            return
+        frames = self._input_source.read()
+        for stage in self._stages:
+            stage(self._context, frames)

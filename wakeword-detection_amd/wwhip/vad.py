@@ -5,8 +5,8 @@ out of scope); everything around it - the run-length hysteresis of ``VoiceActivi
 (``webrtc.py:52-77``) and ``VoiceActivityTrigger`` (``:88-110``) - is host logic and is mirrored
 here.  The classifier is a plug-in ``classifier(frame_bytes, sample_rate) -> bool`` (webrtcvad's
 ``Vad.is_speech`` signature); when webrtcvad is importable it is the default, as in the reference.
-``VadBank`` is the same hysteresis for S streams at once (one NumPy pass per tick), for use next
-to ``WakewordBank``.
+``VadBank`` is the same hysteresis for S streams at once (one pass of the library's ``ww_vad_bank_step``
+per tick), for use next to ``WakewordBank`` and ``ActivationTimeoutBank`` on a ``ContextBank``.
 """
 from __future__ import annotations
 
@@ -92,28 +92,56 @@ class VoiceActivityTrigger:
 
 
 class VadBank:
-    """The detector's hysteresis for S streams in lock step: ``step(raw[S]) -> is_speech[S]``."""
+    """The detector's hysteresis for S streams in lock step, one pass of the library's ``ww_vad_bank_step`` per tick
+    (spokestack/vad/webrtc.py:59-77 per stream).  Two forms: ``step(raw[S]) -> is_speech[S]`` on the bank's own ``is_speech``
+    array, and the pipeline-stage form ``bank(contexts, frames)`` where ``contexts`` is a :class:`~wwhip.context.ContextBank`
+    whose ``is_speech`` array IS the state (as the context is in the reference) and the raw decisions come from a batch
+    classifier ``classifier(frames[S, 320]) -> bool[S]`` (or are passed as ``raw=``)."""
 
-    def __init__(self, n_streams: int, frame_width: int = 20, vad_rise_delay: int = 0, vad_fall_delay: int = 0) -> None:
+    def __init__(self, n_streams: int, frame_width: int = 20, vad_rise_delay: int = 0, vad_fall_delay: int = 0,
+                 classifier: Optional[Callable[[np.ndarray], Sequence[bool]]] = None) -> None:
+        from . import _lib
         self.S = int(n_streams)
         self._rise = vad_rise_delay // frame_width
         self._fall = vad_fall_delay // frame_width
-        self.run_value = np.zeros(self.S, bool)
+        self._classify = classifier
+        self.run_value = np.zeros(self.S, np.uint8)
         self.run_length = np.zeros(self.S, np.int64)
-        self.is_speech = np.zeros(self.S, bool)
+        self.is_speech = np.zeros(self.S, np.uint8)
+        self._raw = np.zeros(self.S, np.uint8)
+        self._n_changed = np.zeros(1, np.int32)
+        self._fn = _lib.load().ww_vad_bank_step
+        self._p = tuple(_lib.addr(a) for a in (self._raw, self.run_value, self.run_length, self.is_speech, self._n_changed))
+        self._bound = None  # the ContextBank whose is_speech array the stage form works on, and that array's address
+
+    def _run(self, raw, p_speech) -> int:
+        np.copyto(self._raw, raw, casting="unsafe")
+        p = self._p
+        if self._fn(self.S, p[0], self._rise, self._fall, p[1], p[2], p_speech, p[4]):
+            raise ValueError("ww_vad_bank_step refused its arguments")
+        return int(self._n_changed[0])
 
     def step(self, raw: Sequence[bool]) -> np.ndarray:
-        raw = np.asarray(raw, bool)
-        same = raw == self.run_value
-        self.run_length = np.where(same, self.run_length + 1, 1)
-        self.run_value = raw
-        differs = self.run_value != self.is_speech
-        rise = differs & self.run_value & (self.run_length >= self._rise)
-        fall = differs & ~self.run_value & (self.run_length >= self._fall)
-        self.is_speech = np.where(rise, True, np.where(fall, False, self.is_speech))
-        return self.is_speech.copy()
+        self._run(raw, self._p[3])
+        return self.is_speech.astype(bool)
+
+    def __call__(self, contexts, frames: Optional[np.ndarray] = None, raw: Optional[Sequence[bool]] = None) -> None:
+        if self._bound is None or self._bound[0] is not contexts:
+            from . import _lib
+            if len(contexts) != self.S:
+                raise ValueError("one context per stream")
+            self._bound = (contexts, _lib.addr(contexts.is_speech))
+        if raw is None:
+            if self._classify is None:
+                raise ValueError("VadBank needs classifier=callable(frames[S, 320]) -> bool[S], or raw= per call")
+            raw = self._classify(frames)
+        if self._run(raw, self._bound[1]) and _LOG.isEnabledFor(logging.INFO):
+            _LOG.info("vad: %d streams speaking", int(contexts.is_speech.sum()))
 
     def reset(self, ids: Optional[Sequence[int]] = None) -> None:
         sel = slice(None) if ids is None else np.asarray(ids, np.int64)
-        self.run_value[sel] = False
+        self.run_value[sel] = 0
         self.run_length[sel] = 0
+
+    def close(self) -> None:
+        self.reset()

@@ -92,36 +92,81 @@ class WakewordTrigger:
 
 
 class WakewordBank:
-    """S streams in lock step (one ``SpeechContext`` each): the batched form of
-    :class:`WakewordTrigger` - one kernel chain per 20 ms tick for all streams."""
+    """S streams in lock step: the batched form of :class:`WakewordTrigger` - one kernel launch per 20 ms tick for all streams,
+    and the trigger's host logic (VAD-edge reset, running maximum, threshold, activation; tflite.py:134-146,232-239) as one pass
+    over arrays inside the same library call (``ww_stream_step_trigger``).
 
-    def __init__(self, n_streams: int, model_dir: str, posterior_threshold: float = 0.5, pre_emphasis: float = 0.0,
-                 device: int = 0) -> None:
-        self._engine = engine_for(model_dir, device)
+    ``contexts`` is a :class:`~wwhip.context.ContextBank` - the stage then reads and writes the bank's flag arrays in place and
+    raises ``activate`` events for the streams that fired, no per-stream Python otherwise - or, as before, a sequence of S
+    ``SpeechContext`` objects (their flags are gathered and written back one by one: the slow form)."""
+
+    def __init__(self, n_streams: int, model_dir: str = "", posterior_threshold: float = 0.5, pre_emphasis: float = 0.0,
+                 device: int = 0, on_wake: Optional[Callable[[np.ndarray], None]] = None, bank=None) -> None:
+        from . import _lib
         self.S = int(n_streams)
-        self._bank = StreamBank(self._engine, self.S, frontend_params(32767.0, True, pre_emphasis, 160, True))
-        self.threshold = posterior_threshold
+        if bank is None:
+            self._engine = engine_for(model_dir, device)
+            bank = StreamBank(self._engine, self.S, frontend_params(32767.0, True, pre_emphasis, 160, True))
+        self._bank = bank  # (anything with StreamBank's step_trigger / reset / close: the host-only tests pass a stub)
+        self.threshold = float(posterior_threshold)
+        self._on_wake = on_wake  # called with the ids of the streams that woke up this tick
         self.posterior_max = np.zeros(self.S, np.float32)
-        self._was_speech = np.zeros(self.S, bool)
+        self._was_speech = np.zeros(self.S, np.uint8)
+        self._post = np.zeros((self.S, 2), np.float32)
+        self._n = np.zeros(self.S, np.int32)
+        self._fired = np.zeros(self.S, np.int32)
+        self._fall = np.zeros(self.S, np.int32)
+        self._counts = np.zeros(2, np.int32)
+        self._p_state = (_lib.addr(self._was_speech), _lib.addr(self.posterior_max), _lib.addr(self._post), _lib.addr(self._n),
+                         _lib.addr(self._fired), _lib.addr(self._counts[0:1]), _lib.addr(self._fall), _lib.addr(self._counts[1:2]))
+        self._bound = None     # (the ContextBank, the addresses of its two flag arrays)
+        self._scratch = None   # flag arrays for the sequence-of-contexts form
 
-    def step(self, contexts: Sequence[SpeechContext], frames: np.ndarray) -> np.ndarray:
-        speech = np.array([c.is_speech for c in contexts], bool)
-        active = np.array([c.is_active for c in contexts], bool)
-        fall = self._was_speech & ~speech
-        self._was_speech = speech
-        post, n = self._bank.step(frames, speech.astype(np.uint8), active.astype(np.uint8))
-        for s in range(self.S):
-            for k in range(int(n[s])):
-                p = float(post[s, k])
-                if p > self.posterior_max[s]:
-                    self.posterior_max[s] = p
-                if p > self.threshold and not contexts[s].is_active:
-                    contexts[s].is_active = True
-        ids = np.nonzero(fall)[0]
-        if len(ids):
-            self._bank.reset(ids)
-            self.posterior_max[ids] = 0.0
-        return post
+    @property
+    def n_post(self) -> np.ndarray:
+        """Posteriors per stream delivered by the last tick (0, 1 or 2)."""
+        return self._n
+
+    def step(self, contexts, frames: np.ndarray) -> np.ndarray:
+        from . import _lib
+        if hasattr(contexts, "emit"):  # a ContextBank: its arrays are the state
+            b = self._bound
+            if b is None or b[0] is not contexts:
+                if len(contexts) != self.S:
+                    raise ValueError("one context per stream")
+                b = self._bound = (contexts, _lib.addr(contexts.is_speech), _lib.addr(contexts.is_active))
+            self._bank.step_trigger(frames, b[1], b[2], self.threshold, self._p_state)
+            nf = self._counts[0]
+            if nf:
+                ids = self._fired[:nf].copy()
+                if self._on_wake is not None:
+                    self._on_wake(ids)
+                contexts.emit("activate", ids)
+            return self._post.copy()
+        # a sequence of SpeechContext objects
+        if len(contexts) != self.S:
+            raise ValueError("one context per stream")
+        sc = self._scratch
+        if sc is None:
+            speech, active = np.zeros(self.S, np.uint8), np.zeros(self.S, np.uint8)
+            sc = self._scratch = (speech, active, _lib.addr(speech), _lib.addr(active))
+        sc[0][:] = [c.is_speech for c in contexts]
+        sc[1][:] = [c.is_active for c in contexts]
+        self._bank.step_trigger(frames, sc[2], sc[3], self.threshold, self._p_state)
+        nf = self._counts[0]
+        if nf:
+            ids = self._fired[:nf].copy()
+            if self._on_wake is not None:
+                self._on_wake(ids)
+            for s in ids:
+                contexts[int(s)].is_active = True  # (the setter raises the activate event)
+        return self._post.copy()
+
+    __call__ = step  # the stage form: bank(contexts, frames)
+
+    def reset(self) -> None:
+        self._bank.reset()
+        self.posterior_max[:] = 0.0
 
     def close(self) -> None:
         self._bank.close()
