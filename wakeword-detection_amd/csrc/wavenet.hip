@@ -90,7 +90,7 @@ struct wave_args {
   float *enc;           // optional [Nw][T][32]
   const float *enc_in;  // HEAD_ONLY: encoder output to run the detect graph on
   const uint4 *wpk;     // split-bf16 mode: parameter pages [NB][WV_PAGE_U4] (A operands of v_mfma_f32_16x16x32_bf16, then the vectors)
-  long long *stamps;    // development (-DWV_STAMPS=1): [windows][12 waves][12] s_memtime inside block WV_STAMP_BLK of the split-bf16 loop
+  long long *stamps;    // development (-DWV_STAMPS=1): [windows][12 waves][WV_STAMP_NB blocks][12] s_memtime inside the split-bf16 loop
   ww_tick_tag tag;      // streaming ticks: the posterior as a {value, tick number} pair instead of the row of `out`
   // TICK != 0 - ONE launch per tick (round 5): the streaming front end's side (common.h) and the model's filterbank
   ww_tick_fe fe;
@@ -112,13 +112,28 @@ static_assert(WT_BUF % 4 == 0 && WW_MEL_TAPS * 64 <= 768 * 4, "tick front end: L
 #ifndef WV_STAMPS
 #define WV_STAMPS 0
 #endif
-#define WV_STAMP_BLK 10
+// probes of round 6 (profiles/r06/wavenet_bf16x3_probes.txt): development builds only (tools/build_variant.sh)
+#ifndef WV_PROBE_NOBAR
+#define WV_PROBE_NOBAR 0
+#endif
+#ifndef WV_PROBE_ACC2
+#define WV_PROBE_ACC2 0
+#endif
+#ifndef WV_PROBE_RCP1
+#define WV_PROBE_RCP1 0
+#endif
+#define WV_STAMP_NB 24
 #if WV_STAMPS
+// Stamp i_ of every block (round 6: all blocks, so that the table can separate the dilations); stamp 11 = the top of the NEXT
+// block, written into this block's row.  Reading s_memtime waits for the wave's outstanding LDS operations as well (one
+// counter): a stamped build runs the same instructions with every counted wait turned into a full one - the table's total per
+// block stands beside the unstamped kernel's so that the price of looking is on record.
 #define WV_STAMP(i_)                                                                                                   \
   {                                                                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
-    if (a.stamps && blk == WV_STAMP_BLK + ((i_) == 11 ? 1 : 0) && lane == 0)                                           \
-      a.stamps[((size_t)blockIdx.x * 12 + wave) * 12 + (i_)] = __builtin_amdgcn_s_memtime();                           \
+    if (a.stamps && lane == 0 && blk - ((i_) == 11 ? 1 : 0) >= 0 && blk < WV_STAMP_NB + ((i_) == 11 ? 1 : 0))          \
+      a.stamps[(((size_t)blockIdx.x * 12 + wave) * WV_STAMP_NB + blk - ((i_) == 11 ? 1 : 0)) * 12 + (i_)] =           \
+          __builtin_amdgcn_s_memtime();                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
   }
 #else
@@ -788,7 +803,11 @@ __global__ __launch_bounds__(WV_NW * 64, WV_NW == 12 ? (SPLIT_BF16 ? WV_BF16_OCC
       WV_STAMP(4)
       // u complete (all rows, all waves).  At most the 8 operand reads above are younger than the u writes, so "at most 8
       // LDS operations outstanding" means the writes have landed; the operands keep streaming across the barrier.
+#if WV_PROBE_NOBAR  // ablation (wrong results, right instruction stream): what the twelve-wave barrier itself costs
+      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+#else
       asm volatile("s_waitcnt lgkmcnt(8)\n\ts_barrier" ::: "memory");
+#endif
       WV_STAMP(5)
       // k-step 1 = (tap 0 | tap 1) = rows t - 2d and t - d (rows < 0 hit the zero pad, d <= 8)
       s16x4 u0h[WV_MPW], u1h[WV_MPW], u0l[WV_MPW], u1l[WV_MPW];
@@ -825,6 +844,18 @@ __global__ __launch_bounds__(WV_NW * 64, WV_NW == 12 ? (SPLIT_BF16 ? WV_BF16_OCC
       for (int mi = 0; mi < WV_MPW; ++mi)
         asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(u0h[mi]), "+v"(u1h[mi]), "+v"(u0l[mi]), "+v"(u1l[mi]) : : "memory");
       WV_STAMP(6)
+#if WV_PROBE_ACC2  // probe (round 6): the delayed taps into accumulators of their own - two MFMA chains of depth 2 and 3 per gate
+                   // instead of one of depth 5, joined by one v_add per row (other bits, still <= 2e-5)
+#pragma unroll
+      for (int mi = 0; mi < WV_MPW; ++mi) {
+        const bf16x8 xdh = cat8(u0h[mi], u1h[mi]), xdl = cat8(u0l[mi], u1l[mi]);
+        f32x4 as2 = {0.f, 0.f, 0.f, 0.f}, at2 = {0.f, 0.f, 0.f, 0.f};
+        MFMA_BF(as2, w4, xdh); MFMA_BF(at2, w6, xdh);
+        MFMA_BF(as2, w5, xdh); MFMA_BF(at2, w7, xdh);
+        MFMA_BF(as2, w4, xdl); MFMA_BF(at2, w6, xdl);
+        as[mi] += as2; at[mi] += at2;
+      }
+#else
 #pragma unroll
       for (int mi = 0; mi < WV_MPW; ++mi) {
         const bf16x8 xdh = cat8(u0h[mi], u1h[mi]), xdl = cat8(u0l[mi], u1l[mi]);
@@ -832,6 +863,7 @@ __global__ __launch_bounds__(WV_NW * 64, WV_NW == 12 ? (SPLIT_BF16 ? WV_BF16_OCC
         MFMA_BF(as[mi], w5, xdh); MFMA_BF(at[mi], w7, xdh);
         MFMA_BF(as[mi], w4, xdl); MFMA_BF(at[mi], w6, xdl);
       }
+#endif
       WV_STAMP(7)
       // gate: tanh(t) * sigmoid(s); biases AND the exp2 scale factors (-log2 e, 2 log2 e) are inside the accumulators
       f32x4 ar[WV_MPW], s0[WV_MPW], s1[WV_MPW];
@@ -840,9 +872,15 @@ __global__ __launch_bounds__(WV_NW * 64, WV_NW == 12 ? (SPLIT_BF16 ? WV_BF16_OCC
         float gv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+#if WV_PROBE_RCP1  // probe (round 6): tanh(t) sigmoid(s) = (et - 1) / ((1 + et)(1 + es)) - ONE reciprocal; et clamped so that inf / inf cannot occur
+          const float et = __builtin_amdgcn_exp2f(__builtin_fminf(at[mi][r], 60.0f));
+          const float es = __builtin_amdgcn_exp2f(as[mi][r]);
+          gv[r] = (et - 1.0f) * __builtin_amdgcn_rcpf((1.0f + et) * (1.0f + es));
+#else
           const float et = __builtin_amdgcn_exp2f(at[mi][r]);    // exp(2 t): inf -> tanh 1, 0 -> -1
           const float es = __builtin_amdgcn_exp2f(as[mi][r]);    // exp(-s)
           gv[r] = (1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + et)) * __builtin_amdgcn_rcpf(1.0f + es);
+#endif
         }
         WV_STAMP(8)
         s16x4 g_h, g_l;
@@ -1003,32 +1041,46 @@ int ww_k_wave_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int64_
   ww_launch_scope scope(ctx, m->precision == WW_PRECISION_BF16X3 ? "wavenet_kernel<bf16x3>" : "wavenet_kernel");
   a.wpk = (const uint4 *)v.wpk;
 #if WV_STAMPS
-  // development build: WWHIP_WV_STAMPS=1 prints the mean phase timeline of block WV_STAMP_BLK (cycles since its first stamp;
-  // the last column is the top of the next block)
+  // development build: WWHIP_WV_STAMPS=1 prints, per block, the mean cycles since the block's top at each stamp (over all windows
+  // and waves), the mean wait at the barrier (stamp 5 - stamp 4) and the spread of the twelve waves' arrivals at it
+  // (max - min of stamp 4 within a window): tools/wv_stamps.py turns the lines into profiles/r06/wavenet_bf16x3_phase_stamps.txt
   struct stamp_dump {
     ww_ctx *ctx; long long *d; int n;
     ~stamp_dump() {
       if (!d) return;
-      std::vector<long long> h((size_t)n * 144);
+      const size_t per_wave = (size_t)WV_STAMP_NB * 12;
+      std::vector<long long> h((size_t)n * 12 * per_wave);
       hipStreamSynchronize(ctx->stream);
       hipMemcpy(h.data(), d, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
       hipFree(d);
-      double sum[12] = {0};
-      long long cnt = 0;
-      for (size_t w = 0; w < (size_t)n * 12; ++w) {
-        const long long *t = &h[w * 12];
-        if (!t[0] || !t[11]) continue;
-        for (int i = 0; i < 12; ++i) sum[i] += (double)(t[i] - t[0]);
-        ++cnt;
+      for (int b = 0; b < WV_STAMP_NB; ++b) {
+        double sum[12] = {0}, wait = 0, spread = 0;
+        long long cnt = 0, wins = 0;
+        for (int w = 0; w < n; ++w) {
+          long long lo = 0, hi = 0;
+          bool any = false;
+          for (int v = 0; v < 12; ++v) {
+            const long long *t = &h[((size_t)w * 12 + v) * per_wave + (size_t)b * 12];
+            if (!t[0] || !t[10]) continue;
+            for (int i = 0; i < 12; ++i) sum[i] += t[i] ? (double)(t[i] - t[0]) : 0.0;
+            wait += (double)(t[5] - t[4]);
+            lo = any ? (t[4] < lo ? t[4] : lo) : t[4];
+            hi = any ? (t[4] > hi ? t[4] : hi) : t[4];
+            any = true;
+            ++cnt;
+          }
+          if (any) { spread += (double)(hi - lo); ++wins; }
+        }
+        fprintf(stderr, "wavenet stamps: block %d waves %lld cycles:", b, cnt);
+        for (int i = 0; i < 12; ++i) fprintf(stderr, " %.0f", sum[i] / (cnt ? cnt : 1));
+        fprintf(stderr, " barrier_wait %.0f arrival_spread %.0f\n", wait / (cnt ? cnt : 1), spread / (wins ? wins : 1));
       }
-      fprintf(stderr, "wavenet stamps: %lld waves, mean cycles since the top of block %d:", cnt, WV_STAMP_BLK);
-      for (int i = 0; i < 12; ++i) fprintf(stderr, " %.0f", sum[i] / (cnt ? cnt : 1));
-      fprintf(stderr, "\n");
     }
   } dump{ctx, nullptr, nw};
-  if (getenv("WWHIP_WV_STAMPS") && m->precision == WW_PRECISION_BF16X3) {
-    WW_HIP(ctx, hipMalloc((void **)&a.stamps, (size_t)nw * 144 * sizeof(long long)));
-    WW_HIP(ctx, hipMemsetAsync(a.stamps, 0, (size_t)nw * 144 * sizeof(long long), ctx->stream));
+  if (getenv("WWHIP_WV_STAMPS") && m->precision == WW_PRECISION_BF16X3 && nw <= WV_BF16_WIDE_FROM) {
+    const size_t bytes = (size_t)nw * 12 * WV_STAMP_NB * 12 * sizeof(long long);
+    WW_HIP(ctx, hipMalloc((void **)&a.stamps, bytes));
+    WW_HIP(ctx, hipMemsetAsync(a.stamps, 0, bytes, ctx->stream));
     dump.d = a.stamps;
   }
 #endif
