@@ -131,6 +131,8 @@ struct ww_model {
 int ww_fail(ww_ctx *ctx, int code, const char *fmt, ...);
 int ww_ensure(ww_ctx *ctx, ww_arena &a, size_t bytes, bool pinned);
 
+#define WW_NUM_CUS 256  // MI355X (gfx950): 8 XCDs x 32 CUs
+
 // No exception crosses the C ABI (every entry point returns a status, never throws): the body of every exported
 // function sits between WW_GUARD_BEGIN and WW_GUARD_END(ctx) - std::bad_alloc from a container or `new` becomes WW_ENOMEM,
 // anything else WW_EINTERNAL, with the text where ww_last_error finds it (ctx may be nullptr: the thread's text).  The few

@@ -1743,6 +1743,7 @@ __global__ __launch_bounds__(128, 4) void gru_tail_kernel(tail_args a) {
 // ------------------------------------------------------------------------------------------
 #define GT16_LD 36   // h exchange row: 32 units + 4
 #define GT16_ELD 68  // enc / hid row: 64 + 4
+#define GT16_SMEM_BYTES ((2 * 2 * 16 * GT16_LD + 2 * 6 * 2 * 64 * 4) * 4)
 struct tail16_args {
   tail_args t;
   float *seq;  // [workgroup][OT][16][64] layer-1 outputs
@@ -1755,7 +1756,8 @@ __global__ __launch_bounds__(128, 2) void gru_tail16_kernel(tail16_args aa) {
   // LDS: the h exchange (9.2 KB) + each wave's recurrent weights as B-operand pages [tile 6][half 2][lane 64] x 16 bytes
   // (24.6 KB: every lane reads back only what it wrote - 48 registers' worth that the four chains per tile need elsewhere);
   // the head's enc / hid rows move into the dead pages at the end.  33.8 KB: four workgroups per CU, as the registers allow
-  __shared__ __align__(16) float sm16[2 * 2 * 16 * GT16_LD + 2 * 6 * 2 * 64 * 4];
+  // (dynamic: the launch asks for MORE than GT16_SMEM_BYTES when its grid does not fill the chip four workgroups deep - launch_tail)
+  extern __shared__ __align__(16) float sm16[];
   float (*hs)[2][16 * GT16_LD] = (float (*)[2][16 * GT16_LD])sm16;
   float *encs = sm16 + 2 * 2 * 16 * GT16_LD, *hid = encs + 16 * GT16_ELD;
   static_assert(2 * 16 * GT16_ELD <= 2 * 6 * 2 * 64 * 4, "enc / hid rows do not fit the weight pages");
@@ -2203,6 +2205,11 @@ static int crnn_forward_generic(ww_ctx *ctx, const ww_model *m, const win_addr &
 // (ww_model_set_option(WW_OPT_CRNN_SPLIT_AT): 0 = always fused.)
 static int crnn_split_threshold(const ww_model *m) { return m->opt_split_at; }
 
+// More than half a CU's LDS: a workgroup that asks for this much has the CU's LDS to itself (development probes only: asked for
+// on crnn_fused_kernel / crnn_stream_kernel<tick> launches of <= 256 workgroups it changed nothing - 33.92 vs 33.90 us, tick
+// p50 37.3 vs 37.0 us: those grids already sit one workgroup per CU; profiles/r06/tail16_probes.txt).
+#define WW_LDS_ONE_PER_CU (82 * 1024)
+
 // Every CRNN kernel that asks for more than the default 64 KB of dynamic LDS.  The attribute is per device, so it is set
 // for the device of every new context (ww_ctx_create, under its device scope) instead of once per process.
 int ww_k_crnn_init_device(ww_ctx *ctx) {
@@ -2210,6 +2217,7 @@ int ww_k_crnn_init_device(ww_ctx *ctx) {
   WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_stream_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
   WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_stream_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
   WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CF_SMEM_BYTES));
+  WW_HIP(ctx, hipFuncSetAttribute((const void *)gru_tail16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WW_LDS_ONE_PER_CU));
   WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, CF_FUSED_SMEM_BYTES));
   WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, CF_FUSED_SMEM_BYTES));
   WW_HIP(ctx, hipFuncSetAttribute((const void *)crnn_fused_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, CFB_SMEM_BYTES));
@@ -2323,7 +2331,12 @@ static void launch_tail(ww_ctx *ctx, const ww_model *m, tail_args t, int nw, flo
   if (m->opt_tail_mfma == 2 || (m->opt_tail_mfma == 1 && nw >= WW_TAIL16_MIN)) {
     tail16_args a16 = {t, seq, nw};
     ww_launch_scope scope(ctx, "gru_tail16_kernel");
-    hipLaunchKernelGGL(gru_tail16_kernel, dim3((unsigned)((nw + 15) / 16)), dim3(128), 0, ctx->stream, a16);
+    // Development (round 6 occupancy probe, tools/tail16_occ.py -> profiles/r06/tail16_probes.txt): WWHIP_TAIL16_DEEP = n asks
+    // for so much LDS that only n workgroups fit on a CU - the shipped instruction stream at 1 / 2 / 3 / 4 workgroups per CU.
+    const int n_wg = (nw + 15) / 16;
+    static const int deep = getenv("WWHIP_TAIL16_DEEP") ? atoi(getenv("WWHIP_TAIL16_DEEP")) : 4;
+    const size_t lds = deep >= 4 ? (size_t)GT16_SMEM_BYTES : deep == 3 ? (size_t)44 * 1024 : deep == 2 ? (size_t)56 * 1024 : (size_t)WW_LDS_ONE_PER_CU;
+    hipLaunchKernelGGL(gru_tail16_kernel, dim3((unsigned)n_wg), dim3(128), lds, ctx->stream, a16);
   } else {
     ww_launch_scope scope(ctx, "gru_tail_kernel");
     hipLaunchKernelGGL(gru_tail_kernel, dim3((unsigned)nw), dim3(128), 0, ctx->stream, t);
