@@ -27,6 +27,8 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.SYMBOLS) == declared
     assert b"gfx950" in lib.ww_version()
     assert lib.ww_num_frames(24000, 160) == 147 and lib.ww_num_frames(511, 160) == 0
+    from wwhip import _wwhostext  # the CPython extension built next to it (csrc/hostext.c): host bookkeeping, no GPU code
+    assert callable(_wwhostext.scan_pcm16)
 
 
 def test_no_exception_can_leave_the_c_abi():

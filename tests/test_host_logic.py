@@ -773,3 +773,80 @@ def test_a_quiet_tick_costs_no_per_stream_python():
     assert handled == [0, 1, 2]
     quiet = large[5]
     assert loud[5] == quiet and loud[7] == quiet and quiet < loud[6] <= quiet + 3 * 8, loud
+
+
+def test_chunk_staging_through_the_extension_equals_the_per_file_path():
+    """wwhip.evaluate._prep_chunk on a list of clips in memory: the per-clip bookkeeping in ONE call of the CPython extension
+    (csrc/hostext.c, scan_pcm16: address, length, "contiguous int16" by the buffer protocol) gives the same copy runs and offset
+    tables as the per-file path it replaces; a list that holds anything else (a float clip, a strided view) falls back to that
+    path by itself; a clip shorter than the plan says is refused before any address leaves for the copy threads (the advisor's
+    out-of-bounds read of round 4); and the staged bytes are what the runs say (ww_host_stage_i16, no GPU)."""
+    from wwhip import _lib, _wwhostext
+    from wwhip import evaluate as E
+
+    class Ctx:
+        device = 0
+
+    class Eng:
+        window, ctx = 151, Ctx()
+
+    rng = np.random.default_rng(8)
+    clips = [rng.integers(-3000, 3000, int(n), dtype=np.int16) for n in rng.integers(9000, 30000, 60)]
+
+    def chunks_of(files, lengths=None, generic=False, world=3, rank=1):
+        ph = E._Phases(None)
+        job = E._PosteriorJob(Eng, "false_negatives", files, 20, 16000, rank, world, None, lengths, True, ph, None, first_chunk=1 << 17)
+        if generic:
+            job.raw_list = None
+        for ch in job.chunks:
+            E._prep_chunk(ch, ph)
+        return job
+
+    fast, slow = chunks_of(E._Int16Clips(clips)), chunks_of(E._Int16Clips(clips), generic=True)
+    assert fast.raw_list is not None and len(fast.chunks) == len(slow.chunks) >= 3
+    for a, b in zip(fast.chunks, slow.chunks):
+        for x, y in zip(a.copy, b.copy):
+            np.testing.assert_array_equal(x, y)
+        np.testing.assert_array_equal(a.soffs, b.soffs)
+        np.testing.assert_array_equal(a.foffs, b.foffs)
+        assert (a.nf_max, a.total_f) == (b.nf_max, b.total_f) and a.host_pieces is None and b.host_pieces is None
+    # the staged samples of a chunk: piece p of file k = the padded stream's samples [s0, s1) (0.5 s of zeros around every clip)
+    ch = fast.chunks[1]
+    d, pp, c = ch.copy
+    total = int(ch.soffs[-1])
+    dst = np.full(total, 77, np.int16)
+    assert _lib.load().ww_host_stage_i16(_lib.ptr(dst), total, len(d), _lib.ptr(d), _lib.ptr(pp), _lib.ptr(c), 0, total, 2) == 0
+    plan = fast.plan
+    whole = np.zeros(int(plan.padded.sum()), np.int16)
+    for k, x in enumerate(clips):
+        whole[plan.pos[k] + plan.pad: plan.pos[k] + plan.pad + len(x)] = x
+    for p, (k, i0, i1) in enumerate(np.asarray(ch.runs).tolist()):
+        s0, s1 = plan.sample_range(k, i0, i1)
+        np.testing.assert_array_equal(dst[ch.soffs[p]:ch.soffs[p + 1]], whole[s0:s1])
+    # a list with other things in it: the extension takes what it can, the job goes back to the per-file path
+    mixed = list(clips)
+    mixed[7] = clips[7].astype(np.float32) / np.float32(32768.0)
+    m = chunks_of(mixed, world=1, rank=0)
+    assert m.raw_list is None and any(ch.host_pieces is not None for ch in m.chunks)  # (float clips: staged through NumPy, as before)
+    strided = list(clips)
+    strided[3] = np.repeat(clips[3], 2)[::2]
+    s = chunks_of(strided, world=1, rank=0)
+    assert s.raw_list is None
+    for a, b in zip(s.chunks, chunks_of(E._Int16Clips(clips), generic=True, world=1, rank=0).chunks):
+        np.testing.assert_array_equal(a.copy[0], b.copy[0])
+        np.testing.assert_array_equal(a.copy[2], b.copy[2])
+    # a declared length larger than the array (a truncated wav whose header says more): refused, in both paths
+    lengths = [len(x) for x in clips]
+    lengths[20] += 5000
+    for generic in (False, True):
+        with pytest.raises(ValueError, match="file 20 holds"):
+            chunks_of(E._Int16Clips(clips), lengths=lengths, generic=generic, world=1, rank=0)
+    # the extension's own contract
+    addr, ns, seen = np.zeros(4, np.int64), np.zeros(4, np.int64), np.zeros(4, np.uint8)
+    things = [clips[0], clips[1][::2], [1, 2, 3], np.zeros((4, 4), np.int16)]
+    assert _wwhostext.scan_pcm16(things, np.arange(4), addr, ns, seen) == 1
+    assert seen.tolist() == [1, 0, 0, 0] and addr[0] == clips[0].ctypes.data and ns[0] == len(clips[0])
+    with pytest.raises(IndexError):
+        _wwhostext.scan_pcm16(things, np.array([4], np.int64), addr, ns, seen)
+    with pytest.raises(ValueError):
+        _wwhostext.scan_pcm16(things, np.arange(4), addr[:3], ns, seen)

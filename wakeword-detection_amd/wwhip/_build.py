@@ -16,6 +16,7 @@ ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(ROOT, "csrc")
 OBJ_DIR = os.path.join(CSRC, "build")
 LIB_PATH = os.path.join(PKG_DIR, "libwwhip.so")
+HOSTEXT_PATH = os.path.join(PKG_DIR, "_wwhostext.so")  # CPython extension: per-clip bookkeeping of the evaluators' staging (csrc/hostext.c)
 
 SOURCES = ["api.hip", "frontend.hip", "crnn.hip", "wavenet.hip", "posterior.hip", "streams.hip", "uploader.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
@@ -61,7 +62,23 @@ def build(force: bool = False, verbose: bool = False) -> str:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB_PATH, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs)
+    build_hostext(force)
     return LIB_PATH
+
+
+def build_hostext(force: bool = False) -> str:
+    """``_wwhostext.so`` - host code only (gcc, the interpreter's own headers); no GPU code in it."""
+    import sysconfig
+    src = os.path.join(CSRC, "hostext.c")
+    if force or _stale(HOSTEXT_PATH, [src]):
+        cc = shutil.which("gcc") or shutil.which("cc")
+        if cc is None:
+            raise RuntimeError("no C compiler: _wwhostext.so cannot be built")
+        r = subprocess.run([cc, "-O2", "-shared", "-fPIC", "-Wall", "-I" + sysconfig.get_paths()["include"], src, "-o", HOSTEXT_PATH],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("building _wwhostext.so failed:\n" + r.stdout + r.stderr)
+    return HOSTEXT_PATH
 
 
 if __name__ == "__main__":

@@ -266,9 +266,11 @@ class JoinedPCM:
         # divides (round 5: the per-clip dtype / layout checks moved from here to first use)
         self._raw = list(clips)
         self._ok = np.zeros(len(self._raw), bool)
+        self._have = np.zeros(len(self._raw), np.uint8)  # the clip's address is in _addrs
         n = np.fromiter(map(len, self._raw), np.int64, len(self._raw))
         self.lens = n
         self._addrs = np.zeros(len(n), np.int64)  # filled range by range (addresses): paid where it is used
+        self._seen_len = np.zeros(len(n), np.int64)
         self.starts = np.concatenate(([0], np.cumsum(n + gap)))[:-1] if len(n) else np.zeros(0, np.int64)
         self.size = int(n.sum() + gap * max(len(n) - 1, 0))
 
@@ -290,10 +292,19 @@ class JoinedPCM:
 
     def addresses(self, c0: int, c1: int) -> np.ndarray:
         """Addresses of the first samples of clips ``c0 .. c1 - 1`` (the staging copies read from there)."""
-        a = self._addrs[c0:c1]
-        for i in np.flatnonzero(a == 0).tolist():
-            a[i] = self.part(c0 + i).__array_interface__["data"][0]
-        return a
+        new = np.flatnonzero(self._have[c0:c1] == 0) + c0
+        if len(new):
+            # the contiguous int16 clips of the range in ONE call (csrc/hostext.c: the buffer protocol per clip instead of ~1.6 us of
+            # interpreter); what it leaves - another integer dtype, a strided view - goes through part() one by one
+            _hostext().scan_pcm16(self._raw, new, self._addrs, self._seen_len, self._have)
+            self._ok[new[self._have[new] != 0]] = True
+            for i in new[self._have[new] == 0].tolist():
+                self._addrs[i] = self.part(i).__array_interface__["data"][0]
+                self._seen_len[i] = len(self._raw[i])
+                self._have[i] = 1
+            if (self._seen_len[new] != self.lens[new]).any():
+                raise ValueError("a clip of the joined stream changed its length after the stream was built")
+        return self._addrs[c0:c1]
 
     def __len__(self) -> int:
         return self.size
@@ -316,6 +327,15 @@ class JoinedPCM:
         return out
 
 
+def _hostext():
+    """The CPython extension next to ``libwwhip.so`` (``csrc/hostext.c``, built by ``wwhip/_build.py``); no fallback."""
+    try:
+        from . import _wwhostext
+    except ImportError as e:  # pragma: no cover
+        raise RuntimeError("wwhip/_wwhostext.so is missing: build it with `python __graft_entry__.py`") from e
+    return _wwhostext
+
+
 def _piece_runs(plan: StreamPlan, runs, data: dict, addr: Optional[np.ndarray] = None):
     """For the window runs ``(file, i0, i1)``: the sample range ``[s0, s1)`` each is a function of (its piece), and the copy
     runs that fill the pieces laid end to end: ``(dst_off, src address, count)`` arrays, ascending in ``dst_off``; whatever
@@ -328,7 +348,7 @@ def _piece_runs(plan: StreamPlan, runs, data: dict, addr: Optional[np.ndarray] =
     s1 = 160 * (F + plan.hop * (i1 - 1) + plan.T - 1) + WINDOW
     soffs = np.concatenate(([0], np.cumsum(s1 - s0))).astype(np.int64)
     d_all, p_all, c_all = [], [], []
-    if any(isinstance(x, JoinedPCM) for x in data.values()):
+    if data is not None and any(isinstance(x, JoinedPCM) for x in data.values()):
         (j,) = data.values()  # (_stage_chunk materialises joined streams that share a list with other files)
         a = (int(plan.pos[0]) if plan.carry else 0) + plan.pad
         st, n = j.starts, j.lens
@@ -398,6 +418,31 @@ def _prep_chunk(ch: "_Chunk", ph: _Phases) -> None:
         runs = np.asarray(runs, np.int64).reshape(-1, 3)
         ks = np.unique(runs[:, 0])
         files = np.unique(np.concatenate((ks, ks[ks > 0] - 1))) if plan.carry else ks
+        raw = getattr(ch.job, "raw_list", None)
+        if raw is not None:
+            # clips in a Python list (the labelled test set in memory): the files of the chunk that have not been looked at yet in
+            # ONE call of the extension (csrc/hostext.c: address, length, "contiguous int16" per clip by the buffer protocol) - no
+            # per-clip interpreter work on the way to the copy runs.  Anything else in the list (another dtype, a strided view, a
+            # JoinedPCM) switches the job to the per-file path below for good.
+            addr, seen_len, have = ch.job._fstate
+            new = files[have[files] == 0]
+            if len(new):
+                if _hostext().scan_pcm16(raw, new, addr, seen_len, have) != len(new):
+                    raw = ch.job.raw_list = None
+                elif (seen_len[new] != plan.lengths[new]).any():
+                    f = int(new[np.flatnonzero(seen_len[new] != plan.lengths[new])[0]])
+                    raise ValueError(f"file {f} holds {int(seen_len[f])} samples, the plan was built on {int(plan.lengths[f])}")
+        if raw is not None:
+            soffs, d, pp, c = _piece_runs(plan, runs, None, addr)
+            lens = np.diff(soffs)
+            nf = np.where(lens >= WINDOW, (lens - WINDOW) // 160 + 1, 0).astype(np.int64)
+            ch.keep = raw  # (the clips must stay where they are until the copy threads have read them: the list holds them)
+            ch.copy = (d, pp, c)
+            ch.soffs, ch.foffs = soffs, np.concatenate(([0], np.cumsum(nf)))
+            ch.nf_max, ch.total_f = int(nf.max()) if len(nf) else 0, int(ch.foffs[-1])
+            n_win = np.asarray(ch.n_win, np.int64)
+            assert ((n_win == 0) | ((n_win - 1) * plan.hop + plan.T <= nf)).all(), "piece too short for its windows"
+            return
         # a file is looked at ONCE per job (it turns up in two chunks at most, and with the carry as its successor's predecessor
         # too): array, address and "is int16 PCM" are kept with the job
         fc = getattr(ch.job, "_files", None)
@@ -545,9 +590,15 @@ class _PosteriorJob:
         in_memory = len(test_files) > 0 and not isinstance(test_files[0], (str, bytes)) and not hasattr(test_files[0], "__fspath__")
         self.cache_files = in_memory  # (_prep_chunk: what it learns about a clip is kept with the job only when the clip stays in memory anyway)
         with ph("plan"):
+            self.raw_list = None
             if in_memory:
                 self.load = lambda k: test_files[k]  # noqa: E731
                 lengths = [len(x) for x in test_files] if lengths is None else lengths
+                raw = test_files.raw if isinstance(test_files, _Int16Clips) else test_files
+                if isinstance(raw, (list, tuple)) and len(raw) > 1:
+                    # (_prep_chunk: per-clip bookkeeping through the extension; the state it keeps per file)
+                    self.raw_list = raw
+                    self._fstate = (np.zeros(len(raw), np.int64), np.zeros(len(raw), np.int64), np.zeros(len(raw), np.uint8))
             else:
                 rd = loader or (lambda p: read_wav_pcm(p, sample_rate))
                 self.load = lambda k: rd(str(test_files[k]))  # noqa: E731
@@ -701,7 +752,10 @@ def _run_jobs(eng: Engine, jobs: Sequence, precise: bool, ph: _Phases, timing: O
     made: List[_PosteriorJob] = []
     pending: "deque[_Chunk]" = deque()   # submitted, not yet launched
     done: List[_Chunk] = []
-    if timing is not None:
+    # timing["kernel_times"] = False: the host phases only (perf_counter reads) - no HIP events around the launches, no read-back
+    # of them: what a pass costs when nobody looks at its kernels (bench.py times such passes and profiles one more)
+    kernel_times = timing is not None and timing.get("kernel_times", True)
+    if kernel_times:
         eng.ctx.profile(True)
     try:
         for j in jobs:
@@ -736,13 +790,14 @@ def _run_jobs(eng: Engine, jobs: Sequence, precise: bool, ph: _Phases, timing: O
             eng.ctx.synchronize()
         for ch in list(done) + list(pending):
             ch.d_pcm = ch.d_mel = ch.d_so = ch.d_fo = ch.keep = None
-    if timing is not None:
+    if kernel_times:
         with ph("profile_read"):
             prof = eng.ctx.profile_read()
             eng.ctx.profile(False)
         timing["device_ms"] = timing.get("device_ms", 0.0) + sum(v["total_ms"] for v in prof.values())
         for k, v in prof.items():
             timing.setdefault("kernels_ms", {})[k] = timing.get("kernels_ms", {}).get(k, 0.0) + v["total_ms"]
+    if timing is not None:
         timing["chunks"] = timing.get("chunks", 0) + len(done)
     for job in made:
         job.collect(ph)
