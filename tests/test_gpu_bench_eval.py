@@ -255,6 +255,21 @@ def test_reference_flow_does_not_depend_on_the_staging_chunks(reference_flow_one
         for key in ("negatives", "positives", "fa_count", "frr"):
             np.testing.assert_array_equal(got[key], one[key])
         assert got["posterior_checksum"] == one["posterior_checksum"] and got["windows"] == one["windows"]
+    # (round 6) consecutive chunks go to alternating lanes - the same model on contexts (HIP streams) of their own, so that two
+    # chunks' kernels run beside each other: one, two or three lanes, the same bits; the kernel table adds up over the lanes
+    monkeypatch.setattr(E, "_CHUNK_SAMPLES", 1_000_000)
+    for lanes in (1, 2, 3):
+        monkeypatch.setattr(E, "_EVAL_LANES", lanes)
+        tm = {}
+        got = E.evaluate_reference_flow_sharded(eng, clips, labels, timing=tm)
+        for key in ("negatives", "positives", "fa_count", "frr"):
+            np.testing.assert_array_equal(got[key], one[key])
+        assert tm["chunks"] > 10 and tm["device_ms"] > 0 and "crnn_rows_kernel" in tm["kernels_ms"]
+    monkeypatch.setattr(E, "_EVAL_LANES", 2)
+    assert eng.lane(0) is eng and eng.lane(1) is not eng and eng.lane(1).ctx.stream != eng.ctx.stream and eng.lane(1) is eng.lane(1)
+    with eng.options(crnn_tail_mfma=0):
+        assert eng.lane(1)._options["crnn_tail_mfma"] == 0   # a lane follows its engine's options at every call
+    assert eng.lane(1)._options["crnn_tail_mfma"] == eng._options["crnn_tail_mfma"]
     # get_posterior_sharded over arrays in memory, one of them float32 (librosa's scale): the chunk that holds it (and only
     # that one) takes the float path; int16 / 32768 is exact, so nothing changes
     monkeypatch.setattr(E, "_CHUNK_SAMPLES", 200_000)

@@ -25,6 +25,7 @@ class Engine:
 
     def __init__(self, model_dir: str, device: int = 0, ctx: Optional[_lib.Context] = None,
                  precision: str = "fp32", weights_fp16: bool = False) -> None:
+        self._weights_fp16 = bool(weights_fp16)
         self.bundle = W.load_model_dir(model_dir)
         if weights_fp16:  # the reference's float16-quantised model variant (weights.quantize_fp16)
             self.bundle = W.quantize_fp16(self.bundle)
@@ -88,6 +89,25 @@ class Engine:
                 for k, v in old.items():
                     self.set_option(k, v)
         return scope()
+
+    def lane(self, k: int) -> "Engine":
+        """Lane ``k`` of this engine: ``self`` for 0, otherwise a twin on a context (HIP stream) of its own - the same files, the
+        same precision and dispatch options (brought in line at every call), its own 0.9 MB of weights.  Independent launches dealt
+        to the lanes run beside each other on the GPU, which one stream's order forbids: the sharded evaluators give consecutive
+        chunks to alternating lanes (wwhip/evaluate.py, as bench.py does with whole steps)."""
+        if k == 0:
+            return self
+        lanes = self.__dict__.setdefault("_lanes", {})
+        e = lanes.get(k)
+        if e is None or e.handle is None:
+            e = lanes[k] = Engine(self.model_dir, device=self.ctx.device, ctx=_lib.Context(self.ctx.device), precision=self.precision,
+                                  weights_fp16=self._weights_fp16)
+        if e.precision != self.precision:
+            e.set_precision(self.precision)
+        for key, v in self._options.items():
+            if e._options[key] != v:
+                e.set_option(key, v)
+        return e
 
     # ------------------------------------------------------------------ properties
     @property

@@ -16,6 +16,7 @@ below reproduces the reference's chunking quirks exactly (frames credited to a f
 """
 from __future__ import annotations
 
+import os
 import wave
 from typing import Callable, List, Optional, Sequence, Tuple
 
@@ -382,6 +383,7 @@ def _piece_runs(plan: StreamPlan, runs, data: dict, addr: Optional[np.ndarray] =
     return soffs, np.ascontiguousarray(d[order]), np.ascontiguousarray(pp[order]), np.ascontiguousarray(c[order])
 
 
+_EVAL_LANES = int(os.environ.get("WWHIP_EVAL_LANES", "2"))  # (the variable: development) contexts (HIP streams) the chunks of a pass are dealt to in turn: a chunk's front end and model kernels run beside the next chunk's
 _TLS = None  # per host thread (threading.local): {device: the library's uploader - page-locked slots, copy threads, copy stream}
 _UPLOAD_SLOTS = 3     # chunks in flight between the interpreter and the kernels: one being written, one uploading, one waiting
 _CHUNK_SAMPLES = 24 << 20  # samples staged, uploaded and evaluated per step of the pipeline (48 MB of PCM, ~26 min of audio)
@@ -405,7 +407,7 @@ def _uploader(eng: Engine):
 class _Chunk:
     """One step of a rank's share on its way to the GPU: ``runs`` (file, i0, i1) -> samples in a page-locked slot -> device."""
     __slots__ = ("job", "runs", "n_win", "copy", "keep", "soffs", "foffs", "nf_max", "total_f", "d_pcm", "d_so", "d_fo", "d_wo", "ticket",
-                 "host_pieces", "d_mel", "d_out")
+                 "host_pieces", "d_mel", "d_out", "lane")
 
 
 def _prep_chunk(ch: "_Chunk", ph: _Phases) -> None:
@@ -752,11 +754,31 @@ def _run_jobs(eng: Engine, jobs: Sequence, precise: bool, ph: _Phases, timing: O
     made: List[_PosteriorJob] = []
     pending: "deque[_Chunk]" = deque()   # submitted, not yet launched
     done: List[_Chunk] = []
+    # Consecutive chunks go to alternating lanes (Engine.lane: the same model on contexts of their own): a chunk is a front-end
+    # launch, a model launch of two or three kernels and a pick, each a chip-wide grid of equal workgroups that start and end
+    # together - on ONE stream the GPU drains between them.  Two chunks in flight fill each other's ramps and tails (the clip
+    # path's pipelined contexts: 57 -> 44 us per step).  A chunk's values land in its own slice of the job's buffer, so the
+    # lanes never touch the same bytes; every lane is synchronised before anything is read.
+    lanes = [eng.lane(k) for k in range(max(1, _EVAL_LANES))] if hasattr(eng, "lane") else [eng]
+    n_launched = 0
+
+    def forward(ch0: "_Chunk") -> None:
+        nonlocal n_launched
+        ch0.lane = lanes[n_launched % len(lanes)]
+        n_launched += 1
+        done.append(ch0)
+        _chunk_forward(ch0.lane, ch0, precise, ph)
+
+    def sync_all() -> None:
+        for le in lanes:
+            le.ctx.synchronize()
+
     # timing["kernel_times"] = False: the host phases only (perf_counter reads) - no HIP events around the launches, no read-back
     # of them: what a pass costs when nobody looks at its kernels (bench.py times such passes and profiles one more)
     kernel_times = timing is not None and timing.get("kernel_times", True)
     if kernel_times:
-        eng.ctx.profile(True)
+        for le in lanes:
+            le.ctx.profile(True)
     try:
         for j in jobs:
             job = j() if callable(j) else j
@@ -769,15 +791,11 @@ def _run_jobs(eng: Engine, jobs: Sequence, precise: bool, ph: _Phases, timing: O
                 pending.append(ch)
                 # launch what is ready; never run more than the uploader's slots ahead of the launches
                 while pending and (len(pending) >= _UPLOAD_SLOTS or pending[0].ticket is None or _uploader(eng).done(pending[0].ticket)):
-                    ch0 = pending.popleft()
-                    done.append(ch0)
-                    _chunk_forward(eng, ch0, precise, ph)
+                    forward(pending.popleft())
         while pending:
-            ch0 = pending.popleft()
-            done.append(ch0)
-            _chunk_forward(eng, ch0, precise, ph)
+            forward(pending.popleft())
         with ph("device_wall"):
-            eng.ctx.synchronize()
+            sync_all()
     finally:
         # on the way out of an error too: nothing enqueued or submitted may outlive its buffers or the clips it reads
         for ch in pending:
@@ -787,16 +805,19 @@ def _run_jobs(eng: Engine, jobs: Sequence, precise: bool, ph: _Phases, timing: O
                 except Exception:  # noqa: BLE001 - the first error is the one that is reported
                     pass
         if done or pending:
-            eng.ctx.synchronize()
+            sync_all()
         for ch in list(done) + list(pending):
             ch.d_pcm = ch.d_mel = ch.d_so = ch.d_fo = ch.keep = None
     if kernel_times:
         with ph("profile_read"):
-            prof = eng.ctx.profile_read()
-            eng.ctx.profile(False)
-        timing["device_ms"] = timing.get("device_ms", 0.0) + sum(v["total_ms"] for v in prof.values())
-        for k, v in prof.items():
-            timing.setdefault("kernels_ms", {})[k] = timing.get("kernels_ms", {}).get(k, 0.0) + v["total_ms"]
+            profs = []
+            for le in lanes:
+                profs.append(le.ctx.profile_read())
+                le.ctx.profile(False)
+        for prof in profs:
+            timing["device_ms"] = timing.get("device_ms", 0.0) + sum(v["total_ms"] for v in prof.values())
+            for k, v in prof.items():
+                timing.setdefault("kernels_ms", {})[k] = timing.get("kernels_ms", {}).get(k, 0.0) + v["total_ms"]
     if timing is not None:
         timing["chunks"] = timing.get("chunks", 0) + len(done)
     for job in made:
