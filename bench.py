@@ -111,11 +111,11 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-PMC_FILE = os.path.join("profiles", "r05", "pmc_counters.json")
+PMC_FILE = os.path.join("profiles", "r06", "pmc_counters.json")
 
 
 def pmc_counters():
-    """profiles/r05/pmc_counters.json (tools/pmc_collect.py: rocprofv3 --pmc passes, mean per launch and kernel) if it
+    """profiles/r06/pmc_counters.json (tools/pmc_collect.py: rocprofv3 --pmc passes, mean per launch and kernel) if it
     was measured on THESE kernel sources, else None."""
     try:
         pmc = json.load(open(os.path.join(ROOT, PMC_FILE)))

@@ -37,7 +37,7 @@ def short(name: str) -> str:
 def main():
     import bench
     out = {"source_sha": bench.kernel_source_sha(),
-           "note": "rocprofv3 --pmc passes (tools/r05_prof.sh), mean per launch.  FETCH_SIZE / WRITE_SIZE in KiB as reported "
+           "note": "rocprofv3 --pmc passes (tools/r06_prof.sh), mean per launch.  FETCH_SIZE / WRITE_SIZE in KiB as reported "
                    "(gfx950: FETCH_SIZE counts half of 16-byte-per-lane streaming reads -> traffic = 2 x FETCH + WRITE, "
                    "MI355X_MICROARCH.md); SQ_VALU_MFMA_BUSY_CYCLES in cycles summed over SIMDs; SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / "
                    "SQ_WAIT_* in quad-cycles summed over waves (same guide, s_memtime row).",
