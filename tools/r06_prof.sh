@@ -52,4 +52,7 @@ python3 tools/pmc_collect.py $O/summary/pmc_counters.json clips256=$O/pmc_clips2
   wave256f=$O/pmc_wave256f_fetch wave256f=$O/pmc_wave256f_write wave256f=$O/pmc_wave256f_sq1 wave256f=$O/pmc_wave256f_sq2 \
   stream128=$O/pmc_stream128_fetch stream128=$O/pmc_stream128_write stream128=$O/pmc_stream128_sq1 stream128=$O/pmc_stream128_sq2
 fi
+# the raw trace directories go (gpurun merges at most 64 MiB back): the summaries and the logs stay
+cd $R
+find $O -mindepth 1 -maxdepth 1 -type d ! -name summary -exec rm -rf {} +
 ls $O/summary
