@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Development (round 6): the reference evaluator's flow at hey-snips size - one GPU, and rank 0's share of a world of 8 run alone
 (no communicator) - timed without kernel events: fastest and median of n passes, the fastest pass's host phases.
-usage: eval_share.py [passes=9] [scale=1]"""
+usage: eval_share.py [passes=9] [scale=1] [only8]"""
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "wakeword-detection_amd")]
@@ -16,7 +16,8 @@ if scale > 1:
     labels = np.concatenate((np.ones(scale * 2529, np.uint8), np.zeros(scale * 2529, np.uint8)))
 eng = engine_for(os.path.join(ROOT, "wakeword-detection_amd/assets/tf_lite_models/CRNN_softmax"), 0)
 out = {}
-for world, comm in ((1, None), (8, SHARE_ONLY)):
+only8 = "only8" in sys.argv[3:]
+for world, comm in (((8, SHARE_ONLY),) if only8 else ((1, None), (8, SHARE_ONLY))):
     runs = []
     for i in range(passes + 2):
         torch.cuda.synchronize()
@@ -29,5 +30,6 @@ for world, comm in ((1, None), (8, SHARE_ONLY)):
     runs.sort(key=lambda x: x[0])
     out[f"world{world}"] = {"seconds_min": round(runs[0][0] * 1e3, 3), "seconds_median": round(runs[len(runs) // 2][0] * 1e3, 3),
                             "phases_ms": {k: round(v * 1e3, 3) for k, v in runs[0][1].items() if isinstance(v, float)}, "chunks": runs[0][1].get("chunks")}
-out["efficiency_8"] = round(out["world1"]["seconds_min"] / (8 * out["world8"]["seconds_min"]), 3)
+if not only8:
+    out["efficiency_8"] = round(out["world1"]["seconds_min"] / (8 * out["world8"]["seconds_min"]), 3)
 print(json.dumps(out))
