@@ -239,21 +239,31 @@ struct ww_uploader {
       s.cap = want;
     }
     int16_t *dst = (int16_t *)s.pin;
-    const int nt = clamp_threads(pool->size(), j.total);
-    if (nt == 1) {
-      stage_range(dst, runs, 0, j.total);
-    } else {
-      const int64_t total = j.total;
-      pool->run([&, dst, total, nt](int t) {
-        if (t >= nt) return;
-        int64_t lo, hi;
-        slice_of(0, total, nt, t, &lo, &hi);
-        if (lo < hi) stage_range(dst, runs, lo, hi);
-      });
-    }
     if (b_meta) memcpy((char *)s.pin + b_pcm, j.meta.data(), b_meta);
-    if (j.total > 0 && (e = hipMemcpyAsync(j.d_pcm, s.pin, (size_t)j.total * 2, hipMemcpyHostToDevice, copy_stream)) != hipSuccess)
-      return fail(WW_EHIP, "ww_uploader: hipMemcpyAsync (samples)", e);
+    // The chunk goes up in slices, each sent as soon as it has been written: a chunk's way to the device takes the longer of
+    // staging and upload, not their sum (round 6: a rank of eight is as much transfer-bound as compute-bound, and the GPU sat
+    // idle for 0.35 ms behind the first chunk waiting for the second - profiles/r06/share_of_8_pass_anatomy.txt).  At most eight
+    // slices of at least a megasample; every slice is written by all copy threads.
+    const int64_t n_slices = j.total >= ((int64_t)3 << 20) ? (j.total >> 20 < 8 ? j.total >> 20 : 8) : 1;
+    const int64_t step = ((j.total + n_slices - 1) / n_slices + 63) & ~(int64_t)63;
+    for (int64_t lo_s = 0; lo_s < j.total; lo_s += step) {
+      const int64_t hi_s = lo_s + step < j.total ? lo_s + step : j.total;
+      const int nt = clamp_threads(pool->size(), hi_s - lo_s);
+      if (nt == 1) {
+        stage_range(dst, runs, lo_s, hi_s);
+      } else {
+        pool->run([&, dst, lo_s, hi_s, nt](int t) {
+          if (t >= nt) return;
+          int64_t lo, hi;
+          slice_of(lo_s, hi_s, nt, t, &lo, &hi);
+          if (lo < hi) stage_range(dst, runs, lo, hi);
+        });
+      }
+      if ((e = hipMemcpyAsync(j.d_pcm + lo_s, dst + lo_s, (size_t)(hi_s - lo_s) * 2, hipMemcpyHostToDevice, copy_stream)) != hipSuccess) {
+        (void)hipStreamSynchronize(copy_stream);  // (earlier slices may be in flight out of this slot)
+        return fail(WW_EHIP, "ww_uploader: hipMemcpyAsync (samples)", e);
+      }
+    }
     // from here on a copy out of the slot may be in flight: a failure must not hand the slot back (the next chunk that lands
     // on it would rewrite - or free - page-locked memory under that DMA) before the copy stream has drained
     if (b_meta && (e = hipMemcpyAsync(j.d_meta, (char *)s.pin + b_pcm, b_meta, hipMemcpyHostToDevice, copy_stream)) != hipSuccess) {
