@@ -104,8 +104,8 @@ def kernel_source_sha():
     for f in sorted(os.listdir(d)):
         if f.endswith((".hip", ".h")):
             text = open(os.path.join(d, f), "rb").read()
-            if f.endswith(".hip") and b"__global__" not in text:
-                continue  # host code only (uploader.hip): no kernel changes with it
+            if (f.endswith(".hip") and b"__global__" not in text) or (f.endswith(".h") and b"__device__" not in text and b"__global__" not in text):
+                continue  # host code only (uploader.hip, host_stage.h): no kernel changes with it
             h.update(f.encode())
             h.update(text)
     return h.hexdigest()[:16]

@@ -850,3 +850,31 @@ def test_chunk_staging_through_the_extension_equals_the_per_file_path():
         _wwhostext.scan_pcm16(things, np.array([4], np.int64), addr, ns, seen)
     with pytest.raises(ValueError):
         _wwhostext.scan_pcm16(things, np.arange(4), addr[:3], ns, seen)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("sanitizer", ["thread", "address,undefined"])
+def test_host_staging_code_under_sanitizers(tmp_path, sanitizer):
+    """csrc/host_stage.h - the uploader's copy-thread pool (threads woken per chunk, a bounded spin in front of every sleep: round 6),
+    the streaming-store copy loops and the run bookkeeping - compiled alone with ThreadSanitizer and with Address + UB sanitizer
+    and hammered on the CPU (tests/native/host_stage_check.cpp: random chunks staged in slices by the pool against a plain loop,
+    hand-offs with and without pauses so that spinning AND sleeping waiters are exercised).  The GPU boxes run no sanitizers;
+    this is where the library's only lock-free hand-off is checked."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cxx = "/opt/rocm/lib/llvm/bin/clang++"  # (the staging loops use clang's __builtin_nontemporal_store, as hipcc compiles them)
+    if not os.path.exists(cxx):
+        cxx = shutil.which("clang++")
+    if cxx is None:
+        pytest.skip("no clang++ in this image")
+    exe = tmp_path / "host_stage_check"
+    b = subprocess.run([cxx, "-std=c++17", "-O1", "-g", f"-fsanitize={sanitizer}", "-pthread", "-I" + os.path.join(root, "wakeword-detection_amd", "csrc"),
+                        os.path.join(root, "tests", "native", "host_stage_check.cpp"), "-o", str(exe)], capture_output=True, text=True)
+    if b.returncode != 0 and "sanitizer" in (b.stderr + b.stdout).lower():
+        pytest.skip("this clang has no sanitizer runtime: " + b.stderr[-300:])
+    assert b.returncode == 0, b.stderr[-2000:]
+    r = subprocess.run([str(exe), "150"], capture_output=True, text=True, timeout=240,
+                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66", ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1"))
+    assert r.returncode == 0 and r.stdout.startswith("ok "), (r.returncode, r.stdout[-500:], r.stderr[-3000:])
+    assert "Sanitizer" not in r.stderr, r.stderr[-3000:]

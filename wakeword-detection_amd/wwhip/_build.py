@@ -40,7 +40,7 @@ def _stale(target: str, deps: List[str]) -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     os.makedirs(OBJ_DIR, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "fft_device.h"),
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "fft_device.h"), os.path.join(CSRC, "host_stage.h"),
                os.path.join(os.path.dirname(ROOT), "include", "wwhip.h")]
     jobs = []
     objs = []
