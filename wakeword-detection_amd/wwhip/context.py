@@ -131,6 +131,12 @@ class ContextBank:
         """A bank-wide handler ``function(view)`` called for every stream the event reaches (after the stream's own)."""
         self._handlers[name] = function
 
+    def event(self, name: str) -> None:
+        """An event of the whole bank (the pipeline's per-tick ``"step"``): the bank-wide handler, called with the bank itself."""
+        fn = self._handlers.get(name)
+        if fn is not None:
+            fn(self)
+
     def emit(self, name: str, ids) -> None:
         """Raise event ``name`` for the streams ``ids`` (whose flags the caller has already written)."""
         fn = self._handlers.get(name)

@@ -103,6 +103,7 @@ class SpeechPipelineBank(SpeechPipeline):
             c.is_active = False
 
     def step(self) -> None:
+        self._context.event("step")  # (spokestack/pipeline.py:26; once per tick, the handler receives the ContextBank)
         if self._is_paused:
             return
         frames = self._input_source.read()

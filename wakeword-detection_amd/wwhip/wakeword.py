@@ -105,6 +105,8 @@ class WakewordBank:
         from . import _lib
         self.S = int(n_streams)
         if bank is None:
+            if not model_dir:
+                raise ValueError("WakewordBank needs model_dir (or bank=: a StreamBank built on an Engine of the caller's)")
             self._engine = engine_for(model_dir, device)
             bank = StreamBank(self._engine, self.S, frontend_params(32767.0, True, pre_emphasis, 160, True))
         self._bank = bank  # (anything with StreamBank's step_trigger / reset / close: the host-only tests pass a stub)
