@@ -123,6 +123,8 @@ class Engine:
         return self.kind == _lib.KIND_CRNN
 
     def close(self) -> None:
+        for e in self.__dict__.pop("_lanes", {}).values():  # the twins on contexts of their own (lane) go with their engine
+            e.close()
         if self._model and not _lib.is_shutdown():
             self._lib.ww_model_free(self._model)
         self._model = None

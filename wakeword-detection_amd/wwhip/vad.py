@@ -115,6 +115,8 @@ class VadBank:
         self._bound = None  # the ContextBank whose is_speech array the stage form works on, and that array's address
 
     def _run(self, raw, p_speech) -> int:
+        if np.shape(raw) != (self.S,):
+            raise ValueError(f"one raw decision per stream is needed ({self.S}), got shape {np.shape(raw)}")
         np.copyto(self._raw, raw, casting="unsafe")
         p = self._p
         if self._fn(self.S, p[0], self._rise, self._fall, p[1], p[2], p_speech, p[4]):
