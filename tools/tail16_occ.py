@@ -18,7 +18,9 @@ valid = torch.full((nmax,), 151, dtype=torch.int32, device="cuda")
 res = torch.zeros((nmax, eng.n_out), device="cuda")
 torch.cuda.synchronize()
 out = {"lib": os.path.basename(os.environ.get("WWHIP_LIB", "libwwhip.so"))}
-with eng.options(crnn_split_at=1, crnn_tail_mfma=2):
+tail_opt = int(os.environ.get("TAIL_OPT", "2"))  # 2: gru_tail16_kernel, 3: gru_tail16h_kernel (hoisted projection, two groups per workgroup)
+out["tail_opt"] = tail_opt
+with eng.options(crnn_split_at=1, crnn_tail_mfma=tail_opt):
     for n in sizes:
         for _ in range(3):
             eng.forward_windows_dev(mel.data_ptr(), nmax * 8 + 151, row.data_ptr(), valid.data_ptr(), n, res.data_ptr())
@@ -29,4 +31,6 @@ with eng.options(crnn_split_at=1, crnn_tail_mfma=2):
         p = ctx.profile_read(); ctx.profile(False)
         out[n] = {k: round(v["total_ms"] / v["calls"] * 1e3, 1) for k, v in p.items()}
 out["checksum"] = float(res[:sizes[-1]].double().sum().item())
+import hashlib
+out["sha"] = hashlib.sha256(res[:sizes[-1]].cpu().numpy().tobytes()).hexdigest()[:16]
 print(json.dumps(out))

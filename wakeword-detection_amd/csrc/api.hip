@@ -781,7 +781,8 @@ int ww_model_set_option(ww_model *m, int key, int64_t value) {
     case WW_OPT_CRNN_SPLIT_AT: m->opt_split_at = (int)value; return WW_OK;
     case WW_OPT_CRNN_SLIDE_MIN: m->opt_slide_min = (int)value; return WW_OK;
     case WW_OPT_CRNN_TAIL_MFMA:
-      if (value > 2) return ww_fail(m->ctx, WW_EINVAL, "WW_OPT_CRNN_TAIL_MFMA takes 0 (never), 1 (from 9,216 windows per launch) or 2 (always)");
+      // (3: development builds with -DWW_TAIL16H=1 - the hoisted-projection probe of round 6; the shipped library treats it as 2)
+      if (value > 3) return ww_fail(m->ctx, WW_EINVAL, "WW_OPT_CRNN_TAIL_MFMA takes 0 (never), 1 (from 9,216 windows per launch) or 2 (always)");
       m->opt_tail_mfma = (int)value;
       return WW_OK;
     case WW_OPT_WAVENET_ROWMAJOR: m->opt_wave_rowmajor = value != 0; return WW_OK;
@@ -1016,7 +1017,9 @@ static int model_forward(ww_ctx *ctx, const ww_model *m, const float *d_mel, int
 }
 
 // windows are processed in chunks so that the workspace stays bounded
+#ifndef WW_MAX_CHUNK
 #define WW_MAX_CHUNK 16384
+#endif
 
 static int forward_host(ww_ctx *ctx, const ww_model *m, const float *mel, int64_t rows, int hop, int64_t nw, float *out,
                         float *enc) {

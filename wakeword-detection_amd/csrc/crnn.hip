@@ -2020,6 +2020,268 @@ __global__ __launch_bounds__(128, 2) void gru_tail16_kernel(tail16_args aa) {
   }
 }
 
+
+#ifndef WW_TAIL16H
+#define WW_TAIL16H 0
+#endif
+#if WW_TAIL16H
+// ------------------------------------------------------------------------------------------
+// gru_tail16h_kernel (round 6): gru_tail16_kernel's work for TWO groups of sixteen windows per four-wave workgroup, with the
+// layer-2 input projection HOISTED out of the 19-step recurrence into a phase of its own:
+//   * the recurrent weight pages (24.6 KB of LDS) are shared by the two groups - 43 KB per workgroup instead of 2 x 33.8:
+//     three workgroups = twelve waves per CU, THREE waves per SIMD where gru_tail16_kernel has two;
+//   * W_x2 (96 registers) is alive only while the projection phase runs: gx2[t] of all 19 steps - the same MFMA chains, bias
+//     last - goes to memory in the layout layer 1 reads its projected inputs in (over the group's own rows of gx1 when the
+//     launch has them to itself, else into aa.gx2), and the layer-2 recurrence IS the layer-1 loop on those rows;
+//   * every sum is associated as before, so a posterior has the same bits whichever tail served it.
+// MEASURED AND NOT ADOPTED (profiles/r06/tail16_probes.txt): bit-identical to gru_tail16_kernel, but 16-20 % slower per window at
+// three waves per SIMD than that kernel at two (690.9 vs 596.9 us per 49,152 windows, 364.4 vs 360.5 per 24,576): the
+// projection's MFMAs no longer cover the h round trip of the recurrence and 29 KB per window take a trip through memory.
+// Kept as a development build (-DWW_TAIL16H=1: WW_OPT_CRNN_TAIL_MFMA = 3 selects it for launches that own their gx1 rows; the
+// prologue and the head spill ~25 registers at the 168 the occupancy allows - outside the loops, but it is not a shipped kernel).
+// ------------------------------------------------------------------------------------------
+#define GT16H_HS (2 * 2 * 2 * 16 * GT16_LD)  // floats: h exchange [group 2][direction 2][buffer 2][16 x GT16_LD]
+#define GT16H_SMEM_BYTES ((GT16H_HS + 2 * 6 * 2 * 64 * 4) * 4)
+struct tail16h_args {
+  tail_args t;
+  float *seq;   // [group][OT][16][64] layer-1 outputs
+  float *gx2;   // [nw][OT][192] projected layer-2 inputs, or nullptr: written over the group's own rows of t.gx1
+  int nw;
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void gru_tail16h_kernel(tail16h_args aa) {
+  constexpr int H = GR_H, OT = CV_OT;
+  const tail_args &a = aa.t;
+  extern __shared__ __align__(16) float sm16[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = wave >> 1, dir = wave & 1;
+  const int c = lane & 15, g = lane >> 4;
+  float (*hs)[2][16 * GT16_LD] = (float (*)[2][16 * GT16_LD])(sm16 + grp * 2 * 2 * 16 * GT16_LD);  // this group's exchange
+  float *pages = sm16 + GT16H_HS;
+  float *encs = pages + grp * 2 * 16 * GT16_ELD, *hid = encs + 16 * GT16_ELD;
+  static_assert(2 * 2 * 16 * GT16_ELD <= 2 * 6 * 2 * 64 * 4, "enc / hid rows of two groups do not fit the weight pages");
+  float4 *whl = (float4 *)pages + (size_t)dir * 6 * 2 * 64 + lane;  // this lane's slot of page 0 (both groups read the same pages)
+  const int gi = blockIdx.x * 2 + grp;  // group number in the launch
+  const int w0 = gi * 16;
+  float *seq = aa.seq + (size_t)gi * OT * 16 * 2 * H;
+
+  // This form serves launches that own their projected inputs t.gx1 [window][t][192] (the rows of a window are nobody else's:
+  // front + tail over explicit windows): a lane's four windows (rows of its accumulator tiles, 4 g + r; clamped in a partial
+  // group: computed twice, stored once) as 32-bit element offsets - the index arithmetic of the three gx sources that
+  // gru_tail16_kernel carries through its loops costs registers this kernel does not have.
+  int ro[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ro[r] = min(w0 + 4 * g + r, aa.nw - 1) * (OT * 6 * H) + dir * 3 * H + c;
+  const float *const g1base = a.gx1;
+  // where layer 2's projected inputs go: the same layout, over the group's own rows of gx1 (or aa.gx2 when the caller gave one)
+  float *const g2base = aa.gx2 ? aa.gx2 : const_cast<float *>(a.gx1);
+  auto gx_row = [&](int r, int t) -> const float * { return g1base + ro[r] + t * (6 * H); };
+  auto gx2_row = [&](int r, int t) -> float * { return g2base + ro[r] + t * (6 * H); };
+  // (GT16_POS, GT16_PRE_ALL, GT16_PRE_FIRST: gru_tail16_kernel's, still defined)
+  float bh[6];
+  auto load_wh = [&](const float *whp, const float *bhp) {  // group 0 writes the pages, everybody takes the biases
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt) {
+      const int row = (nt >> 1) * H + (nt & 1) * 16 + c;
+      if (grp == 0) {
+        const float *p = whp + ((size_t)dir * 3 * H + row) * H + 2 * g;
+        float wv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wv[i] = p[16 * (i >> 2) + 8 * ((i >> 1) & 1) + (i & 1)];
+        whl[(2 * nt) * 64] = make_float4(wv[0], wv[1], wv[2], wv[3]);
+        whl[(2 * nt + 1) * 64] = make_float4(wv[4], wv[5], wv[6], wv[7]);
+      }
+      bh[nt] = bhp[dir * 3 * H + row];
+    }
+  };
+  const int pos0 = GT16_POS(c), pos1 = GT16_POS(16 + c);
+  float h_own[4][2];
+  float gxn[4][6];
+  // One layer's recurrence over projected inputs in the [window][t][192] layout (LAYER 1: gx_row, from the kernels in front; LAYER
+  // 2: gx2_row, from this kernel's projection phase): the loop of gru_tail16_kernel's layer 1, statement for statement.
+#define GT16H_RECUR(ROW_, STORE_SEQ_)                                                                         \
+  {                                                                                                           \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) h_own[r][0] = h_own[r][1] = 0.f;                             \
+    {                                                                                                         \
+      const int t = dir ? OT - 1 : 0;                                                                         \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                         \
+        const float *row = ROW_(r, t);                                                      \
+        _Pragma("unroll") for (int nt = 0; nt < 6; ++nt) gxn[r][nt] = row[(nt >> 1) * H + (nt & 1) * 16];      \
+      }                                                                                                       \
+    }                                                                                                         \
+    __syncthreads();                                                                                          \
+    _Pragma("unroll 1") for (int s = 0; s < OT; ++s) {                                                        \
+      const int t = dir ? OT - 1 - s : s, cur = s & 1;                                                        \
+      f32x4 x0[4];                                                                                            \
+      _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) x0[nt] = (f32x4){gxn[0][nt], gxn[1][nt], gxn[2][nt], gxn[3][nt]}; \
+      float gxc[4][2];                                                                                        \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) { gxc[r][0] = gxn[r][4]; gxc[r][1] = gxn[r][5]; }          \
+      if (s + 1 < OT) {                                                                                       \
+        const int tn = dir ? t - 1 : t + 1;                                                                   \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                       \
+          const float *row = ROW_(r, tn);                                                   \
+          _Pragma("unroll") for (int nt = 0; nt < 6; ++nt) gxn[r][nt] = row[(nt >> 1) * H + (nt & 1) * 16];    \
+        }                                                                                                     \
+      }                                                                                                       \
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};                                                               \
+      float ha[8];                                                                                            \
+      if (s > 0) {                                                                                            \
+        const float4 *hp = (const float4 *)(&hs[dir][cur][c * GT16_LD + 8 * g]);                              \
+        const float4 a0 = hp[0], a1 = hp[1];                                                                  \
+        ha[0] = a0.x; ha[1] = a0.y; ha[2] = a0.z; ha[3] = a0.w; ha[4] = a1.x; ha[5] = a1.y; ha[6] = a1.z; ha[7] = a1.w; \
+      }                                                                                                       \
+      /* the six tiles in the order z, r, c of unit half 0, then of unit half 1: a half's gates are evaluated as soon as its  \
+         three tiles are in (12 pre-activation registers alive instead of 24); a tile's sums are gru_tail16_kernel's */     \
+      float4 wb[2][2];                                                                                        \
+      if (s > 0) { wb[0][0] = whl[0]; wb[0][1] = whl[64]; }                                                   \
+      _Pragma("unroll") for (int uh = 0; uh < 2; ++uh) {                                                      \
+        f32x4 pre3[3];                                                                                        \
+        _Pragma("unroll") for (int gt = 0; gt < 3; ++gt) {                                                    \
+          const int nt = 2 * gt + uh, q = 3 * uh + gt;                /* q: position in the visiting order */ \
+          const f32x4 xin = gt < 2 ? x0[nt < 4 ? nt : 0] : zero4;                                             \
+          const f32x4 o0i = {bh[nt], bh[nt], bh[nt], bh[nt]};                                                 \
+          if (s > 0) {                                                                                        \
+            if (q + 1 < 6) {                                                                                  \
+              const int ntn = 2 * ((q + 1) % 3) + (q + 1) / 3;                                                \
+              wb[(q + 1) & 1][0] = whl[(2 * ntn) * 64];                                                       \
+              wb[(q + 1) & 1][1] = whl[(2 * ntn + 1) * 64];                                                   \
+            }                                                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+            const float4 b0 = wb[q & 1][0], b1 = wb[q & 1][1];                                                \
+            f32x4 e0 = xin, o0 = o0i;                                                                         \
+            e0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[0], b0.x, e0, 0, 0, 0);                              \
+            o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[1], b0.y, o0, 0, 0, 0);                              \
+            e0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[2], b0.z, e0, 0, 0, 0);                              \
+            o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[3], b0.w, o0, 0, 0, 0);                              \
+            f32x4 e1 = zero4, o1 = zero4;                                                                     \
+            e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[4], b1.x, e1, 0, 0, 0);                              \
+            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[5], b1.y, o1, 0, 0, 0);                              \
+            e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[6], b1.z, e1, 0, 0, 0);                              \
+            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[7], b1.w, o1, 0, 0, 0);                              \
+            pre3[gt] = (e0 + o0) + (e1 + o1);                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+          } else {                                                                                            \
+            pre3[gt] = (xin + o0i) + (zero4 + zero4);   /* h = 0: the chains are their initial values */      \
+          }                                                                                                   \
+        }                                                                                                     \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                       \
+          const float z = fast_sigmoid(pre3[0][r]);                                                           \
+          const float rr = fast_sigmoid(pre3[1][r]);                                                          \
+          const float hn = gru_blend(z, h_own[r][uh], gru_candidate(rr, pre3[2][r], gxc[r][uh]));             \
+          h_own[r][uh] = hn;                                                                                  \
+          hs[dir][cur ^ 1][(4 * g + r) * GT16_LD + (uh ? pos1 : pos0)] = hn;                                  \
+          if (STORE_SEQ_) seq[((size_t)t * 16 + 4 * g + r) * 2 * H + dir * H + uh * 16 + c] = hn;             \
+        }                                                                                                     \
+      }                                                                                                       \
+      wsync_h();                                                                                              \
+    }                                                                                                         \
+  }
+
+  // ---- layer 1 ------------------------------------------------------------------------------
+  load_wh(a.wh1, a.bh1);
+  for (int i = tid; i < GT16H_HS; i += 256) sm16[i] = 0.f;
+  GT16H_RECUR(gx_row, true)
+  __syncthreads();  // seq1 of both directions is in memory; every wave is done with the layer-1 pages and with its rows of gx1
+
+  // ---- layer 2, projection phase: gx2[t] for all t, one fmaf chain per value over k = 16 kb + 4 kk + e in the order kb, e, kk,
+  //      the bias added last (phase E of crnn_fused_kernel); A = seq1[t] of the sixteen windows, B = this direction's 96 rows of W_x2
+  load_wh(a.wh2, a.bh2);
+  // Three of the six n-tiles at a time (48 registers of W_x2 instead of 96: the phase fits three waves per SIMD without a spill);
+  // seq1[t] is read once per half - 2 KB per wave and step out of L2.  Every value is still ONE chain in k order, bias last.
+#define GT16H_PROJ_HALF(NT0_)                                                                                   \
+  {                                                                                                             \
+    float wx[3][16];                                                                                            \
+    float bx[3];                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                             \
+      const int nt = (NT0_) + i;                                                                                \
+      const int row = dir * 3 * H + (nt >> 1) * H + (nt & 1) * 16 + c;                                          \
+      const float4 *p = (const float4 *)(a.wx2 + (size_t)row * 2 * H + 4 * g);                                  \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                           \
+        const float4 v = p[4 * q];                                                                              \
+        wx[i][4 * q] = v.x; wx[i][4 * q + 1] = v.y; wx[i][4 * q + 2] = v.z; wx[i][4 * q + 3] = v.w;             \
+      }                                                                                                         \
+      bx[i] = a.bx2[row];                                                                                       \
+    }                                                                                                           \
+    _Pragma("unroll 1") for (int t = 0; t < OT; ++t) {                                                          \
+      const float4 *sp = (const float4 *)(seq + ((size_t)t * 16 + c) * 2 * H + 4 * g);                          \
+      const float4 q0 = sp[0], q1 = sp[4], q2 = sp[8], q3 = sp[12];                                             \
+      f32x4 gx2[3];                                                                                             \
+      _Pragma("unroll") for (int i = 0; i < 3; ++i) gx2[i] = (f32x4){0.f, 0.f, 0.f, 0.f};                       \
+      GT16H_PROJ(q0, 0)                                                                                         \
+      GT16H_PROJ(q1, 1)                                                                                         \
+      GT16H_PROJ(q2, 2)                                                                                         \
+      GT16H_PROJ(q3, 3)                                                                                         \
+      _Pragma("unroll") for (int i = 0; i < 3; ++i) gx2[i] += (f32x4){bx[i], bx[i], bx[i], bx[i]};              \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                           \
+        float *row = gx2_row(r, t);                                                           \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) row[(((NT0_) + i) >> 1) * H + (((NT0_) + i) & 1) * 16] = gx2[i][r]; \
+      }                                                                                                         \
+    }                                                                                                           \
+  }
+#define GT16H_PROJ(q_, kb_)                                                                          \
+  _Pragma("unroll") for (int i = 0; i < 3; ++i) gx2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.x, wx[i][4 * kb_ + 0], gx2[i], 0, 0, 0); \
+  _Pragma("unroll") for (int i = 0; i < 3; ++i) gx2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.y, wx[i][4 * kb_ + 1], gx2[i], 0, 0, 0); \
+  _Pragma("unroll") for (int i = 0; i < 3; ++i) gx2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.z, wx[i][4 * kb_ + 2], gx2[i], 0, 0, 0); \
+  _Pragma("unroll") for (int i = 0; i < 3; ++i) gx2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.w, wx[i][4 * kb_ + 3], gx2[i], 0, 0, 0);
+  GT16H_PROJ_HALF(0)
+  GT16H_PROJ_HALF(3)
+#undef GT16H_PROJ
+#undef GT16H_PROJ_HALF
+  for (int i = tid; i < GT16H_HS; i += 256) sm16[i] = 0.f;
+  __threadfence_block();  // (a lane reads back what it - or its clamped twin with the same values - wrote: program order suffices)
+  // ---- layer 2, recurrence: the layer-1 loop on the rows written above
+  GT16H_RECUR(gx2_row, false)
+  __syncthreads();  // every wave is done with the weight pages: enc / hid take their place
+#pragma unroll
+  for (int uh = 0; uh < 2; ++uh)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      encs[(4 * g + r) * GT16_ELD + dir * H + uh * 16 + c] = h_own[r][uh];
+      if (a.enc && w0 + 4 * g + r < aa.nw) a.enc[(size_t)(w0 + 4 * g + r) * 2 * H + dir * H + uh * 16 + c] = h_own[r][uh];
+    }
+  __syncthreads();
+  // ---- detect head per group: wave `dir` takes windows 8 dir .. 8 dir + 7; lane = hidden unit, its w1 row in registers
+  {
+    float4 w1r[16];
+    const float4 *wr = (const float4 *)(a.w1 + (size_t)lane * 2 * H);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) w1r[q] = wr[q];
+    const float b1v = a.b1[lane];
+#pragma unroll 1
+    for (int wq = dir * 8; wq < dir * 8 + 8; ++wq) {
+      float acc = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float4 ev = *(const float4 *)(&encs[wq * GT16_ELD + q * 4]);
+        acc = fmaf(w1r[q].x, ev.x, acc); acc = fmaf(w1r[q].y, ev.y, acc);
+        acc = fmaf(w1r[q].z, ev.z, acc); acc = fmaf(w1r[q].w, ev.w, acc);
+      }
+      hid[wq * GT16_ELD + lane] = fmaxf(acc + b1v, 0.f);
+    }
+  }
+  __syncthreads();
+  {
+    const int tg = tid & 127, wq = tg >> 3, o = tg & 7;  // per group: 16 windows x up to 8 outputs
+    float y = 0.f;
+    if (o < a.NOUT) {
+      for (int k = 0; k < 2 * H; ++k) y = fmaf(a.w2[o * 64 + k], hid[wq * GT16_ELD + k], y);
+      y += a.b2[o];
+    }
+    const bool live = o < a.NOUT && w0 + wq < aa.nw;
+    if (a.HEAD == 0) {
+      if (live) a.out[(size_t)(w0 + wq) * a.NOUT + o] = sigmoid_f(y);
+    } else {
+      float mx = (o < a.NOUT) ? y : -INFINITY;
+      for (int d = 1; d < 8; d <<= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+      const float e = (o < a.NOUT) ? expf(y - mx) : 0.f;
+      float sum = e;
+      for (int d = 1; d < 8; d <<= 1) sum += __shfl_xor(sum, d);
+      if (live) a.out[(size_t)(w0 + wq) * a.NOUT + o] = e / sum;
+    }
+  }
+}
+#undef GT16H_RECUR
+#endif  // WW_TAIL16H
+
 #undef CF_ROUND
 #undef CF_ROUND_L2
 #undef GT16_PRE_ALL
@@ -2325,10 +2587,18 @@ int ww_k_crnn_stream_forward(ww_ctx *ctx, const ww_model *m, const float *d_hist
 // front + tail per launch 743 vs 745 us at 9,216 windows, 1,204 vs 1,309 at 16,384, but 226 vs 188 at 2,048), so
 // WW_OPT_CRNN_TAIL_MFMA = 1 (default) takes it from WW_TAIL16_MIN windows per launch on; 2 = always, 0 = never.
 #define WW_TAIL16_MIN 9216
-static size_t tail_seq_bytes(int nw) { return ww_bump::need((size_t)((nw + 15) / 16) * CV_OT * 16 * 2 * GR_H, 4); }
+static size_t tail_seq_bytes(int nw) { return ww_bump::need((size_t)((((nw + 15) / 16) + 1) & ~1) * CV_OT * 16 * 2 * GR_H, 4); }  // (an even number of groups: gru_tail16h_kernel takes two per workgroup)
 static void launch_tail(ww_ctx *ctx, const ww_model *m, tail_args t, int nw, float *seq) {
   t.wx2 = m->crnn.wx2;
-  if (m->opt_tail_mfma == 2 || (m->opt_tail_mfma == 1 && nw >= WW_TAIL16_MIN)) {
+#if WW_TAIL16H
+  if (m->opt_tail_mfma == 3 && t.gx1) {  // (round 6 probe) hoisted projection, two groups per workgroup: launches that own their gx1 rows
+    tail16h_args ah = {t, seq, nullptr, nw};
+    ww_launch_scope scope(ctx, "gru_tail16h_kernel");
+    hipLaunchKernelGGL(gru_tail16h_kernel, dim3((unsigned)((nw + 31) / 32)), dim3(256), GT16H_SMEM_BYTES, ctx->stream, ah);
+    return;
+  }
+#endif
+  if (m->opt_tail_mfma >= 2 || (m->opt_tail_mfma == 1 && nw >= WW_TAIL16_MIN)) {
     tail16_args a16 = {t, seq, nw};
     ww_launch_scope scope(ctx, "gru_tail16_kernel");
     // Development (round 6 occupancy probe, tools/tail16_occ.py -> profiles/r06/tail16_probes.txt): WWHIP_TAIL16_DEEP = n asks
