@@ -901,7 +901,7 @@ def main():
         job.warm(W, fp)
         n_rep = args.repeats
         if n_rep <= 0:
-            probe = job.region(fp)[0]
+            probe = sorted(job.region(fp)[0] for _ in range(3))[1]  # (the median of three: one slow probe region must not halve the count)
             # >= 1 s of timed headline work (round 5 timed 41 regions of 1 ms under the driver's --steps 20: 39 ms in all)
             n_rep = int(min(2001, max(5, 1.1 / max(probe, 1e-6)))) | 1
         stats, med = job.regions(n_rep, fp)

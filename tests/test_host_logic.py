@@ -768,7 +768,7 @@ def test_a_quiet_tick_costs_no_per_stream_python():
     small, _ = calls_per_tick(8)
     large, _ = calls_per_tick(512)
     assert small[2:] == large[2:], (small, large)       # (the first ticks bind the stages to the ContextBank)
-    assert max(large[2:]) <= 16, large                   # three stage calls and their few helpers, whatever S is
+    assert max(large[2:]) <= 24, large                   # three stage calls and their few helpers (13 today), whatever S is
     loud, handled = calls_per_tick(512, loud_at=6)
     assert handled == [0, 1, 2]
     quiet = large[5]
