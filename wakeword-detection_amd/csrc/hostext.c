@@ -85,7 +85,52 @@ done:
   return ret;
 }
 
+/* take(seq, idx) -> (list, lengths): the items seq[idx[i]] as a new list and len() of each as an int64 bytes-like (a
+ * bytearray of 8 n bytes; np.frombuffer(..., np.int64) views it) - what the evaluators' "prepare" phase needs of EVERY clip of a test
+ * split on EVERY rank (the plan is a function of all lengths): two list comprehensions and two passes of len() in the interpreter
+ * before (0.22 ms per 2 x 2,529 clips), one call here. */
+static PyObject *take(PyObject *self, PyObject *args) {
+  PyObject *seq, *o_idx;
+  if (!PyArg_ParseTuple(args, "OO", &seq, &o_idx)) return NULL;
+  PyObject *fast = PySequence_Fast(seq, "take: a list or tuple is needed");
+  if (!fast) return NULL;
+  Py_buffer idx;
+  if (get_i64(o_idx, &idx, 0) != 0) { Py_DECREF(fast); return NULL; }
+  const Py_ssize_t n_seq = PySequence_Fast_GET_SIZE(fast), n = idx.len / 8;
+  const int64_t *ix = (const int64_t *)idx.buf;
+  PyObject *out = PyList_New(n), *lens = PyByteArray_FromStringAndSize(NULL, n * 8), *ret = NULL;
+  if (!out || !lens) goto done;
+  {
+    int64_t *pl = (int64_t *)PyByteArray_AS_STRING(lens);
+    for (Py_ssize_t i = 0; i < n; ++i) {
+      const int64_t k = ix[i];
+      if (k < 0 || k >= n_seq) {
+        PyErr_SetString(PyExc_IndexError, "take: index out of range");
+        goto done;
+      }
+      PyObject *item = PySequence_Fast_GET_ITEM(fast, k);
+      const Py_ssize_t len = PyObject_Length(item);
+      if (len < 0) goto done;  /* (the item's own error: an object without len()) */
+      Py_INCREF(item);
+      PyList_SET_ITEM(out, i, item);
+      pl[i] = (int64_t)len;
+    }
+    ret = PyTuple_Pack(2, out, lens);
+  }
+done:
+  PyBuffer_Release(&idx);
+  Py_DECREF(fast);
+  if (!ret && out) {  /* slots not filled yet are NULL: fill them so that the list can be released */
+    for (Py_ssize_t i = 0; i < n; ++i)
+      if (!PyList_GET_ITEM(out, i)) { Py_INCREF(Py_None); PyList_SET_ITEM(out, i, Py_None); }
+  }
+  Py_XDECREF(out);
+  Py_XDECREF(lens);
+  return ret;
+}
+
 static PyMethodDef methods[] = {
+    {"take", take, METH_VARARGS, "(seq[idx[i]] as a list, their len() as int64 bytes) - see csrc/hostext.c"},
     {"scan_pcm16", scan_pcm16, METH_VARARGS, "addresses and lengths of the contiguous int16 clips seq[idx[i]] (see csrc/hostext.c)"},
     {NULL, NULL, 0, NULL}};
 static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_wwhostext", "host-side staging helpers of wwhip.evaluate", -1, methods};

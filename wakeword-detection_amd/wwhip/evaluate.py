@@ -219,21 +219,26 @@ class StreamPlan:
         where a range crosses a file boundary."""
         return [[tuple(r) for r in a.tolist()] for a in self.shares_arr(eval_type, world)]
 
-    def shares_arr(self, eval_type: str, world: int) -> List[np.ndarray]:
+    def shares_arr(self, eval_type: str, world: int, ranks: Optional[Sequence[int]] = None) -> List[np.ndarray]:
         """:meth:`shares` as one ``int64 [n, 3]`` array per rank, built without a Python-level pass over the files (every
         rank works out EVERY rank's share - the gather needs to know where any rank's values go - so at 5,000 files and 8
-        ranks the per-file loops were the part of a call that no rank count divides)."""
+        ranks the per-file loops were the part of a call that no rank count divides).  ``ranks``: only these ranks' shares, in
+        this order (a job needs its own share to start and the others only when the gather comes: :class:`_PosteriorJob`)."""
         from . import dist as D
         out: List[np.ndarray] = []
+        which = range(world) if ranks is None else ranks
         if eval_type == "false_negatives":
-            order = np.argsort(-self.lengths, kind="stable")  # = dist.shard_by_length: rank r gets order[r::world]
-            for r in range(world):
+            order = getattr(self, "_order", None)
+            if order is None:
+                order = self._order = np.argsort(-self.lengths, kind="stable")  # = dist.shard_by_length: rank r gets order[r::world]
+            for r in which:
                 files = np.sort(order[r::world])
                 files = files[self.n_win[files] > 0]
                 out.append(np.stack((files, np.zeros_like(files), self.n_win[files]), axis=1) if len(files) else np.zeros((0, 3), np.int64))
         else:
             offs = self.offs
-            for lo, hi in D.split_stream(self.total, world):
+            ranges = D.split_stream(self.total, world)
+            for lo, hi in (ranges[r] for r in which):
                 if hi <= lo:
                     out.append(np.zeros((0, 3), np.int64))
                     continue
@@ -261,14 +266,17 @@ class JoinedPCM:
 
     dtype = np.dtype(np.int16)
 
-    def __init__(self, clips: Sequence[np.ndarray], gap: int) -> None:
+    def __init__(self, clips: Sequence[np.ndarray], gap: int, lengths: Optional[np.ndarray] = None) -> None:
         # the clips are LOOKED AT where they are used (part()): building the object is a length per clip and nothing else - a
         # rank of eight reads an eighth of a two-hour stream, and what every rank does for every clip is time no rank count
         # divides (round 5: the per-clip dtype / layout checks moved from here to first use)
-        self._raw = list(clips)
+        # (``lengths``: the clips' len() when the caller has them already - then ``clips`` is taken as it is, a list of the caller's)
+        self._raw = clips if lengths is not None and isinstance(clips, list) else list(clips)
         self._ok = np.zeros(len(self._raw), bool)
         self._have = np.zeros(len(self._raw), np.uint8)  # the clip's address is in _addrs
-        n = np.fromiter(map(len, self._raw), np.int64, len(self._raw))
+        n = np.fromiter(map(len, self._raw), np.int64, len(self._raw)) if lengths is None else np.array(lengths, np.int64)
+        if len(n) != len(self._raw):
+            raise ValueError("one length per clip")
         self.lens = n
         self._addrs = np.zeros(len(n), np.int64)  # filled range by range (addresses): paid where it is used
         self._seen_len = np.zeros(len(n), np.int64)
@@ -386,6 +394,11 @@ def _piece_runs(plan: StreamPlan, runs, data: dict, addr: Optional[np.ndarray] =
 _EVAL_LANES = int(os.environ.get("WWHIP_EVAL_LANES", "2"))  # (the variable: development) contexts (HIP streams) the chunks of a pass are dealt to in turn: a chunk's front end and model kernels run beside the next chunk's
 _TLS = None  # per host thread (threading.local): {device: the library's uploader - page-locked slots, copy threads, copy stream}
 _UPLOAD_SLOTS = 3     # chunks in flight between the interpreter and the kernels: one being written, one uploading, one waiting
+# samples of a job's first chunk; sizes double from there (the variable: development).  Round 6, one box, one GPU / one rank's share of
+# eight at hey-snips size: 0.5 M 11.2 / 3.09 ms, 1 M 11.0 / 3.17, 2 M 11.0 / 2.91, 4 M 10.6 / 2.59-2.62, 6 M 10.8 / 2.75, 8 M 10.7 / 2.70,
+# 24 M 11.4 / 2.74 - a chunk costs the host ~0.1 ms whatever its size, and since a chunk goes up in slices a larger first one no longer
+# holds the first kernel back by its whole staging time
+_FIRST_CHUNK = int(os.environ.get("WWHIP_FIRST_CHUNK", str(1 << 22)))
 _CHUNK_SAMPLES = 24 << 20  # samples staged, uploaded and evaluated per step of the pipeline (48 MB of PCM, ~26 min of audio)
 
 
@@ -586,7 +599,7 @@ class _PosteriorJob:
     chunks of about ``_CHUNK_SAMPLES`` samples, and - after :func:`_run_jobs` - the posteriors of the share."""
 
     def __init__(self, eng: Engine, eval_type: str, test_files, frame_width: int, sample_rate: int, rank: int, world: int,
-                 loader, lengths, carry_over: bool, ph: _Phases, info: Optional[dict], first_chunk: int = 1 << 21) -> None:
+                 loader, lengths, carry_over: bool, ph: _Phases, info: Optional[dict], first_chunk: Optional[int] = None) -> None:
         self.eng, self.eval_type, self.rank, self.world = eng, eval_type, rank, world
         frame_length = sample_rate // 1000 * frame_width
         in_memory = len(test_files) > 0 and not isinstance(test_files[0], (str, bytes)) and not hasattr(test_files[0], "__fspath__")
@@ -609,10 +622,10 @@ class _PosteriorJob:
             self.plan = plan = StreamPlan(lengths, eng.window, frame_length, sample_rate, 2, carry_over)
             if info is not None:
                 info["windows"] = info.get("windows", 0) + plan.total  # inferences of the whole call, all ranks
-            self.shares = plan.shares_arr(eval_type, world)
-            self.mine = self.shares[rank]
+            self._shares: Optional[List[np.ndarray]] = None
+            (self.mine,) = plan.shares_arr(eval_type, world, (rank,))  # (the other ranks' shares: when the gather needs them)
             self.chunks: List[_Chunk] = []
-            for runs in self._cut(self.mine, first_chunk):
+            for runs in self._cut(self.mine, _FIRST_CHUNK if first_chunk is None else first_chunk):
                 ch = _Chunk()
                 ch.job, ch.runs, ch.n_win = self, runs, runs[:, 2] - runs[:, 1]
                 ch.host_pieces = ch.d_pcm = ch.d_mel = ch.d_out = ch.d_wo = ch.ticket = ch.copy = ch.keep = None
@@ -665,6 +678,19 @@ class _PosteriorJob:
             cur_n += n
         close()
         return out
+
+    @property
+    def shares(self) -> List[np.ndarray]:
+        """Every rank's share (the gather places any rank's values by them), worked out on first use - :func:`_run_jobs` asks for it
+        once everything is launched, i.e. while the GPU is still busy with this rank's chunks."""
+        if self._shares is None:
+            others = [r for r in range(self.world) if r != self.rank]
+            rest = self.plan.shares_arr(self.eval_type, self.world, others)
+            self._shares = [None] * self.world  # type: ignore[list-item]
+            self._shares[self.rank] = self.mine
+            for r, sh in zip(others, rest):
+                self._shares[r] = sh
+        return self._shares
 
     def slots_of(self, runs: np.ndarray):
         """Global slot of every window of the runs: offs[k] + i0 .. offs[k] + i1 - 1, run after run."""
@@ -794,6 +820,9 @@ def _run_jobs(eng: Engine, jobs: Sequence, precise: bool, ph: _Phases, timing: O
                     forward(pending.popleft())
         while pending:
             forward(pending.popleft())
+        with ph("plan"):
+            for job in made:  # every rank's share, for the gather: worked out now, beside the kernels that are still running
+                job.shares
         with ph("device_wall"):
             sync_all()
     finally:
@@ -836,7 +865,7 @@ def get_posterior_sharded(models_dir, model_type, eval_type, test_files, frame_w
     ``"false_accepts"``: the window list - for the reference's evaluator ONE long wav (``evaluate_models.py:317-321``) -
     cut into ``world`` contiguous posterior ranges (``dist.split_stream``).  A rank loads and front-ends only the samples
     its windows are functions of: posterior ``i`` of a file needs the global frames ``[F + 2 i, F + 2 i + T)``, i.e. each
-    range re-reads a ``T - 2``-frame overlap and the results are exact.  The share goes to the GPU in chunks (2 M samples
+    range re-reads a ``T - 2``-frame overlap and the results are exact.  The share goes to the GPU in chunks (4 M samples
     doubling up to ``_CHUNK_SAMPLES`` = 24 M, ~26 minutes of audio) through the library's uploader (:func:`_run_jobs`).  The one
     exchange is the posterior gather.  Every rank returns the full list :func:`get_posterior` returns.
 
@@ -923,10 +952,11 @@ def evaluate_reference_flow_sharded(engine: Engine, clips: Sequence[np.ndarray],
     # half seconds of padding around every clip), so the GPU has work for the time the wake-word clips take to stage
     def negative_job():
         with ph("prepare"):
-            idx = np.flatnonzero(~labels)[:max(num_wakewords, 1)].tolist()
-            other = [clips[i] for i in idx]
+            # the clips the stream joins and their lengths in ONE call of the extension (csrc/hostext.c: take) - what every rank needs
+            # of every clip, whatever the world size
+            other, lens = _hostext().take(clips, np.flatnonzero(~labels)[:max(num_wakewords, 1)].astype(np.int64))
             made["n_joined"] = len(other)
-            stream = made["stream"] = join_negatives_lazy(other, num_wakewords) if other else None  # (a length per clip, nothing else)
+            stream = made["stream"] = JoinedPCM(other, 16000 // 10, np.frombuffer(lens, np.int64)) if other else None
         if stream is None or len(stream) == 0:
             return None
         made["neg"] = _PosteriorJob(engine, "false_accepts", [stream], 20, 16000, rank, world, None, None, True, ph, info)
@@ -938,15 +968,16 @@ def evaluate_reference_flow_sharded(engine: Engine, clips: Sequence[np.ndarray],
         with ph("prepare"):
             # what every rank needs of every clip is its LENGTH (the plan); a clip itself is looked at by the rank whose share
             # holds it, when its chunk is staged (_prep_chunk)
-            wake = _Int16Clips([clips[i] for i in np.flatnonzero(labels).tolist()])
-            lengths = np.fromiter(map(len, wake.raw), np.int64, len(wake.raw))
+            raw, lens = _hostext().take(clips, np.flatnonzero(labels).astype(np.int64))
+            wake = _Int16Clips(raw)
+            lengths = np.frombuffer(lens, np.int64)
         # full-size chunks at once when the negative share keeps the pipeline busy for a while (two full chunks or more: one GPU at
         # hey-snips size); a rank of eight holds a ninth of that - its wake-word clips start small again, so that the first of
         # them are on the GPU while the rest are still being staged (one 27 MB chunk: stage, upload, compute, one after the other)
         neg = made.get("neg")
         busy = neg is not None and neg.share_samples() >= 2 * _CHUNK_SAMPLES
         made["wake"] = _PosteriorJob(engine, "false_negatives", wake, 20, 16000, rank, world, None, lengths, True, ph, info,
-                                     first_chunk=_CHUNK_SAMPLES if busy else 1 << 21)
+                                     first_chunk=_CHUNK_SAMPLES if busy else None)
         return made["wake"]
 
     _run_jobs(engine, [negative_job, wake_job], precise, ph, timing)
