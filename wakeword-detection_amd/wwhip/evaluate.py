@@ -646,7 +646,9 @@ class _PosteriorJob:
         if len(runs) == 0:
             return []
         nw = runs[:, 2] - runs[:, 1]
-        if int(nw.max()) <= (size + size // 2) // per_win:  # no run is ever cut: sizes only grow
+        # (the wake-word clips' share keeps one value per run - the clip's maximum, picked on the device - so its runs are never cut:
+        # a clip longer than a chunk is a chunk of its own)
+        if int(nw.max()) <= (size + size // 2) // per_win or self.eval_type == "false_negatives":  # no run is ever cut: sizes only grow
             c = np.cumsum(160 * (plan.hop * (nw - 1) + plan.T - 1) + WINDOW)
             out, j0, base = [], 0, 0
             while j0 < len(runs):
@@ -728,10 +730,26 @@ class _PosteriorJob:
         (smoothing and sweep read them there: :func:`evaluate_reference_flow_sharded`)."""
         import torch
         plan = self.plan
-        vals = self.d_vals if self.d_vals is not None else torch.from_numpy(np.ascontiguousarray(self.vals, np.float32))
         per_run = self.eval_type == "false_negatives"
+        every = self.gather_vals(comm_device, ph)
+        vals = every[self.rank]
         with ph("gather"):
-            if per_run and (plan.n_win == 0).any():
+            if per_run:
+                return self.place_host(every, comm_device)
+            if self.world == 1:
+                return vals  # (one rank: its windows are the stream, in order)
+            post_t = torch.zeros(plan.total, dtype=torch.float32, device=vals.device)
+            for sh, v in zip(self.shares, every):
+                if v is not None and len(sh):
+                    post_t[self.slots_of(sh)] = v  # (a rank's windows are a contiguous range of the stream: a slice)
+            return post_t
+
+    def gather_vals(self, comm_device: Optional[str], ph: _Phases) -> list:
+        """The one exchange: every rank's values as tensors where this rank's are (``None`` for a rank that was not run: SHARE_ONLY)."""
+        import torch
+        vals = self.d_vals if self.d_vals is not None else torch.from_numpy(np.ascontiguousarray(self.vals, np.float32))
+        with ph("gather"):
+            if self.eval_type == "false_negatives" and (self.plan.n_win == 0).any():
                 raise ValueError("max() arg is an empty sequence")  # an empty clip: what np.max raises in the reference's loop
             every: list = [None] * self.world
             if self.world > 1 and comm_device != SHARE_ONLY:
@@ -741,21 +759,17 @@ class _PosteriorJob:
                 every = D.gather_values_t(vals, [self.n_values(sh) for sh in self.shares], device=comm_device)
             else:
                 every[self.rank] = vals  # (SHARE_ONLY: one rank's share timed without its peers - their slots stay zero)
-            if per_run:
-                # a file's windows are one run unless the file is longer than a chunk: the maximum over its runs, on the host
-                # (one float per run; 2,529 of them at hey-snips size)
-                post = np.full(len(plan.lengths), -np.inf if self.world == 1 or comm_device != SHARE_ONLY else 0.0, np.float32)
-                for sh, v in zip(self.shares, every):
-                    if v is not None and len(sh):
-                        np.maximum.at(post, sh[:, 0], v.cpu().numpy())
-                return post
-            if self.world == 1:
-                return vals  # (one rank: its windows are the stream, in order)
-            post_t = torch.zeros(plan.total, dtype=torch.float32, device=vals.device)
-            for sh, v in zip(self.shares, every):
-                if v is not None and len(sh):
-                    post_t[self.slots_of(sh)] = v  # (a rank's windows are a contiguous range of the stream: a slice)
-            return post_t
+        return every
+
+    def place_host(self, every: list, comm_device: Optional[str]) -> np.ndarray:
+        """The wake-word clips' maxima per FILE on the host from the gathered values (one float per clip; 2,529 at hey-snips size)."""
+        post = np.full(len(self.plan.lengths), -np.inf if self.world == 1 or comm_device != SHARE_ONLY else 0.0, np.float32)
+        for r, v in enumerate(every):
+            if v is not None:
+                sh = self.mine if r == self.rank else self.shares[r]
+                if len(sh):
+                    np.maximum.at(post, sh[:, 0], v.cpu().numpy())
+        return post
 
     def finish(self, comm_device: Optional[str], ph: _Phases, as_array: bool):
         """:meth:`finish_dev` on the host: what ``get_posterior`` returns, on every rank."""
@@ -982,23 +996,37 @@ def evaluate_reference_flow_sharded(engine: Engine, clips: Sequence[np.ndarray],
 
     _run_jobs(engine, [negative_job, wake_job], precise, ph, timing)
     import torch
-    pos = made["wake"].finish_dev(comm_device, ph) if "wake" in made else np.zeros(0, np.float32)
+    wake = made.get("wake")
+    every = wake.gather_vals(comm_device, ph) if wake is not None else []
     neg_t = made["neg"].finish_dev(comm_device, ph) if "neg" in made else None
     stream = made.get("stream")
     if rank != 0:
         return None
     hours = (len(stream) if stream is not None else 0) / 16000.0 / 3600.0
     thr = default_thresholds() if thresholds is None else np.asarray(thresholds, np.float64)
+    pos = None
     if neg_t is not None and neg_t.is_cuda and len(neg_t):
-        # smoothing + sweep where the gathered values are (ww_far_frr_dev): the thresholds go up, 2 x 100 counters come back
+        # smoothing + sweep where the gathered values are (ww_far_frr_dev): the thresholds go up, 2 x 100 counters come back.  The
+        # positives are counted where they are as well: one value per wake-word clip (its runs are never cut, _PosteriorJob._cut),
+        # as the pick kernels - or the gather - left them; their order does not matter to a count.  The per-file array the caller
+        # gets is put together afterwards.
+        there = [v for v in every if v is not None and v.numel()]
         with ph("sweep"):
-            d_pos = torch.from_numpy(pos).to(neg_t.device)
-            torch.cuda.current_stream(neg_t.device).synchronize()  # (the gather's copies, this upload: done before the library's stream reads)
-            frr, fa, cnt = engine.far_frr_dev(d_pos.data_ptr(), len(pos), neg_t.data_ptr(), len(neg_t), thr, float(max(num_wakewords, 1)),
+            if there and all(v.is_cuda and v.device == neg_t.device for v in there):
+                d_pos = there[0] if len(there) == 1 else torch.cat(there)
+            else:
+                pos = wake.place_host(every, comm_device) if wake is not None else np.zeros(0, np.float32)
+                d_pos = torch.from_numpy(pos).to(neg_t.device)
+            if wake is None or wake.world > 1 or pos is not None:
+                torch.cuda.current_stream(neg_t.device).synchronize()  # (the gather's copies, a cat, an upload: done before the library's stream reads)
+            frr, fa, cnt = engine.far_frr_dev(d_pos.data_ptr(), int(d_pos.numel()), neg_t.data_ptr(), len(neg_t), thr, float(max(num_wakewords, 1)),
                                               hours, windowsize)
         with ph("d2h"):
-            neg = neg_t.cpu().numpy()  # (for the caller: the curves above did not need it)
+            if pos is None:
+                pos = wake.place_host(every, comm_device)  # (for the caller: the curves above did not need them on the host)
+            neg = neg_t.cpu().numpy()
     else:
+        pos = wake.place_host(every, comm_device) if wake is not None else np.zeros(0, np.float32)
         neg = np.zeros(0, np.float32) if neg_t is None else neg_t.cpu().numpy()
         with ph("sweep"):
             thr, frr, fa, cnt = far_frr(pos, neg, max(num_wakewords, 1), hours, thr, windowsize, engine=engine)
