@@ -570,18 +570,18 @@ def eval_at_scale(torch, np, dist, comm_dev, rank, world, eng, n_wake, with_orac
             "predicted_seconds": {str(w): serial * 1e-3 + (el - serial * 1e-3) / w for w in (2, 4, 8)},
             "predicted_efficiency_8_ranks": el / (8 * (serial * 1e-3 + (el - serial * 1e-3) / 8))}
 
-    runs = passes(clips, labels, 5, rank, world, comm_dev)
+    runs = passes(clips, labels, 9, rank, world, comm_dev)
     one_of_8 = x16 = x16_of_8 = None
     if world == 1:
         # what ONE rank of eight costs, measured: rank 0's share of a world of 8 on this GPU, no communicator (its peers' slots
         # stay zero; the posterior gather - one RCCL all_gather per leg, latency - is what this leaves out)
-        one_of_8 = passes(clips, labels, 5, 0, 8, SHARE_ONLY)
+        one_of_8 = passes(clips, labels, 9, 0, 8, SHARE_ONLY)
         # the same flow over 16 x the clips (each clip object referenced 16 times: ~38 h of audio, 5.7 GB uploaded): a device
         # time large enough to show a curve
         clips16 = clips[:n_wake] * 16 + clips[n_wake:] * 16
         labels16 = np.concatenate((np.ones(16 * n_wake, np.uint8), np.zeros(16 * (len(clips) - n_wake), np.uint8)))
-        x16 = passes(clips16, labels16, 2, 0, 1, None)
-        x16_of_8 = passes(clips16, labels16, 2, 0, 8, SHARE_ONLY)
+        x16 = passes(clips16, labels16, 3, 0, 1, None)
+        x16_of_8 = passes(clips16, labels16, 3, 0, 8, SHARE_ONLY)
     if rank != 0:
         return None
     r, audio_s, out = describe(runs, clips, n_wake)
@@ -589,7 +589,7 @@ def eval_at_scale(torch, np, dist, comm_dev, rank, world, eng, n_wake, with_orac
     out = {"workload": f"{n_wake} wake-word clips (file by file, C2 carry) + the first {n_wake} other clips joined by 100 ms of silence "
                        f"into one {r['hours']:.2f} h stream; synthetic clips 0.8-2.5 s (float32 generator, seed 4321), CRNN_softmax",
            "world_size": world, **out,
-           "note": "rank 0's clock and phases of the FASTEST of five passes (median beside it; serial_ms = the median over the passes), timed WITHOUT kernel events; device_ms / "
+           "note": "rank 0's clock and phases of the FASTEST of nine passes (median beside it; three at 16 x; serial_ms = the median over the passes), timed WITHOUT kernel events; device_ms / "
                    "kernels_ms come from one more pass with HIP events around every launch (profiled_pass_seconds); every rank stages, uploads and runs "
                    "only its share; host_share = 1 - device_ms / "
                    "seconds; the share goes to the GPU in chunks of up to ~26 min of audio: this thread plans a chunk (prepare / plan / slicing: "
