@@ -381,12 +381,18 @@ int ww_stream_reset(ww_streams *st, const int32_t *ids, int32_t n) {
 
 // Wait for a tick's posteriors by polling their {value, tick number} pairs in page-locked memory.  The runtime is asked only
 // now and then whether the stream has drained (a kernel that died would otherwise leave the host spinning for ever).
+// A tick that has not delivered after WW_TICK_TIMEOUT_S seconds (a kernel that neither finishes nor fails: a hung GPU) is an error
+// as well - the caller gets WW_EHIP and a bank that refuses further ticks instead of a host thread that spins for ever.
+#ifndef WW_TICK_TIMEOUT_S
+#define WW_TICK_TIMEOUT_S 10
+#endif
 static int st_poll_tags(ww_streams *st) {
   ww_ctx *ctx = st->ctx;
   const size_t n = st->expect.size();
   const unsigned seq = st->seq;
   size_t i = 0;
   unsigned spins = 0;
+  uint64_t t_slow = 0;  // when the wait left the fast path (first runtime query)
   while (i < n) {
     const unsigned long long v = __atomic_load_n(st->h_tag + st->expect[i], __ATOMIC_ACQUIRE);
     if ((unsigned)(v >> 32) == seq) {
@@ -397,7 +403,14 @@ static int st_poll_tags(ww_streams *st) {
     if (spins > (1u << 18)) sched_yield();  // (a tick that is milliseconds late - a GPU busy elsewhere - stops pinning the core)
     if ((++spins & 0x3fffu) == 0) {
       const hipError_t q = hipStreamQuery(ctx->stream);
-      if (q == hipErrorNotReady) continue;
+      if (q == hipErrorNotReady) {
+        const uint64_t now = st_now_ns();
+        if (!t_slow) t_slow = now;
+        if (now - t_slow > (uint64_t)WW_TICK_TIMEOUT_S * 1000000000ull)
+          return ww_fail(ctx, WW_EHIP, "streaming tick %u did not complete within %d s (posterior slot %d still missing)", seq, WW_TICK_TIMEOUT_S,
+                         st->expect[i]);
+        continue;
+      }
       if (q != hipSuccess) return ww_fail(ctx, WW_EHIP, "streaming tick failed: %s", hipGetErrorString(q));
       for (size_t r = i; r < n; ++r)  // the stream has drained: what will ever arrive has
         if ((unsigned)(__atomic_load_n(st->h_tag + st->expect[r], __ATOMIC_ACQUIRE) >> 32) != seq)
