@@ -844,6 +844,20 @@ def test_chunk_staging_through_the_extension_equals_the_per_file_path():
         with pytest.raises(ValueError, match="file 20 holds"):
             chunks_of(E._Int16Clips(clips), lengths=lengths, generic=generic, world=1, rank=0)
     # the extension's own contract
+    import sys
+    picked, lens = _wwhostext.take(clips, np.array([5, 0, 59, 5], np.int64))
+    assert [p is clips[i] for p, i in zip(picked, (5, 0, 59, 5))] == [True] * 4
+    assert np.frombuffer(lens, np.int64).tolist() == [len(clips[5]), len(clips[0]), len(clips[59]), len(clips[5])]
+    before = sys.getrefcount(clips[5])
+    del picked
+    assert sys.getrefcount(clips[5]) == before - 2             # the list held its own references, and gave them back
+    assert _wwhostext.take((), np.zeros(0, np.int64))[0] == []
+    with pytest.raises(IndexError):
+        _wwhostext.take(clips, np.array([60], np.int64))
+    with pytest.raises(TypeError):
+        _wwhostext.take([1, 2], np.array([0], np.int64))      # an item without len(): its own error, nothing leaked
+    with pytest.raises(TypeError):
+        _wwhostext.take(clips, np.array([0], np.int32))        # idx must be int64
     addr, ns, seen = np.zeros(4, np.int64), np.zeros(4, np.int64), np.zeros(4, np.uint8)
     things = [clips[0], clips[1][::2], [1, 2, 3], np.zeros((4, 4), np.int16)]
     assert _wwhostext.scan_pcm16(things, np.arange(4), addr, ns, seen) == 1
