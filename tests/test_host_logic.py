@@ -845,12 +845,15 @@ def test_chunk_staging_through_the_extension_equals_the_per_file_path():
             chunks_of(E._Int16Clips(clips), lengths=lengths, generic=generic, world=1, rank=0)
     # the extension's own contract
     import sys
+    x5 = clips[5]
+    before = sys.getrefcount(x5)
     picked, lens = _wwhostext.take(clips, np.array([5, 0, 59, 5], np.int64))
-    assert [p is clips[i] for p, i in zip(picked, (5, 0, 59, 5))] == [True] * 4
-    assert np.frombuffer(lens, np.int64).tolist() == [len(clips[5]), len(clips[0]), len(clips[59]), len(clips[5])]
-    before = sys.getrefcount(clips[5])
+    held = sys.getrefcount(x5)
+    same = all(p is clips[i] for p, i in zip(picked, (5, 0, 59, 5)))
     del picked
-    assert sys.getrefcount(clips[5]) == before - 2             # the list held its own references, and gave them back
+    after = sys.getrefcount(x5)
+    assert same and (held, after) == (before + 2, before)      # the list holds its own references and gives them back
+    assert np.frombuffer(lens, np.int64).tolist() == [len(clips[5]), len(clips[0]), len(clips[59]), len(clips[5])]
     assert _wwhostext.take((), np.zeros(0, np.int64))[0] == []
     with pytest.raises(IndexError):
         _wwhostext.take(clips, np.array([60], np.int64))
