@@ -1299,3 +1299,31 @@ def test_uploader_delivers_what_host_staging_writes(assets):
     got = d_pcm.cpu().numpy()
     np.testing.assert_array_equal(got[100:100 + n], src[:n])
     assert not got[:100].any() and not got[100 + n:].any()
+
+
+def test_an_exception_inside_an_entry_point_comes_back_as_a_status():
+    """SURVEY 8(b): no entry point throws.  ww_uploader_submit copies the caller's run arrays into std::vectors; told that there are
+    2^60 runs, the copy raises std::length_error (or std::bad_alloc) inside the library - WW_GUARD_END turns it into WW_EINTERNAL /
+    WW_ENOMEM, the process lives, and the uploader still serves the next, honest chunk."""
+    import ctypes as C
+    import torch
+    from wwhip import _lib
+    lib = _lib.load()
+    ctx = _lib.default_context(0)
+    up = _lib.Uploader(ctx, slots=2, copy_threads=2)
+    try:
+        one = np.zeros(1, np.int64)
+        src = np.zeros(16, np.int16)
+        addr = np.array([src.ctypes.data], np.int64)
+        d_pcm = torch.zeros(64, dtype=torch.int16, device="cuda:0")
+        ticket = C.c_int64(-1)
+        rc = lib.ww_uploader_submit(up._h, 16, 1 << 60, _lib.ptr(one), _lib.ptr(addr), _lib.ptr(one), C.c_void_p(d_pcm.data_ptr()), 0, None, None, C.byref(ticket))
+        assert rc in (_lib.WW_EINTERNAL, _lib.WW_ENOMEM), rc
+        assert ticket.value == 0                                  # nothing was queued
+        t = up.submit(16, np.array([2], np.int64), addr, np.array([5], np.int64), d_pcm.data_ptr(), np.zeros(0, np.int64), 0)
+        up.wait(t, ctx)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        assert t == 1 and not d_pcm.cpu().numpy()[:16].any()      # (the honest chunk: zeros copied where zeros were)
+    finally:
+        up.close()

@@ -897,3 +897,87 @@ def test_host_staging_code_under_sanitizers(tmp_path, sanitizer):
                        env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66", ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1"))
     assert r.returncode == 0 and r.stdout.startswith("ok "), (r.returncode, r.stdout[-500:], r.stderr[-3000:])
     assert "Sanitizer" not in r.stderr, r.stderr[-3000:]
+
+
+def test_pipeline_bank_and_context_bank_surface():
+    """SpeechPipelineBank keeps SpeechPipeline's control surface (spokestack/pipeline.py:30-111) over a ContextBank: start / stop /
+    pause / resume / step / run / cleanup / event; stages are called once per tick with (contexts, frames) in list order; the
+    per-tick "step" event reaches the bank-wide handler; activate() / deactivate() raise each stream's event once; ContextBank
+    views behave like SpeechContext objects (reset, transcript, confidence) and index like a sequence."""
+    from wwhip.context import ContextBank, SpeechContext
+    from wwhip.pipeline import SpeechPipelineBank
+    S = 5
+    log = []
+
+    class Source:
+        def __init__(self):
+            self.t = 0
+
+        def read(self):
+            self.t += 1
+            return np.full((S, 320), self.t, np.int16)
+
+        def start(self):
+            log.append("src.start")
+
+        def stop(self):
+            log.append("src.stop")
+
+        def close(self):
+            log.append("src.close")
+
+    class Stage:
+        def __init__(self, name):
+            self.name = name
+
+        def __call__(self, contexts, frames):
+            log.append((self.name, len(contexts), int(frames[0, 0])))
+            if self.name == "b" and frames[0, 0] == 2:
+                pipe.stop()  # a stage may stop the loop (run() returns after this tick)
+
+        def close(self):
+            log.append(self.name + ".close")
+
+    pipe = SpeechPipelineBank(Source(), [Stage("a"), Stage("b")], S)
+    ctx = pipe.context
+    assert isinstance(ctx, ContextBank) and len(ctx) == S and isinstance(ctx[2], SpeechContext) and ctx[2] is ctx[2]
+    assert [c._s for c in ctx] == list(range(S))
+    with pytest.raises(IndexError):
+        ctx[S]
+    events = []
+    pipe.event(lambda bank: events.append(("step", bank.S)), name="step")
+
+    @pipe.event
+    def on_activate(c):
+        events.append(("activate", c._s))
+
+    pipe.event(lambda c: events.append(("deactivate", c._s)), name="deactivate")
+    ctx[3].add_handler("activate", lambda c: events.append(("own", c._s)))
+    pipe.start(); pipe.start()
+    assert pipe.is_running and log == ["src.start"]
+    pipe.pause(); pipe.step(); pipe.resume()
+    assert log == ["src.start", "src.stop", "src.start"] and events == [("step", S)]   # a paused step reads nothing, runs no stage
+    pipe.run()                                                                          # two ticks, then stage b stops the loop
+    assert [e for e in log if isinstance(e, tuple)] == [("a", S, 1), ("b", S, 1), ("a", S, 2), ("b", S, 2)]
+    assert log[-4:] == ["src.stop", "a.close", "b.close", "src.close"] and not pipe.is_running
+    assert events.count(("step", S)) == 3
+    # activation from outside: one event per stream, the stream's own handler first
+    del events[:]
+    ctx[3].is_active = True
+    assert events == [("own", 3), ("activate", 3)] and ctx.is_active.tolist() == [0, 0, 0, 1, 0]
+    pipe2 = SpeechPipelineBank(Source(), [], 3)
+    seen = []
+    pipe2.event(lambda c: seen.append(c._s), name="activate")
+    pipe2.activate(); pipe2.activate()
+    assert seen == [0, 1, 2] and pipe2.context.is_active.all()
+    pipe2.event(lambda c: seen.append(-c._s - 1), name="deactivate")
+    pipe2.deactivate()
+    assert seen[3:] == [-1, -2, -3]
+    # views are SpeechContexts: state of their own, reset through the bank
+    v = ctx[1]
+    v.transcript, v.confidence, v.is_speech = "hi", 0.5, True
+    assert ctx.is_speech.tolist() == [0, 1, 0, 0, 0]
+    del events[:]
+    ctx.reset()
+    assert not ctx.is_speech.any() and not ctx.is_active.any() and (v.transcript, v.confidence) == ("", 0.0)
+    assert events == [("deactivate", 3)]                      # only the stream that WAS active hears about it
