@@ -477,6 +477,20 @@ def test_demo_pipeline_on_a_wav(assets, tmp_path):
     assert "wake events at (s):" in r.stdout and "Script completed" in r.stdout
 
 
+@pytest.mark.parametrize("model_type", ["CRNN", "Wavenet"])
+def test_time_tf_models_script(model_type):
+    """tools/time_tf_models.py: the reference's batch-1 timing harness (utils/time_tf_models.py) on the TFLiteModel surface -
+    encode alone (what the reference's loop times, quirk C7), encode + detect, and the one-call form."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "time_tf_models.py"), "--model_type", model_type, "--num_runs", "5"],
+                       capture_output=True, text=True, check=True)
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["model_type"] == model_type and 0 < res["encode_only"] <= res["encode_and_detect"] * 1.5 and 0 < res["engine_forward"] < 0.01
+    assert "Script completed" in r.stdout
+
+
 def test_many_stream_pipeline_matches_single_stream_stages(assets):
     """SURVEY 8(f) rank 3 / BASELINE configs[4] as a PIPELINE: VadBank -> WakewordBank -> one ActivationTimeout per stream
     over 128 streams in lock step, against 128 independent single-stream chains
