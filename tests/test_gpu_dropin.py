@@ -481,6 +481,7 @@ def test_demo_pipeline_on_a_wav(assets, tmp_path):
 def test_time_tf_models_script(model_type):
     """tools/time_tf_models.py: the reference's batch-1 timing harness (utils/time_tf_models.py) on the TFLiteModel surface -
     encode alone (what the reference's loop times, quirk C7), encode + detect, and the one-call form."""
+    import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
