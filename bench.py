@@ -436,14 +436,14 @@ def stream_leg(torch, np, dist, comm_dev, local_rank, S, ticks, warm=100):
     """BASELINE configs[4] per GPU: S streams x int16[320] per 20 ms tick, is_speech = 1 (2 posteriors per
     stream and tick); latency = tick submitted on the host -> posteriors visible on the host."""
     from wwhip.activation_timeout import ActivationTimeoutBank
-    from wwhip.context import ContextBank
     from wwhip.engine import Engine, StreamBank, frontend_params
     from wwhip.vad import VadBank
     from wwhip.wakeword import WakewordBank
     out = {"streams_per_gpu": S, "ticks": ticks, "warmup_ticks": warm,
            "pipeline_note": "pipeline = the same tick at the plugin surface (spokestack/pipeline.py:25-28 with demo.py's stage list, "
-                            "for S streams): VadBank -> WakewordBank -> ActivationTimeoutBank on a ContextBank, one library pass per "
-                            "stage and tick (ww_vad_bank_step, ww_stream_step_trigger, ww_timeout_bank_step), raw VAD decision = "
+                            "for S streams): SpeechPipelineBank.step() over VadBank -> WakewordBank -> ActivationTimeoutBank on a ContextBank: the input "
+                            "source's read(), the batch classifier, ONE library call for the three stages' passes (ww_pipeline_bank_step = "
+                            "ww_vad_bank_step + ww_stream_step_trigger + ww_timeout_bank_step in stage order), raw VAD decision = "
                             "speech on every stream (the worst case: every stream owes 2 posteriors), threshold 0.5; "
                             "over_tick_us = pipeline p50 - StreamBank.step p50 of the same bank kind, measured back to back",
            "note": "per-tick latency, host frames in -> host posteriors out; MAX over ranks of each rank's percentile; a tick is ONE "
@@ -483,24 +483,35 @@ def stream_leg(torch, np, dist, comm_dev, local_rank, S, ticks, warm=100):
             "python_wrapper_us": round(own_mean_us - sum(tl.values()), 3)}
         bank.close()
         # ---- the same tick at the plugin surface: three banked stages on a ContextBank
-        wake = WakewordBank(S, posterior_threshold=0.5, bank=StreamBank(eng, S, frontend_params(32767.0, True, 0.0, 160, True)))
-        vad, timeout, ctxs = VadBank(S), ActivationTimeoutBank(S), ContextBank(S)
-        events = []
-        ctxs.add_handler("activate", lambda c: events.append(1))
-        ctxs.add_handler("deactivate", lambda c: events.append(0))
+        from wwhip.pipeline import SpeechPipelineBank
         raw = np.ones(S, bool)
 
-        def pipeline_tick(f):
-            vad(ctxs, f, raw=raw)
-            wake.step(ctxs, f)
-            timeout(ctxs, f)
+        class Source:  # pipeline.step() reads its frames from the input source (spokestack/pipeline.py:25)
+            frame = frames[0]
+
+            def read(self):
+                return self.frame
+
+            def start(self):
+                pass
+
+            stop = close = start
+
+        src = Source()
+        wake = WakewordBank(S, posterior_threshold=0.5, bank=StreamBank(eng, S, frontend_params(32767.0, True, 0.0, 160, True)))
+        pipe = SpeechPipelineBank(src, [VadBank(S, classifier=lambda f: raw), wake, ActivationTimeoutBank(S)], S)
+        events = []
+        pipe.event(lambda c: events.append(1), name="activate")
+        pipe.event(lambda c: events.append(0), name="deactivate")
+        pipe.start()
         for t in range(warm):
-            pipeline_tick(frames[t % 64])
+            src.frame = frames[t % 64]
+            pipe.step()
         plat = np.empty(ticks)
         for t in range(ticks):
-            f = frames[t % 64]
+            src.frame = frames[t % 64]
             t0 = time.perf_counter()
-            pipeline_tick(f)
+            pipe.step()
             plat[t] = time.perf_counter() - t0
         pstats = [float(np.percentile(plat, 50) * 1e3), float(np.percentile(plat, 99) * 1e3), float(plat.mean() * 1e3)]
         if dist is not None:
@@ -511,6 +522,7 @@ def stream_leg(torch, np, dist, comm_dev, local_rank, S, ticks, warm=100):
         out[key]["pipeline"] = {"p50_ms": pstats[0], "p99_ms": pstats[1], "mean_ms": pstats[2],
                                 "over_tick_us": round((pstats[0] - out[key]["p50_ms"]) * 1e3, 3),
                                 "activations": int(sum(events)), "deactivations": len(events) - int(sum(events))}
+        pipe.stop()
         wake.close()
         eng.close()
     return out

@@ -307,6 +307,28 @@ int ww_timeout_bank_step(int32_t n_streams, const uint8_t *is_speech, uint8_t *i
 int ww_stream_step_trigger(ww_streams *st, const int16_t *frames, const uint8_t *is_speech, uint8_t *is_active, double threshold,
                            uint8_t *was_speech, float *posterior_max, float *post, int32_t *n_post, int32_t *fired_ids,
                            int32_t *n_fired, int32_t *fall_ids, int32_t *n_fall);
+/* ww_pipeline_bank_step - ONE tick of the whole stage list of demo.py:29-36 for S streams (spokestack/pipeline.py:25-28: for stage in
+ * stages: stage(context, frame)) as one call: ww_vad_bank_step, ww_stream_step_trigger, ww_timeout_bank_step in this order on the
+ * arrays the state block points to (the caller owns them all; the block itself may be reused from tick to tick).  Equivalent to
+ * the three calls, stage by stage; what it saves is two trips through the host language's call layer per tick (wwhip/pipeline.py:
+ * SpeechPipelineBank takes it when its stages are exactly VadBank, WakewordBank, ActivationTimeoutBank).  On return n_vad_changed,
+ * n_fired / fired_ids, n_fall / fall_ids, n_deact / deact_ids say which streams changed. */
+typedef struct ww_pipeline_state {
+  uint8_t *is_speech, *is_active;          /* the S contexts' flags (updated in place) */
+  const uint8_t *raw;                      /* VAD: the classifier's decisions of this tick */
+  uint8_t *run_value;                      /*      run state */
+  int64_t *run_length;
+  uint8_t *wake_was_speech;                /* wake word: VAD edge detector, */
+  float *posterior_max, *post;             /*            running maxima [S], this tick's posteriors [S][2] */
+  int32_t *n_post;                         /*            and their counts [S] */
+  uint8_t *timeout_was_speech;             /* timeout: VAD edge detector, */
+  int32_t *active_frames;                  /*          frames since activation [S] */
+  int32_t *fired_ids, *fall_ids, *deact_ids; /* out: ids (up to S each) */
+  double threshold, min_frames, max_frames;
+  int32_t rise_frames, fall_frames;
+  int32_t n_vad_changed, n_fired, n_fall, n_deact; /* out */
+} ww_pipeline_state;
+int ww_pipeline_bank_step(ww_streams *st, const int16_t *frames, ww_pipeline_state *ps);
 /* Where a tick's time goes on the HOST side of ww_stream_step (the loop of spokestack/pipeline.py:25-28 is host-paced, so
  * BASELINE config 5's per-tick latency is this call): mean nanoseconds per phase over the ticks since the last reset -
  * [0] plan (control words and window descriptors of the tick), [1] the caller's frames into the page-locked block,

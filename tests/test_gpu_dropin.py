@@ -565,9 +565,11 @@ def test_many_stream_pipeline_matches_single_stream_stages(assets):
     assert np.isfinite(np.array(b_post)).all()
 
 
-def test_banked_pipeline_on_a_context_bank_equals_the_per_context_form(assets):
+@pytest.mark.parametrize("fused", [True, False])
+def test_banked_pipeline_on_a_context_bank_equals_the_per_context_form(assets, fused):
     """BASELINE configs[4] at the plugin surface, the fast form: SpeechPipelineBank([VadBank, WakewordBank, ActivationTimeoutBank])
-    on a ContextBank - one library pass per stage and tick, events only for the streams that change - against the form the test
+    on a ContextBank - one library pass per stage and tick (fused=False), or ONE library call for the whole stage list
+    (ww_pipeline_bank_step, the default for exactly this trio), events only for the streams that change - against the form the test
     above holds equal to 128 single-stream chains (a list of SpeechContext objects, one ActivationTimeout per stream): the same
     is_speech / is_active after every tick, the same activate / deactivate events per stream, the same posteriors, bit for bit."""
     from wwhip.activation_timeout import ActivationTimeout, ActivationTimeoutBank
@@ -632,7 +634,8 @@ def test_banked_pipeline_on_a_context_bank_equals_the_per_context_form(assets):
     woke = []
     pipe = SpeechPipelineBank(src, [VadBank(S, classifier=lambda f: raw[src.t - 1], **kw_vad),
                                     WakewordBank(S, mdir, posterior_threshold=THR, on_wake=lambda ids: woke.extend(int(i) for i in ids)),
-                                    ActivationTimeoutBank(S, **kw_to)], S)
+                                    ActivationTimeoutBank(S, **kw_to)], S, fused=fused)
+    assert (pipe._fused is not None) == fused
     b_logs = [[] for _ in range(S)]
     for s in range(0, S, 3):  # per-stream handlers on a third of the streams ...
         for name in ("activate", "deactivate"):

@@ -708,6 +708,24 @@ int ww_stream_step_trigger(ww_streams *st, const int16_t *frames, const uint8_t 
   WW_GUARD_END(st ? st->ctx : nullptr)
 }
 
+// The three stages of a tick in one call (include/wwhip.h): exactly the three entry points above, in stage order.
+int ww_pipeline_bank_step(ww_streams *st, const int16_t *frames, ww_pipeline_state *ps) {
+  WW_GUARD_BEGIN
+  if (!st) return WW_EINVAL;
+  if (!ps) return ww_fail(st->ctx, WW_EINVAL, "NULL state block");
+  ps->n_vad_changed = ps->n_fired = ps->n_fall = ps->n_deact = 0;
+  int rc = ww_vad_bank_step(st->S, ps->raw, ps->rise_frames, ps->fall_frames, ps->run_value, ps->run_length, ps->is_speech, &ps->n_vad_changed);
+  if (rc) return ww_fail(st->ctx, rc, "ww_pipeline_bank_step: the VAD stage's arrays");
+  rc = ww_stream_step_trigger(st, frames, ps->is_speech, ps->is_active, ps->threshold, ps->wake_was_speech, ps->posterior_max, ps->post,
+                              ps->n_post, ps->fired_ids, &ps->n_fired, ps->fall_ids, &ps->n_fall);
+  if (rc) return rc;
+  rc = ww_timeout_bank_step(st->S, ps->is_speech, ps->is_active, ps->timeout_was_speech, ps->active_frames, ps->min_frames, ps->max_frames,
+                            ps->deact_ids, &ps->n_deact);
+  if (rc) return ww_fail(st->ctx, rc, "ww_pipeline_bank_step: the timeout stage's arrays");
+  return WW_OK;
+  WW_GUARD_END(st ? st->ctx : nullptr)
+}
+
 int ww_stream_timeline(ww_streams *st, double *mean_ns, int64_t *ticks, int32_t reset) {
   WW_GUARD_BEGIN
   if (!st) return WW_EINVAL;

@@ -32,6 +32,14 @@ class ModelInfo(C.Structure):
                 ("kind", "window", "n_mel", "n_bins", "n_out", "enc_rows", "enc_width", "reserved")]
 
 
+class PipelineState(C.Structure):
+    """``ww_pipeline_state`` (include/wwhip.h): the arrays of the three banked stages, for ``ww_pipeline_bank_step``."""
+    _fields_ = ([(n, C.c_void_p) for n in ("is_speech", "is_active", "raw", "run_value", "run_length", "wake_was_speech", "posterior_max", "post",
+                                           "n_post", "timeout_was_speech", "active_frames", "fired_ids", "fall_ids", "deact_ids")]
+                + [(n, C.c_double) for n in ("threshold", "min_frames", "max_frames")]
+                + [(n, C.c_int32) for n in ("rise_frames", "fall_frames", "n_vad_changed", "n_fired", "n_fall", "n_deact")])
+
+
 class FrontendParams(C.Structure):
     _fields_ = [("pcm_divisor", C.c_float), ("clip", C.c_int32), ("pre_emphasis", C.c_float),
                 ("hop", C.c_int32), ("precise", C.c_int32)]
@@ -85,6 +93,7 @@ SYMBOLS: Dict[str, tuple] = {
     "ww_trigger_bank_step": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ww_timeout_bank_step": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _f64, _f64, _vp, _vp]),
     "ww_stream_step_trigger": (C.c_int, [_vp, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ww_pipeline_bank_step": (C.c_int, [_vp, _vp, _P(PipelineState)]),
     "ww_superframe_smooth": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _i32, _vp, _vp]),
     "ww_far_frr": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _f64, _f64, _vp, _vp, _vp, _vp]),
     "ww_far_frr_dev": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _f64, _f64, _vp, _vp, _vp, _vp]),
