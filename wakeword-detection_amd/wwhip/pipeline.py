@@ -122,6 +122,10 @@ class SpeechPipelineBank(SpeechPipeline):
         import ctypes as C
         return (ps, C.byref(ps), _lib.load().ww_pipeline_bank_step, wake._bank, vad, wake)
 
+    def cleanup(self) -> None:
+        self._fused = None  # (the state block points into the stages' arrays: it goes before they do)
+        super().cleanup()
+
     def activate(self) -> None:
         for c in self._context:
             c.is_active = True
